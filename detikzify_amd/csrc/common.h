@@ -1,0 +1,85 @@
+// common.h — device helpers shared by the gfx950 kernels of libdtk_hip.so.
+// wave = 64 lanes everywhere (CDNA4); bf16 values travel as raw uint16 bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DTK_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// fp32 -> bf16, round-to-nearest-even (v_cvt_pk_bf16_f32), same as torch .to(bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+// round an fp32 value through bf16 (every place HF materialises a bf16 tensor)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ float pk_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float pk_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// c + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a),
+                                         __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b, float c) {
+  c = dot2(a[0], b[0], c);
+  c = dot2(a[1], b[1], c);
+  c = dot2(a[2], b[2], c);
+  c = dot2(a[3], b[3], c);
+  return c;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// streamed-once weights: non-temporal 16-byte load
+__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// Decode-step state that lives in device memory so a captured hipGraph can be
+// replayed unchanged: kernels read the position / token from here.
+struct DecState {
+  int32_t pos;       // position index of the token being forwarded this step
+  int32_t next_pos;  // number of tokens that have KV after this step
+  int32_t token;     // token sampled this step (input of the forward)
+  uint32_t draw;     // number of tokens sampled since dtk_set_sampling
+  int32_t prompt_len_unused;
+  int32_t pad[3];
+};
+
+struct SamplingDev {
+  int32_t do_sample;
+  float temperature;
+  float top_p;
+  int32_t top_k;
+  uint64_t seed;
+  int32_t n_bad;
+  int32_t bad_ids[8];
+  int32_t n_begin;
+  int32_t begin_ids[8];
+  int32_t n_always;
+  int32_t always_ids[8];
+};
+
+// splitmix64: the counter-based RNG shared with oracle/sampling.py
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}

@@ -1,0 +1,990 @@
+// dtk_api.hip — the C ABI (include/dtk.h): context, weight registry, ViT / prefill /
+// decode orchestration, hipGraph capture of the per-token decode step.
+//
+// Reference call sites this replaces (all Python in potamides/DeTikZify):
+//   DetikzifyVisionModel.forward / get_intermediate_layers  v1/modeling_detikzify.py:63-72
+//   DetikzifyModel.get_vision_features + mm_projector        v1/modeling_detikzify.py:132-137,163
+//   embedding splice                                          v1/modeling_detikzify.py:158-189
+//   LlamaModel.forward / lm_head                              v1/modeling_detikzify.py:191-200,250-257
+//   HF GenerationMixin._sample loop body                      via infer/generate.py:218-227
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dtk.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct TensorEntry {
+  std::string name;
+  bf16_t* ptr = nullptr;   // destination (view into the arena)
+  int64_t rows = 1;        // logical rows
+  int64_t cols = 0;        // logical row length (elements)
+  int64_t stride = 0;      // destination row stride (elements), >= cols
+  float synth_scale = 0.02f;
+  float synth_offset = 0.f;
+  int64_t numel() const { return rows * cols; }
+};
+
+struct LayerW {
+  bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
+};
+struct VitBlockW {
+  bf16_t *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
+};
+
+}  // namespace
+
+struct dtk_ctx {
+  dtk_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // derived sizes
+  int d, L, H, ff, V, Tmax, S;
+  int vD, vDepth, vH, vHd, vMlp, vN, vPatchK, vPatchLd, nImg;
+
+  // weights
+  unsigned char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<TensorEntry> tensors;
+  std::unordered_map<std::string, int> tindex;
+  std::vector<LayerW> layers;
+  bf16_t *embed, *final_norm, *lm_head, *mm_w, *mm_b;
+  bf16_t *rope_cos, *rope_sin;
+  std::vector<VitBlockW> vblocks;
+  bf16_t *pe_w, *pe_b, *pos_embed, *vnorm_w, *vnorm_b;
+  bf16_t *ap_latent, *ap_qw, *ap_qb, *ap_kvw, *ap_kvb, *ap_pw, *ap_pb, *ap_nw, *ap_nb, *ap_f1w,
+      *ap_f1b, *ap_f2w, *ap_f2b;
+
+  // KV cache [L][2][H][Tmax][128]
+  bf16_t* kv = nullptr;
+
+  // activations: decoder prefill
+  bf16_t *X, *Xn, *QKV, *Qh, *AO, *GU, *ACT;
+  int32_t* ids_dev = nullptr;
+  // decode step
+  bf16_t *x, *q, *act;
+  float *logits, *pm, *pl, *po;
+  DecState* st = nullptr;
+  SamplingDev* sp = nullptr;
+  int64_t* tok_ring_dev = nullptr;   // device ring
+  int64_t* tok_ring_host = nullptr;  // pinned host mirror
+  float* probs_dev = nullptr;        // op_sample output
+  // ViT
+  float* pixels_dev = nullptr;
+  bf16_t *patches, *VX, *VN, *VQKV, *VAO, *VH, *feats, *last_hidden;
+  bf16_t *pq, *pkv, *pao, *px, *pn, *ph, *pooled;
+  bf16_t* IMG;  // projected image embeddings [nImg][d]
+  // op-level scratch
+  unsigned char* scratch = nullptr;
+  size_t scratch_bytes = 0;
+
+  // host state
+  std::vector<int64_t> cached_ids;
+  uint64_t cached_image_key = 0;
+  bool have_image = false;
+  bool cached_with_image = false;  // the cached KV was computed with image features spliced in
+  int host_next_pos = 0;     // tokens with KV after all launched steps
+  bool have_logits = false;
+  dtk_sampling sampling{};
+  uint64_t launched = 0, waited = 0;
+  hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  hipEvent_t probe_a = nullptr, probe_b = nullptr;
+  bool use_graph = true;
+  bool graph_ready = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool gemm_naive = false;
+  int probe = 0;
+  dtk_stats stats{};
+};
+
+namespace {
+
+int fail(dtk_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), DTK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+uint16_t host_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float host_bf2f(uint16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+float host_h2f(uint16_t h) {
+  const uint32_t sign = (h >> 15) & 1u, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  float v;
+  if (exp == 0) v = ldexpf((float)man, -24);
+  else if (exp == 31) v = man ? NAN : INFINITY;
+  else v = ldexpf((float)(man | 0x400u), (int)exp - 25);
+  return sign ? -v : v;
+}
+
+// ---- arena planning: first pass sums sizes, second pass hands out pointers
+struct Planner {
+  size_t off = 0;
+  unsigned char* base = nullptr;
+  template <typename T>
+  T* take(size_t n_elems) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n_elems * sizeof(T);
+    return p;
+  }
+};
+
+void add_tensor(dtk_ctx* c, const std::string& name, bf16_t* ptr, int64_t rows, int64_t cols,
+                int64_t stride, float scale, float offset) {
+  TensorEntry t;
+  t.name = name; t.ptr = ptr; t.rows = rows; t.cols = cols; t.stride = stride;
+  t.synth_scale = scale; t.synth_offset = offset;
+  c->tindex[name] = (int)c->tensors.size();
+  c->tensors.push_back(t);
+}
+
+// Lays out every device buffer.  Called twice (size pass with base == nullptr, then for real).
+void plan(dtk_ctx* c, Planner& P, bool reg) {
+  const int d = c->d, L = c->L, ff = c->ff, V = c->V, T = c->Tmax;
+  const int D = c->vD, N = c->vN, mlp = c->vMlp;
+  const float ws = 0.02f;
+  auto R = [&](const std::string& n, bf16_t* p, int64_t r, int64_t cl, int64_t st, float sc,
+               float of) { if (reg) add_tensor(c, n, p, r, cl, st, sc, of); };
+  // ---- decoder weights
+  c->embed = P.take<bf16_t>((size_t)V * d);
+  R("model.embed_tokens.weight", c->embed, V, d, d, ws, 0.f);
+  if (reg) c->layers.resize(L);
+  for (int i = 0; i < L; ++i) {
+    LayerW w;
+    w.ln1 = P.take<bf16_t>(d);
+    w.wqkv = P.take<bf16_t>((size_t)3 * d * d);
+    w.wo = P.take<bf16_t>((size_t)d * d);
+    w.ln2 = P.take<bf16_t>(d);
+    w.wgu = P.take<bf16_t>((size_t)2 * ff * d);
+    w.wdown = P.take<bf16_t>((size_t)d * ff);
+    if (reg) {
+      c->layers[i] = w;
+      const std::string p = "model.layers." + std::to_string(i) + ".";
+      R(p + "input_layernorm.weight", w.ln1, 1, d, d, 0.1f, 1.f);
+      R(p + "self_attn.q_proj.weight", w.wqkv, d, d, d, ws, 0.f);
+      R(p + "self_attn.k_proj.weight", w.wqkv + (size_t)d * d, d, d, d, ws, 0.f);
+      R(p + "self_attn.v_proj.weight", w.wqkv + (size_t)2 * d * d, d, d, d, ws, 0.f);
+      R(p + "self_attn.o_proj.weight", w.wo, d, d, d, ws, 0.f);
+      R(p + "post_attention_layernorm.weight", w.ln2, 1, d, d, 0.1f, 1.f);
+      R(p + "mlp.gate_proj.weight", w.wgu, ff, d, d, ws, 0.f);
+      R(p + "mlp.up_proj.weight", w.wgu + (size_t)ff * d, ff, d, d, ws, 0.f);
+      R(p + "mlp.down_proj.weight", w.wdown, d, ff, ff, ws, 0.f);
+    }
+  }
+  c->final_norm = P.take<bf16_t>(d);
+  R("model.norm.weight", c->final_norm, 1, d, d, 0.1f, 1.f);
+  c->lm_head = P.take<bf16_t>((size_t)V * d);
+  R("lm_head.weight", c->lm_head, V, d, d, ws, 0.f);
+  c->mm_w = P.take<bf16_t>((size_t)d * 3 * D);
+  c->mm_b = P.take<bf16_t>(d);
+  R("model.mm_projector.weight", c->mm_w, d, (int64_t)c->cfg.concat_patches * D,
+    (int64_t)c->cfg.concat_patches * D, ws, 0.f);
+  R("model.mm_projector.bias", c->mm_b, 1, d, d, 0.01f, 0.f);
+  c->rope_cos = P.take<bf16_t>((size_t)T * 64);
+  c->rope_sin = P.take<bf16_t>((size_t)T * 64);
+  R("rope.cos", c->rope_cos, T, 64, 64, 0.f, 0.f);
+  R("rope.sin", c->rope_sin, T, 64, 64, 0.f, 0.f);
+  // ---- vision tower (timm VisionTransformer state-dict names)
+  const std::string vp = "vision_model.";
+  c->pe_w = P.take<bf16_t>((size_t)D * c->vPatchLd);
+  c->pe_b = P.take<bf16_t>(D);
+  c->pos_embed = P.take<bf16_t>((size_t)N * D);
+  R(vp + "patch_embed.proj.weight", c->pe_w, D, c->vPatchK, c->vPatchLd, ws, 0.f);
+  R(vp + "patch_embed.proj.bias", c->pe_b, 1, D, D, 0.01f, 0.f);
+  R(vp + "pos_embed", c->pos_embed, N, D, D, ws, 0.f);
+  if (reg) c->vblocks.resize(c->vDepth);
+  for (int i = 0; i < c->vDepth; ++i) {
+    VitBlockW w;
+    w.n1w = P.take<bf16_t>(D); w.n1b = P.take<bf16_t>(D);
+    w.qkvw = P.take<bf16_t>((size_t)3 * D * D); w.qkvb = P.take<bf16_t>(3 * D);
+    w.projw = P.take<bf16_t>((size_t)D * D); w.projb = P.take<bf16_t>(D);
+    w.n2w = P.take<bf16_t>(D); w.n2b = P.take<bf16_t>(D);
+    w.fc1w = P.take<bf16_t>((size_t)mlp * D); w.fc1b = P.take<bf16_t>(mlp);
+    w.fc2w = P.take<bf16_t>((size_t)D * mlp); w.fc2b = P.take<bf16_t>(D);
+    if (reg) {
+      c->vblocks[i] = w;
+      const std::string p = vp + "blocks." + std::to_string(i) + ".";
+      R(p + "norm1.weight", w.n1w, 1, D, D, 0.1f, 1.f);
+      R(p + "norm1.bias", w.n1b, 1, D, D, 0.01f, 0.f);
+      R(p + "attn.qkv.weight", w.qkvw, 3 * D, D, D, ws, 0.f);
+      R(p + "attn.qkv.bias", w.qkvb, 1, 3 * D, 3 * D, 0.01f, 0.f);
+      R(p + "attn.proj.weight", w.projw, D, D, D, ws, 0.f);
+      R(p + "attn.proj.bias", w.projb, 1, D, D, 0.01f, 0.f);
+      R(p + "norm2.weight", w.n2w, 1, D, D, 0.1f, 1.f);
+      R(p + "norm2.bias", w.n2b, 1, D, D, 0.01f, 0.f);
+      R(p + "mlp.fc1.weight", w.fc1w, mlp, D, D, ws, 0.f);
+      R(p + "mlp.fc1.bias", w.fc1b, 1, mlp, mlp, 0.01f, 0.f);
+      R(p + "mlp.fc2.weight", w.fc2w, D, mlp, mlp, ws, 0.f);
+      R(p + "mlp.fc2.bias", w.fc2b, 1, D, D, 0.01f, 0.f);
+    }
+  }
+  c->vnorm_w = P.take<bf16_t>(D); c->vnorm_b = P.take<bf16_t>(D);
+  R(vp + "norm.weight", c->vnorm_w, 1, D, D, 0.1f, 1.f);
+  R(vp + "norm.bias", c->vnorm_b, 1, D, D, 0.01f, 0.f);
+  c->ap_latent = P.take<bf16_t>(D);
+  c->ap_qw = P.take<bf16_t>((size_t)D * D); c->ap_qb = P.take<bf16_t>(D);
+  c->ap_kvw = P.take<bf16_t>((size_t)2 * D * D); c->ap_kvb = P.take<bf16_t>(2 * D);
+  c->ap_pw = P.take<bf16_t>((size_t)D * D); c->ap_pb = P.take<bf16_t>(D);
+  c->ap_nw = P.take<bf16_t>(D); c->ap_nb = P.take<bf16_t>(D);
+  c->ap_f1w = P.take<bf16_t>((size_t)mlp * D); c->ap_f1b = P.take<bf16_t>(mlp);
+  c->ap_f2w = P.take<bf16_t>((size_t)D * mlp); c->ap_f2b = P.take<bf16_t>(D);
+  R(vp + "attn_pool.latent", c->ap_latent, 1, D, D, ws, 0.f);
+  R(vp + "attn_pool.q.weight", c->ap_qw, D, D, D, ws, 0.f);
+  R(vp + "attn_pool.q.bias", c->ap_qb, 1, D, D, 0.01f, 0.f);
+  R(vp + "attn_pool.kv.weight", c->ap_kvw, 2 * D, D, D, ws, 0.f);
+  R(vp + "attn_pool.kv.bias", c->ap_kvb, 1, 2 * D, 2 * D, 0.01f, 0.f);
+  R(vp + "attn_pool.proj.weight", c->ap_pw, D, D, D, ws, 0.f);
+  R(vp + "attn_pool.proj.bias", c->ap_pb, 1, D, D, 0.01f, 0.f);
+  R(vp + "attn_pool.norm.weight", c->ap_nw, 1, D, D, 0.1f, 1.f);
+  R(vp + "attn_pool.norm.bias", c->ap_nb, 1, D, D, 0.01f, 0.f);
+  R(vp + "attn_pool.mlp.fc1.weight", c->ap_f1w, mlp, D, D, ws, 0.f);
+  R(vp + "attn_pool.mlp.fc1.bias", c->ap_f1b, 1, mlp, mlp, 0.01f, 0.f);
+  R(vp + "attn_pool.mlp.fc2.weight", c->ap_f2w, D, mlp, mlp, ws, 0.f);
+  R(vp + "attn_pool.mlp.fc2.bias", c->ap_f2b, 1, D, D, 0.01f, 0.f);
+
+  // ---- KV cache + activations
+  c->kv = P.take<bf16_t>((size_t)L * 2 * c->H * T * 128);
+  c->X = P.take<bf16_t>((size_t)T * d);
+  c->Xn = P.take<bf16_t>((size_t)T * d);
+  c->QKV = P.take<bf16_t>((size_t)T * 3 * d);
+  c->Qh = P.take<bf16_t>((size_t)T * d);
+  c->AO = P.take<bf16_t>((size_t)T * d);
+  c->GU = P.take<bf16_t>((size_t)T * 2 * ff);
+  c->ACT = P.take<bf16_t>((size_t)T * ff);
+  c->ids_dev = P.take<int32_t>(T);
+  c->x = P.take<bf16_t>(d);
+  c->q = P.take<bf16_t>(d);
+  c->act = P.take<bf16_t>(ff);
+  c->logits = P.take<float>(V);
+  c->pm = P.take<float>((size_t)c->H * c->S);
+  c->pl = P.take<float>((size_t)c->H * c->S);
+  c->po = P.take<float>((size_t)c->H * c->S * 128);
+  c->st = P.take<DecState>(1);
+  c->sp = P.take<SamplingDev>(1);
+  c->tok_ring_dev = P.take<int64_t>(DTK_MAX_INFLIGHT);
+  c->probs_dev = P.take<float>(V);
+  c->pixels_dev = P.take<float>((size_t)3 * c->cfg.vit_image * c->cfg.vit_image);
+  c->patches = P.take<bf16_t>((size_t)N * c->vPatchLd);
+  c->VX = P.take<bf16_t>((size_t)N * D);
+  c->VN = P.take<bf16_t>((size_t)N * D);
+  c->VQKV = P.take<bf16_t>((size_t)N * 3 * D);
+  c->VAO = P.take<bf16_t>((size_t)N * D);
+  c->VH = P.take<bf16_t>((size_t)N * mlp);
+  c->feats = P.take<bf16_t>((size_t)N * D);
+  c->last_hidden = P.take<bf16_t>((size_t)N * D);
+  c->pq = P.take<bf16_t>(D);
+  c->pkv = P.take<bf16_t>((size_t)N * 2 * D);
+  c->pao = P.take<bf16_t>(D);
+  c->px = P.take<bf16_t>(D);
+  c->pn = P.take<bf16_t>(D);
+  c->ph = P.take<bf16_t>(mlp);
+  c->pooled = P.take<bf16_t>(D);
+  c->IMG = P.take<bf16_t>((size_t)c->nImg * d);
+  c->scratch_bytes = (size_t)64 << 20;
+  c->scratch = P.take<unsigned char>(c->scratch_bytes);
+}
+
+void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
+          const bf16_t* res, int ldr, bf16_t* C, int ldc, int M, int N, int K, int flags) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags;
+  if (c->gemm_naive) launch_gemm_naive(g, c->stream);
+  else launch_gemm_mfma(g, c->stream);
+}
+
+int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
+
+bf16_t* kcache(dtk_ctx* c, int layer) { return c->kv + (size_t)layer * 2 * c->H * c->Tmax * 128; }
+bf16_t* vcache(dtk_ctx* c, int layer) { return kcache(c, layer) + (size_t)c->H * c->Tmax * 128; }
+
+// ViT trunk + (optionally) MAP head for the image already in pixels_dev.
+void vit_forward(dtk_ctx* c, bool want_pooled) {
+  const int D = c->vD, N = c->vN, mlp = c->vMlp, Hh = c->vH, hd = c->vHd;
+  hipStream_t s = c->stream;
+  launch_im2col(c->pixels_dev, c->patches, c->cfg.vit_image, c->cfg.vit_patch, c->vPatchLd, s);
+  // conv(patch)+bias -> bf16, then + pos_embed -> bf16 (timm PatchEmbed, _pos_embed)
+  gemm(c, c->patches, c->vPatchLd, c->pe_w, c->vPatchLd, c->pe_b, c->pos_embed, D, c->VX, D, N, D,
+       c->vPatchLd, GEMM_BIAS | GEMM_RESIDUAL);
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int fl = c->cfg.vit_feature_layer;
+  const int last = want_pooled ? c->vDepth - 1 : fl;
+  for (int i = 0; i <= last; ++i) {
+    const VitBlockW& w = c->vblocks[i];
+    launch_layernorm_rows(c->VX, D, w.n1w, w.n1b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
+    gemm(c, c->VN, D, w.qkvw, D, w.qkvb, nullptr, 0, c->VQKV, 3 * D, N, 3 * D, D, GEMM_BIAS);
+    AttnArgs a;
+    a.Q = c->VQKV; a.q_sh = hd; a.q_st = 3 * D;
+    a.K = c->VQKV + D; a.k_sh = hd; a.k_st = 3 * D;
+    a.V = c->VQKV + 2 * D; a.v_sh = hd; a.v_st = 3 * D;
+    a.O = c->VAO; a.o_sh = hd; a.o_st = D;
+    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale;
+    launch_attention(a, s);
+    gemm(c, c->VAO, D, w.projw, D, w.projb, c->VX, D, c->VX, D, N, D, D, GEMM_BIAS | GEMM_RESIDUAL);
+    launch_layernorm_rows(c->VX, D, w.n2w, w.n2b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
+    gemm(c, c->VN, D, w.fc1w, D, w.fc1b, nullptr, 0, c->VH, mlp, N, mlp, D, GEMM_BIAS | gelu_flag(c));
+    gemm(c, c->VH, mlp, w.fc2w, mlp, w.fc2b, c->VX, D, c->VX, D, N, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
+    if (i == fl)  // get_intermediate_layers(n=[layer], norm=True)
+      launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->feats, D, N, D, c->cfg.vit_ln_eps, s);
+  }
+  if (!want_pooled) return;
+  // forward_features -> final norm; forward_head -> AttentionPoolLatent ('map')
+  const bf16_t* lh = c->feats;
+  if (fl != c->vDepth - 1) {
+    launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->last_hidden, D, N, D, c->cfg.vit_ln_eps, s);
+    lh = c->last_hidden;
+  }
+  gemm(c, c->ap_latent, D, c->ap_qw, D, c->ap_qb, nullptr, 0, c->pq, D, 1, D, D, GEMM_BIAS);
+  gemm(c, lh, D, c->ap_kvw, D, c->ap_kvb, nullptr, 0, c->pkv, 2 * D, N, 2 * D, D, GEMM_BIAS);
+  AttnArgs a;
+  a.Q = c->pq; a.q_sh = hd; a.q_st = D;
+  a.K = c->pkv; a.k_sh = hd; a.k_st = 2 * D;
+  a.V = c->pkv + D; a.v_sh = hd; a.v_st = 2 * D;
+  a.O = c->pao; a.o_sh = hd; a.o_st = D;
+  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale;
+  launch_attention(a, s);
+  gemm(c, c->pao, D, c->ap_pw, D, c->ap_pb, nullptr, 0, c->px, D, 1, D, D, GEMM_BIAS);
+  launch_layernorm_rows(c->px, D, c->ap_nw, c->ap_nb, c->pn, D, 1, D, c->cfg.vit_ln_eps, s);
+  gemm(c, c->pn, D, c->ap_f1w, D, c->ap_f1b, nullptr, 0, c->ph, mlp, 1, mlp, D, GEMM_BIAS | gelu_flag(c));
+  gemm(c, c->ph, mlp, c->ap_f2w, mlp, c->ap_f2b, c->px, D, c->pooled, D, 1, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
+}
+
+void project_image(dtk_ctx* c) {
+  // feats [N][D] viewed as [N/concat][concat*D] (3 consecutive patch tokens), Linear with bias
+  const int K = c->cfg.concat_patches * c->vD;
+  gemm(c, c->feats, K, c->mm_w, K, c->mm_b, nullptr, 0, c->IMG, c->d, c->nImg, c->d, K, GEMM_BIAS);
+}
+
+// launches of one decoded token (captured into the graph, or issued directly)
+void decode_step_launches(dtk_ctx* c, bool with_probe) {
+  hipStream_t s = c->stream;
+  SampleArgs sa;
+  sa.logits = c->logits; sa.V = c->V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed;
+  sa.x = c->x; sa.d = c->d; sa.tok_ring = c->tok_ring_dev; sa.ring = DTK_MAX_INFLIGHT;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1;
+  launch_sample(sa, s);
+  const float scale = 1.0f / sqrtf(128.f);
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    GemvArgs g{};
+    g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin;
+    g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
+    // 1. input_layernorm + q/k/v projections + RoPE + KV append
+    g.W = w.wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1;
+    g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l);
+    launch_gemv(PRO_RMSNORM, EPI_QKV, g, s);
+    // 2. split-K attention over the cache
+    AttnDecArgs ad;
+    ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
+    ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax;
+    ad.scale = scale;
+    launch_attn_decode(ad, s);
+    // 3. combine + o_proj + residual
+    g.W = w.wo; g.N = c->d; g.K = c->d; g.y = c->x;
+    launch_gemv(PRO_ATTN, EPI_RESID, g, s);
+    // 4. post_attention_layernorm + gate/up + SiLU*mul
+    g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act;
+    const bool probe_here = with_probe && (l == c->L / 2);
+    if (probe_here) (void)hipEventRecord(c->probe_a, s);
+    launch_gemv(PRO_RMSNORM, EPI_SWIGLU, g, s);
+    if (probe_here) (void)hipEventRecord(c->probe_b, s);
+    // 5. down + residual
+    g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->x;
+    launch_gemv(PRO_COPY, EPI_RESID, g, s);
+  }
+  GemvArgs g{};
+  g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm;
+  g.eps = c->cfg.rms_eps; g.logits = c->logits;
+  launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
+}
+
+int ensure_graph(dtk_ctx* c) {
+  if (c->graph_ready) return DTK_OK;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  decode_step_launches(c, false);
+  HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
+  HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+  c->graph_ready = true;
+  return DTK_OK;
+}
+
+void compute_rope_tables(const dtk_config& cfg, std::vector<uint16_t>& cosv, std::vector<uint16_t>& sinv) {
+  // HF LlamaRotaryEmbedding: inv_freq = 1/theta^(2i/hd) (/factor for 'linear'), fp32;
+  // freqs = pos * inv_freq in fp32; cos/sin cast to the activation dtype (bf16).
+  const int T = cfg.max_positions;
+  cosv.resize((size_t)T * 64); sinv.resize((size_t)T * 64);
+  for (int i = 0; i < 64; ++i) {
+    float inv = (float)(1.0 / pow((double)cfg.rope_theta, (double)(2 * i) / 128.0));
+    if (cfg.rope_factor > 0.f && cfg.rope_factor != 1.f) inv = inv / cfg.rope_factor;
+    for (int p = 0; p < T; ++p) {
+      const float fr = inv * (float)p;
+      cosv[(size_t)p * 64 + i] = host_f2bf((float)cos((double)fr));
+      sinv[(size_t)p * 64 + i] = host_f2bf((float)sin((double)fr));
+    }
+  }
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+int dtk_abi_version(void) { return DTK_ABI_VERSION; }
+
+const char* dtk_last_error(const dtk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, DTK_ERR_ARG, "dtk_create: null argument");
+  *out = nullptr;
+  if (cfg->head_dim != 128) return fail(nullptr, DTK_ERR_ARG, "head_dim must be 128 (got %d)", cfg->head_dim);
+  if (cfg->hidden != cfg->heads * cfg->head_dim)
+    return fail(nullptr, DTK_ERR_ARG, "hidden (%d) != heads*head_dim", cfg->hidden);
+  if (cfg->hidden % 8 || cfg->ffn % 8 || cfg->vit_dim % 8 || cfg->vit_mlp % 8)
+    return fail(nullptr, DTK_ERR_ARG, "dims must be multiples of 8");
+  if (cfg->vit_dim % cfg->vit_heads) return fail(nullptr, DTK_ERR_ARG, "vit_dim %% vit_heads != 0");
+  const int vhd = cfg->vit_dim / cfg->vit_heads;
+  if (vhd != 72 && vhd != 128 && vhd != 64 && vhd != 32)
+    return fail(nullptr, DTK_ERR_ARG, "unsupported ViT head dim %d", vhd);
+  if (cfg->vit_image % cfg->vit_patch) return fail(nullptr, DTK_ERR_ARG, "image %% patch != 0");
+  const int np = cfg->vit_image / cfg->vit_patch;
+  if ((np * np) % cfg->concat_patches) return fail(nullptr, DTK_ERR_ARG, "patches %% concat != 0");
+  if (cfg->max_positions < 8 || cfg->vocab < 2) return fail(nullptr, DTK_ERR_ARG, "bad sizes");
+  if (cfg->vit_feature_layer < 0 || cfg->vit_feature_layer >= cfg->vit_depth)
+    return fail(nullptr, DTK_ERR_ARG, "vit_feature_layer out of range");
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= device)
+    return fail(nullptr, DTK_ERR_HIP, "no HIP device %d (count %d: %s)", device, ndev, hipGetErrorString(e));
+  dtk_ctx* c = new dtk_ctx();
+  c->cfg = *cfg;
+  c->device = device;
+  c->d = cfg->hidden; c->L = cfg->layers; c->H = cfg->heads; c->ff = cfg->ffn; c->V = cfg->vocab;
+  c->Tmax = cfg->max_positions;
+  c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
+  c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
+  c->vMlp = cfg->vit_mlp; c->vN = np * np;
+  c->vPatchK = 3 * cfg->vit_patch * cfg->vit_patch;
+  c->vPatchLd = (int)align_up((size_t)c->vPatchK, 8);
+  c->nImg = c->vN / cfg->concat_patches;
+  const char* gm = getenv("DTK_GEMM");
+  c->gemm_naive = gm && !strcmp(gm, "naive");
+
+#define CCHK(call)                                                                         \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      fail(nullptr, DTK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));           \
+      dtk_destroy(c);                                                                      \
+      return DTK_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+  CCHK(hipSetDevice(device));
+  CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  Planner sz;
+  plan(c, sz, false);
+  c->arena_bytes = align_up(sz.off, 256) + 256;
+  CCHK(hipMalloc((void**)&c->arena, c->arena_bytes));
+  Planner real;
+  real.base = c->arena;
+  plan(c, real, true);
+  CCHK(hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
+  CCHK(hipHostMalloc((void**)&c->tok_ring_host, sizeof(int64_t) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
+  for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+  CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
+  CCHK(hipEventCreate(&c->probe_a)); CCHK(hipEventCreate(&c->probe_b));
+  // default RoPE tables (the Python loader overrides them with torch-computed ones)
+  std::vector<uint16_t> cosv, sinv;
+  compute_rope_tables(*cfg, cosv, sinv);
+  CCHK(hipMemcpyAsync(c->rope_cos, cosv.data(), cosv.size() * 2, hipMemcpyHostToDevice, c->stream));
+  CCHK(hipMemcpyAsync(c->rope_sin, sinv.data(), sinv.size() * 2, hipMemcpyHostToDevice, c->stream));
+  CCHK(hipStreamSynchronize(c->stream));
+#undef CCHK
+  // accounting: W = decoder layers + final norm + lm_head, K = 2*L*d*2
+  const uint64_t per_layer = (uint64_t)4 * c->d * c->d + (uint64_t)3 * c->d * c->ff + 2 * (uint64_t)c->d;
+  c->stats.weight_bytes_per_token = 2 * (per_layer * c->L + (uint64_t)c->d + (uint64_t)c->V * c->d);
+  c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * c->d * 2;
+  c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * 2;
+  *out = c;
+  return DTK_OK;
+}
+
+void dtk_destroy(dtk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->step_done[i]) (void)hipEventDestroy(c->step_done[i]);
+  hipEvent_t evs[] = {c->ev_a, c->ev_b, c->ev_c, c->probe_a, c->probe_b};
+  for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+  if (c->tok_ring_host) (void)hipHostFree(c->tok_ring_host);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dtk_num_tensors(const dtk_ctx* c) { return c ? (int)c->tensors.size() : 0; }
+const char* dtk_tensor_name(const dtk_ctx* c, int i) {
+  if (!c || i < 0 || i >= (int)c->tensors.size()) return nullptr;
+  return c->tensors[i].name.c_str();
+}
+int64_t dtk_tensor_numel(const dtk_ctx* c, const char* name) {
+  if (!c || !name) return -1;
+  auto it = c->tindex.find(name);
+  return it == c->tindex.end() ? -1 : c->tensors[it->second].numel();
+}
+
+int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, const int64_t* shape, int ndim) {
+  if (!c || !name || !host || !shape || ndim < 1) return fail(c, DTK_ERR_ARG, "dtk_load_tensor: null argument");
+  auto it = c->tindex.find(name);
+  if (it == c->tindex.end()) return fail(c, DTK_ERR_ARG, "unknown tensor '%s'", name);
+  const TensorEntry& t = c->tensors[it->second];
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= shape[i];
+  if (n != t.numel()) return fail(c, DTK_ERR_ARG, "tensor '%s': %lld elements given, %lld expected", name, (long long)n, (long long)t.numel());
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint16_t> tmp;
+  const uint16_t* src16 = nullptr;
+  if (dtype == DTK_BF16) {
+    src16 = static_cast<const uint16_t*>(host);
+  } else if (dtype == DTK_F32) {
+    tmp.resize((size_t)n);
+    const float* f = static_cast<const float*>(host);
+    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = host_f2bf(f[i]);
+    src16 = tmp.data();
+  } else if (dtype == DTK_F16) {
+    tmp.resize((size_t)n);
+    const uint16_t* hf = static_cast<const uint16_t*>(host);
+    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = host_f2bf(host_h2f(hf[i]));
+    src16 = tmp.data();
+  } else {
+    return fail(c, DTK_ERR_ARG, "bad dtype %d", dtype);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy2D(t.ptr, (size_t)t.stride * 2, src16, (size_t)t.cols * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyHostToDevice));
+  c->have_image = false;
+  c->cached_ids.clear();
+  return DTK_OK;
+}
+
+int dtk_read_tensor(dtk_ctx* c, const char* name, void* host_out, int64_t n_elems) {
+  if (!c || !name || !host_out) return fail(c, DTK_ERR_ARG, "dtk_read_tensor: null argument");
+  auto it = c->tindex.find(name);
+  if (it == c->tindex.end()) return fail(c, DTK_ERR_ARG, "unknown tensor '%s'", name);
+  const TensorEntry& t = c->tensors[it->second];
+  if (n_elems != t.numel()) return fail(c, DTK_ERR_ARG, "tensor '%s' has %lld elements", name, (long long)t.numel());
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy2D(host_out, (size_t)t.cols * 2, t.ptr, (size_t)t.stride * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyDeviceToHost));
+  return DTK_OK;
+}
+
+int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
+  if (!c) return DTK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (size_t i = 0; i < c->tensors.size(); ++i) {
+    const TensorEntry& t = c->tensors[i];
+    if (t.name == "rope.cos" || t.name == "rope.sin") continue;
+    if (t.stride == t.cols) {
+      launch_fill_synth(t.ptr, t.numel(), seed, (uint32_t)i, t.synth_scale, t.synth_offset, c->stream);
+    } else {  // padded rows: fill contiguously in scratch, then pitch-copy
+      if ((size_t)t.numel() * 2 > c->scratch_bytes) return fail(c, DTK_ERR_ARG, "scratch too small");
+      bf16_t* tmp = reinterpret_cast<bf16_t*>(c->scratch);
+      launch_fill_synth(tmp, t.numel(), seed, (uint32_t)i, t.synth_scale, t.synth_offset, c->stream);
+      HIPCHK(c, hipMemcpy2DAsync(t.ptr, (size_t)t.stride * 2, tmp, (size_t)t.cols * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_image = false;
+  c->cached_ids.clear();
+  return DTK_OK;
+}
+
+int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, void* pooled_out) {
+  if (!c || !pixels || batch < 1) return fail(c, DTK_ERR_ARG, "dtk_vit_encode: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
+  for (int b = 0; b < batch; ++b) {
+    HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b * img, img * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+    vit_forward(c, pooled_out != nullptr);
+    HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+    if (feats_out)
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, c->feats, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, c->stream));
+    if (pooled_out)
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b * c->vD, c->pooled, (size_t)c->vD * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.last_vit_ms = ms;
+    c->stats.vit_images++;
+  }
+  return DTK_OK;  // IMG (the projected prefix of the cached prefill image) is left untouched
+}
+
+int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
+  if (!c || !ids || T < 1) return fail(c, DTK_ERR_ARG, "dtk_prefill: bad argument");
+  if (T > c->Tmax) return fail(c, DTK_ERR_RANGE, "prompt of %d tokens exceeds max_positions %d", T, c->Tmax);
+  HIPCHK(c, hipSetDevice(c->device));
+  // drain pending decode steps (their tokens are dropped)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
+  // ---- locate the image placeholder run (reference v1/modeling_detikzify.py:179-184)
+  int img_start = -1, img_count = 0;
+  for (int t = 0; t < T; ++t) {
+    if (ids[t] < 0 || ids[t] >= c->V) return fail(c, DTK_ERR_ARG, "token id %lld out of range", (long long)ids[t]);
+    if (ids[t] == c->cfg.image_token_id) { if (img_start < 0) img_start = t; img_count++; }
+  }
+  const bool has_img = img_count > 0;
+  const bool use_img = has_img && (pixels != nullptr || ((flags & DTK_PREFILL_REUSE_IMAGE) && c->have_image && c->cached_image_key == image_key));
+  if (use_img) {
+    if (img_count != c->nImg)
+      return fail(c, DTK_ERR_ARG, "The number of image patch tokens should be the same as the number of image patches.");
+    for (int t = 0; t < c->nImg; ++t)
+      if (ids[img_start + t] != c->cfg.image_token_id)
+        return fail(c, DTK_ERR_ARG, "The image patch tokens should be consecutive.");
+  }
+  HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+  bool image_changed = false;
+  if (use_img) {
+    const bool reuse = (flags & DTK_PREFILL_REUSE_IMAGE) && c->have_image && c->cached_image_key == image_key;
+    if (!reuse) {
+      if (!pixels) return fail(c, DTK_ERR_ARG, "pixels required (no cached image for this key)");
+      const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
+      HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels, img * 4, hipMemcpyHostToDevice, c->stream));
+      vit_forward(c, false);
+      project_image(c);
+      c->stats.vit_images++;
+      c->have_image = true;
+      c->cached_image_key = image_key;
+      image_changed = true;
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+  // ---- longest common prefix with the cached sequence (output-identical KV reuse)
+  int start = 0;
+  if ((flags & DTK_PREFILL_REUSE_PREFIX) && !image_changed && !c->cached_ids.empty()) {
+    const int lim = (int)std::min<size_t>(c->cached_ids.size(), (size_t)T - 1);
+    while (start < lim && c->cached_ids[start] == ids[start]) ++start;
+  }
+  // KV computed with / without spliced image features never mixes
+  if (has_img && c->cached_with_image != use_img) start = 0;
+  const int n = T - start;
+  std::vector<int32_t> ids32((size_t)n);
+  for (int t = 0; t < n; ++t) ids32[(size_t)t] = (int32_t)ids[start + t];
+  HIPCHK(c, hipMemcpyAsync(c->ids_dev, ids32.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  hipStream_t s = c->stream;
+  const int d = c->d, ff = c->ff;
+  launch_embed_gather(c->ids_dev, c->embed, c->X, n, d, s);
+  if (use_img) {  // splice projected image features over the placeholder embeddings
+    const int lo = std::max(img_start, start), hi = img_start + c->nImg;
+    if (hi > lo) launch_copy_rows(c->IMG + (size_t)(lo - img_start) * d, d, c->X + (size_t)(lo - start) * d, d, hi - lo, d, s);
+  }
+  const float scale = 1.0f / sqrtf(128.f);
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    launch_rmsnorm_rows(c->X, d, w.ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
+    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, 3 * d, n, 3 * d, d, 0);
+    launch_rope_scatter(c->QKV, c->Qh, kcache(c, l), vcache(c, l), c->rope_cos, c->rope_sin, n, start, c->H, c->Tmax, s);
+    AttnArgs a;
+    a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
+    a.K = kcache(c, l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
+    a.V = vcache(c, l); a.v_sh = (long)c->Tmax * 128; a.v_st = 128;
+    a.O = c->AO; a.o_sh = 128; a.o_st = d;
+    a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale;
+    launch_attention(a, s);
+    gemm(c, c->AO, d, w.wo, d, nullptr, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL);
+    launch_rmsnorm_rows(c->X, d, w.ln2, c->Xn, d, n, d, c->cfg.rms_eps, s);
+    gemm(c, c->Xn, d, w.wgu, d, nullptr, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0);
+    launch_silu_mul(c->GU, ff, c->ACT, n, s);
+    gemm(c, c->ACT, ff, w.wdown, ff, nullptr, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL);
+  }
+  // final norm + lm_head on the last position only (the sampler consumes logits[:, -1])
+  GemvArgs g{};
+  g.W = c->lm_head; g.N = c->V; g.K = d; g.x = c->X + (size_t)(n - 1) * d; g.norm_w = c->final_norm;
+  g.eps = c->cfg.rms_eps; g.logits = c->logits;
+  launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
+  DecState st0{};
+  st0.pos = T - 1; st0.next_pos = T; st0.token = (int32_t)ids[T - 1]; st0.draw = 0;
+  HIPCHK(c, hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(c->ev_c, s));
+  if (logits_out) HIPCHK(c, hipMemcpyAsync(logits_out, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c->ev_a, c->ev_c) == hipSuccess) c->stats.last_prefill_ms = ms;
+  if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.last_vit_ms = ms;
+  c->stats.prefill_tokens += (uint64_t)n;
+  c->cached_ids.assign(ids, ids + T);
+  c->cached_with_image = use_img;
+  c->host_next_pos = T;
+  c->have_logits = true;
+  // a new prefill starts a new generation: reset the draw counter of the sampler
+  return DTK_OK;
+}
+
+int dtk_set_sampling(dtk_ctx* c, const dtk_sampling* sp) {
+  if (!c || !sp) return fail(c, DTK_ERR_ARG, "dtk_set_sampling: null argument");
+  if (sp->n_bad < 0 || sp->n_bad > 8 || sp->n_begin_suppress < 0 || sp->n_begin_suppress > 8 ||
+      sp->n_always_suppress < 0 || sp->n_always_suppress > 8)
+    return fail(c, DTK_ERR_ARG, "at most 8 ids per suppression list");
+  if (sp->do_sample && !(sp->temperature > 0.f)) return fail(c, DTK_ERR_ARG, "temperature must be > 0");
+  if (sp->do_sample && !(sp->top_p > 0.f && sp->top_p <= 1.f)) return fail(c, DTK_ERR_ARG, "top_p must be in (0, 1]");
+  HIPCHK(c, hipSetDevice(c->device));
+  SamplingDev dv{};
+  dv.do_sample = sp->do_sample; dv.temperature = sp->temperature; dv.top_p = sp->top_p; dv.top_k = sp->top_k;
+  dv.seed = sp->seed;
+  dv.n_bad = sp->n_bad; dv.n_begin = sp->n_begin_suppress; dv.n_always = sp->n_always_suppress;
+  for (int i = 0; i < 8; ++i) {
+    dv.bad_ids[i] = sp->bad_ids[i]; dv.begin_ids[i] = sp->begin_suppress_ids[i]; dv.always_ids[i] = sp->always_suppress_ids[i];
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->sp, &dv, sizeof dv, hipMemcpyHostToDevice));
+  const uint32_t zero = 0;
+  HIPCHK(c, hipMemcpy(&c->st->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
+  c->sampling = *sp;
+  c->launched = c->waited = 0;
+  return DTK_OK;
+}
+
+int dtk_set_graph_mode(dtk_ctx* c, int enabled) {
+  if (!c) return DTK_ERR_ARG;
+  c->use_graph = enabled == 1;
+  c->probe = enabled == 2;   // 2: plain launches with HIP-event probe around the gate/up GEMV
+  return DTK_OK;
+}
+
+int dtk_decode_launch(dtk_ctx* c) {
+  if (!c) return DTK_ERR_ARG;
+  if (!c->have_logits) return fail(c, DTK_ERR_STATE, "dtk_decode before dtk_prefill");
+  if (c->launched - c->waited >= DTK_MAX_INFLIGHT) return fail(c, DTK_ERR_STATE, "too many decode steps in flight");
+  if (c->host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "context length %d reached max_positions", c->host_next_pos);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->use_graph) {
+    int rc = ensure_graph(c);
+    if (rc) return rc;
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+  } else {
+    decode_step_launches(c, c->probe != 0);
+    HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->step_done[c->launched % DTK_MAX_INFLIGHT], c->stream));
+  c->launched++;
+  c->host_next_pos++;
+  c->stats.decode_steps++;
+  c->cached_ids.push_back(-1);  // filled in by dtk_decode_wait
+  return DTK_OK;
+}
+
+int dtk_decode_wait(dtk_ctx* c, int64_t* token_out) {
+  if (!c || !token_out) return fail(c, DTK_ERR_ARG, "dtk_decode_wait: null argument");
+  if (c->waited >= c->launched) return fail(c, DTK_ERR_STATE, "no decode step in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t k = c->waited;
+  HIPCHK(c, hipEventSynchronize(c->step_done[k % DTK_MAX_INFLIGHT]));
+  // the ring slot of draw k is rewritten only by draw k + DTK_MAX_INFLIGHT, which cannot have
+  // been launched yet; later copies of the whole ring rewrite it with the same value
+  const int64_t tok = ((volatile int64_t*)c->tok_ring_host)[k % DTK_MAX_INFLIGHT];
+  *token_out = tok;
+  const size_t idx = c->cached_ids.size() - (size_t)(c->launched - k);
+  c->cached_ids[idx] = tok;
+  if (c->probe) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->probe_a, c->probe_b) == hipSuccess) {
+      c->stats.probe_kernel_ms_sum += ms;
+      c->stats.probe_kernel_launches++;
+    }
+  }
+  c->waited++;
+  return DTK_OK;
+}
+
+int dtk_decode(dtk_ctx* c, int64_t* token_out) {
+  int rc = dtk_decode_launch(c);
+  if (rc) return rc;
+  return dtk_decode_wait(c, token_out);
+}
+
+int dtk_get_logits(dtk_ctx* c, float* out) {
+  if (!c || !out) return fail(c, DTK_ERR_ARG, "dtk_get_logits: null argument");
+  if (!c->have_logits) return fail(c, DTK_ERR_STATE, "no logits yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost));
+  return DTK_OK;
+}
+
+int dtk_context_len(const dtk_ctx* c) { return c ? c->host_next_pos : -1; }
+
+int dtk_synchronize(dtk_ctx* c) {
+  if (!c) return DTK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+int dtk_get_stats(dtk_ctx* c, dtk_stats* out) {
+  if (!c || !out) return DTK_ERR_ARG;
+  *out = c->stats;
+  return DTK_OK;
+}
+
+// ------------------------------------------------------------------ op-level test entry points
+static int op_scratch(dtk_ctx* c, size_t bytes, size_t& off, void** p) {
+  off = align_up(off, 256);
+  if (off + bytes > c->scratch_bytes) return fail(c, DTK_ERR_ARG, "op scratch exhausted (%zu bytes)", off + bytes);
+  *p = c->scratch + off;
+  off += bytes;
+  return DTK_OK;
+}
+#define OPBUF(T, var, n)                                                    \
+  T* var = nullptr;                                                         \
+  { void* p_; int rc_ = op_scratch(c, (size_t)(n) * sizeof(T), off, &p_); if (rc_) return rc_; var = (T*)p_; }
+
+int dtk_op_gemm(dtk_ctx* c, const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* residual, int M, int N, int K, int flags, uint16_t* C) {
+  if (!c || !A || !W || !C || K % 8) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(bf16_t, dA, (size_t)M * K); OPBUF(bf16_t, dW, (size_t)N * K); OPBUF(bf16_t, dB, N);
+  OPBUF(bf16_t, dR, (size_t)M * N); OPBUF(bf16_t, dC, (size_t)M * N);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, s));
+  int gf = 0;
+  if ((flags & (DTK_EPI_BIAS | DTK_EPI_GELU)) && bias) { HIPCHK(c, hipMemcpyAsync(dB, bias, (size_t)N * 2, hipMemcpyHostToDevice, s)); gf |= GEMM_BIAS; }
+  if (flags & DTK_EPI_GELU) gf |= gelu_flag(c);
+  if ((flags & DTK_EPI_RESIDUAL) && residual) { HIPCHK(c, hipMemcpyAsync(dR, residual, (size_t)M * N * 2, hipMemcpyHostToDevice, s)); gf |= GEMM_RESIDUAL; }
+  GemmArgs g;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.residual = dR; g.ldr = N; g.C = dC; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.flags = gf;
+  if (flags & DTK_GEMM_NAIVE) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s);
+  HIPCHK(c, hipMemcpyAsync(C, dC, (size_t)M * N * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+int dtk_op_gemv(dtk_ctx* c, const uint16_t* W, const uint16_t* x, const uint16_t* norm_w, int N, int K, int mode, float eps, uint16_t* y) {
+  if (!c || !W || !x || !y || K % 8) return fail(c, DTK_ERR_ARG, "dtk_op_gemv: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(bf16_t, dW, (size_t)N * K); OPBUF(bf16_t, dx, K); OPBUF(bf16_t, dn, K); OPBUF(bf16_t, dy, N);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dx, x, (size_t)K * 2, hipMemcpyHostToDevice, s));
+  if (mode == 1) { if (!norm_w) return fail(c, DTK_ERR_ARG, "norm_w required"); HIPCHK(c, hipMemcpyAsync(dn, norm_w, (size_t)K * 2, hipMemcpyHostToDevice, s)); }
+  GemvArgs g{};
+  g.W = dW; g.N = N; g.K = K; g.x = dx; g.norm_w = dn; g.eps = eps; g.y = dy;
+  launch_gemv(mode == 1 ? PRO_RMSNORM : PRO_COPY, EPI_STORE, g, s);
+  HIPCHK(c, hipMemcpyAsync(y, dy, (size_t)N * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+int dtk_op_attention(dtk_ctx* c, const uint16_t* Q, const uint16_t* K, const uint16_t* V, int H, int Tq, int Tk, int hd, int causal, int q_offset, uint16_t* O) {
+  if (!c || !Q || !K || !V || !O) return fail(c, DTK_ERR_ARG, "dtk_op_attention: null argument");
+  if (hd != 72 && hd != 128 && hd != 64 && hd != 32) return fail(c, DTK_ERR_ARG, "unsupported head dim %d", hd);
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(bf16_t, dQ, (size_t)H * Tq * hd); OPBUF(bf16_t, dK, (size_t)H * Tk * hd);
+  OPBUF(bf16_t, dV, (size_t)H * Tk * hd); OPBUF(bf16_t, dO, (size_t)H * Tq * hd);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(dQ, Q, (size_t)H * Tq * hd * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dK, K, (size_t)H * Tk * hd * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dV, V, (size_t)H * Tk * hd * 2, hipMemcpyHostToDevice, s));
+  AttnArgs a;
+  a.Q = dQ; a.q_sh = (long)Tq * hd; a.q_st = hd;
+  a.K = dK; a.k_sh = (long)Tk * hd; a.k_st = hd;
+  a.V = dV; a.v_sh = (long)Tk * hd; a.v_st = hd;
+  a.O = dO; a.o_sh = (long)Tq * hd; a.o_st = hd;
+  a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.causal = causal; a.q_offset = q_offset;
+  a.scale = 1.0f / sqrtf((float)hd);
+  launch_attention(a, s);
+  HIPCHK(c, hipMemcpyAsync(O, dO, (size_t)H * Tq * hd * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+int dtk_op_layernorm(dtk_ctx* c, const uint16_t* X, const uint16_t* w, const uint16_t* b, int M, int D, float eps, uint16_t* Y) {
+  if (!c || !X || !w || !b || !Y || D % 8) return fail(c, DTK_ERR_ARG, "dtk_op_layernorm: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(bf16_t, dX, (size_t)M * D); OPBUF(bf16_t, dw, D); OPBUF(bf16_t, db, D); OPBUF(bf16_t, dY, (size_t)M * D);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(dX, X, (size_t)M * D * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dw, w, (size_t)D * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(db, b, (size_t)D * 2, hipMemcpyHostToDevice, s));
+  launch_layernorm_rows(dX, D, dw, db, dY, D, M, D, eps, s);
+  HIPCHK(c, hipMemcpyAsync(Y, dY, (size_t)M * D * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+int dtk_op_sample(dtk_ctx* c, const float* logits, int V, int step, int64_t* token_out, float* probs_out) {
+  if (!c || !logits || !token_out || V < 1 || V > c->V) return fail(c, DTK_ERR_ARG, "dtk_op_sample: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(float, dl, V); OPBUF(int64_t, dtok, 1);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(dl, logits, (size_t)V * 4, hipMemcpyHostToDevice, s));
+  SampleArgs sa;
+  sa.logits = dl; sa.V = V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed; sa.x = c->x; sa.d = c->d;
+  sa.tok_ring = dtok; sa.ring = 1; sa.probs_out = probs_out ? c->probs_dev : nullptr; sa.advance = 0;
+  sa.step_override = step;
+  launch_sample(sa, s);
+  HIPCHK(c, hipMemcpyAsync(token_out, dtok, 8, hipMemcpyDeviceToHost, s));
+  if (probs_out) HIPCHK(c, hipMemcpyAsync(probs_out, c->probs_dev, (size_t)V * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// kernels.h — host-callable launchers of the gfx950 kernels (one stream argument each).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- decode-step GEMV family
+enum { PRO_COPY = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4 };
+
+struct GemvArgs {
+  const bf16_t* W;       // [N][K] row-major, K contiguous
+  int N;                 // weight rows
+  int K;                 // input dim (multiple of 8)
+  // prologue inputs
+  const bf16_t* x;       // PRO_COPY / PRO_RMSNORM: input vector [K]
+  const bf16_t* norm_w;  // PRO_RMSNORM: weight [K]
+  float eps;
+  const float* pm;       // PRO_ATTN: split maxima   [H][S]
+  const float* pl;       //           split sums     [H][S]
+  const float* po;       //           split outputs  [H][S][128]
+  int S;
+  // epilogue outputs
+  bf16_t* y;             // EPI_STORE: out[N]; EPI_RESID: residual stream (in place); EPI_SWIGLU: act[ff]
+  float* logits;         // EPI_LOGITS
+  // EPI_QKV
+  bf16_t* q_out;         // [d]
+  bf16_t* kcache;        // this layer's K cache [H][T_max][128]
+  bf16_t* vcache;        // this layer's V cache
+  const bf16_t* rope_cos;  // [max_pos][64]
+  const bf16_t* rope_sin;
+  const DecState* st;
+  int T_max;
+  int d;                 // hidden (QKV: N == 3*d)
+  int ff;                // EPI_SWIGLU: N == 2*ff
+};
+
+void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s);
+
+struct AttnDecArgs {
+  const bf16_t* q;       // [H*128] (RoPE applied)
+  const bf16_t* kcache;  // [H][T_max][128]
+  const bf16_t* vcache;
+  const DecState* st;    // keys 0..st->pos
+  float* pm; float* pl; float* po;   // [H][S], [H][S], [H][S][128]
+  int H; int S; int T_max; float scale;
+};
+void launch_attn_decode(const AttnDecArgs& a, hipStream_t s);
+
+struct SampleArgs {
+  const float* logits; int V;
+  const SamplingDev* sp;
+  DecState* st;
+  const bf16_t* embed;   // [V][d]
+  bf16_t* x;             // residual stream [d] (embedding of the sampled token is written here)
+  int d;
+  int64_t* tok_ring;     // pinned/mapped or device ring [ring]
+  int ring;
+  float* probs_out;      // optional (tests): filtered, renormalised distribution [V]
+  int advance;           // 1: product path (advance DecState, gather embedding)
+  int step_override;     // >=0: use as draw index (tests)
+};
+void launch_sample(const SampleArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- batched (prefill / ViT) kernels
+#define GEMM_BIAS 1
+#define GEMM_GELU_ERF 2
+#define GEMM_GELU_TANH 4
+#define GEMM_RESIDUAL 8
+struct GemmArgs {
+  const bf16_t* A; int lda;      // [M][K]
+  const bf16_t* W; int ldw;      // [N][K]
+  const bf16_t* bias;            // [N] or null
+  const bf16_t* residual; int ldr; // [M][N] or null
+  bf16_t* C; int ldc;            // [M][N]
+  int M, N, K;                   // K multiple of 8
+  int flags;
+};
+void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
+void launch_gemm_naive(const GemmArgs& a, hipStream_t s);
+
+void launch_layernorm_rows(const bf16_t* X, int ldx, const bf16_t* w, const bf16_t* b,
+                           bf16_t* Y, int ldy, int M, int D, float eps, hipStream_t s);
+void launch_rmsnorm_rows(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy,
+                         int M, int D, float eps, hipStream_t s);
+void launch_silu_mul(const bf16_t* GU, int ff, bf16_t* ACT, int M, hipStream_t s);
+void launch_embed_gather(const int32_t* ids, const bf16_t* embed, bf16_t* X, int T, int d,
+                         hipStream_t s);
+void launch_copy_rows(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int D,
+                      hipStream_t s);
+void launch_im2col(const float* pixels, bf16_t* patches, int image, int patch, int ldp,
+                   hipStream_t s);
+// q,k RoPE + scatter of one prefill chunk: QKV [T][3d] -> Qh [H][T][128], caches at start_pos+t
+void launch_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
+                         const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos,
+                         int H, int T_max, hipStream_t s);
+
+struct AttnArgs {
+  const bf16_t* Q; long q_sh; long q_st;   // element strides: head, token
+  const bf16_t* K; long k_sh; long k_st;
+  const bf16_t* V; long v_sh; long v_st;
+  bf16_t* O; long o_sh; long o_st;
+  int H, Tq, Tk, hd;
+  int causal; int q_offset;   // query i sits at absolute position q_offset + i
+  float scale;
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+void launch_fill_synth(bf16_t* dst, int64_t n, uint64_t seed, uint32_t tag, float scale,
+                       float offset, hipStream_t s);
+void launch_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);

@@ -1,0 +1,591 @@
+// kernels_decode.hip — the tokens/sec kernel set: one decoded token = 5 kernels per
+// LLaMA layer + lm_head + sampler, all HBM-bound weight streaming (SURVEY §8 rows
+// a·D-step, a·H, a·S).  Numerics follow HF modeling_llama.py in bf16: every tensor HF
+// materialises is rounded to bf16 at the same point, dot products accumulate in fp32.
+//
+// GEMV family (k_gemv): y = W . x with W [N][K] bf16 streamed exactly once with
+// non-temporal 16-byte loads straight into VGPRs (no LDS round trip: each weight byte is
+// used by one wave once), x staged in LDS (bf16) by a fused prologue:
+//   PRO_RMSNORM  x = rmsnorm(residual)            (input_layernorm / post_attention / final norm)
+//   PRO_ATTN     x = combine of the split-K attention partials (flash-decode reduction)
+//   PRO_COPY     x = activation vector
+// and a fused epilogue on the wave-reduced sums:
+//   EPI_QKV      RoPE (rotate-half) on q,k pairs, q -> scratch, k,v -> KV cache at pos
+//   EPI_SWIGLU   silu(gate)*up
+//   EPI_RESID    residual += y
+//   EPI_LOGITS   fp32 logits
+// Each wave owns NR weight rows for the full K, lanes stride K in 16-byte chunks
+// (64 lanes x 16 B = 1 KiB per row per load instruction), two register stages so the
+// next stage's loads are in flight while the current one is consumed by v_dot2c_f32_bf16.
+#include "kernels.h"
+
+#define GEMV_THREADS 256
+#define GEMV_WAVES 4
+
+template <int NR, int U>
+__device__ __forceinline__ void gemv_load(u32x4 (&w)[NR][U], const u32x4* (&rows)[NR],
+                                          int g, int lane, int K8) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = lane + 64 * (g * U + u);
+    const bool ok = c < K8;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      w[r][u] = ok ? ld_nt(rows[r] + c) : z;
+    }
+  }
+}
+
+template <int NR, int U>
+__device__ __forceinline__ void gemv_fma(float (&acc)[NR], const u32x4 (&w)[NR][U],
+                                         const u32x4* xs, int g, int lane, int K8) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = lane + 64 * (g * U + u);
+    u32x4 xv = {0u, 0u, 0u, 0u};
+    if (c < K8) xv = xs[c];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xv, acc[r]);
+  }
+}
+
+// R = output units per wave; paired epilogues (QKV, SWIGLU) stream 2 rows per unit.
+template <int PRO, int EPI, int R, int U>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
+  constexpr bool PAIRED = (EPI == EPI_QKV) || (EPI == EPI_SWIGLU);
+  constexpr int NR = PAIRED ? 2 * R : R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);
+  const int K8 = a.K >> 3;
+  float* red = reinterpret_cast<float*>(smem + (size_t)K8 * 16);  // 8 floats of scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int gw = blockIdx.x * GEMV_WAVES + wave;  // global wave index
+
+  int n_units;
+  if (EPI == EPI_QKV) n_units = (a.N >> 1);
+  else if (EPI == EPI_SWIGLU) n_units = a.ff;
+  else n_units = a.N;
+  const int unit0 = gw * R;
+  const bool active = unit0 < n_units;  // wave-uniform
+
+  // ---- weight row pointers of this wave (clamped so inactive tails never fault)
+  const u32x4* rows[NR];
+  int rowidx[NR];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int u = unit0 + j;
+    if (u >= n_units) u = n_units - 1;
+    if (EPI == EPI_QKV) {
+      const int half = a.d >> 1;
+      const int sec = u / half;
+      const int pi = u - sec * half;
+      const int head = pi >> 6, i = pi & 63;
+      rowidx[2 * j] = sec * a.d + head * 128 + i;
+      rowidx[2 * j + 1] = rowidx[2 * j] + 64;
+    } else if (EPI == EPI_SWIGLU) {
+      rowidx[2 * j] = u;
+      rowidx[2 * j + 1] = a.ff + u;
+    } else {
+      rowidx[j] = u;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+    rows[r] = reinterpret_cast<const u32x4*>(a.W + (size_t)rowidx[r] * a.K);
+
+  const int iters = (K8 + 63) >> 6;
+  const int G = (iters + U - 1) / U;
+  u32x4 wa[NR][U], wb[NR][U];
+  float acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+
+  // first stage of weights goes in flight before the prologue touches x
+  gemv_load<NR, U>(wa, rows, 0, lane, K8);
+
+  // ---- prologue: build the bf16 input vector in LDS
+  if (PRO == PRO_COPY) {
+    const u32x4* x4 = reinterpret_cast<const u32x4*>(a.x);
+    for (int c = tid; c < K8; c += GEMV_THREADS) xs[c] = x4[c];
+  } else if (PRO == PRO_RMSNORM) {
+    const u32x4* x4 = reinterpret_cast<const u32x4*>(a.x);
+    const u32x4* w4 = reinterpret_cast<const u32x4*>(a.norm_w);
+    float ss = 0.f;
+    for (int c = tid; c < K8; c += GEMV_THREADS) {
+      const u32x4 v = x4[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = pk_lo(v[e]), hi = pk_hi(v[e]);
+        ss += lo * lo;
+        ss += hi * hi;
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = rsqrtf(tot / (float)a.K + a.eps);
+    for (int c = tid; c < K8; c += GEMV_THREADS) {
+      const u32x4 v = x4[c];
+      const u32x4 g = w4[c];
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // HF LlamaRMSNorm: weight * (x * rsqrt(var+eps)).to(bf16)
+        const float nlo = rbf(pk_lo(v[e]) * inv), nhi = rbf(pk_hi(v[e]) * inv);
+        o[e] = pack2(pk_lo(g[e]) * nlo, pk_hi(g[e]) * nhi);
+      }
+      xs[c] = o;
+    }
+  } else {  // PRO_ATTN: reduce the S split-K partials of every head (flash-decode combine)
+    const int S = a.S;
+    for (int c = tid; c < K8; c += GEMV_THREADS) {
+      const int head = c >> 4;       // 16 chunks of 8 dims per 128-dim head
+      const int d0 = (c & 15) * 8;
+      float M = -1e30f;
+      for (int s = 0; s < S; ++s) M = fmaxf(M, a.pm[head * S + s]);
+      float L = 0.f;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float w = __expf(a.pm[head * S + s] - M);
+        L += w * a.pl[head * S + s];
+        const f32x4* po4 =
+            reinterpret_cast<const f32x4*>(a.po + ((size_t)(head * S + s)) * 128 + d0);
+        const f32x4 p0 = po4[0], p1 = po4[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] += w * p0[e];
+          o[4 + e] += w * p1[e];
+        }
+      }
+      const float invL = 1.f / L;
+      u32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = pack2(o[2 * e] * invL, o[2 * e + 1] * invL);
+      xs[c] = ov;
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop: two register stages
+  for (int g = 0; g < G; g += 2) {
+    if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, K8);
+    gemv_fma<NR, U>(acc, wa, xs, g, lane, K8);
+    if (g + 1 < G) {
+      if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, K8);
+      gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, K8);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+
+  if (!active || lane != 0) return;
+
+  // ---- epilogue (one lane per wave; a handful of scalars)
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int u = unit0 + j;
+    if (u >= n_units) break;
+    if (EPI == EPI_STORE) {
+      a.y[u] = f2bf(acc[j]);
+    } else if (EPI == EPI_RESID) {
+      // HF: hidden = residual + proj(x); proj output is a bf16 tensor
+      a.y[u] = f2bf(bf2f(a.y[u]) + rbf(acc[j]));
+    } else if (EPI == EPI_LOGITS) {
+      a.logits[u] = rbf(acc[j]);  // lm_head output is bf16, then .float()
+    } else if (EPI == EPI_SWIGLU) {
+      const float gte = rbf(acc[2 * j]);
+      const float up = rbf(acc[2 * j + 1]);
+      const float sl = rbf(gte / (1.f + expf(-gte)));
+      a.y[u] = f2bf(sl * up);
+    } else if (EPI == EPI_QKV) {
+      const int half = a.d >> 1;
+      const int sec = u / half;
+      const int pi = u - sec * half;
+      const int head = pi >> 6, i = pi & 63;
+      const int pos = a.st->pos;
+      const float x1 = rbf(acc[2 * j]);      // dim i
+      const float x2 = rbf(acc[2 * j + 1]);  // dim i + 64
+      if (sec == 2) {
+        bf16_t* dst = a.vcache + ((size_t)head * a.T_max + pos) * 128;
+        dst[i] = f2bf(x1);
+        dst[i + 64] = f2bf(x2);
+      } else {
+        // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
+        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+        const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+        const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+        bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
+                                 : (a.kcache + ((size_t)head * a.T_max + pos) * 128);
+        dst[i] = f2bf(o1);
+        dst[i + 64] = f2bf(o2);
+      }
+    }
+  }
+}
+
+template <int PRO, int EPI, int R, int U>
+static void launch_gemv_t(const GemvArgs& a, hipStream_t s) {
+  int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
+  const int per_block = GEMV_WAVES * R;
+  const int grid = (n_units + per_block - 1) / per_block;
+  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
+  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U>), dim3(grid), dim3(GEMV_THREADS), lds, s, a);
+}
+
+void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s) {
+  // R/U: 4 streamed rows per wave, 2x2 16-byte loads per row in flight
+  if (pro == PRO_RMSNORM && epi == EPI_QKV) return launch_gemv_t<PRO_RMSNORM, EPI_QKV, 2, 2>(a, s);
+  if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_gemv_t<PRO_RMSNORM, EPI_SWIGLU, 2, 2>(a, s);
+  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_gemv_t<PRO_RMSNORM, EPI_LOGITS, 4, 2>(a, s);
+  if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_gemv_t<PRO_RMSNORM, EPI_STORE, 4, 2>(a, s);
+  if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_t<PRO_ATTN, EPI_RESID, 2, 4>(a, s);
+  if (pro == PRO_COPY && epi == EPI_RESID) return launch_gemv_t<PRO_COPY, EPI_RESID, 2, 4>(a, s);
+  if (pro == PRO_COPY && epi == EPI_STORE) return launch_gemv_t<PRO_COPY, EPI_STORE, 4, 2>(a, s);
+  // unreachable for the product path
+  launch_gemv_t<PRO_COPY, EPI_STORE, 4, 2>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Decode attention, split-K ("flash-decode"): grid (H, S).  Block (h, s) scans keys
+// [s*chunk, (s+1)*chunk) of head h: 16 lanes share one 256-byte K/V row (16 B each), so a
+// wave covers 4 rows per load instruction and a block 16 rows; every 16-lane group keeps
+// its own online-softmax stream (m, l, o[8 dims]); streams merge through shuffles + LDS.
+// Scores and probabilities stay fp32 (fused-attention semantics: one bf16 rounding of the
+// head output, done by the consumer's PRO_ATTN prologue).
+__global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
+  const int h = blockIdx.x, sp = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15;   // which 16-byte piece of the row
+  const int grp = lane >> 4;   // which of the wave's 4 rows
+  const int n = a.st->pos + 1; // keys 0..pos (this step's k/v were appended by the QKV kernel)
+  int chunk = (n + a.S - 1) / a.S;
+  chunk = (chunk + 15) & ~15;
+  const int j_begin = sp * chunk;
+  const int j_end = min(n, j_begin + chunk);
+
+  // q piece of this lane: dims sub*8 .. sub*8+7 as packed bf16
+  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + h * 128)[sub];
+  const bf16_t* kbase = a.kcache + (size_t)h * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)h * a.T_max * 128;
+
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+
+  for (int j0 = j_begin; j0 < j_end; j0 += 16) {
+    const int j = j0 + wave * 4 + grp;
+    const bool ok = j < j_end;
+    const int jj = ok ? j : j_begin;  // clamp: always a valid row
+    const u32x4 kv = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
+    const u32x4 vv = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
+    float s = dot8(qv, kv, 0.f);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s *= a.scale;
+    if (ok) {
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn);
+      const float p = __expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[e]);
+        o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[e]);
+      }
+      m = mn;
+    }
+  }
+  // merge the 4 row-groups of the wave (lanes with equal sub)
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64);
+    const float l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * c1 + o2 * c2;
+    }
+    m = mn;
+  }
+  // merge the 4 waves through LDS
+  __shared__ float sm_m[4][16], sm_l[4][16], sm_o[4][16][8];
+  if (grp == 0) {
+    sm_m[wave][sub] = m;
+    sm_l[wave][sub] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float M = sm_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_m[w][tid]);
+    float L = 0.f;
+    float oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = __expf(sm_m[w][tid] - M);
+      L += c * sm_l[w][tid];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+    }
+    const size_t slot = (size_t)h * a.S + sp;
+    float* dst = a.po + slot * 128 + tid * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = oo[e];
+    if (tid == 0) {
+      a.pm[slot] = M;
+      a.pl[slot] = L;
+    }
+  }
+}
+
+void launch_attn_decode(const AttnDecArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_attn_decode, dim3(a.H, a.S), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// Sampler: HF logits processors + argmax | multinomial for ONE sequence, one 1024-thread
+// block (the logits are 126-513 KB and L2 resident).  Mirrors generation/utils.py _sample:
+// NoBadWords(-inf) -> SuppressTokensAtBegin(-inf on the first generated token) ->
+// Temperature -> TopK -> TopP -> softmax -> draw.  Top-k/top-p thresholds come from a
+// 4x8-bit radix descent over order-preserving keys with fixed-point (integer) probability
+// mass, so the kept set and the inverse-CDF draw are deterministic and reproducible by
+// oracle/sampling.py.  The block then advances DecState and gathers the token embedding
+// into the residual stream (first op of the next forward).
+#define SAMPLE_THREADS 1024
+
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ bool is_banned(const SamplingDev* sp, int i, bool first) {
+  for (int k = 0; k < sp->n_bad; ++k)
+    if (sp->bad_ids[k] == i) return true;
+  for (int k = 0; k < sp->n_always; ++k)
+    if (sp->always_ids[k] == i) return true;
+  if (first)
+    for (int k = 0; k < sp->n_begin; ++k)
+      if (sp->begin_ids[k] == i) return true;
+  return false;
+}
+
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
+  __shared__ float s_f[16];
+  __shared__ int s_i[16];
+  __shared__ unsigned long long s_q[16];
+  __shared__ unsigned long long h_mass[256];
+  __shared__ unsigned int h_cnt[256];
+  __shared__ unsigned long long sc_above_q;
+  __shared__ unsigned int sc_above_c;
+  __shared__ unsigned int sc_prefix;
+  __shared__ unsigned int sc_bin;
+  __shared__ unsigned long long scan[SAMPLE_THREADS];
+  __shared__ int s_token;
+  __shared__ float s_max;
+  __shared__ unsigned long long s_total;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V;
+  const SamplingDev* sp = a.sp;
+  const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
+  const bool first = (draw == 0);
+  const bool sampling = sp->do_sample != 0;
+  const float invT = sampling ? 1.f / sp->temperature : 1.f;
+
+  // ---- pass 1: masked (scaled) max and first argmax
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < V; i += SAMPLE_THREADS) {
+    float z = a.logits[i] * invT;
+    if (is_banned(sp, i, first)) z = -INFINITY;
+    if (z > best || (z == best && i < besti)) { best = z; besti = i; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(besti, off, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) { s_f[wave] = best; s_i[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    float b = s_f[0]; int bi = s_i[0];
+    for (int w = 1; w < 16; ++w)
+      if (s_f[w] > b || (s_f[w] == b && s_i[w] < bi)) { b = s_f[w]; bi = s_i[w]; }
+    s_max = b; s_token = bi;
+  }
+  __syncthreads();
+  const float zmax = s_max;
+
+  if (sampling) {
+    // fixed-point mass q_i = floor(exp(z_i - zmax) * 2^32)  (exact integer sums)
+    auto mass = [&](int i, float& z) -> unsigned long long {
+      z = a.logits[i] * invT;
+      if (is_banned(sp, i, first)) z = -INFINITY;
+      const float e = expf(z - zmax);
+      return (unsigned long long)((double)e * 4294967296.0);
+    };
+    // ---- radix descent for the keep-threshold key.  Top-k then top-p, as HF orders the
+    // warpers: top-k keeps keys >= (k-th largest); top-p then works on the softmax of the
+    // survivors: keep token iff the mass strictly above it is < top_p * total.
+    uint32_t thr_k = 0;  // keep keys >= thr_k
+    if (sp->top_k > 0 && sp->top_k < V) {
+      uint32_t prefix = 0; unsigned int above = 0;
+      for (int level = 3; level >= 0; --level) {
+        const int shift = level * 8;
+        for (int b = tid; b < 256; b += SAMPLE_THREADS) h_cnt[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += SAMPLE_THREADS) {
+          float z; (void)mass(i, z);
+          const uint32_t key = fkey(z);
+          const bool match = (level == 3) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+          if (match) atomicAdd(&h_cnt[(key >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned int ab = above; int bsel = 0;
+          for (int b = 255; b >= 0; --b) {
+            if (h_cnt[b] == 0) continue;
+            if (ab + h_cnt[b] >= (unsigned)sp->top_k) { bsel = b; break; }
+            ab += h_cnt[b];
+          }
+          sc_above_c = ab; sc_bin = bsel;
+        }
+        __syncthreads();
+        above = sc_above_c;
+        prefix |= (sc_bin << shift);
+        __syncthreads();
+      }
+      thr_k = prefix;
+    }
+    // total mass of top-k survivors
+    unsigned long long loc = 0;
+    for (int i = tid; i < V; i += SAMPLE_THREADS) {
+      float z; const unsigned long long q = mass(i, z);
+      if (fkey(z) >= thr_k) loc += q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loc += __shfl_xor(loc, off, 64);
+    if (lane == 0) s_q[wave] = loc;
+    __syncthreads();
+    if (tid == 0) { unsigned long long t = 0; for (int w = 0; w < 16; ++w) t += s_q[w]; s_total = t; }
+    __syncthreads();
+    const unsigned long long total_k = s_total;
+
+    uint32_t thr = thr_k;
+    if (sp->top_p < 1.0f) {
+      const unsigned long long pq = (unsigned long long)((double)sp->top_p * (double)total_k);
+      uint32_t prefix = 0; unsigned long long above = 0;
+      for (int level = 3; level >= 0; --level) {
+        const int shift = level * 8;
+        for (int b = tid; b < 256; b += SAMPLE_THREADS) { h_mass[b] = 0; h_cnt[b] = 0; }
+        __syncthreads();
+        for (int i = tid; i < V; i += SAMPLE_THREADS) {
+          float z; const unsigned long long q = mass(i, z);
+          const uint32_t key = fkey(z);
+          if (key < thr_k) continue;
+          const bool match = (level == 3) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+          if (match) {
+            atomicAdd(&h_mass[(key >> shift) & 255], q);
+            atomicAdd(&h_cnt[(key >> shift) & 255], 1u);
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          // lowest non-empty bin whose strictly-above mass is still < pq
+          unsigned long long ab = above; int bsel = -1; unsigned long long ab_sel = above;
+          for (int b = 255; b >= 0; --b) {
+            if (h_cnt[b] == 0) continue;
+            if (ab < pq || bsel < 0) { bsel = b; ab_sel = ab; } else break;
+            ab += h_mass[b];
+          }
+          sc_above_q = ab_sel; sc_bin = (unsigned)bsel;
+        }
+        __syncthreads();
+        above = sc_above_q;
+        prefix |= (sc_bin << shift);
+        __syncthreads();
+      }
+      thr = prefix > thr_k ? prefix : thr_k;
+    }
+    // ---- kept mass + inverse-CDF draw in index order
+    const int per = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;
+    const int i0 = tid * per, i1 = min(V, i0 + per);
+    unsigned long long mine = 0;
+    for (int i = i0; i < i1; ++i) {
+      float z; const unsigned long long q = mass(i, z);
+      if (fkey(z) >= thr) mine += q;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < SAMPLE_THREADS; off <<= 1) {
+      unsigned long long v = 0;
+      if (tid >= off) v = scan[tid - off];
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const unsigned long long kept = scan[SAMPLE_THREADS - 1];
+    const uint64_t r = splitmix64(sp->seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(draw + 1))) >> 32;
+    const unsigned long long target = __umul64hi(kept, r << 32);  // floor(kept * r / 2^32)
+    const unsigned long long excl = scan[tid] - mine;
+    if (mine > 0 && target >= excl && target < excl + mine) {
+      unsigned long long run = excl;
+      for (int i = i0; i < i1; ++i) {
+        float z; const unsigned long long q = mass(i, z);
+        if (fkey(z) >= thr) {
+          if (target < run + q) { s_token = i; break; }
+          run += q;
+        }
+      }
+    }
+    if (a.probs_out) {
+      for (int i = tid; i < V; i += SAMPLE_THREADS) {
+        float z; const unsigned long long q = mass(i, z);
+        a.probs_out[i] = (fkey(z) >= thr) ? (float)((double)q / (double)kept) : 0.f;
+      }
+    }
+    __syncthreads();
+  } else if (a.probs_out) {
+    for (int i = tid; i < V; i += SAMPLE_THREADS) a.probs_out[i] = (i == s_token) ? 1.f : 0.f;
+  }
+
+  const int tok = s_token;
+  if (tid == 0) {
+    a.tok_ring[draw % (uint32_t)a.ring] = (int64_t)tok;
+    if (a.advance) {
+      a.st->token = tok;
+      a.st->pos = a.st->next_pos;
+      a.st->next_pos = a.st->next_pos + 1;
+      a.st->draw = draw + 1;
+    }
+  }
+  if (a.advance) {
+    // embedding gather: first op of the forward that follows
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)tok * a.d);
+    u32x4* dst = reinterpret_cast<u32x4*>(a.x);
+    for (int c = tid; c < (a.d >> 3); c += SAMPLE_THREADS) dst[c] = src[c];
+  }
+}
+
+void launch_sample(const SampleArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sample, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
+}

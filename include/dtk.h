@@ -1,0 +1,196 @@
+/*
+ * dtk.h — C ABI of libdtk_hip.so, the MI355X (gfx950) image->TikZ decoder behind
+ * DeTikZify's Python inference API.
+ *
+ * The reference (potamides/DeTikZify) has NO native/FFI seam: its boundary is the
+ * duck-typed (model, processor) pair returned by detikzify.model.load
+ * (reference detikzify/model/__init__.py:28-61) and consumed by
+ * DetikzifyGenerator.generate (detikzify/infer/generate.py:209-227) and
+ * ImageSim.from_detikzify (detikzify/evaluate/imagesim.py:61-89).  This header is
+ * the C ABI that sits *underneath* that Python surface: each entry point names the
+ * reference call it replaces.  Plain C, opaque handle, int status (0 = ok,
+ * negative = error; text via dtk_last_error), caller-owned host buffers,
+ * library-owned device buffers, one HIP stream per context.  A context is not
+ * thread-safe, but may be driven from any one thread at a time (the reference
+ * calls model.generate from a ThreadPool(1) worker, generate.py:248-258);
+ * contexts are independent -> one context per GPU / rank.
+ */
+#ifndef DTK_H
+#define DTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTK_ABI_VERSION 1
+
+typedef struct dtk_ctx dtk_ctx;
+
+enum { DTK_F32 = 0, DTK_BF16 = 1, DTK_F16 = 2 };
+
+enum {
+  DTK_OK = 0,
+  DTK_ERR_ARG = -1,     /* bad argument / shape / unknown tensor name          */
+  DTK_ERR_HIP = -2,     /* a HIP runtime call failed                            */
+  DTK_ERR_STATE = -3,   /* call sequence violated (e.g. decode before prefill)  */
+  DTK_ERR_RANGE = -4    /* context length would exceed max_positions            */
+};
+
+/* Architecture of one checkpoint.  Decoder fields are HF LlamaConfig fields
+ * (read from the checkpoint's config.json, never hard-coded; reference
+ * detikzify/model/v1/configuration_detikzify.py:3-13).  Vision fields describe the
+ * timm ViT created at detikzify/model/v1/modeling_detikzify.py:94. */
+typedef struct dtk_config {
+  /* LLaMA decoder */
+  int32_t hidden;          /* d                                   */
+  int32_t layers;          /* L                                   */
+  int32_t heads;           /* H (MHA: kv_heads == heads)          */
+  int32_t head_dim;        /* hd (must be 128)                    */
+  int32_t ffn;             /* intermediate_size                   */
+  int32_t vocab;           /* V                                   */
+  int32_t max_positions;   /* KV capacity in tokens (<= 2048 for v1, generate.py:383) */
+  float   rms_eps;
+  float   rope_theta;
+  float   rope_factor;     /* linear RoPE scaling factor (1 = none) */
+  /* vision tower (timm vit_so400m_patch14_siglip_384 family) */
+  int32_t vit_dim;         /* D (1152)                            */
+  int32_t vit_depth;       /* 27                                  */
+  int32_t vit_heads;       /* 16 -> head dim 72                   */
+  int32_t vit_mlp;         /* 4304                                */
+  int32_t vit_patch;       /* 14                                  */
+  int32_t vit_image;       /* 384                                 */
+  int32_t vit_feature_layer; /* block index whose output feeds the LM (modeling_detikzify.py:104) */
+  float   vit_ln_eps;      /* 1e-6                                */
+  int32_t vit_gelu_tanh;   /* 0 = erf GELU (timm default), 1 = tanh approximation */
+  /* glue */
+  int32_t concat_patches;  /* 3  (modeling_detikzify.py:101)       */
+  int32_t image_token_id;  /* == BOS for v1 (v1/__init__.py:49)    */
+  int32_t attn_splits;     /* split-K factor of decode attention; 0 = default */
+  int32_t reserved[7];
+} dtk_config;
+
+/* Per-generation sampling state: the HF logits processors + sampler that
+ * DetikzifyGenerator.generate configures (generate.py:218-227; HF
+ * generation/utils.py _sample, logits_process.py:300-303,528-540,1395,1860-1866). */
+typedef struct dtk_sampling {
+  int32_t do_sample;       /* 0 = greedy argmax, 1 = multinomial                     */
+  float   temperature;     /* used when do_sample                                    */
+  float   top_p;           /* nucleus; 1.0 disables                                  */
+  int32_t top_k;           /* 0 disables                                             */
+  uint64_t seed;           /* counter-based RNG key; draw n uses counter n           */
+  int32_t n_bad;           /* banned single-token ids (bad_words_ids=[[id]])         */
+  int32_t bad_ids[8];
+  int32_t n_begin_suppress;/* ids suppressed only for the first generated token      */
+  int32_t begin_suppress_ids[8];
+  int32_t n_always_suppress; /* extra ids banned at every step (fixed-work benches)  */
+  int32_t always_suppress_ids[8];
+} dtk_sampling;
+
+typedef struct dtk_stats {
+  uint64_t weight_bytes_per_token;  /* W: decoder layers + final norm + lm_head       */
+  uint64_t kv_bytes_per_ctx_token;  /* K: 2*L*d*sizeof(bf16)                          */
+  uint64_t decode_steps;            /* decode-step launches since create              */
+  uint64_t prefill_tokens;          /* tokens pushed through the batched prefill      */
+  uint64_t vit_images;              /* images encoded                                 */
+  double   last_prefill_ms;         /* device time of last dtk_prefill (HIP events)   */
+  double   last_vit_ms;             /* ViT part of it                                 */
+  double   probe_kernel_ms_sum;     /* in-graph event probe around the gate/up GEMV of the middle layer */
+  uint64_t probe_kernel_launches;
+  uint64_t probe_kernel_bytes;      /* algorithmic bytes of one such launch           */
+} dtk_stats;
+
+int  dtk_abi_version(void);
+/* last error of a context; ctx may be NULL for the error of a failed dtk_create */
+const char* dtk_last_error(const dtk_ctx* ctx);
+
+/* Lifetime.  Allocates every weight, activation and KV buffer up front
+ * (replaces DetikzifyForCausalLM.from_pretrained + initialize_vision_modules,
+ * reference v1/__init__.py:35-54). */
+int  dtk_create(const dtk_config* cfg, int device, dtk_ctx** out);
+void dtk_destroy(dtk_ctx* ctx);
+
+/* Weights.  Names are the checkpoint's state-dict keys: HF Llama keys
+ * ("model.layers.3.self_attn.q_proj.weight", "model.embed_tokens.weight",
+ * "model.norm.weight", "lm_head.weight", "model.mm_projector.weight|bias") and
+ * timm ViT keys prefixed "vision_model." ("vision_model.blocks.0.attn.qkv.weight",
+ * "vision_model.attn_pool.latent", ...).  Host data may be f32/bf16/f16; storage is bf16. */
+int  dtk_load_tensor(dtk_ctx* ctx, const char* name, const void* host, int dtype,
+                     const int64_t* shape, int ndim);
+/* copy a stored tensor (bf16, same logical shape as the checkpoint tensor) back to the host */
+int  dtk_read_tensor(dtk_ctx* ctx, const char* name, void* host_out_bf16, int64_t n_elems);
+/* deterministic synthetic weights generated on the device (no real checkpoints
+ * exist offline); bit-identical to oracle/synth.py for the same seed. */
+int  dtk_fill_synthetic(dtk_ctx* ctx, uint64_t seed);
+/* number of tensor names / i-th name / element count (for loaders and tests) */
+int  dtk_num_tensors(const dtk_ctx* ctx);
+const char* dtk_tensor_name(const dtk_ctx* ctx, int i);
+int64_t dtk_tensor_numel(const dtk_ctx* ctx, const char* name);
+
+/* Vision tower: replaces DetikzifyVisionModel.forward / get_intermediate_layers
+ * (reference v1/modeling_detikzify.py:63-72).  pixels: B x 3 x S x S fp32 NCHW
+ * (host).  feats_out: B x N x D bf16 (post final-LayerNorm features of the
+ * configured feature layer), pooled_out: B x D bf16 (MAP head), either may be NULL. */
+int  dtk_vit_encode(dtk_ctx* ctx, const float* pixels, int batch,
+                    void* feats_out_bf16, void* pooled_out_bf16);
+
+/* Prefill: replaces DetikzifyForCausalLM.forward with input_ids.shape[1] != 1
+ * (reference v1/modeling_detikzify.py:144-200,218-257).  ids: T int64 (host);
+ * pixels (1x3xSxS fp32 host) may be NULL when the ids contain no image tokens or
+ * when image_key matches the previously encoded image.  flags: DTK_PREFILL_*.
+ * logits_last_out (V fp32, host) may be NULL.  Afterwards the context holds KV
+ * for T positions and the logits of position T-1. */
+#define DTK_PREFILL_REUSE_PREFIX 1   /* keep KV of the longest common prefix with the cached ids */
+#define DTK_PREFILL_REUSE_IMAGE  2   /* skip the ViT when image_key equals the cached key        */
+int  dtk_prefill(dtk_ctx* ctx, const int64_t* ids, int T, const float* pixels,
+                 uint64_t image_key, int flags, float* logits_last_out);
+
+/* Sampling configuration for the following decode calls (resets the draw counter). */
+int  dtk_set_sampling(dtk_ctx* ctx, const dtk_sampling* s);
+
+/* Decode: one call = one iteration of HF GenerationMixin._sample (logits
+ * processors -> argmax|multinomial on the pending logits -> append -> forward of
+ * the new token), hipGraph-replayed.  dtk_decode_launch enqueues a step without
+ * waiting; dtk_decode_wait returns the oldest un-read token (at most
+ * DTK_MAX_INFLIGHT steps may be pending).  dtk_decode = launch + wait. */
+#define DTK_MAX_INFLIGHT 4
+int  dtk_decode_launch(dtk_ctx* ctx);
+int  dtk_decode_wait(dtk_ctx* ctx, int64_t* token_out);
+int  dtk_decode(dtk_ctx* ctx, int64_t* token_out);
+/* logits (V fp32) the next sampling step will consume, copied to the host */
+int  dtk_get_logits(dtk_ctx* ctx, float* logits_out);
+/* current context length (tokens with KV) */
+int  dtk_context_len(const dtk_ctx* ctx);
+/* 1 = replay the decode step as a hipGraph (default), 0 = plain launches */
+int  dtk_set_graph_mode(dtk_ctx* ctx, int enabled);
+int  dtk_synchronize(dtk_ctx* ctx);
+int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
+
+/* Op-level entry points used by the parity tests (tests/): run ONE kernel of the
+ * hot path on host buffers.  All matrices row-major; bf16 as uint16.  They exist so a
+ * failing kernel can be isolated on the GPU box; the product path never calls them. */
+#define DTK_EPI_NONE 0
+#define DTK_EPI_BIAS 1        /* + bias[n]                         */
+#define DTK_EPI_GELU 2        /* gelu(acc + bias)                   */
+#define DTK_EPI_RESIDUAL 4    /* bf16(acc + bias) + residual[m,n]   */
+#define DTK_GEMM_NAIVE 256    /* use the non-MFMA reference kernel  */
+/* C[M,N] = A[M,K] . W[N,K]^T (+epilogue) */
+int  dtk_op_gemm(dtk_ctx* ctx, const uint16_t* A, const uint16_t* W, const uint16_t* bias,
+                 const uint16_t* residual, int M, int N, int K, int flags, uint16_t* C);
+/* mode 0: y = W.x ; mode 1: y = W.rmsnorm(x, norm_w) ; fp32 result of the bf16-rounded output */
+int  dtk_op_gemv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* x, const uint16_t* norm_w,
+                 int N, int K, int mode, float eps, uint16_t* y);
+/* softmax(Q K^T * scale [+ causal mask with q_offset]) V, heads-major [H][T][hd] bf16 */
+int  dtk_op_attention(dtk_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* V,
+                      int H, int Tq, int Tk, int hd, int causal, int q_offset, uint16_t* O);
+int  dtk_op_layernorm(dtk_ctx* ctx, const uint16_t* X, const uint16_t* w, const uint16_t* b,
+                      int M, int D, float eps, uint16_t* Y);
+/* run the sampler on host logits with the context's sampling config; step = draw index */
+int  dtk_op_sample(dtk_ctx* ctx, const float* logits, int V, int step, int64_t* token_out,
+                   float* filtered_probs_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTK_H */
