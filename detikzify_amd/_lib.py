@@ -1,0 +1,121 @@
+"""ctypes binding of include/dtk.h.  No CPU fallback: a missing library is a hard error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
+
+DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
+DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
+DTK_MAX_INFLIGHT = 4
+DTK_EPI_BIAS, DTK_EPI_GELU, DTK_EPI_RESIDUAL, DTK_GEMM_NAIVE = 1, 2, 4, 256
+
+
+class DtkConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("ffn", C.c_int32), ("vocab", C.c_int32), ("max_positions", C.c_int32),
+        ("rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_factor", C.c_float),
+        ("vit_dim", C.c_int32), ("vit_depth", C.c_int32), ("vit_heads", C.c_int32),
+        ("vit_mlp", C.c_int32), ("vit_patch", C.c_int32), ("vit_image", C.c_int32),
+        ("vit_feature_layer", C.c_int32), ("vit_ln_eps", C.c_float), ("vit_gelu_tanh", C.c_int32),
+        ("concat_patches", C.c_int32), ("image_token_id", C.c_int32), ("attn_splits", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class DtkSampling(C.Structure):
+    _fields_ = [
+        ("do_sample", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
+        ("top_k", C.c_int32), ("seed", C.c_uint64),
+        ("n_bad", C.c_int32), ("bad_ids", C.c_int32 * 8),
+        ("n_begin_suppress", C.c_int32), ("begin_suppress_ids", C.c_int32 * 8),
+        ("n_always_suppress", C.c_int32), ("always_suppress_ids", C.c_int32 * 8),
+    ]
+
+
+class DtkStats(C.Structure):
+    _fields_ = [
+        ("weight_bytes_per_token", C.c_uint64), ("kv_bytes_per_ctx_token", C.c_uint64),
+        ("decode_steps", C.c_uint64), ("prefill_tokens", C.c_uint64), ("vit_images", C.c_uint64),
+        ("last_prefill_ms", C.c_double), ("last_vit_ms", C.c_double),
+        ("probe_kernel_ms_sum", C.c_double), ("probe_kernel_launches", C.c_uint64),
+        ("probe_kernel_bytes", C.c_uint64),
+    ]
+
+
+# every symbol include/dtk.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "dtk_abi_version": (C.c_int, []),
+    "dtk_last_error": (C.c_char_p, [_P]),
+    "dtk_create": (C.c_int, [C.POINTER(DtkConfig), C.c_int, C.POINTER(_P)]),
+    "dtk_destroy": (None, [_P]),
+    "dtk_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "dtk_read_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "dtk_fill_synthetic": (C.c_int, [_P, C.c_uint64]),
+    "dtk_num_tensors": (C.c_int, [_P]),
+    "dtk_tensor_name": (C.c_char_p, [_P, C.c_int]),
+    "dtk_tensor_numel": (C.c_int64, [_P, C.c_char_p]),
+    "dtk_vit_encode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "dtk_prefill": (C.c_int, [_P, _P, C.c_int, _P, C.c_uint64, C.c_int, _P]),
+    "dtk_set_sampling": (C.c_int, [_P, C.POINTER(DtkSampling)]),
+    "dtk_decode_launch": (C.c_int, [_P]),
+    "dtk_decode_wait": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "dtk_decode": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "dtk_get_logits": (C.c_int, [_P, _P]),
+    "dtk_context_len": (C.c_int, [_P]),
+    "dtk_set_graph_mode": (C.c_int, [_P, C.c_int]),
+    "dtk_synchronize": (C.c_int, [_P]),
+    "dtk_get_stats": (C.c_int, [_P, C.POINTER(DtkStats)]),
+    "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "dtk_op_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "dtk_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "dtk_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    "dtk_op_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int64), _P]),
+}
+
+_lib = None
+
+
+class DtkError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load libdtk_hip.so once.  If torch is importable it is imported FIRST so that exactly one
+    HIP runtime (torch's bundled libamdhip64.so.7) is in the process — the library's NEEDED
+    libamdhip64.so.7 then resolves to the already-loaded copy and torch.distributed (RCCL) can
+    share the process.  DTK_HIP_RUNTIME=system skips that and uses /opt/rocm via RUNPATH."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DtkError(
+            f"{LIB_PATH} is missing: build it with ./build.sh (hipcc --offload-arch=gfx950). "
+            "detikzify_amd has no CPU fallback.")
+    if os.environ.get("DTK_HIP_RUNTIME", "torch") != "system":
+        try:
+            import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
+        except Exception:  # pragma: no cover - torch-less deployments use the system runtime
+            pass
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, loud by design
+        fn.restype, fn.argtypes = res, args
+    if lib.dtk_abi_version() != 1:
+        raise DtkError(f"ABI version {lib.dtk_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc: int, what: str):
+    if rc != 0:
+        msg = lib.dtk_last_error(ctx)
+        text = msg.decode(errors="replace") if msg else ""
+        if rc == -1 and ("image patch tokens" in text):
+            raise ValueError(text)          # same exception type/message as the reference
+        raise DtkError(f"{what} failed ({rc}): {text}")

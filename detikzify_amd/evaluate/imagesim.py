@@ -1,0 +1,88 @@
+"""
+SelfSim — the MCTS reward (row a·W): cosine similarity of the model's own vision-tower pooled
+outputs for (rendered image, input image).  Same behaviour as reference
+detikzify/evaluate/imagesim.py:21-147 for the v1 models, whose config reports pooling_mode "cos"
+(v1/configuration_detikzify.py:11-13): each image -> load -> expand(trim) -> image processor ->
+vision_model(pixel_values).pooler_output -> cosine in float64 (:91-125).  `cos_avg` (mean of the
+patch features) is kept; `emd` (v2 models, POT solver) is out of scope for this build.
+torchmetrics is absent here: update/compute/reset are restated with plain attributes (the
+reference disables metric state sync on this path anyway, infer/generate.py:373).
+
+The features of the *reference* image are identical for every rollout; `cache_reference=True`
+ memoises them by image bytes — output-identical, one ViT pass per rollout saved.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Literal, Optional, Union
+
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+from ..util import expand, load, unwrap_processor
+
+
+class ImageSim:
+    higher_is_better = True
+
+    def __init__(self, model=None, processor=None, mode: Literal["cos", "cos_avg"] = "cos",
+                 preprocess: bool = True, cache_reference: bool = False, **_):
+        if mode not in ("cos", "cos_avg"):
+            raise NotImplementedError(f"mode {mode!r}: only the v1 'cos' / 'cos_avg' poolings are built")
+        self.model, self.processor = model, processor
+        self.mode, self.preprocess = mode, preprocess
+        self.cache_reference = cache_reference
+        self._ref_cache: Dict[bytes, torch.Tensor] = {}
+        self.reset()
+
+    def __str__(self):
+        return self.__class__.__name__ + f" ({self.mode.upper().replace('_', '-')})"
+
+    @classmethod
+    def from_detikzify(cls, model, processor, mode=None, *args, **kwargs):
+        mode = getattr(model.config, "pooling_mode", "emd") if mode is None else mode
+        kwargs.pop("sync_on_compute", None)
+        return cls(model=model.model.vision_model, processor=unwrap_processor(processor).image_processor,
+                   mode=mode, *args, **kwargs)
+
+    # ---- features --------------------------------------------------------------------------------
+    def get_vision_features(self, image: Union[Image.Image, str]) -> torch.Tensor:
+        image = load(image)
+        if self.preprocess:
+            image = expand(image, max(image.size), do_trim=True)
+        with torch.inference_mode():
+            enc = self.processor(images=image, return_tensors="pt")
+            out = self.model(**enc)
+            if self.mode == "cos":
+                return out.pooler_output.squeeze()
+            return out.last_hidden_state.squeeze().mean(dim=0)
+
+    def _reference_features(self, image) -> torch.Tensor:
+        if not self.cache_reference or not isinstance(image, Image.Image):
+            return self.get_vision_features(image)
+        key = image.tobytes()
+        if key not in self._ref_cache:
+            self._ref_cache[key] = self.get_vision_features(image)
+        return self._ref_cache[key]
+
+    def get_similarity(self, img1=None, img2=None, **_) -> float:
+        f1 = self.get_vision_features(img1)
+        f2 = self._reference_features(img2)
+        return F.cosine_similarity(f1.double(), f2.double(), dim=0).item()
+
+    # ---- metric protocol (update / compute / reset) ---------------------------------------------
+    def update(self, img1=None, img2=None, text1=None, text2=None):
+        if text1 is not None or text2 is not None:
+            pass  # text conditioning needs the TikZero adapter (out of scope)
+        a = img1 if isinstance(img1, list) else [img1]
+        b = img2 if isinstance(img2, list) else [img2]
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            self.score += self.get_similarity(x, y)
+            self.n_samples += 1
+
+    def compute(self) -> float:
+        return self.score / self.n_samples
+
+    def reset(self):
+        self.score, self.n_samples = 0.0, 0

@@ -1,0 +1,365 @@
+"""
+Inference API + MCTS glue (rows a·G, a·R, a·M): DetikzifyGenerator / DetikzifyPipeline with the
+reference's semantics (detikzify/infer/generate.py:35-467), `TikzGenerator` as the alias the
+north-star names.  What each piece preserves:
+
+  NodeState / WideNode      :35-82    a tree node = token prefix + #lines; every real node owns a
+                                      "widen" child whose expansion re-rolls from the same prefix
+  DynMinMaxNorm             :85-142   scores are min-max normalised LAZILY against all scores seen
+  generate()                :209-227  early-out on EOS / max_length, re-run the processor, call
+                                      model.generate with bad_words_ids=[[image_token]] and
+                                      begin_suppress_tokens=[eos]
+  newlineinfo               :229-244  vocabulary scan: which tokens contain newlines
+  rollout()                 :246-282  generate in a ThreadPool(1) worker, split the token stream
+                                      at newline tokens into (prefix, #lines) states on the caller
+  child_finder()/merge()    :305-353  sqrt(n) node insertion, error-line pruning, failed-tail memo,
+                                      (normalised) back-propagation
+  DetikzifyPipeline         :356-467  sample() / simulate() front-end
+The model object is detikzify_amd.model.DetikzifyForCausalLM (HIP); nothing here touches the GPU
+directly.  `document_class` selects the reward back-end (TikzDocument = latexmk, unchanged).
+"""
+from __future__ import annotations
+
+import re
+from collections import deque
+from dataclasses import dataclass
+from functools import cached_property
+from math import sqrt
+from multiprocessing.pool import ThreadPool
+from time import time
+from types import SimpleNamespace
+from typing import Any, Dict, Generator, List, Literal, Optional, Set, Tuple, Type, Union
+
+import torch
+from PIL import Image
+
+from ..evaluate.imagesim import ImageSim
+from ..mcts import MonteCarlo, Node
+from ..util import ExplicitAbort, StreamerList, TokenStreamer, cache_cast, expand, load
+from ..util import unwrap_processor as unwrap
+from .tikz import TikzDocument
+
+Numeric = Union[int, float]
+
+
+@dataclass(frozen=True)
+class NodeState:
+    token_ids: torch.Tensor
+    num_lines: int = 0
+
+    def __eq__(self, other: Any) -> bool:
+        try:
+            return self.token_ids.equal(other.token_ids)
+        except (AttributeError, TypeError):
+            return False
+
+    def __hash__(self):
+        return hash(tuple(self.token_ids.tolist()))
+
+
+class WideNode(Node):
+    state: NodeState
+
+    def __init__(self, *args, exploration: float = 0.6, is_widen_node: bool = False, **kwargs):
+        super().__init__(NodeState(*args, **kwargs))
+        self.discovery_factor = exploration
+        self.is_widen_node = is_widen_node
+        self.update_policy_value(1.0)
+        if not is_widen_node:  # the sibling that widens the tree at this prefix
+            self.add_child(WideNode(*args, exploration=exploration, is_widen_node=True, **kwargs))
+
+    def add_child(self, child: "WideNode"):
+        # only real children make a node "expanded" (selectable for descent)
+        self.expanded = self.expanded or not child.is_widen_node
+        super().add_child(child)
+
+    @property
+    def depth(self) -> int:
+        d, cur = 0, self
+        while cur.parent is not None:
+            d, cur = d + 1, cur.parent
+        return d
+
+    @property
+    def token_ids(self) -> torch.Tensor:
+        return self.state.token_ids
+
+    @property
+    def num_lines(self) -> int:
+        return self.state.num_lines
+
+
+class DynMinMaxNorm:
+    """normalize(score) returns a lazy value whose `.score` is (s-min)/(max-min) over ALL scores
+    registered so far (re-evaluated at read time), summable with further scores / plain numbers."""
+
+    def __init__(self, default_value: Numeric = 0):
+        self.scores: Set[Numeric] = set()
+        self.default_value = default_value
+
+    def normalize(self, score: Numeric) -> "DynMinMaxNorm.MinMaxScore":
+        self.scores.add(score)
+        return self.MinMaxScore(score, all_scores=self.scores, default_value=self.default_value)
+
+    __call__ = normalize
+
+    class MinMaxScore:
+        def __init__(self, *scores: Numeric, all_scores: Set[Numeric], default_value: Numeric,
+                     no_minmax_scores: Optional[List[Numeric]] = None):
+            self.scores = list(scores)
+            self.all_scores = all_scores
+            self.default_value = default_value
+            self.no_minmax_scores = list(no_minmax_scores or [])
+
+        @property
+        def score(self) -> Numeric:
+            lo, hi = min(self.all_scores), max(self.all_scores)
+            try:
+                value = sum((s - lo) / (hi - lo) for s in self.scores)
+            except ZeroDivisionError:
+                value = self.default_value
+            return value + sum(self.no_minmax_scores)
+
+        def __add__(self, other: Any) -> "DynMinMaxNorm.MinMaxScore":
+            merged = type(self)(*self.scores, all_scores=self.all_scores, default_value=self.default_value,
+                                no_minmax_scores=self.no_minmax_scores)
+            if hasattr(other, "scores") and hasattr(other, "no_minmax_scores"):
+                merged.scores.extend(other.scores)
+                merged.no_minmax_scores.extend(other.no_minmax_scores)
+            else:
+                merged.no_minmax_scores.append(other)
+            return merged
+
+        def __mul__(self, other: Any):
+            return self.score * other
+
+        def __truediv__(self, other: Any):
+            return self.score / other
+
+        def __rtruediv__(self, other: Any):
+            return other / self.score
+
+        __radd__, __rmul__ = __add__, __mul__
+
+
+class DetikzifyGenerator:
+    def __init__(self, model, processor, image: Optional[Image.Image], text: Optional[str] = None,
+                 metric=None, compile_timeout: Optional[int] = 60, mcts_timeout: Optional[int] = None,
+                 streamer=None, control: Optional[ExplicitAbort] = None, exploration: float = 0.6,
+                 strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, **gen_kwargs):
+        self.model, self.processor = model, processor
+        self.metric, self.image, self.text = metric, image, text
+        self.compile_timeout, self.mcts_timeout = compile_timeout, mcts_timeout
+        self.streamer, self.exploration, self.strict = streamer, exploration, strict
+        self.document_class = document_class
+        self.gen_kwargs = gen_kwargs
+
+        self.solution: deque = deque(maxlen=1)
+        self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}
+        self.norm = DynMinMaxNorm()
+        self.control = control or ExplicitAbort()
+        root_ids = processor(images=self.image, text=self.text, return_tensors="pt").input_ids
+        self.montecarlo = MonteCarlo(root_node=WideNode(root_ids.to(model.device).squeeze(),
+                                                        exploration=self.exploration))
+        self.montecarlo.child_finder = self.child_finder
+        # memoise by value: token tuples / image bytes (reference :191-192)
+        self.decode = cache_cast(lambda token_ids: tuple(token_ids.tolist()))(self.decode)
+        self.score = cache_cast(lambda image: image.tobytes())(self.score)
+
+    def __call__(self, *args, **kwargs):
+        return self.simulate(*args, **kwargs)
+
+    def simulate(self, expansions: Optional[Numeric] = 1) -> Generator[Tuple[Numeric, TikzDocument], None, None]:
+        """One MCTS expansion per iteration; yields every rollout as (score, document)."""
+        started = time()
+        while expansions is None or (expansions := expansions - 1) >= 0:
+            self.montecarlo.simulate()
+            yield self.solution.pop()
+            if self.mcts_timeout is not None and time() - started > self.mcts_timeout:
+                return
+
+    # ---- a·G -------------------------------------------------------------------------------------
+    def generate(self, input_ids: torch.Tensor, streamer=None, **gen_kwargs) -> torch.Tensor:
+        streamers = StreamerList(filter(bool, [streamer, self.streamer]))
+        numel = input_ids.numel()
+        max_length = {**self.model.generation_config.to_dict(), **self.gen_kwargs, **gen_kwargs}["max_length"]
+        eos = unwrap(self.processor).tokenizer.eos_token_id
+        if (numel and input_ids[-1] == eos) or numel >= max_length:
+            streamers.end()
+            return input_ids  # never continue past EOS / the length budget
+        with torch.inference_mode():
+            enc = self.processor(images=self.image, text=self.text, text_kwargs={"truncation": True},
+                                 return_tensors="pt")
+            adapter_kwargs = {k: v for k, v in enc.to(self.model.device).items() if k.startswith("adapter")}
+            return self.model.generate(
+                input_ids=input_ids.unsqueeze(0),
+                bad_words_ids=[[self.model.config.image_token_id]],
+                begin_suppress_tokens=[self.model.config.text_config.eos_token_id],
+                pixel_values=enc.get("pixel_values"),
+                streamer=streamers,
+                **adapter_kwargs, **self.gen_kwargs, **gen_kwargs,
+            ).squeeze()
+
+    # ---- a·R -------------------------------------------------------------------------------------
+    @cached_property
+    def newlineinfo(self) -> Dict[int, SimpleNamespace]:
+        """token id -> (#newlines it contains, whether it ends with one); tokens may hold several."""
+        info = {}
+        for token_id in unwrap(self.processor).tokenizer.vocab.values():
+            text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
+            if n := text.count("\n"):
+                info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
+        assert info
+        return info
+
+    def rollout(self, state: NodeState) -> Generator[Tuple[torch.Tensor, int], None, None]:
+        """Continue `state` to completion in a worker thread; yield one (prefix, #lines) per
+        generated source line as the tokens stream in."""
+        input_ids, num_lines, continuation = state.token_ids, state.num_lines, False
+        with ThreadPool(processes=1) as pool:
+            streamer = TokenStreamer()
+            pending = pool.apply_async(
+                func=self.generate, args=[input_ids], error_callback=streamer.propagate_error,
+                kwds=dict(stopping_criteria=[self.control.reset()], streamer=streamer))
+            try:
+                prefix, line = input_ids, []
+                for token in streamer:
+                    line.append(token)
+                    if nl := self.newlineinfo.get(token):
+                        # a token may continue with text after its newline ("continuation")
+                        num_lines += nl.num_lines - continuation
+                        continuation = not nl.trailing
+                        prefix = torch.cat((prefix, torch.tensor(line, device=prefix.device)))
+                        line.clear()
+                        yield prefix, num_lines
+                if line:
+                    yield torch.cat((prefix, torch.tensor(line, device=prefix.device))), num_lines - continuation
+            except (GeneratorExit, KeyboardInterrupt):
+                self.control.abort()
+                raise
+            else:
+                if self.control.should_stop:
+                    raise InterruptedError
+            finally:
+                pending.wait()
+
+    def decode(self, token_ids: torch.Tensor) -> TikzDocument:
+        n_prompt = len(self.montecarlo.root_node.token_ids)
+        return self.document_class(
+            timeout=self.compile_timeout,
+            code=self.processor.decode(token_ids[n_prompt:], skip_special_tokens=True))
+
+    def score(self, image: Image.Image) -> Numeric:
+        assert self.metric
+        self.metric.update(img1=image, img2=self.image, text2=self.text)
+        value = self.metric.compute()
+        self.metric.reset()
+        return value
+
+    def sample(self) -> TikzDocument:
+        return self.decode(self.generate(input_ids=self.montecarlo.root_node.token_ids))
+
+    # ---- a·M -------------------------------------------------------------------------------------
+    def child_finder(self, node: WideNode, montecarlo: MonteCarlo):
+        new_nodes: List[WideNode] = []
+        rollout = self.rollout(node.state)
+        for state in rollout:
+            candidate = WideNode(*state, exploration=self.exploration)
+            if candidate.state in self.failed_rollouts:  # known-bad tail: splice it, stop generating
+                new_nodes.extend(self.failed_rollouts[candidate.state])
+                rollout.close()
+                break
+            new_nodes.append(candidate)
+
+        if node.is_widen_node:
+            node.visits += 1
+            node, new_nodes = self.merge(node.parent, new_nodes)
+
+        tikz = self.decode((new_nodes or [node])[-1].token_ids)
+        skip_idx = round(sqrt(len(new_nodes)))
+
+        scorable = tikz.is_rasterizable and not (self.strict and tikz.compiled_with_errors)
+        if scorable:
+            for new_node in new_nodes[:skip_idx]:   # a chain of the first sqrt(n) line-nodes
+                node.add_child(new_node)
+                node = new_node
+        elif errorln := min(tikz.errors or [0]):
+            # keep what precedes the first located error; memoise the failing tail
+            for idx, new_node in enumerate(new_nodes):
+                # NB: the reference looks the 0-dim *tensor* up (generate.py:330); tensors hash by
+                # identity, so this is None there — kept verbatim for identical tree statistics.
+                ends_with_eol = self.newlineinfo.get(new_node.token_ids[-1])
+                if new_node.num_lines < errorln and idx < skip_idx:
+                    node.add_child(new_node)
+                    node = new_node
+                elif new_node.num_lines > errorln or (new_node.num_lines == errorln and ends_with_eol):
+                    self.failed_rollouts[new_node.state] = new_nodes[idx:]
+                    break
+
+        if self.metric:
+            score = self.score(tikz.rasterize()) if scorable else -1
+        else:  # compiler diagnostics as the reward
+            score = scorable - tikz.compiled_with_errors
+
+        node.update_win_value(self.norm(score) if scorable and self.metric else score)
+        self.solution.append((score, tikz))
+
+    def merge(self, node: WideNode, nodes_to_merge: List[WideNode]) -> Tuple[WideNode, List[WideNode]]:
+        """walk down existing children while the new chain repeats them"""
+        for candidate in list(nodes_to_merge):
+            match = next((c for c in node.children if c.state == candidate.state), None)
+            if match is None:
+                break
+            node, nodes_to_merge = match, nodes_to_merge[1:]
+        return node, nodes_to_merge
+
+
+class DetikzifyPipeline:
+    def __init__(self, model, processor, temperature: float = 0.8, top_p: float = 0.95, top_k: int = 0,
+                 compile_timeout: Optional[int] = 60,
+                 metric: Union[Literal["model", "fast"], Any] = "model", **gen_kwargs):
+        self.model, self.processor = model, processor
+        if metric == "model":      # SelfSim
+            self.metric = ImageSim.from_detikzify(model, processor, sync_on_compute=False)
+        elif metric == "fast":     # compiler diagnostics
+            self.metric = None
+        else:
+            self.metric = metric
+        self.gen_kwargs: Dict[str, Any] = {**dict(
+            temperature=temperature, top_p=top_p, top_k=top_k,
+            max_length=unwrap(processor).tokenizer.model_max_length,
+            do_sample=True, compile_timeout=compile_timeout), **gen_kwargs}
+
+    def load(self, image: Union[Image.Image, str], preprocess: bool = True) -> Image.Image:
+        image = load(image)
+        return expand(image, max(image.size), do_trim=True) if preprocess else image
+
+    def check_inputs(self, image, text):
+        assert text is None or hasattr(self.model, "adapter"), "You need to load an adapter for textual inputs!"
+        assert image or text, "Either image or text (or both) required!"
+
+    def _generator(self, image, text, preprocess, **kw) -> DetikzifyGenerator:
+        self.check_inputs(image, text)
+        return DetikzifyGenerator(
+            model=self.model, processor=self.processor,
+            image=self.load(image, preprocess=preprocess) if image is not None else None,
+            text=text, **{**self.gen_kwargs, **kw})
+
+    def sample(self, image=None, text: Optional[str] = None, preprocess: bool = True, **gen_kwargs) -> TikzDocument:
+        """One sampled TikZ program for the image."""
+        return self._generator(image, text, preprocess, **gen_kwargs).sample()
+
+    def simulate(self, image=None, text: Optional[str] = None, preprocess: bool = True,
+                 expansions: Optional[Numeric] = None, timeout: Optional[int] = None,
+                 **gen_kwargs) -> Generator[Tuple[Numeric, TikzDocument], None, None]:
+        """MCTS: yields (score, document) for every rollout until `expansions` / `timeout`."""
+        generator = self._generator(image, text, preprocess, metric=self.metric,
+                                    mcts_timeout=timeout or None, **gen_kwargs)
+        yield from generator.simulate(expansions or None)
+
+    def __call__(self, *args, **kwargs) -> TikzDocument:
+        return self.sample(*args, **kwargs)
+
+
+# the name BASELINE.json's north_star uses for the drop-in
+TikzGenerator = DetikzifyGenerator

@@ -1,0 +1,109 @@
+"""
+load(): the producer side of the drop-in boundary (reference detikzify/model/__init__.py:28-61 and
+detikzify/model/v1/__init__.py:24-56).  Returns the (model, processor) pair that
+DetikzifyPipeline / DetikzifyGenerator / ImageSim.from_detikzify consume.
+
+Two sources of weights:
+  * a local checkpoint directory in HF layout (config.json + *.safetensors [+ tokenizer files],
+    vision tower tensors under the "vision_model." prefix in timm naming);
+  * `synthetic=<seed>`: seeded synthetic weights at a preset's shapes — the only option offline
+    (no checkpoints or tokenizer files exist in this environment).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Optional, Tuple
+
+from .config import DetikzifyConfig, PRESETS, preset
+from .modeling import DetikzifyForCausalLM, DetikzifyVisionModel, GenerationConfig
+from .processing import BatchFeature, DetikzifyImageProcessor, DetikzifyProcessor
+from .tokenizer import SyntheticTokenizer, load_tokenizer
+
+# names the reference resolves to its v1 loader (detikzify/model/v1/__init__.py:10-15)
+v1_models = ["nllg/detikzify-ds-1.3b", "nllg/detikzify-ds-7b", "nllg/detikzify-tl-1.1b", "nllg/detikzify-cl-7b"]
+
+
+def _default_device() -> int:
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v1: bool = False,
+         synthetic: Optional[int] = None, device_map=None, torch_dtype=None, max_positions: Optional[int] = None,
+         **unused) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
+    """(model, processor).  `device_map` may be an int GPU index (the reference passes
+    device_map=RANK, examples/eval.py:112); torch_dtype is accepted and must be bf16/None."""
+    dev = device_map if isinstance(device_map, int) else _default_device()
+    path = Path(model_name_or_path)
+    if path.is_dir() and (path / "config.json").exists() and synthetic is None:
+        cfg = DetikzifyConfig.from_hf_json(str(path / "config.json"))
+        cfg.name_or_path = str(path)
+        if max_positions:
+            cfg.max_positions = max_positions
+        tokenizer = load_tokenizer(str(path), cfg.max_positions)
+        cfg.patch_token_id = tokenizer.bos_token_id          # v1/__init__.py:49
+        model = DetikzifyForCausalLM(cfg, dev)
+        _load_safetensors_dir(model, path)
+        if modality_projector:
+            _load_projector(model, modality_projector)
+    else:
+        cfg = preset(model_name_or_path)
+        if max_positions:
+            cfg.max_positions = max_positions
+        if synthetic is None:
+            raise FileNotFoundError(
+                f"{model_name_or_path!r} is not a local checkpoint directory and there is no network; "
+                "pass synthetic=<seed> for seeded synthetic weights at this preset's shapes")
+        tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
+                                       pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions)
+        model = DetikzifyForCausalLM(cfg, dev)
+        model.fill_synthetic(int(synthetic))
+    model.generation_config.pad_token_id = tokenizer.pad_token_id     # v1/__init__.py:41
+    image_processor = DetikzifyImageProcessor(size={"height": cfg.vit_image, "width": cfg.vit_image})
+    processor = DetikzifyProcessor(
+        image_processor=image_processor, tokenizer=tokenizer, image_seq_len=cfg.num_patches,
+        image_token=tokenizer.convert_ids_to_tokens(cfg.patch_token_id))
+    return model, processor
+
+
+def _load_safetensors_dir(model: DetikzifyForCausalLM, path: Path):
+    """HF-layout checkpoint -> device.  The v1 checkpoints carry the decoder + mm_projector; the
+    timm tower ships separately (pretrained=True at v1/modeling_detikzify.py:94): accept it either
+    inside the same files under "vision_model." / "model.vision_model.model.0." or as
+    vision_tower.safetensors with bare timm names."""
+    from safetensors import safe_open
+    known = set(model.tensor_names())
+    seen = set()
+    files = sorted(path.glob("*.safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    for f in files:
+        bare_timm = f.name == "vision_tower.safetensors"
+        with safe_open(str(f), framework="pt") as sf:
+            for k in sf.keys():
+                name = k
+                if bare_timm:
+                    name = "vision_model." + k
+                for pre in ("model.vision_model.model.0.", "model.vision_model."):
+                    if k.startswith(pre):
+                        name = "vision_model." + k[len(pre):]
+                if name in known:
+                    model.load_tensor(name, sf.get_tensor(k))
+                    seen.add(name)
+    missing = [k for k in known if k not in seen and not k.startswith("rope.")]
+    if missing:
+        raise KeyError(f"checkpoint {path} lacks {len(missing)} tensors, e.g. {missing[:4]}")
+    model._install_rope_tables()
+    model._weights_ready = True
+
+
+def _load_projector(model: DetikzifyForCausalLM, filename: str):
+    """modality_projector file (v1/modeling_detikzify.py:116-121): keys end in .weight / .bias."""
+    from safetensors.torch import load_file
+    for k, v in load_file(filename).items():
+        model.load_tensor("model.mm_projector." + k.split(".")[-1], v)
+
+
+__all__ = ["load", "DetikzifyConfig", "DetikzifyForCausalLM", "DetikzifyVisionModel", "DetikzifyProcessor",
+           "DetikzifyImageProcessor", "BatchFeature", "SyntheticTokenizer", "GenerationConfig", "PRESETS",
+           "preset", "v1_models"]

@@ -1,0 +1,342 @@
+"""
+The (model, processor) pair's model half: an object with the attribute surface DeTikZify's
+inference code touches, over the C ABI of libdtk_hip.so.
+
+Replaces (reference, all Python): DetikzifyForCausalLM / DetikzifyModel / DetikzifyVisionModel
+(detikzify/model/v1/modeling_detikzify.py:49-305) and the HF GenerationMixin.generate loop they
+inherit (called at detikzify/infer/generate.py:218-227).  Surface kept:
+  model.generate(input_ids, bad_words_ids, begin_suppress_tokens, pixel_values, streamer,
+                 stopping_criteria, temperature, top_p, top_k, max_length, do_sample, ...)
+  model.device / .dtype / .name_or_path / .generation_config.to_dict() / .config.{image_token_id,
+  text_config.eos_token_id, pooling_mode} / model.model.vision_model(pixel_values=...)
+There is no CPU fallback: constructing the model without the HIP library or a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+from types import SimpleNamespace
+from typing import Any, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .config import DetikzifyConfig
+
+
+class GenerationConfig:
+    """transformers.GenerationConfig stand-in: only `.to_dict()` and attribute reads are used
+    (infer/generate.py:211; v1/__init__.py:41)."""
+
+    def __init__(self, **kw):
+        self.max_length = 20           # HF default; the pipeline overrides it (generate.py:383)
+        self.max_new_tokens = None
+        self.do_sample = False
+        self.temperature = 1.0
+        self.top_p = 1.0
+        self.top_k = 50
+        self.eos_token_id = None
+        self.pad_token_id = None
+        self.bos_token_id = None
+        self.__dict__.update(kw)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return dict(self.__dict__)
+
+
+class VisionOutput(SimpleNamespace):
+    """BaseModelOutputWithPoolingAndNoAttention stand-in (last_hidden_state, pooler_output)."""
+
+
+class DetikzifyVisionModel:
+    """model.model.vision_model: timm ViT forward_features + forward_head on the GPU
+    (reference v1/modeling_detikzify.py:63-69)."""
+
+    def __init__(self, owner: "DetikzifyForCausalLM"):
+        self._owner = owner
+
+    def __call__(self, pixel_values: torch.Tensor, **_) -> VisionOutput:
+        return self.forward(pixel_values)
+
+    def forward(self, pixel_values: torch.Tensor) -> VisionOutput:
+        feats, pooled = self._owner.vit_encode(pixel_values, want_pooled=True)
+        return VisionOutput(last_hidden_state=feats, pooler_output=pooled)
+
+    def get_intermediate_layers(self, pixel_values: torch.Tensor, *_, **__):
+        feats, _ = self._owner.vit_encode(pixel_values, want_pooled=False)
+        return [feats]
+
+
+def _bf16_tensor_from_bits(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16)
+
+
+class DetikzifyForCausalLM:
+    def __init__(self, config: DetikzifyConfig, device_index: int = 0):
+        self.config = config
+        self.lib = _lib.load_library()
+        self.hip_device = int(device_index)
+        kd = config.kernel_dict()
+        cc = _lib.DtkConfig(**kd)
+        ctx = C.c_void_p()
+        rc = self.lib.dtk_create(C.byref(cc), self.hip_device, C.byref(ctx))
+        if rc != 0:
+            msg = self.lib.dtk_last_error(None)
+            raise _lib.DtkError(f"dtk_create failed ({rc}): {msg.decode() if msg else ''} — "
+                                "detikzify_amd needs an MI355X-class GPU; there is no CPU path")
+        self._ctx = ctx
+        self.generation_config = GenerationConfig(
+            eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id,
+            bos_token_id=config.bos_token_id)
+        self.name_or_path = config.name_or_path
+        self.model = SimpleNamespace(vision_model=DetikzifyVisionModel(self))
+        self.reuse_prefix = False     # output-identical KV/image reuse across rollouts
+        self._weights_ready = False
+
+    # ---- HF-shaped attributes ---------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        # ids / pixels cross the C ABI as HOST buffers, so tensors handed to this model live on
+        # the CPU; the GPU is self.hip_device.
+        return torch.device("cpu")
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    def eval(self):
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self.lib.dtk_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        _lib.check(self.lib, self._ctx, rc, what)
+
+    # ---- weights ------------------------------------------------------------------------------
+    def tensor_names(self) -> List[str]:
+        n = self.lib.dtk_num_tensors(self._ctx)
+        return [self.lib.dtk_tensor_name(self._ctx, i).decode() for i in range(n)]
+
+    def load_tensor(self, name: str, t: torch.Tensor):
+        t = t.detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:
+            arr, dt = t.view(torch.int16).numpy(), _lib.DTK_BF16
+        elif t.dtype == torch.float16:
+            arr, dt = t.view(torch.int16).numpy(), _lib.DTK_F16
+        else:
+            arr, dt = t.float().numpy(), _lib.DTK_F32
+        shape = (C.c_int64 * t.dim())(*t.shape) if t.dim() else (C.c_int64 * 1)(1)
+        self._check(self.lib.dtk_load_tensor(self._ctx, name.encode(), arr.ctypes.data_as(C.c_void_p), dt,
+                                             shape, max(t.dim(), 1)), f"dtk_load_tensor({name})")
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
+        known = set(self.tensor_names())
+        missing = sorted(k for k in known if k not in state and not k.startswith("rope."))
+        unexpected = sorted(k for k in state if k not in known)
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing: {missing[:5]}... unexpected: {unexpected[:5]}...")
+        for k, v in state.items():
+            if k in known:
+                self.load_tensor(k, v)
+        self._install_rope_tables()
+        self._weights_ready = True
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def read_tensor(self, name: str) -> torch.Tensor:
+        """stored bf16 tensor -> flat torch.bfloat16 (tests / CPU baseline)"""
+        n = self.lib.dtk_tensor_numel(self._ctx, name.encode())
+        if n < 0:
+            raise KeyError(name)
+        buf = np.empty(n, dtype=np.uint16)
+        self._check(self.lib.dtk_read_tensor(self._ctx, name.encode(), buf.ctypes.data_as(C.c_void_p), n),
+                    f"dtk_read_tensor({name})")
+        return _bf16_tensor_from_bits(buf)
+
+    def fill_synthetic(self, seed: int = 1234):
+        self._check(self.lib.dtk_fill_synthetic(self._ctx, C.c_uint64(seed)), "dtk_fill_synthetic")
+        self._install_rope_tables()
+        self._weights_ready = True
+
+    def _install_rope_tables(self):
+        """cos/sin exactly as HF LlamaRotaryEmbedding computes them (modeling_llama.py:108-140):
+        fp32 inv_freq (linear scaling: / factor), fp32 pos*inv_freq, cos/sin cast to bf16."""
+        c = self.config
+        inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.int64).float() / c.head_dim))
+        if c.rope_factor and c.rope_factor != 1.0:
+            inv = inv / c.rope_factor
+        freqs = torch.arange(c.max_positions, dtype=torch.float32)[:, None] * inv[None, :]
+        self.load_tensor("rope.cos", freqs.cos().to(torch.bfloat16))
+        self.load_tensor("rope.sin", freqs.sin().to(torch.bfloat16))
+
+    # ---- vision tower -------------------------------------------------------------------------
+    def vit_encode(self, pixel_values: torch.Tensor, want_pooled: bool = True):
+        px = pixel_values.detach().to("cpu", torch.float32).contiguous()
+        if px.dim() == 3:
+            px = px[None]
+        B = px.shape[0]
+        c = self.config
+        n = (c.vit_image // c.vit_patch) ** 2
+        feats = np.empty((B, n, c.vit_dim), dtype=np.uint16)
+        pooled = np.empty((B, c.vit_dim), dtype=np.uint16)
+        self._check(self.lib.dtk_vit_encode(
+            self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p),
+            pooled.ctypes.data_as(C.c_void_p) if want_pooled else None), "dtk_vit_encode")
+        f = _bf16_tensor_from_bits(feats.reshape(-1)).view(B, n, c.vit_dim)
+        p = _bf16_tensor_from_bits(pooled.reshape(-1)).view(B, c.vit_dim) if want_pooled else None
+        return f, p
+
+    # ---- decoder ------------------------------------------------------------------------------
+    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor] = None,
+                return_logits: bool = False, reuse: Optional[bool] = None) -> Optional[torch.Tensor]:
+        ids = input_ids.detach().to("cpu", torch.int64).reshape(-1).contiguous()
+        T = ids.numel()
+        px_ptr, key = None, 0
+        if pixel_values is not None:
+            px = pixel_values.detach().to("cpu", torch.float32).contiguous()
+            if px.dim() == 4:
+                if px.shape[0] != 1:
+                    raise ValueError("batch size 1 only")
+                px = px[0]
+            self._px_keepalive = px
+            px_ptr = px.numpy().ctypes.data_as(C.c_void_p)
+            key = int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
+        reuse = self.reuse_prefix if reuse is None else reuse
+        flags = (_lib.DTK_PREFILL_REUSE_PREFIX | _lib.DTK_PREFILL_REUSE_IMAGE) if reuse else 0
+        logits = np.empty(self.config.vocab, dtype=np.float32) if return_logits else None
+        self._check(self.lib.dtk_prefill(
+            self._ctx, ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr, C.c_uint64(key), flags,
+            logits.ctypes.data_as(C.c_void_p) if return_logits else None), "dtk_prefill")
+        return torch.from_numpy(logits) if return_logits else None
+
+    def set_sampling(self, do_sample=False, temperature=1.0, top_p=1.0, top_k=0, seed=0,
+                     bad_ids: Iterable[int] = (), begin_suppress_ids: Iterable[int] = (),
+                     always_suppress_ids: Iterable[int] = ()):
+        s = _lib.DtkSampling()
+        s.do_sample, s.temperature, s.top_p, s.top_k = int(bool(do_sample)), float(temperature), float(top_p), int(top_k or 0)
+        s.seed = int(seed) & ((1 << 64) - 1)
+        for field, cnt, vals in (("bad_ids", "n_bad", bad_ids), ("begin_suppress_ids", "n_begin_suppress", begin_suppress_ids),
+                                 ("always_suppress_ids", "n_always_suppress", always_suppress_ids)):
+            vals = [int(v) for v in vals]
+            if len(vals) > 8:
+                raise ValueError("at most 8 ids per suppression list")
+            setattr(s, cnt, len(vals))
+            arr = getattr(s, field)
+            for i, v in enumerate(vals):
+                arr[i] = v
+        self._check(self.lib.dtk_set_sampling(self._ctx, C.byref(s)), "dtk_set_sampling")
+
+    def decode_launch(self):
+        self._check(self.lib.dtk_decode_launch(self._ctx), "dtk_decode_launch")
+
+    def decode_wait(self) -> int:
+        tok = C.c_int64()
+        self._check(self.lib.dtk_decode_wait(self._ctx, C.byref(tok)), "dtk_decode_wait")
+        return int(tok.value)
+
+    def get_logits(self) -> torch.Tensor:
+        out = np.empty(self.config.vocab, dtype=np.float32)
+        self._check(self.lib.dtk_get_logits(self._ctx, out.ctypes.data_as(C.c_void_p)), "dtk_get_logits")
+        return torch.from_numpy(out)
+
+    def context_len(self) -> int:
+        return int(self.lib.dtk_context_len(self._ctx))
+
+    def set_graph_mode(self, mode: int):
+        self._check(self.lib.dtk_set_graph_mode(self._ctx, int(mode)), "dtk_set_graph_mode")
+
+    def synchronize(self):
+        self._check(self.lib.dtk_synchronize(self._ctx), "dtk_synchronize")
+
+    def stats(self) -> Dict[str, Any]:
+        st = _lib.DtkStats()
+        self._check(self.lib.dtk_get_stats(self._ctx, C.byref(st)), "dtk_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    # ---- generation ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                 bad_words_ids: Optional[List[List[int]]] = None,
+                 begin_suppress_tokens: Optional[List[int]] = None,
+                 suppress_tokens: Optional[List[int]] = None,
+                 streamer=None, stopping_criteria=None, do_sample: Optional[bool] = None,
+                 temperature: Optional[float] = None, top_p: Optional[float] = None,
+                 top_k: Optional[int] = None, max_length: Optional[int] = None,
+                 max_new_tokens: Optional[int] = None, eos_token_id=None, seed: Optional[int] = None,
+                 inputs: Optional[torch.Tensor] = None, **unused) -> torch.Tensor:
+        """One sequence of HF GenerationMixin.generate/_sample semantics (generation/utils.py
+        :2783-2950): streamer.put(prompt) once, then per token: processors -> argmax|draw ->
+        append -> streamer.put(token) -> stopping criteria (max length, EOS, user criteria);
+        streamer.end().  Returns (1, T') int64 on the host."""
+        if not self._weights_ready:
+            raise _lib.DtkError("no weights loaded (load_state_dict / fill_synthetic first)")
+        if input_ids is None:
+            input_ids = inputs
+        ids = input_ids.detach().to("cpu", torch.int64)
+        if ids.dim() == 1:
+            ids = ids[None]
+        if ids.shape[0] != 1:
+            raise ValueError("batch size 1 only (the reference generates one sequence per call)")
+        gc = self.generation_config
+        do_sample = gc.do_sample if do_sample is None else do_sample
+        temperature = gc.temperature if temperature is None else temperature
+        top_p = gc.top_p if top_p is None else top_p
+        top_k = gc.top_k if top_k is None else top_k
+        T = ids.shape[1]
+        if max_new_tokens is not None:
+            max_length = T + int(max_new_tokens)
+        elif max_length is None:
+            max_length = gc.max_length
+        max_length = min(int(max_length), self.config.max_positions)
+        eos = eos_token_id if eos_token_id is not None else gc.eos_token_id
+        eos_set = set(eos if isinstance(eos, (list, tuple)) else ([] if eos is None else [eos]))
+        bad = []
+        for w in (bad_words_ids or []):
+            if len(w) != 1:
+                raise NotImplementedError("multi-token bad words are not used by DeTikZify")
+            bad.append(int(w[0]))
+        if seed is None:  # reproducible under torch.manual_seed / transformers.set_seed, like HF
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item()) if do_sample else 0
+
+        if streamer is not None:
+            streamer.put(ids.cpu())
+        criteria = list(stopping_criteria) if stopping_criteria is not None else []
+        n_new_max = max_length - T
+        buf = torch.empty((1, max(max_length, T)), dtype=torch.int64)
+        buf[0, :T] = ids[0]
+        cur = T
+        if n_new_max > 0:
+            self.set_sampling(do_sample, temperature, top_p, top_k, seed, bad,
+                              begin_suppress_tokens or (), suppress_tokens or ())
+            self.prefill(ids[0], pixel_values)
+            launched = received = 0
+            stop = False
+            ahead = 2  # one step always in flight while the host handles the previous token
+            while launched < min(ahead, n_new_max):
+                self.decode_launch(); launched += 1
+            while received < launched:
+                tok = self.decode_wait(); received += 1
+                buf[0, cur] = tok
+                cur += 1
+                if streamer is not None:
+                    streamer.put(torch.tensor([tok], dtype=torch.int64))
+                stop = tok in eos_set or cur >= max_length
+                for crit in criteria:
+                    r = crit(buf[:, :cur], None)
+                    stop = stop or bool(r.all() if isinstance(r, torch.Tensor) else r)
+                if stop:
+                    break
+                if launched < n_new_max:
+                    self.decode_launch(); launched += 1
+        if streamer is not None:
+            streamer.end()
+        return buf[:, :cur].clone()

@@ -1,0 +1,137 @@
+"""
+Thread/stream plumbing the generate loop drives (same contracts as reference
+detikzify/util/generation.py:7-101).  Written against duck-typed protocols so neither
+transformers' StoppingCriteria nor its BaseStreamer is needed on the hot path:
+  stopping criterion: callable(input_ids, scores) -> bool          (ExplicitAbort :7-23)
+  streamer:           .put(tensor) per token, .end() once           (TokenStreamer :25-66)
+Errors raised in the generating thread travel through the queue and re-raise in the consumer
+(:53, :59-66) — the rollout contract of infer/generate.py:248-258.
+"""
+from __future__ import annotations
+
+from queue import Queue
+from typing import Optional
+
+
+class ExplicitAbort:
+    """Cooperative cancel, polled once per generated token."""
+
+    def __init__(self):
+        self.should_stop = False
+
+    def __call__(self, input_ids, scores, **kwargs) -> bool:
+        return self.should_stop
+
+    def reset(self):
+        self.should_stop = False
+        return self
+
+    def abort(self):
+        self.should_stop = True
+
+
+class _QueueStreamer:
+    _END = None
+
+    def __init__(self, timeout: Optional[float] = None):
+        self.queue: Queue = Queue()
+        self.timeout = timeout
+
+    def end(self):
+        self.queue.put(self._END, timeout=self.timeout)
+
+    def propagate_error(self, exc: BaseException):
+        self.queue.put(exc, timeout=self.timeout)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.queue.get(timeout=self.timeout)
+        if isinstance(item, BaseException):
+            raise item
+        if item is self._END:
+            raise StopIteration()
+        return item
+
+
+class TokenStreamer(_QueueStreamer):
+    """Streams raw token ids; the first put() (the prompt) is dropped when skip_prompt."""
+
+    def __init__(self, skip_prompt: bool = True, timeout: Optional[float] = None):
+        super().__init__(timeout)
+        self.skip_prompt = skip_prompt
+        self.next_tokens_are_prompt = True
+        self.token_queue = self.queue  # reference attribute name
+
+    def put(self, value):
+        if len(value.shape) > 1:
+            if value.shape[0] > 1:
+                raise ValueError("TokenStreamer only supports batch size 1")
+            value = value[0]
+        if self.skip_prompt and self.next_tokens_are_prompt:
+            self.next_tokens_are_prompt = False
+            return
+        for token_id in value.tolist():
+            self.queue.put(token_id, timeout=self.timeout)
+
+    def end(self):
+        self.next_tokens_are_prompt = True
+        super().end()
+
+
+class TextIteratorStreamer(_QueueStreamer):
+    """Streams decoded text (used by the web UI caller of the boundary, webui/webui.py:36-55).
+    Emits text whenever the decoded suffix ends in whitespace/newline or at end()."""
+
+    def __init__(self, tokenizer, skip_prompt: bool = True, timeout: Optional[float] = None, **decode_kwargs):
+        super().__init__(timeout)
+        self.tokenizer, self.skip_prompt, self.decode_kwargs = tokenizer, skip_prompt, decode_kwargs
+        self.next_tokens_are_prompt = True
+        self._cache, self._printed = [], 0
+        self.text_queue = self.queue
+
+    def put(self, value):
+        if len(value.shape) > 1:
+            if value.shape[0] > 1:
+                raise ValueError("TextIteratorStreamer only supports batch size 1")
+            value = value[0]
+        if self.skip_prompt and self.next_tokens_are_prompt:
+            self.next_tokens_are_prompt = False
+            return
+        self._cache.extend(value.tolist())
+        text = self.tokenizer.decode(self._cache, **self.decode_kwargs)
+        if text.endswith("\n"):
+            out, self._cache, self._printed = text[self._printed:], [], 0
+        else:
+            cut = text.rfind(" ") + 1
+            out, self._printed = text[self._printed:cut], max(cut, self._printed)
+        if out:
+            self.queue.put(out, timeout=self.timeout)
+
+    def end(self):
+        if self._cache:
+            text = self.tokenizer.decode(self._cache, **self.decode_kwargs)
+            if text[self._printed:]:
+                self.queue.put(text[self._printed:], timeout=self.timeout)
+        self._cache, self._printed, self.next_tokens_are_prompt = [], 0, True
+        super().end()
+
+
+class StreamerList(list):
+    """Fan one generate() out to several streamers (reference :81-91)."""
+
+    def put(self, value):
+        for s in self:
+            s.put(value)
+
+    def end(self):
+        for s in self:
+            s.end()
+
+
+def unwrap_processor(processor):
+    """Adapter processors nest the real one under `.processor` (reference :93-101)."""
+    while hasattr(processor, "processor"):
+        processor = processor.processor
+    return processor

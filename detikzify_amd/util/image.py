@@ -1,0 +1,49 @@
+"""Image preparation applied before the processor (row a·P1; reference detikzify/util/image.py:24-60,
+called from infer/generate.py:389-393): RGBA -> RGB on white, trim the uniform border, pad to a
+square with LANCZOS resampling."""
+from __future__ import annotations
+
+from base64 import b64decode
+from io import BytesIO
+from os.path import isfile
+
+from PIL import Image, ImageChops, ImageOps
+
+
+def remove_alpha(image: Image.Image, bg="white") -> Image.Image:
+    canvas = Image.new("RGBA", image.size, bg)
+    return Image.alpha_composite(canvas, image.convert("RGBA")).convert("RGB")
+
+
+def trim(image: Image.Image, bg="white") -> Image.Image:
+    """crop to the bounding box of everything that differs from the background colour"""
+    box = ImageChops.difference(image, Image.new(image.mode, image.size, bg)).getbbox()
+    return image.crop(box) if box else image
+
+
+def expand(image: Image.Image, size: int, do_trim: bool = False, bg="white") -> Image.Image:
+    if do_trim:
+        image = trim(image, bg=bg)
+    return ImageOps.pad(image, (size, size), color=bg, method=Image.Resampling.LANCZOS)
+
+
+def load(image, bg="white", timeout=None) -> Image.Image:
+    """PIL image | path | bytes | base64 string -> RGB PIL image (no network in this build)."""
+    if isinstance(image, bytes):
+        image = Image.open(BytesIO(image))
+    elif isinstance(image, str):
+        if image.startswith(("http://", "https://")):
+            import requests
+            headers = {"user-agent": "Mozilla/5.0"}
+            image = Image.open(BytesIO(requests.get(image, timeout=timeout, headers=headers).content))
+        elif isfile(image):
+            image = Image.open(image)
+        else:
+            try:
+                payload = image.split(",", 1)[1] if image.startswith("data:image/") else image
+                image = Image.open(BytesIO(b64decode(payload)))
+            except Exception as e:
+                raise ValueError("Incorrect image source. Must be a URL, a path to an image file, bytes, "
+                                 f"or a base64 encoded string. Failed with {e}")
+    image = ImageOps.exif_transpose(image)
+    return remove_alpha(image, bg=bg)

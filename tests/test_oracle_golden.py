@@ -1,0 +1,98 @@
+"""Pins the CPU oracle against the golden vectors produced by tests/golden/make_golden.py (installed
+HuggingFace Llama / SigLIP / logits processors).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import sampling
+from oracle.llama import LlamaOracle
+from oracle.model import DetikzifyOracle
+from oracle.synth import make_weights
+from oracle.vit import VitOracle
+from tests.helpers import TINY_CFG, rel_l2
+
+
+def test_llama_fp32_matches_hf(golden_dir):
+    g = np.load(golden_dir / "llama_tiny.npz")
+    w = make_weights(TINY_CFG, 1234)
+    llm = LlamaOracle(TINY_CFG, w, precision="fp32")
+    h = llm.forward(torch.from_numpy(g["embeds"]))
+    logits = llm.logits(h)
+    assert rel_l2(logits, g["logits_embeds_fp32"]) < 2e-5          # same math, fp32 round-off only
+    llm.reset()
+    ids = torch.from_numpy(g["ids"][0])
+    lo = llm.logits(llm.forward(llm.embed(ids))[-1])
+    assert rel_l2(lo, g["logits_ids_fp32"]) < 2e-5
+
+
+def test_llama_bf16_policy_close_to_hf_bf16(golden_dir):
+    """the bf16 rounding policy tracks HF's own bf16 run (not bit-equal: HF eager/sdpa rounds the
+    scores differently; documented in oracle/__init__.py)"""
+    g = np.load(golden_dir / "llama_tiny.npz")
+    w = make_weights(TINY_CFG, 1234)
+    llm = LlamaOracle(TINY_CFG, w, precision="bf16")
+    logits = llm.logits(llm.forward(torch.from_numpy(g["embeds"])))
+    assert rel_l2(logits, g["logits_embeds_bf16"]) < 2e-2
+    assert rel_l2(logits, g["logits_embeds_fp32"]) < 2e-2
+
+
+def test_greedy_tokens_match_hf_generate(golden_dir):
+    """HF generate() with bad_words_ids=[[1]], begin_suppress_tokens=[2] vs the oracle loop (fp32)"""
+    g = np.load(golden_dir / "llama_tiny.npz")
+    w = make_weights(TINY_CFG, 1234)
+    o = DetikzifyOracle(TINY_CFG, w, precision="fp32")
+    toks = o.generate(torch.from_numpy(g["ids"][0]), None, 24, bad=[1], begin=[2], eos=2)
+    ref = g["greedy_fp32"].tolist()
+    assert toks == ref[: len(toks)] and len(toks) >= min(24, len(ref))
+
+
+def test_vit_matches_hf_siglip(golden_dir):
+    """timm-layout weights through the oracle == HF SiglipVisionModel through the name mapping"""
+    g = np.load(golden_dir / "siglip_tiny.npz")
+    w = make_weights(TINY_CFG, 1234, only_prefix="vision_model.")
+    px = torch.from_numpy(g["pixels"])
+    for tanh, tag in ((0, "erf"), (1, "tanh")):
+        cfg = dict(TINY_CFG, vit_gelu_tanh=tanh)
+        lh, pooled = VitOracle(cfg, w, precision="fp32").forward(px)
+        assert rel_l2(lh, g[f"last_hidden_{tag}"]) < 2e-5
+        assert rel_l2(pooled, g[f"pooled_{tag}"]) < 2e-5
+        lh16, pooled16 = VitOracle(cfg, w, precision="bf16").forward(px)
+        assert rel_l2(lh16, g[f"last_hidden_{tag}"]) < 2e-2
+    # get_intermediate_layers(n=[last], norm=True) == forward_features
+    v = VitOracle(TINY_CFG, w, precision="fp32")
+    assert torch.equal(v.intermediate(px, TINY_CFG["vit_depth"] - 1), v.forward_features(px))
+
+
+def test_logits_processors_match_hf(golden_dir):
+    g = np.load(golden_dir / "processors.npz")
+    logits = torch.from_numpy(g["logits"])
+    for row, (T, k, p, first) in enumerate(g["cases"]):
+        s = sampling.processed_scores(logits[row], temperature=float(T), top_k=int(k), top_p=float(p),
+                                      bad=[1], begin=[2], first=bool(first))
+        ref = torch.from_numpy(g[f"scores_{row}"])
+        assert torch.equal(torch.isinf(s), torch.isinf(ref))
+        keep = ~torch.isinf(ref)
+        assert torch.allclose(s[keep], ref[keep], rtol=0, atol=0)
+
+
+def test_deterministic_sampler_keeps_hf_nucleus(golden_dir):
+    """the integer-mass sampler keeps exactly the HF top-k/top-p set (boundary ties aside) and
+    draws reproducibly from it"""
+    g = np.load(golden_dir / "processors.npz")
+    logits = torch.from_numpy(g["logits"])
+    for row, (T, k, p, first) in enumerate(g["cases"]):
+        kw = dict(bad=[1], begin=[2], first=bool(first))
+        z, q = sampling.integer_masses(logits[row], float(T), **kw)
+        keep = sampling.kept_mask(z, q, int(k), float(p))
+        ref_keep = ~torch.isinf(torch.from_numpy(g[f"scores_{row}"]))
+        assert int((keep ^ ref_keep).sum()) <= 1
+        toks = [sampling.draw(logits[row], float(T), int(k), float(p), seed=42, n=n, **kw)[0] for n in range(64)]
+        assert all(bool(keep[t]) for t in toks)
+        assert toks == [sampling.draw(logits[row], float(T), int(k), float(p), seed=42, n=n, **kw)[0] for n in range(64)]
+        assert len(set(toks)) > 4
+
+
+def test_synth_weights_are_bf16_representable():
+    w = make_weights(TINY_CFG, 1234)
+    for k, v in w.items():
+        assert torch.equal(v, v.to(torch.bfloat16).float()), k
+    assert abs(float(w["lm_head.weight"].std()) - 0.02) < 2e-3
