@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""
+bench.py — TikZ tokens/sec (+ MCTS rollouts/sec) of the MI355X-native DeTikZify hot path.
+
+Metric (BASELINE.json): TikZ tokens/sec + MCTS rollouts/sec, detikzify-ds-7b, 1 image, N MI355X.
+One "step" = one rollout of the hot path through the product API (model.generate, the call
+DetikzifyGenerator.generate makes, reference infer/generate.py:218-227): image already preprocessed
+on the host -> ViT (666 GF) -> projector -> 243-token prefill -> 512 decoded tokens (EOS suppressed:
+fixed work) with bad_words/begin-suppress processors, one D2H per token.  `value` is
+generated tokens / wall time of the whole step loop (ViT + prefill INCLUDED); the decode-only rate and
+the prefill time are reported beside it.  N > 1 (torchrun, one rank per GPU): every rank runs its own
+independent rollouts on a full replica (root-parallel rollouts), the generated token
+strings are gathered to all ranks over RCCL inside the timed region; scaling is weak.
+
+Extra objects: `roofline` (dominant kernel = the fused RMSNorm + gate/up GEMV + SiLU·mul kernel,
+44 % of the weight bytes; duration measured live with HIP events on the library's stream in a probe
+pass of plain launches; HBM peak 8 TB/s) and `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="detikzify-ds-7b")
+    ap.add_argument("--new-tokens", type=int, default=512)
+    ap.add_argument("--sample", action="store_true", help="sampling decode (T=.8, p=.95) instead of greedy")
+    ap.add_argument("--reuse", action="store_true", help="SURVEY §8 f1: reuse image embeds / prefix KV across rollouts")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=8)
+    ap.add_argument("--probe-tokens", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, cfg, ids, n_tokens):
+    """The oracle (a port: HF LlamaModel restated, oracle/llama.py) timed on the host cores:
+    greedy decode steps at context 243+ on the SAME weights (copied back from the device)."""
+    import torch
+    from oracle import sampling
+    from oracle.llama import LlamaOracle
+    t0 = time.perf_counter()
+    names = [n for n in model.tensor_names() if n.startswith(("model.layers.", "model.norm", "lm_head", "model.embed"))]
+    w = {}
+    for n in names:
+        t = model.read_tensor(n)
+        numel = t.numel()
+        if n.endswith("layernorm.weight") or n == "model.norm.weight":
+            w[n] = t.float()
+        elif "down_proj" in n:
+            w[n] = t.view(cfg["hidden"], cfg["ffn"])
+        elif "gate_proj" in n or "up_proj" in n:
+            w[n] = t.view(cfg["ffn"], cfg["hidden"])
+        elif n in ("model.embed_tokens.weight", "lm_head.weight"):
+            w[n] = t.view(cfg["vocab"], cfg["hidden"])
+        else:
+            w[n] = t.view(cfg["hidden"], cfg["hidden"])
+        assert w[n].numel() == numel
+    w["model.embed_tokens.weight"] = w["model.embed_tokens.weight"].float()
+    llm = LlamaOracle(cfg, w, precision="bf16")
+    t_load = time.perf_counter() - t0
+    with torch.no_grad():
+        h = llm.forward(llm.embed(ids))            # 243-token prefix, not timed (text-only: no CPU ViT)
+        logits = llm.logits(h[-1])
+        t1 = time.perf_counter()
+        done = 0
+        for i in range(n_tokens):
+            tok = sampling.greedy(logits, [cfg["image_token_id"]], [], False)
+            logits = llm.logits(llm.forward(llm.embed(torch.tensor([tok])))[-1])
+            done += 1
+            if time.perf_counter() - t1 > 30.0 and done >= 2:
+                break
+        dt = time.perf_counter() - t1
+    return {
+        "value": done / dt, "unit": "tokens/s", "cores": torch.get_num_threads(),
+        "host_cpus": len(os.sched_getaffinity(0)), "kind": "port",
+        "sample": f"{done} greedy decode steps at context {ids.numel()}+ of the {cfg['layers']}-layer d={cfg['hidden']} decoder "
+                  f"(bf16 weights, native bf16 GEMV with fp32 accumulate; prefix prefill and weight copy-back "
+                  f"({t_load:.0f} s) not timed; no CPU ViT)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from detikzify_amd import dist as ddist
+    from detikzify_amd.model import load
+    from detikzify_amd.util import expand
+    from tests.helpers import sketch_image
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        ddist.init_process_group("nccl", timeout_s=1800)
+
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank)
+    model.reuse_prefix = bool(args.reuse)
+    cfg = model.config
+    img = sketch_image(0, 224)
+    img = expand(img, max(img.size), do_trim=True)                 # P1 (host)
+    enc = proc(images=img, return_tensors="pt")                    # P2/P3 (host): pixels resident before timing
+    ids, px = enc.input_ids, enc.pixel_values
+    T0 = ids.shape[1]
+    n_new = args.new_tokens
+    gen_kw = dict(pixel_values=px, bad_words_ids=[[cfg.image_token_id]], begin_suppress_tokens=[cfg.eos_token_id],
+                  suppress_tokens=[cfg.eos_token_id], max_new_tokens=n_new, eos_token_id=-1)
+    if args.sample:
+        gen_kw.update(do_sample=True, temperature=0.8, top_p=0.95, top_k=0)
+    else:
+        gen_kw.update(do_sample=False)
+
+    def rollout(i):
+        out = model.generate(input_ids=ids, seed=1000 + rank + 7919 * i, **gen_kw)
+        assert out.shape[1] == T0 + n_new
+        return out[0, T0:]
+
+    def fence():
+        model.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        rollout(-1 - i)
+    fence()
+    per_step, prefill_ms, vit_ms = [], [], []
+    t0 = time.perf_counter()
+    codes = []
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        toks = rollout(i)
+        per_step.append(time.perf_counter() - ts)
+        st = model.stats()
+        prefill_ms.append(st["last_prefill_ms"]); vit_ms.append(st["last_vit_ms"])
+        codes.append(proc.decode(toks, skip_special_tokens=True))
+    if world > 1:   # the path's one exchange: finished TikZ strings to every rank (rank 0 scores them)
+        gathered = ddist.gather_objects(codes)
+        assert len(gathered) == world
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_tokens = world * args.steps * n_new
+    value = total_tokens / elapsed
+    st = model.stats()
+    W, Kb = st["weight_bytes_per_token"], st["kv_bytes_per_ctx_token"]
+    mean_ctx = T0 + (n_new - 1) / 2.0
+    bytes_per_token = W + Kb * mean_ctx
+    dec_s = [s - p / 1e3 for s, p in zip(per_step, prefill_ms)]
+    decode_tok_s = n_new / (sum(dec_s) / len(dec_s))
+    result = {
+        "metric": "tikz_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} (synthetic weights, seed 1234), 1 image 224x224->384x384, 243-token prefix, "
+                               f"{'sampling T=.8 p=.95' if args.sample else 'greedy'} decode of {n_new} tokens per rollout, "
+                               f"batch 1 per GPU, hipGraph per token" + (", image/prefix reuse" if args.reuse else ""),
+                   "tokens_per_rollout": n_new, "prefix_tokens": T0, "rollouts_per_gpu": args.steps},
+        "rollouts_per_sec": world * args.steps / elapsed,
+        "decode_tokens_per_sec_per_gpu": decode_tok_s,
+        "prefill_ms": sum(prefill_ms) / len(prefill_ms), "vit_ms": sum(vit_ms) / len(vit_ms),
+        "decode_step": {"algorithmic_bytes_per_token": bytes_per_token, "achieved_GBps": bytes_per_token * decode_tok_s / 1e9,
+                        "frac_of_hbm_peak": bytes_per_token * decode_tok_s / 1e9 / HBM_PEAK_GBS,
+                        "roofline_tokens_per_sec": HBM_PEAK_GBS * 1e9 / bytes_per_token},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)
+        roof = {"bound": "hbm", "kernel": "k_gemv<PRO_RMSNORM,EPI_SWIGLU> (post_attention_layernorm + gate/up GEMV + SiLU*mul)",
+                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        try:
+            model.set_graph_mode(2)
+            before = model.stats()
+            model.generate(input_ids=ids, **{**gen_kw, "max_new_tokens": args.probe_tokens})
+            after = model.stats()
+            model.set_graph_mode(1)
+            n = after["probe_kernel_launches"] - before["probe_kernel_launches"]
+            ms = after["probe_kernel_ms_sum"] - before["probe_kernel_ms_sum"]
+            if n > 0 and ms > 0:
+                avg_ms = ms / n
+                ach = after["probe_kernel_bytes"] / (avg_ms * 1e-3) / 1e9
+                roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_us=avg_ms * 1e3,
+                            bytes_per_launch=after["probe_kernel_bytes"], launches_timed=n)
+        except Exception as e:  # the bench line must still be printed
+            roof["error"] = repr(e)
+            model.set_graph_mode(1)
+        result["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(model, cfg.kernel_dict(), ids[0], args.cpu_tokens)
+            except Exception as e:
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

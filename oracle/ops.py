@@ -10,7 +10,12 @@ def rb(x: torch.Tensor, precision: str = "bf16") -> torch.Tensor:
 
 
 def linear(x, w, b=None, precision="bf16"):
-    """nn.Linear on bf16 tensors: fp32 accumulate (+ bias), one rounding of the output."""
+    """nn.Linear on bf16 tensors: fp32 accumulate (+ bias), one rounding of the output.
+    Weights stored as torch.bfloat16 take the native bf16 GEMM (fp32 accumulate, bf16 output —
+    the same rounding point, half the memory: what HF does on a CPU in bf16)."""
+    if w.dtype == torch.bfloat16:
+        y = torch.nn.functional.linear(x.to(torch.bfloat16), w, None if b is None else b.to(torch.bfloat16))
+        return y.float()
     y = x @ w.t()
     if b is not None:
         y = y + b
