@@ -488,7 +488,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   const int vhd = cfg->vit_dim / cfg->vit_heads;
   if (vhd != 72 && vhd != 128 && vhd != 64 && vhd != 32)
     return fail(nullptr, DTK_ERR_ARG, "unsupported ViT head dim %d", vhd);
-  if (cfg->vit_image % cfg->vit_patch) return fail(nullptr, DTK_ERR_ARG, "image %% patch != 0");
+  // timm PatchEmbed = Conv2d(stride p): 384/14 -> 27 patches per side, the 6 trailing pixels are dropped
   const int np = cfg->vit_image / cfg->vit_patch;
   if ((np * np) % cfg->concat_patches) return fail(nullptr, DTK_ERR_ARG, "patches %% concat != 0");
   if (cfg->max_positions < 8 || cfg->vocab < 2) return fail(nullptr, DTK_ERR_ARG, "bad sizes");

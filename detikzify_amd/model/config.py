@@ -114,12 +114,12 @@ class DetikzifyConfig:
 
 def _tiny() -> DetikzifyConfig:
     # exercises every kernel path of the real models at toy size: hd 128 decoder heads, ViT head
-    # dim 72, mlp % 32 == 16, patch K (588) padded to 592, N=36 patches (not a tile multiple)
+    # dim 72, mlp % 32 == 16, patch K (588) padded to 592, image 90 % 14 = 6 trailing pixels dropped like 384 % 14, N=36 patches
     return DetikzifyConfig(hidden=256, layers=2, heads=2, ffn=688, vocab=512, max_positions=160,
                            rms_eps=1e-6, rope_theta=100000.0, rope_factor=4.0,
                            bos_token_id=1, eos_token_id=2, pad_token_id=0, patch_token_id=1,
                            vit_dim=144, vit_depth=2, vit_heads=2, vit_mlp=304, vit_patch=14,
-                           vit_image=84, vit_feature_layer=1, attn_splits=4,
+                           vit_image=90, vit_feature_layer=1, attn_splits=4,
                            name_or_path="detikzify-tiny")
 
 

@@ -38,8 +38,9 @@ def gelu(x, tanh: bool, precision="bf16"):
 def im2col(pixels: torch.Tensor, patch: int) -> torch.Tensor:
     """[3,S,S] -> [N, 3*p*p] with column order (c, kh, kw) = flattening of the conv weight."""
     c, s, _ = pixels.shape
-    n = s // patch
-    x = pixels.view(c, n, patch, n, patch).permute(1, 3, 0, 2, 4)  # py, px, c, kh, kw
+    n = s // patch                      # Conv2d(stride=patch) drops the trailing s % patch pixels
+    pixels = pixels[:, : n * patch, : n * patch]
+    x = pixels.reshape(c, n, patch, n, patch).permute(1, 3, 0, 2, 4)  # py, px, c, kh, kw
     return x.reshape(n * n, c * patch * patch)
 
 

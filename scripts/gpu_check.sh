@@ -11,8 +11,8 @@ echo "== rocminfo"; (rocminfo | grep -E "Marketing Name|gfx" | head -4) 2>&1 | t
 nproc | tee -a "$OUT/device.txt"; free -g | head -2 | tee -a "$OUT/device.txt"
 
 echo "== pytest -m gpu"
-if [ "$MODE" = quick ]; then K='-k not full_size'; else K=''; fi
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -s $K -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
+if [ "$MODE" = quick ]; then KARGS=(-k "not full_size"); else KARGS=(); fi
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -s "${KARGS[@]}" -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/pytest_gpu.log"
 grep -E "passed|failed|error" "$OUT/pytest_gpu.log" | tail -3
 
