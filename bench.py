@@ -54,22 +54,22 @@ def cpu_baseline(model, cfg, ids, n_tokens):
     from oracle import sampling
     from oracle.llama import LlamaOracle
     t0 = time.perf_counter()
+    import psutil
     names = [n for n in model.tensor_names() if n.startswith(("model.layers.", "model.norm", "lm_head", "model.embed"))]
+    total = sum(model.lib.dtk_tensor_numel(model._ctx, n.encode()) for n in names)
+    fp32 = psutil.virtual_memory().available > 6 * total + (8 << 30)   # fp32 copies when the host has the RAM
+    shapes = {"down_proj": (cfg["hidden"], cfg["ffn"]), "gate_proj": (cfg["ffn"], cfg["hidden"]),
+              "up_proj": (cfg["ffn"], cfg["hidden"])}
     w = {}
     for n in names:
         t = model.read_tensor(n)
-        numel = t.numel()
         if n.endswith("layernorm.weight") or n == "model.norm.weight":
             w[n] = t.float()
-        elif "down_proj" in n:
-            w[n] = t.view(cfg["hidden"], cfg["ffn"])
-        elif "gate_proj" in n or "up_proj" in n:
-            w[n] = t.view(cfg["ffn"], cfg["hidden"])
-        elif n in ("model.embed_tokens.weight", "lm_head.weight"):
-            w[n] = t.view(cfg["vocab"], cfg["hidden"])
-        else:
-            w[n] = t.view(cfg["hidden"], cfg["hidden"])
-        assert w[n].numel() == numel
+            continue
+        key = n.split(".")[-2]
+        shape = shapes.get(key, (cfg["vocab"], cfg["hidden"]) if n in ("model.embed_tokens.weight", "lm_head.weight")
+                           else (cfg["hidden"], cfg["hidden"]))
+        w[n] = t.view(*shape).float() if fp32 else t.view(*shape)
     w["model.embed_tokens.weight"] = w["model.embed_tokens.weight"].float()
     llm = LlamaOracle(cfg, w, precision="bf16")
     t_load = time.perf_counter() - t0
@@ -89,7 +89,7 @@ def cpu_baseline(model, cfg, ids, n_tokens):
         "value": done / dt, "unit": "tokens/s", "cores": torch.get_num_threads(),
         "host_cpus": len(os.sched_getaffinity(0)), "kind": "port",
         "sample": f"{done} greedy decode steps at context {ids.numel()}+ of the {cfg['layers']}-layer d={cfg['hidden']} decoder "
-                  f"(bf16 weights, native bf16 GEMV with fp32 accumulate; prefix prefill and weight copy-back "
+                  f"({'bf16 weights upcast to fp32, fp32 GEMV' if fp32 else 'bf16 weights, native bf16 GEMV'}; prefix prefill and weight copy-back "
                   f"({t_load:.0f} s) not timed; no CPU ViT)",
     }
 

@@ -71,6 +71,8 @@ SYMBOLS = {
     "dtk_set_graph_mode": (C.c_int, [_P, C.c_int]),
     "dtk_synchronize": (C.c_int, [_P]),
     "dtk_get_stats": (C.c_int, [_P, C.POINTER(DtkStats)]),
+    "dtk_bench_gemv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "dtk_set_gemv_variant": (C.c_int, [_P, C.c_int, C.c_int]),
     "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "dtk_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

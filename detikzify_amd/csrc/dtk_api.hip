@@ -77,6 +77,9 @@ struct dtk_ctx {
   // decode step
   bf16_t *x, *q, *act;
   float *logits, *pm, *pl, *po;
+  bf16_t* attn_out = nullptr;        // combined attention output [d] (in-kernel combine)
+  unsigned* attn_ctr = nullptr;      // [H] arrival tickets
+  bool attn_combine = true;
   DecState* st = nullptr;
   SamplingDev* sp = nullptr;
   int64_t* tok_ring_dev = nullptr;   // device ring
@@ -109,6 +112,7 @@ struct dtk_ctx {
   hipGraphExec_t graph_exec = nullptr;
   bool gemm_naive = false;
   int probe = 0;
+  bool probe_pending = false;
   dtk_stats stats{};
 };
 
@@ -298,7 +302,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->logits = P.take<float>(V);
   c->pm = P.take<float>((size_t)c->H * c->S);
   c->pl = P.take<float>((size_t)c->H * c->S);
-  c->po = P.take<float>((size_t)c->H * c->S * 128);
+  c->po = P.take<float>((size_t)c->H * c->S * 130);
+  c->attn_out = P.take<bf16_t>(d);
+  c->attn_ctr = P.take<unsigned>(c->H);
   c->st = P.take<DecState>(1);
   c->sp = P.take<SamplingDev>(1);
   c->tok_ring_dev = P.take<int64_t>(DTK_MAX_INFLIGHT);
@@ -419,10 +425,12 @@ void decode_step_launches(dtk_ctx* c, bool with_probe) {
     ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
     ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax;
     ad.scale = scale;
+    ad.combine = c->attn_combine ? 1 : 0; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     launch_attn_decode(ad, s);
-    // 3. combine + o_proj + residual
+    // 3. (combine +) o_proj + residual
     g.W = w.wo; g.N = c->d; g.K = c->d; g.y = c->x;
-    launch_gemv(PRO_ATTN, EPI_RESID, g, s);
+    if (c->attn_combine) { g.x = c->attn_out; launch_gemv(PRO_COPY, EPI_RESID, g, s); }
+    else launch_gemv(PRO_ATTN, EPI_RESID, g, s);
     // 4. post_attention_layernorm + gate/up + SiLU*mul
     g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act;
     const bool probe_here = with_probe && (l == c->L / 2);
@@ -512,6 +520,19 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->nImg = c->vN / cfg->concat_patches;
   const char* gm = getenv("DTK_GEMM");
   c->gemm_naive = gm && !strcmp(gm, "naive");
+  const char* ac = getenv("DTK_ATTN_COMBINE");
+  c->attn_combine = !(ac && !strcmp(ac, "consumer"));
+  if (c->S > 16) c->S = 16;
+  if (const char* gv = getenv("DTK_GEMV_VARIANTS")) {  // "epi:variant,epi:variant" (tuning aid)
+    int e = 0, v = 0;
+    const char* p = gv;
+    while (sscanf(p, "%d:%d", &e, &v) == 2) {
+      set_gemv_default_variant(e, v);
+      p = strchr(p, ',');
+      if (!p) break;
+      ++p;
+    }
+  }
 
 #define CCHK(call)                                                                         \
   do {                                                                                     \
@@ -809,7 +830,18 @@ int dtk_decode_launch(dtk_ctx* c) {
     if (rc) return rc;
     HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
   } else {
+    if (c->probe && c->launched > c->waited) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->probe && c->probe_pending) {  // read the previous step's pair before re-recording it
+      float ms = 0.f;
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (hipEventElapsedTime(&ms, c->probe_a, c->probe_b) == hipSuccess) {
+        c->stats.probe_kernel_ms_sum += ms;
+        c->stats.probe_kernel_launches++;
+      }
+      c->probe_pending = false;
+    }
     decode_step_launches(c, c->probe != 0);
+    if (c->probe) c->probe_pending = true;
     HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->step_done[c->launched % DTK_MAX_INFLIGHT], c->stream));
@@ -832,13 +864,6 @@ int dtk_decode_wait(dtk_ctx* c, int64_t* token_out) {
   *token_out = tok;
   const size_t idx = c->cached_ids.size() - (size_t)(c->launched - k);
   c->cached_ids[idx] = tok;
-  if (c->probe) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->probe_a, c->probe_b) == hipSuccess) {
-      c->stats.probe_kernel_ms_sum += ms;
-      c->stats.probe_kernel_launches++;
-    }
-  }
   c->waited++;
   return DTK_OK;
 }
@@ -871,6 +896,48 @@ int dtk_synchronize(dtk_ctx* c) {
 int dtk_get_stats(dtk_ctx* c, dtk_stats* out) {
   if (!c || !out) return DTK_ERR_ARG;
   *out = c->stats;
+  return DTK_OK;
+}
+
+// In-situ microbenchmark of one decode GEMV role over all layers (distinct weights per launch,
+// so nothing is served from the 256 MB Infinity Cache): avg microseconds per launch via HIP events.
+// role: 0 qkv, 1 o_proj, 2 gate/up, 3 down, 4 lm_head.  Clobbers the decode state.
+int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
+  if (!c || !avg_us || reps < 1) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  auto one_pass = [&]() {
+    for (int l = 0; l < c->L; ++l) {
+      const LayerW& w = c->layers[l];
+      GemvArgs g{};
+      g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
+      if (role == 0) { g.W = w.wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch_gemv_variant(PRO_RMSNORM, EPI_QKV, variant, g, s); }
+      else if (role == 1) { g.W = w.wo; g.N = c->d; g.K = c->d; g.x = c->attn_out; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
+      else if (role == 2) { g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act; launch_gemv_variant(PRO_RMSNORM, EPI_SWIGLU, variant, g, s); }
+      else if (role == 3) { g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
+      else { g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm; g.logits = c->logits; launch_gemv_variant(PRO_RMSNORM, EPI_LOGITS, variant, g, s); }
+    }
+  };
+  one_pass();  // warm-up (code objects, clocks)
+  HIPCHK(c, hipEventRecord(c->ev_a, s));
+  for (int r = 0; r < reps; ++r) one_pass();
+  HIPCHK(c, hipEventRecord(c->ev_b, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+  *avg_us = ms * 1e3f / (float)(reps * c->L);
+  c->have_logits = false;
+  return DTK_OK;
+}
+
+int dtk_set_gemv_variant(dtk_ctx* c, int epi, int variant) {
+  if (!c) return DTK_ERR_ARG;
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  c->graph_ready = false;
+  set_gemv_default_variant(epi, variant);
   return DTK_OK;
 }
 

@@ -34,14 +34,19 @@ struct GemvArgs {
 };
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s);
+void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipStream_t s);
+void set_gemv_default_variant(int epi, int variant);
 
 struct AttnDecArgs {
   const bf16_t* q;       // [H*128] (RoPE applied)
   const bf16_t* kcache;  // [H][T_max][128]
   const bf16_t* vcache;
   const DecState* st;    // keys 0..st->pos
-  float* pm; float* pl; float* po;   // [H][S], [H][S], [H][S][128]
+  float* pm; float* pl; float* po;   // [H][S], [H][S], [H][S][130] (130 = 128 o + m + l when combine)
   int H; int S; int T_max; float scale;
+  int combine;           // 1: the last-arriving split of a head writes the bf16 head output
+  bf16_t* out;           // [H*128] attention output (combine)
+  unsigned* counters;    // [H] arrival tickets, zero between launches
 };
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s);
 

@@ -19,9 +19,6 @@
 // next stage's loads are in flight while the current one is consumed by v_dot2c_f32_bf16.
 #include "kernels.h"
 
-#define GEMV_THREADS 256
-#define GEMV_WAVES 4
-
 template <int NR, int U>
 __device__ __forceinline__ void gemv_load(u32x4 (&w)[NR][U], const u32x4* (&rows)[NR],
                                           int g, int lane, int K8) {
@@ -50,59 +47,65 @@ __device__ __forceinline__ void gemv_fma(float (&acc)[NR], const u32x4 (&w)[NR][
   }
 }
 
-// R = output units per wave; paired epilogues (QKV, SWIGLU) stream 2 rows per unit.
-template <int PRO, int EPI, int R, int U>
-__global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
+// R = output units per wave-chunk; paired epilogues (QKV, SWIGLU) stream 2 rows per unit.
+// WAVES = waves per block.  PERSIST: grid-stride over chunks (chunk c -> block c % grid,
+// wave (c / grid) % WAVES) so a grid sized to the machine covers any N with <= 1 chunk of
+// imbalance per wave; otherwise one chunk per wave and the grid covers N.
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST>
+__global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   constexpr bool PAIRED = (EPI == EPI_QKV) || (EPI == EPI_SWIGLU);
   constexpr int NR = PAIRED ? 2 * R : R;
+  constexpr int THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   const int K8 = a.K >> 3;
-  float* red = reinterpret_cast<float*>(smem + (size_t)K8 * 16);  // 8 floats of scratch
+  float* red = reinterpret_cast<float*>(smem + (size_t)K8 * 16);  // WAVES floats of scratch
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int gw = blockIdx.x * GEMV_WAVES + wave;  // global wave index
 
   int n_units;
   if (EPI == EPI_QKV) n_units = (a.N >> 1);
   else if (EPI == EPI_SWIGLU) n_units = a.ff;
   else n_units = a.N;
-  const int unit0 = gw * R;
-  const bool active = unit0 < n_units;  // wave-uniform
+  const int chunk_stride = PERSIST ? (int)gridDim.x * WAVES : 0;
+  int chunk = PERSIST ? (int)blockIdx.x + (int)gridDim.x * wave : (int)blockIdx.x * WAVES + wave;
+  int unit0 = chunk * R;
 
-  // ---- weight row pointers of this wave (clamped so inactive tails never fault)
   const u32x4* rows[NR];
-  int rowidx[NR];
+  auto set_rows = [&](int u0) {
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    int u = unit0 + j;
-    if (u >= n_units) u = n_units - 1;
-    if (EPI == EPI_QKV) {
-      const int half = a.d >> 1;
-      const int sec = u / half;
-      const int pi = u - sec * half;
-      const int head = pi >> 6, i = pi & 63;
-      rowidx[2 * j] = sec * a.d + head * 128 + i;
-      rowidx[2 * j + 1] = rowidx[2 * j] + 64;
-    } else if (EPI == EPI_SWIGLU) {
-      rowidx[2 * j] = u;
-      rowidx[2 * j + 1] = a.ff + u;
-    } else {
-      rowidx[j] = u;
+    for (int j = 0; j < R; ++j) {
+      int u = u0 + j;
+      if (u >= n_units) u = n_units - 1;  // clamped: inactive tails never fault
+      int r0, r1 = 0;
+      if (EPI == EPI_QKV) {
+        const int half = a.d >> 1;
+        const int sec = u / half;
+        const int pi = u - sec * half;
+        r0 = sec * a.d + (pi >> 6) * 128 + (pi & 63);
+        r1 = r0 + 64;
+      } else if (EPI == EPI_SWIGLU) {
+        r0 = u;
+        r1 = a.ff + u;
+      } else {
+        r0 = u;
+      }
+      if (PAIRED) {
+        rows[2 * j] = reinterpret_cast<const u32x4*>(a.W + (size_t)r0 * a.K);
+        rows[2 * j + 1] = reinterpret_cast<const u32x4*>(a.W + (size_t)r1 * a.K);
+      } else {
+        rows[j] = reinterpret_cast<const u32x4*>(a.W + (size_t)r0 * a.K);
+      }
     }
-  }
-#pragma unroll
-  for (int r = 0; r < NR; ++r)
-    rows[r] = reinterpret_cast<const u32x4*>(a.W + (size_t)rowidx[r] * a.K);
+  };
+  set_rows(unit0);
 
   const int iters = (K8 + 63) >> 6;
   const int G = (iters + U - 1) / U;
   u32x4 wa[NR][U], wb[NR][U];
   float acc[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
 
   // first stage of weights goes in flight before the prologue touches x
   gemv_load<NR, U>(wa, rows, 0, lane, K8);
@@ -110,12 +113,12 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   // ---- prologue: build the bf16 input vector in LDS
   if (PRO == PRO_COPY) {
     const u32x4* x4 = reinterpret_cast<const u32x4*>(a.x);
-    for (int c = tid; c < K8; c += GEMV_THREADS) xs[c] = x4[c];
+    for (int c = tid; c < K8; c += THREADS) xs[c] = x4[c];
   } else if (PRO == PRO_RMSNORM) {
     const u32x4* x4 = reinterpret_cast<const u32x4*>(a.x);
     const u32x4* w4 = reinterpret_cast<const u32x4*>(a.norm_w);
     float ss = 0.f;
-    for (int c = tid; c < K8; c += GEMV_THREADS) {
+    for (int c = tid; c < K8; c += THREADS) {
       const u32x4 v = x4[c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -127,9 +130,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) tot += red[w];
     const float inv = rsqrtf(tot / (float)a.K + a.eps);
-    for (int c = tid; c < K8; c += GEMV_THREADS) {
+    for (int c = tid; c < K8; c += THREADS) {
       const u32x4 v = x4[c];
       const u32x4 g = w4[c];
       u32x4 o;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     }
   } else {  // PRO_ATTN: reduce the S split-K partials of every head (flash-decode combine)
     const int S = a.S;
-    for (int c = tid; c < K8; c += GEMV_THREADS) {
+    for (int c = tid; c < K8; c += THREADS) {
       const int head = c >> 4;       // 16 chunks of 8 dims per 128-dim head
       const int d0 = (c & 15) * 8;
       float M = -1e30f;
@@ -173,84 +178,162 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   }
   __syncthreads();
 
-  // ---- main loop: two register stages
-  for (int g = 0; g < G; g += 2) {
-    if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, K8);
-    gemv_fma<NR, U>(acc, wa, xs, g, lane, K8);
-    if (g + 1 < G) {
-      if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, K8);
-      gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, K8);
-    }
-  }
+  for (;;) {
+    const bool active = unit0 < n_units;  // wave-uniform
 #pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
-
-  if (!active || lane != 0) return;
-
-  // ---- epilogue (one lane per wave; a handful of scalars)
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int u = unit0 + j;
-    if (u >= n_units) break;
-    if (EPI == EPI_STORE) {
-      a.y[u] = f2bf(acc[j]);
-    } else if (EPI == EPI_RESID) {
-      // HF: hidden = residual + proj(x); proj output is a bf16 tensor
-      a.y[u] = f2bf(bf2f(a.y[u]) + rbf(acc[j]));
-    } else if (EPI == EPI_LOGITS) {
-      a.logits[u] = rbf(acc[j]);  // lm_head output is bf16, then .float()
-    } else if (EPI == EPI_SWIGLU) {
-      const float gte = rbf(acc[2 * j]);
-      const float up = rbf(acc[2 * j + 1]);
-      const float sl = rbf(gte / (1.f + expf(-gte)));
-      a.y[u] = f2bf(sl * up);
-    } else if (EPI == EPI_QKV) {
-      const int half = a.d >> 1;
-      const int sec = u / half;
-      const int pi = u - sec * half;
-      const int head = pi >> 6, i = pi & 63;
-      const int pos = a.st->pos;
-      const float x1 = rbf(acc[2 * j]);      // dim i
-      const float x2 = rbf(acc[2 * j + 1]);  // dim i + 64
-      if (sec == 2) {
-        bf16_t* dst = a.vcache + ((size_t)head * a.T_max + pos) * 128;
-        dst[i] = f2bf(x1);
-        dst[i + 64] = f2bf(x2);
-      } else {
-        // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
-        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
-        const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
-        const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
-        bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
-                                 : (a.kcache + ((size_t)head * a.T_max + pos) * 128);
-        dst[i] = f2bf(o1);
-        dst[i + 64] = f2bf(o2);
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    // ---- main loop: two register stages (wa holds stage 0 on entry)
+    for (int g = 0; g < G; g += 2) {
+      if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, K8);
+      gemv_fma<NR, U>(acc, wa, xs, g, lane, K8);
+      if (g + 1 < G) {
+        if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, K8);
+        gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, K8);
       }
     }
+    const int cur = unit0;
+    if (PERSIST) {  // next chunk's first stage goes in flight before this chunk's reduction
+      chunk += chunk_stride;
+      unit0 = chunk * R;
+      if (unit0 < n_units) {
+        set_rows(unit0);
+        gemv_load<NR, U>(wa, rows, 0, lane, K8);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+
+    // ---- epilogue (one lane per wave; a handful of scalars)
+    if (active && lane == 0) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int u = cur + j;
+        if (u >= n_units) break;
+        if (EPI == EPI_STORE) {
+          a.y[u] = f2bf(acc[j]);
+        } else if (EPI == EPI_RESID) {
+          // HF: hidden = residual + proj(x); proj output is a bf16 tensor
+          a.y[u] = f2bf(bf2f(a.y[u]) + rbf(acc[j]));
+        } else if (EPI == EPI_LOGITS) {
+          a.logits[u] = rbf(acc[j]);  // lm_head output is bf16, then .float()
+        } else if (EPI == EPI_SWIGLU) {
+          const float gte = rbf(acc[2 * j]);
+          const float up = rbf(acc[2 * j + 1]);
+          const float sl = rbf(gte / (1.f + expf(-gte)));
+          a.y[u] = f2bf(sl * up);
+        } else if (EPI == EPI_QKV) {
+          const int half = a.d >> 1;
+          const int sec = u / half;
+          const int pi = u - sec * half;
+          const int head = pi >> 6, i = pi & 63;
+          const int pos = a.st->pos;
+          const float x1 = rbf(acc[2 * j]);      // dim i
+          const float x2 = rbf(acc[2 * j + 1]);  // dim i + 64
+          if (sec == 2) {
+            bf16_t* dst = a.vcache + ((size_t)head * a.T_max + pos) * 128;
+            dst[i] = f2bf(x1);
+            dst[i + 64] = f2bf(x2);
+          } else {
+            // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
+            const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+            const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+            const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+            const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+            bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
+                                     : (a.kcache + ((size_t)head * a.T_max + pos) * 128);
+            dst[i] = f2bf(o1);
+            dst[i + 64] = f2bf(o2);
+          }
+        }
+      }
+    }
+    if (!PERSIST || unit0 >= n_units) break;
   }
 }
 
-template <int PRO, int EPI, int R, int U>
-static void launch_gemv_t(const GemvArgs& a, hipStream_t s) {
-  int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
-  const int per_block = GEMV_WAVES * R;
-  const int grid = (n_units + per_block - 1) / per_block;
-  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
-  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U>), dim3(grid), dim3(GEMV_THREADS), lds, s, a);
+// number of CUs of the current device (cached) — persistent grids are sized from it
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
 }
 
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST>
+static void launch_gemv_t(const GemvArgs& a, hipStream_t s, int blocks_per_cu) {
+  int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
+  const int per_block = WAVES * R;
+  int grid = (n_units + per_block - 1) / per_block;
+  if (PERSIST) {
+    const int cap = num_cus() * (blocks_per_cu > 0 ? blocks_per_cu : 2);
+    if (grid > cap) grid = cap;
+  }
+  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
+  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, PERSIST>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+}
+
+// Tuning table: variant -> instantiation.  Variant 0 is the product default for each role; the
+// others exist for the in-situ microbenchmark (dtk_bench_gemv) that picked the default.
+#define GV(PRO, EPI, R, U, W, P, BPC) return launch_gemv_t<PRO, EPI, R, U, W, P>(a, s, BPC)
+void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipStream_t s) {
+  if (pro == PRO_RMSNORM && epi == EPI_QKV) {
+    switch (variant) {
+      default: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 4, false, 0);
+      case 1: GV(PRO_RMSNORM, EPI_QKV, 1, 4, 4, false, 0);
+      case 2: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 8, false, 0);
+      case 3: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 4, true, 4);
+      case 4: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 8, true, 2);
+      case 5: GV(PRO_RMSNORM, EPI_QKV, 1, 4, 8, true, 2);
+      case 6: GV(PRO_RMSNORM, EPI_QKV, 4, 1, 4, false, 0);
+      case 7: GV(PRO_RMSNORM, EPI_QKV, 1, 2, 4, false, 0);
+    }
+  }
+  if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) {
+    switch (variant) {
+      default: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, false, 0);
+      case 1: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 4, 4, false, 0);
+      case 2: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 8, false, 0);
+      case 3: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, true, 4);
+      case 4: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 8, true, 2);
+      case 5: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 4, 8, true, 2);
+      case 6: GV(PRO_RMSNORM, EPI_SWIGLU, 4, 1, 4, false, 0);
+      case 7: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4, false, 0);
+    }
+  }
+  if (pro == PRO_COPY && epi == EPI_RESID) {
+    switch (variant) {
+      default: GV(PRO_COPY, EPI_RESID, 2, 4, 4, false, 0);
+      case 1: GV(PRO_COPY, EPI_RESID, 1, 4, 4, false, 0);
+      case 2: GV(PRO_COPY, EPI_RESID, 4, 2, 4, false, 0);
+      case 3: GV(PRO_COPY, EPI_RESID, 2, 4, 8, false, 0);
+      case 4: GV(PRO_COPY, EPI_RESID, 2, 4, 4, true, 4);
+      case 5: GV(PRO_COPY, EPI_RESID, 2, 4, 8, true, 2);
+      case 6: GV(PRO_COPY, EPI_RESID, 1, 8, 4, false, 0);
+      case 7: GV(PRO_COPY, EPI_RESID, 2, 2, 4, false, 0);
+    }
+  }
+  if (pro == PRO_ATTN && epi == EPI_RESID) GV(PRO_ATTN, EPI_RESID, 2, 4, 4, false, 0);
+  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) {
+    switch (variant) {
+      default: GV(PRO_RMSNORM, EPI_LOGITS, 4, 2, 4, false, 0);
+      case 1: GV(PRO_RMSNORM, EPI_LOGITS, 4, 2, 8, true, 2);
+      case 2: GV(PRO_RMSNORM, EPI_LOGITS, 2, 4, 4, false, 0);
+    }
+  }
+  if (pro == PRO_RMSNORM && epi == EPI_STORE) GV(PRO_RMSNORM, EPI_STORE, 4, 2, 4, false, 0);
+  GV(PRO_COPY, EPI_STORE, 4, 2, 4, false, 0);
+}
+#undef GV
+
+static int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-epilogue default variant (tuned)
+void set_gemv_default_variant(int epi, int variant) { if (epi >= 0 && epi < 8) g_variant[epi] = variant; }
+
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s) {
-  // R/U: 4 streamed rows per wave, 2x2 16-byte loads per row in flight
-  if (pro == PRO_RMSNORM && epi == EPI_QKV) return launch_gemv_t<PRO_RMSNORM, EPI_QKV, 2, 2>(a, s);
-  if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_gemv_t<PRO_RMSNORM, EPI_SWIGLU, 2, 2>(a, s);
-  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_gemv_t<PRO_RMSNORM, EPI_LOGITS, 4, 2>(a, s);
-  if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_gemv_t<PRO_RMSNORM, EPI_STORE, 4, 2>(a, s);
-  if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_t<PRO_ATTN, EPI_RESID, 2, 4>(a, s);
-  if (pro == PRO_COPY && epi == EPI_RESID) return launch_gemv_t<PRO_COPY, EPI_RESID, 2, 4>(a, s);
-  if (pro == PRO_COPY && epi == EPI_STORE) return launch_gemv_t<PRO_COPY, EPI_STORE, 4, 2>(a, s);
-  // unreachable for the product path
-  launch_gemv_t<PRO_COPY, EPI_STORE, 4, 2>(a, s);
+  launch_gemv_variant(pro, epi, g_variant[epi & 7], a, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -346,13 +429,64 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
       for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
     }
     const size_t slot = (size_t)h * a.S + sp;
-    float* dst = a.po + slot * 128 + tid * 8;
+    if (!a.combine) {  // consumer-side combine (k_gemv<PRO_ATTN>)
+      float* dst = a.po + slot * 128 + tid * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = oo[e];
-    if (tid == 0) {
-      a.pm[slot] = M;
-      a.pl[slot] = L;
+      for (int e = 0; e < 8; ++e) dst[e] = oo[e];
+      if (tid == 0) {
+        a.pm[slot] = M;
+        a.pl[slot] = L;
+      }
+      return;
     }
+    // ---- in-kernel combine by the last-arriving split of this head (placement independent):
+    // partials are published with 8-byte agent-scope (write-through, sc1) stores, drained, then
+    // one relaxed agent-scope ticket; the block that draws S-1 reads them back with agent-scope
+    // loads (guide: "8-B agent atomics both sides"), normalises, rounds once to bf16.
+    typedef unsigned long long u64;
+    u64* part = reinterpret_cast<u64*>(a.po) + slot * 65;  // 64 x {o,o} + {m,l}
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u64 v = (u64)__float_as_uint(oo[2 * e]) | ((u64)__float_as_uint(oo[2 * e + 1]) << 32);
+      __hip_atomic_store(part + tid * 4 + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+      const u64 v = (u64)__float_as_uint(M) | ((u64)__float_as_uint(L) << 32);
+      __hip_atomic_store(part + 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing lane is in this wave
+    unsigned ticket = 0;
+    if (tid == 0) ticket = __hip_atomic_fetch_add(a.counters + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket != (unsigned)(a.S - 1)) return;
+    const u64* base = reinterpret_cast<u64*>(a.po) + (size_t)h * a.S * 65;
+    float Mg = -1e30f;
+    for (int s = 0; s < a.S; ++s) {
+      const u64 v = __hip_atomic_load(base + (size_t)s * 65 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Mg = fmaxf(Mg, __uint_as_float((unsigned)v));
+    }
+    float Lg = 0.f;
+    float og[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) og[e] = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const u64 mlv = __hip_atomic_load(base + (size_t)s * 65 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = __expf(__uint_as_float((unsigned)mlv) - Mg);
+      Lg += w * __uint_as_float((unsigned)(mlv >> 32));
+      const u64* src = base + (size_t)s * 65 + tid * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u64 v = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        og[2 * e] += w * __uint_as_float((unsigned)v);
+        og[2 * e + 1] += w * __uint_as_float((unsigned)(v >> 32));
+      }
+    }
+    const float invL = 1.f / Lg;
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack2(og[2 * e] * invL, og[2 * e + 1] * invL);
+    reinterpret_cast<u32x4*>(a.out + h * 128)[tid] = ov;
+    if (tid == 0) __hip_atomic_store(a.counters + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -167,6 +167,12 @@ int  dtk_set_graph_mode(dtk_ctx* ctx, int enabled);
 int  dtk_synchronize(dtk_ctx* ctx);
 int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
 
+/* Tuning aids (tools/, bench): time one decode GEMV role (0 qkv, 1 o_proj, 2 gate/up, 3 down,
+ * 4 lm_head) in kernel variant `variant` over all layers with HIP events (clobbers the decode
+ * state); select the variant the decode step uses for an epilogue class. */
+int  dtk_bench_gemv(dtk_ctx* ctx, int role, int variant, int reps, float* avg_us);
+int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
+
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the
  * hot path on host buffers.  All matrices row-major; bf16 as uint16.  They exist so a
  * failing kernel can be isolated on the GPU box; the product path never calls them. */
