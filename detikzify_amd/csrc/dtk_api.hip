@@ -79,7 +79,7 @@ struct dtk_ctx {
   float *logits, *pm, *pl, *po;
   bf16_t* attn_out = nullptr;        // combined attention output [d] (in-kernel combine)
   unsigned* attn_ctr = nullptr;      // [H] arrival tickets
-  bool attn_combine = true;
+  int attn_combine = 2;              // 0: consumer (o_proj prologue), 1: last-arriver in k_attn_decode, 2: own kernel
   DecState* st = nullptr;
   SamplingDev* sp = nullptr;
   int64_t* tok_ring_dev = nullptr;   // device ring
@@ -425,7 +425,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe) {
     ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
     ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax;
     ad.scale = scale;
-    ad.combine = c->attn_combine ? 1 : 0; ad.out = c->attn_out; ad.counters = c->attn_ctr;
+    ad.combine = c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.N = c->d; g.K = c->d; g.y = c->x;
@@ -521,7 +521,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   const char* gm = getenv("DTK_GEMM");
   c->gemm_naive = gm && !strcmp(gm, "naive");
   const char* ac = getenv("DTK_ATTN_COMBINE");
-  c->attn_combine = !(ac && !strcmp(ac, "consumer"));
+  c->attn_combine = !ac ? 2 : (!strcmp(ac, "consumer") ? 0 : (!strcmp(ac, "inkernel") ? 1 : 2));
   if (c->S > 16) c->S = 16;
   if (const char* gv = getenv("DTK_GEMV_VARIANTS")) {  // "epi:variant,epi:variant" (tuning aid)
     int e = 0, v = 0;

@@ -282,7 +282,11 @@ static void launch_gemv_t(const GemvArgs& a, hipStream_t s, int blocks_per_cu) {
 void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipStream_t s) {
   if (pro == PRO_RMSNORM && epi == EPI_QKV) {
     switch (variant) {
-      default: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 4, false, 0);
+      default: GV(PRO_RMSNORM, EPI_QKV, 1, 2, 4, false, 0);
+      case 8: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 4, false, 0);
+      case 9: GV(PRO_RMSNORM, EPI_QKV, 1, 1, 4, false, 0);
+      case 10: GV(PRO_RMSNORM, EPI_QKV, 1, 2, 8, false, 0);
+      case 11: GV(PRO_RMSNORM, EPI_QKV, 1, 2, 2, false, 0);
       case 1: GV(PRO_RMSNORM, EPI_QKV, 1, 4, 4, false, 0);
       case 2: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 8, false, 0);
       case 3: GV(PRO_RMSNORM, EPI_QKV, 2, 2, 4, true, 4);
@@ -294,7 +298,11 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
   }
   if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) {
     switch (variant) {
-      default: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, false, 0);
+      default: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4, false, 0);
+      case 8: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, false, 0);
+      case 9: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 1, 4, false, 0);
+      case 10: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 8, false, 0);
+      case 11: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 2, false, 0);
       case 1: GV(PRO_RMSNORM, EPI_SWIGLU, 1, 4, 4, false, 0);
       case 2: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 8, false, 0);
       case 3: GV(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, true, 4);
@@ -306,7 +314,12 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
   }
   if (pro == PRO_COPY && epi == EPI_RESID) {
     switch (variant) {
-      default: GV(PRO_COPY, EPI_RESID, 2, 4, 4, false, 0);
+      default: GV(PRO_COPY, EPI_RESID, 1, 8, 4, false, 0);
+      case 8: GV(PRO_COPY, EPI_RESID, 2, 4, 4, false, 0);
+      case 9: GV(PRO_COPY, EPI_RESID, 1, 2, 4, false, 0);
+      case 10: GV(PRO_COPY, EPI_RESID, 1, 8, 8, false, 0);
+      case 11: GV(PRO_COPY, EPI_RESID, 1, 8, 2, false, 0);
+      case 12: GV(PRO_COPY, EPI_RESID, 1, 4, 2, false, 0);
       case 1: GV(PRO_COPY, EPI_RESID, 1, 4, 4, false, 0);
       case 2: GV(PRO_COPY, EPI_RESID, 4, 2, 4, false, 0);
       case 3: GV(PRO_COPY, EPI_RESID, 2, 4, 8, false, 0);
@@ -319,9 +332,11 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
   if (pro == PRO_ATTN && epi == EPI_RESID) GV(PRO_ATTN, EPI_RESID, 2, 4, 4, false, 0);
   if (pro == PRO_RMSNORM && epi == EPI_LOGITS) {
     switch (variant) {
-      default: GV(PRO_RMSNORM, EPI_LOGITS, 4, 2, 4, false, 0);
+      default: GV(PRO_RMSNORM, EPI_LOGITS, 2, 4, 4, false, 0);
       case 1: GV(PRO_RMSNORM, EPI_LOGITS, 4, 2, 8, true, 2);
-      case 2: GV(PRO_RMSNORM, EPI_LOGITS, 2, 4, 4, false, 0);
+      case 2: GV(PRO_RMSNORM, EPI_LOGITS, 4, 2, 4, false, 0);
+      case 3: GV(PRO_RMSNORM, EPI_LOGITS, 1, 4, 4, false, 0);
+      case 4: GV(PRO_RMSNORM, EPI_LOGITS, 1, 8, 4, false, 0);
     }
   }
   if (pro == PRO_RMSNORM && epi == EPI_STORE) GV(PRO_RMSNORM, EPI_STORE, 4, 2, 4, false, 0);
@@ -364,29 +379,39 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
 
-  for (int j0 = j_begin; j0 < j_end; j0 += 16) {
-    const int j = j0 + wave * 4 + grp;
-    const bool ok = j < j_end;
-    const int jj = ok ? j : j_begin;  // clamp: always a valid row
-    const u32x4 kv = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
-    const u32x4 vv = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
-    float s = dot8(qv, kv, 0.f);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    s *= a.scale;
-    if (ok) {
-      const float mn = fmaxf(m, s);
-      const float corr = __expf(m - mn);
-      const float p = __expf(s - mn);
-      l = l * corr + p;
+  // 64 rows per block iteration: every 16-lane group has 4 K rows + 4 V rows (8 x 16 B per lane)
+  // in flight before the first dot product, so a ~500-token context is one memory round trip
+  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+    u32x4 kv[4], vv[4];
+    bool ok[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[e]);
-        o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[e]);
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i * 16 + wave * 4 + grp;
+      ok[i] = j < j_end;
+      const int jj = ok[i] ? j : j_begin;  // clamp: always a valid row
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = dot8(qv, kv[i], 0.f);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s *= a.scale;
+      if (ok[i]) {
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn);
+        const float p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[i][e]);
+          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[i][e]);
+        }
+        m = mn;
       }
-      m = mn;
     }
   }
   // merge the 4 row-groups of the wave (lanes with equal sub)
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
       for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
     }
     const size_t slot = (size_t)h * a.S + sp;
-    if (!a.combine) {  // consumer-side combine (k_gemv<PRO_ATTN>)
+    if (a.combine != 1) {  // partials for k_attn_combine / the consumer-side combine (k_gemv<PRO_ATTN>)
       float* dst = a.po + slot * 128 + tid * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) dst[e] = oo[e];
@@ -490,8 +515,27 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
   }
 }
 
+// Reduction of the S split-K partials of every head: one 128-thread block per head, thread = dim.
+// A kernel boundary (not an in-launch hand-off) publishes the partials: measured cheaper than both
+// the consumer-side combine in o_proj's prologue (133 KB re-read by every block) and a
+// last-arriver combine inside k_attn_decode (agent-scope stores + ticket + serialized loads).
+__global__ __launch_bounds__(128) void k_attn_combine(AttnDecArgs a) {
+  const int h = blockIdx.x, t = threadIdx.x;
+  const int S = a.S;
+  float M = -1e30f;
+  for (int s = 0; s < S; ++s) M = fmaxf(M, a.pm[h * S + s]);
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float w = __expf(a.pm[h * S + s] - M);
+    L += w * a.pl[h * S + s];
+    o += w * a.po[((size_t)(h * S + s)) * 128 + t];
+  }
+  a.out[h * 128 + t] = f2bf(o / L);
+}
+
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_attn_decode, dim3(a.H, a.S), dim3(256), 0, s, a);
+  if (a.combine == 2) hipLaunchKernelGGL(k_attn_combine, dim3(a.H), dim3(128), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------
