@@ -204,6 +204,19 @@ def main():
         except Exception as e:  # the bench line must still be printed
             roof["error"] = repr(e)
             model.set_graph_mode(1)
+        # HBM traffic of that kernel from the separate rocprofv3 --pmc FETCH_SIZE pass committed under
+        # profiles/ (x2 gfx950 correction, guides/MI355X_MICROARCH.md §HBM); null if no profile matches
+        try:
+            import csv
+            prof = ROOT / "profiles" / "r01_pmc_fetch.csv"
+            if prof.exists() and args.model == "detikzify-ds-7b":
+                for row in csv.DictReader(prof.open()):
+                    if row["counter"] == "FETCH_SIZE" and row["kernel"].startswith("void k_gemv<1, 3,"):
+                        roof["traffic"] = float(row["hbm_read_bytes_per_launch_x2"])
+                        roof["traffic_source"] = "profiles/r01_pmc_fetch.csv (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)"
+                        break
+        except Exception:
+            pass
         result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             try:

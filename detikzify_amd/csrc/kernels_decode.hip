@@ -522,13 +522,25 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
 __global__ __launch_bounds__(128) void k_attn_combine(AttnDecArgs a) {
   const int h = blockIdx.x, t = threadIdx.x;
   const int S = a.S;
+  // all loads first (one memory round trip), then the arithmetic
+  float pm[16], pl[16], po[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const bool ok = s < S;
+    const int ss = ok ? s : 0;
+    pm[s] = ok ? a.pm[h * S + ss] : -1e30f;
+    pl[s] = ok ? a.pl[h * S + ss] : 0.f;
+    po[s] = ok ? a.po[((size_t)(h * S + ss)) * 128 + t] : 0.f;
+  }
   float M = -1e30f;
-  for (int s = 0; s < S; ++s) M = fmaxf(M, a.pm[h * S + s]);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) M = fmaxf(M, pm[s]);
   float L = 0.f, o = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float w = __expf(a.pm[h * S + s] - M);
-    L += w * a.pl[h * S + s];
-    o += w * a.po[((size_t)(h * S + s)) * 128 + t];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float w = __expf(pm[s] - M);
+    L += w * pl[s];
+    o += w * po[s];
   }
   a.out[h * 128 + t] = f2bf(o / L);
 }
