@@ -906,9 +906,11 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   if (!c || !avg_us || reps < 1) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  const bool same_layer = (variant & 0x100) != 0;  // every launch re-reads layer 0 (Infinity Cache probe)
+  variant &= 0xff;
   auto one_pass = [&]() {
     for (int l = 0; l < c->L; ++l) {
-      const LayerW& w = c->layers[l];
+      const LayerW& w = c->layers[same_layer ? 0 : l];
       GemvArgs g{};
       g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
       g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;

@@ -11,7 +11,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from detikzify_amd.model import load  # noqa: E402
 
-ROLES = {0: ("qkv", 12), 1: ("o_proj", 13), 2: ("gate_up", 12), 3: ("down", 13), 4: ("lm_head", 5)}
+ROLES = {0: ("qkv", 1), 1: ("o_proj", 1), 2: ("gate_up", 1), 3: ("down", 1), 4: ("lm_head", 1)}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")
@@ -33,5 +33,14 @@ for role, (name, nvar) in ROLES.items():
         gbs = bytes_of[role] / (best * 1e-6) / 1e9
         res[f"{name}/v{v}"] = {"us": best, "GBps": gbs}
         print(f"{name:8s} v{v}: {best:8.2f} us  {gbs:8.1f} GB/s", flush=True)
+# Infinity Cache probe: the same layer's weights re-read back to back (fits the 256 MB MALL for
+# every role but lm_head) vs the rotating-layer numbers above
+for role, (name, _) in ROLES.items():
+    if role == 4:
+        continue
+    us = C.c_float()
+    model._check(model.lib.dtk_bench_gemv(model._ctx, role, 0x100, args.reps, C.byref(us)), "dtk_bench_gemv")
+    res[f"{name}/same_layer"] = {"us": us.value, "GBps": bytes_of[role] / (us.value * 1e-6) / 1e9}
+    print(f"{name:8s} same-layer: {us.value:8.2f} us  {res[name + '/same_layer']['GBps']:8.1f} GB/s", flush=True)
 Path(args.out).parent.mkdir(parents=True, exist_ok=True)
 Path(args.out).write_text(json.dumps(res, indent=1))
