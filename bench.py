@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
     ap.add_argument("--probe-tokens", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8, help="independent rollouts decoded as one batch per GPU in the "
+                    "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     return ap.parse_args()
 
 
@@ -110,7 +112,7 @@ def main():
         torch.cuda.set_device(local_rank)
         ddist.init_process_group("nccl", timeout_s=1800)
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank)
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=max(0, min(16, args.batch)))
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config
     img = sketch_image(0, 224)
@@ -183,6 +185,40 @@ def main():
                         "frac_of_hbm_peak": bytes_per_token * decode_tok_s / 1e9 / HBM_PEAK_GBS,
                         "roofline_tokens_per_sec": HBM_PEAK_GBS * 1e9 / bytes_per_token},
     }
+
+    # ---- extra phase: B independent rollouts per GPU decoded as ONE batch (root-parallel trees of one
+    # GPU): the weights are streamed once per step for all B sequences
+    if args.batch > 1:
+        import threading
+        from detikzify_amd.infer.batching import BatchEngine
+        engine = BatchEngine(model, max_batch=args.batch)
+        try:
+            def one(i):
+                model.generate(input_ids=ids, seed=5000 + rank * 100 + i, **gen_kw)
+            for rep_i in range(2):          # first pass warms the batch graph up
+                fence()
+                tb = time.perf_counter()
+                ths = [threading.Thread(target=one, args=(i,)) for i in range(args.batch)]
+                [t.start() for t in ths]
+                [t.join() for t in ths]
+                fence()
+                tb = time.perf_counter() - tb
+            if world > 1:
+                t = torch.tensor([tb], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tb = float(t.item())
+            mean_ctx_b = T0 + (n_new - 1) / 2.0
+            bytes_step = W + args.batch * Kb * mean_ctx_b
+            result["batched_rollouts"] = {
+                "batch_per_gpu": args.batch, "rollouts_per_sec": world * args.batch / tb,
+                "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
+                "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
+                "note": "B independent rollouts (own KV slot, seed, prefill incl. ViT) per GPU through model.generate "
+                        "from B threads; one dtk_decode_batch step serves all of them"}
+        except Exception as e:
+            result["batched_rollouts"] = {"error": repr(e)}
+        finally:
+            engine.close()
 
     if rank == 0:
         # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)

@@ -71,6 +71,13 @@ SYMBOLS = {
     "dtk_set_graph_mode": (C.c_int, [_P, C.c_int]),
     "dtk_synchronize": (C.c_int, [_P]),
     "dtk_get_stats": (C.c_int, [_P, C.POINTER(DtkStats)]),
+    "dtk_num_slots": (C.c_int, [_P]),
+    "dtk_prefill_slot": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64, C.c_int, _P]),
+    "dtk_set_sampling_slot": (C.c_int, [_P, C.c_int, C.POINTER(DtkSampling)]),
+    "dtk_decode_batch_launch": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "dtk_decode_batch_wait": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "dtk_get_logits_slot": (C.c_int, [_P, C.c_int, _P]),
+    "dtk_context_len_slot": (C.c_int, [_P, C.c_int]),
     "dtk_bench_gemv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "dtk_set_gemv_variant": (C.c_int, [_P, C.c_int, C.c_int]),
     "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

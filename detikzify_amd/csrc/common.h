@@ -62,6 +62,13 @@ struct DecState {
   int32_t pad[3];
 };
 
+// Batched decode (kernels_batch_decode.hip): which of the 16 slots take part in this step.
+struct BatchState {
+  int32_t active[16];
+  int32_t step;      // global step counter (token ring index)
+  int32_t pad[15];
+};
+
 struct SamplingDev {
   int32_t do_sample;
   float temperature;

@@ -36,6 +36,13 @@ struct TensorEntry {
   int64_t numel() const { return rows * cols; }
 };
 
+struct SeqHost {   // host-side mirror of one sequence's decode state
+  std::vector<int64_t> cached_ids;
+  bool cached_with_image = false;  // the cached KV was computed with image features spliced in
+  int host_next_pos = 0;           // tokens with KV after all launched steps
+  bool have_logits = false;
+};
+
 struct LayerW {
   bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
 };
@@ -95,12 +102,27 @@ struct dtk_ctx {
   size_t scratch_bytes = 0;
 
   // host state
-  std::vector<int64_t> cached_ids;
+  SeqHost seq0;              // the single-sequence API (dtk_prefill / dtk_decode*)
   uint64_t cached_image_key = 0;
   bool have_image = false;
-  bool cached_with_image = false;  // the cached KV was computed with image features spliced in
-  int host_next_pos = 0;     // tokens with KV after all launched steps
-  bool have_logits = false;
+  // ---- batched decode (dtk_*_slot / dtk_decode_batch_*): up to 16 slots with their own KV
+  int nb = 0;                        // number of batch slots (dtk_config.reserved[0])
+  std::vector<SeqHost> bseq;
+  bf16_t* kvb = nullptr;             // [nb][L][2][H][Tmax][128]
+  size_t kv_slot_stride = 0;
+  bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
+  float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
+  DecState* st_b = nullptr;          // [16]
+  SamplingDev* sp_b = nullptr;       // [16]
+  BatchState* bs_dev = nullptr;
+  BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
+  int64_t* tokb_dev = nullptr;       // [DTK_MAX_INFLIGHT][16]
+  int64_t* tokb_host = nullptr;      // pinned mirror
+  uint64_t blaunched = 0, bwaited = 0;
+  hipEvent_t bstep_done[DTK_MAX_INFLIGHT] = {};
+  bool bgraph_ready = false;
+  hipGraph_t bgraph = nullptr;
+  hipGraphExec_t bgraph_exec = nullptr;
   dtk_sampling sampling{};
   uint64_t launched = 0, waited = 0;
   hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
@@ -326,6 +348,23 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->ph = P.take<bf16_t>(mlp);
   c->pooled = P.take<bf16_t>(D);
   c->IMG = P.take<bf16_t>((size_t)c->nImg * d);
+  if (c->nb > 0) {
+    c->kv_slot_stride = (size_t)L * 2 * c->H * T * 128;
+    c->kvb = P.take<bf16_t>((size_t)c->nb * c->kv_slot_stride);
+    c->xb = P.take<bf16_t>((size_t)16 * d);
+    c->xnb = P.take<bf16_t>((size_t)16 * (d > ff ? d : ff));
+    c->qb = P.take<bf16_t>((size_t)16 * d);
+    c->aob = P.take<bf16_t>((size_t)16 * d);
+    c->actb = P.take<bf16_t>((size_t)16 * ff);
+    c->logits_b = P.take<float>((size_t)c->nb * V);
+    c->pmb = P.take<float>((size_t)c->nb * c->H * c->S);
+    c->plb = P.take<float>((size_t)c->nb * c->H * c->S);
+    c->pob = P.take<float>((size_t)c->nb * c->H * c->S * 128);
+    c->st_b = P.take<DecState>(16);
+    c->sp_b = P.take<SamplingDev>(16);
+    c->bs_dev = P.take<BatchState>(1);
+    c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * 16);
+  }
   c->scratch_bytes = (size_t)64 << 20;
   c->scratch = P.take<unsigned char>(c->scratch_bytes);
 }
@@ -407,7 +446,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe) {
   SampleArgs sa;
   sa.logits = c->logits; sa.V = c->V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed;
   sa.x = c->x; sa.d = c->d; sa.tok_ring = c->tok_ring_dev; sa.ring = DTK_MAX_INFLIGHT;
-  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = nullptr; sa.logits_stride = 0;
   launch_sample(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   for (int l = 0; l < c->L; ++l) {
@@ -445,6 +484,59 @@ void decode_step_launches(dtk_ctx* c, bool with_probe) {
   g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm;
   g.eps = c->cfg.rms_eps; g.logits = c->logits;
   launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
+}
+
+// launches of one batched decode step (all 16 slot columns; inactive slots are skipped in-kernel)
+void batch_step_launches(dtk_ctx* c) {
+  hipStream_t s = c->stream;
+  const int d = c->d, ff = c->ff;
+  SampleArgs sa;
+  sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
+  sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V;
+  launch_sample_b(sa, s);
+  const float scale = 1.0f / sqrtf(128.f);
+  const size_t kv_layer = (size_t)2 * c->H * c->Tmax * 128;
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    bf16_t* kc = c->kvb + (size_t)l * kv_layer;
+    bf16_t* vc = kc + (size_t)c->H * c->Tmax * 128;
+    GemvBArgs g{};
+    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff;
+    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
+    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+    g.W = w.wqkv; g.N = 3 * d; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    launch_gemv_b(EPI_QKV, g, s);
+    AttnDecBArgs ad;
+    ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d;
+    ad.scale = scale;
+    launch_attn_decode_b(ad, s);
+    g.W = w.wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
+    launch_gemv_b(EPI_RESID, g, s);
+    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+    g.W = w.wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
+    launch_gemv_b(EPI_SWIGLU, g, s);
+    g.W = w.wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
+    launch_gemv_b(EPI_RESID, g, s);
+  }
+  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+  GemvBArgs g{};
+  g.bs = c->bs_dev; g.st = c->st_b; g.W = c->lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
+  g.d = d; g.ff = ff;
+  launch_gemv_b(EPI_LOGITS, g, s);
+}
+
+int ensure_batch_graph(dtk_ctx* c) {
+  if (c->bgraph_ready) return DTK_OK;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  batch_step_launches(c);
+  HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph));
+  HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec, c->bgraph, nullptr, nullptr, 0));
+  c->bgraph_ready = true;
+  return DTK_OK;
 }
 
 int ensure_graph(dtk_ctx* c) {
@@ -513,6 +605,8 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->d = cfg->hidden; c->L = cfg->layers; c->H = cfg->heads; c->ff = cfg->ffn; c->V = cfg->vocab;
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
+  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > 16 ? 16 : cfg->reserved[0]);
+  c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
   c->vMlp = cfg->vit_mlp; c->vN = np * np;
   c->vPatchK = 3 * cfg->vit_patch * cfg->vit_patch;
@@ -555,6 +649,11 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   CCHK(hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
   CCHK(hipHostMalloc((void**)&c->tok_ring_host, sizeof(int64_t) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
+  if (c->nb > 0) {
+    CCHK(hipHostMalloc((void**)&c->bs_host, sizeof(BatchState) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16, hipHostMallocDefault));
+    for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->bstep_done[i], hipEventDisableTiming));
+  }
   CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
   CCHK(hipEventCreate(&c->probe_a)); CCHK(hipEventCreate(&c->probe_b));
   // default RoPE tables (the Python loader overrides them with torch-computed ones)
@@ -579,6 +678,11 @@ void dtk_destroy(dtk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->bgraph_exec) (void)hipGraphExecDestroy(c->bgraph_exec);
+  if (c->bgraph) (void)hipGraphDestroy(c->bgraph);
+  for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->bstep_done[i]) (void)hipEventDestroy(c->bstep_done[i]);
+  if (c->bs_host) (void)hipHostFree(c->bs_host);
+  if (c->tokb_host) (void)hipHostFree(c->tokb_host);
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->step_done[i]) (void)hipEventDestroy(c->step_done[i]);
   hipEvent_t evs[] = {c->ev_a, c->ev_b, c->ev_c, c->probe_a, c->probe_b};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -628,7 +732,8 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy2D(t.ptr, (size_t)t.stride * 2, src16, (size_t)t.cols * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyHostToDevice));
   c->have_image = false;
-  c->cached_ids.clear();
+  c->seq0.cached_ids.clear();
+  for (auto& b : c->bseq) b.cached_ids.clear();
   return DTK_OK;
 }
 
@@ -661,7 +766,8 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_image = false;
-  c->cached_ids.clear();
+  c->seq0.cached_ids.clear();
+  for (auto& b : c->bseq) b.cached_ids.clear();
   return DTK_OK;
 }
 
@@ -687,13 +793,18 @@ int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, 
   return DTK_OK;  // IMG (the projected prefix of the cached prefill image) is left untouched
 }
 
-int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
+static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_dst, DecState* st_dst, bool is_single,
+                        const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
+  const size_t kv_layer = (size_t)2 * c->H * c->Tmax * 128;
+  auto kc = [&](int l) { return kvbase + (size_t)l * kv_layer; };
+  auto vc = [&](int l) { return kvbase + (size_t)l * kv_layer + (size_t)c->H * c->Tmax * 128; };
   if (!c || !ids || T < 1) return fail(c, DTK_ERR_ARG, "dtk_prefill: bad argument");
   if (T > c->Tmax) return fail(c, DTK_ERR_RANGE, "prompt of %d tokens exceeds max_positions %d", T, c->Tmax);
   HIPCHK(c, hipSetDevice(c->device));
   // drain pending decode steps (their tokens are dropped)
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
+  if (is_single) c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
+  else c->bwaited = c->blaunched;
   // ---- locate the image placeholder run (reference v1/modeling_detikzify.py:179-184)
   int img_start = -1, img_count = 0;
   for (int t = 0; t < T; ++t) {
@@ -728,12 +839,12 @@ int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
   // ---- longest common prefix with the cached sequence (output-identical KV reuse)
   int start = 0;
-  if ((flags & DTK_PREFILL_REUSE_PREFIX) && !image_changed && !c->cached_ids.empty()) {
-    const int lim = (int)std::min<size_t>(c->cached_ids.size(), (size_t)T - 1);
-    while (start < lim && c->cached_ids[start] == ids[start]) ++start;
+  if ((flags & DTK_PREFILL_REUSE_PREFIX) && !image_changed && !sh.cached_ids.empty()) {
+    const int lim = (int)std::min<size_t>(sh.cached_ids.size(), (size_t)T - 1);
+    while (start < lim && sh.cached_ids[start] == ids[start]) ++start;
   }
   // KV computed with / without spliced image features never mixes
-  if (has_img && c->cached_with_image != use_img) start = 0;
+  if (has_img && sh.cached_with_image != use_img) start = 0;
   const int n = T - start;
   std::vector<int32_t> ids32((size_t)n);
   for (int t = 0; t < n; ++t) ids32[(size_t)t] = (int32_t)ids[start + t];
@@ -750,11 +861,11 @@ int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint
     const LayerW& w = c->layers[l];
     launch_rmsnorm_rows(c->X, d, w.ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
     gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, 3 * d, n, 3 * d, d, 0);
-    launch_rope_scatter(c->QKV, c->Qh, kcache(c, l), vcache(c, l), c->rope_cos, c->rope_sin, n, start, c->H, c->Tmax, s);
+    launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->Tmax, s);
     AttnArgs a;
     a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
-    a.K = kcache(c, l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
-    a.V = vcache(c, l); a.v_sh = (long)c->Tmax * 128; a.v_st = 128;
+    a.K = kc(l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
+    a.V = vc(l); a.v_sh = (long)c->Tmax * 128; a.v_st = 128;
     a.O = c->AO; a.o_sh = 128; a.o_st = d;
     a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale;
     launch_attention(a, s);
@@ -767,28 +878,39 @@ int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint
   // final norm + lm_head on the last position only (the sampler consumes logits[:, -1])
   GemvArgs g{};
   g.W = c->lm_head; g.N = c->V; g.K = d; g.x = c->X + (size_t)(n - 1) * d; g.norm_w = c->final_norm;
-  g.eps = c->cfg.rms_eps; g.logits = c->logits;
+  g.eps = c->cfg.rms_eps; g.logits = logits_dst;
   launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
   DecState st0{};
   st0.pos = T - 1; st0.next_pos = T; st0.token = (int32_t)ids[T - 1]; st0.draw = 0;
-  HIPCHK(c, hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(st_dst, &st0, sizeof st0, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipEventRecord(c->ev_c, s));
-  if (logits_out) HIPCHK(c, hipMemcpyAsync(logits_out, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, s));
+  if (logits_out) HIPCHK(c, hipMemcpyAsync(logits_out, logits_dst, (size_t)c->V * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, c->ev_a, c->ev_c) == hipSuccess) c->stats.last_prefill_ms = ms;
   if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.last_vit_ms = ms;
   c->stats.prefill_tokens += (uint64_t)n;
-  c->cached_ids.assign(ids, ids + T);
-  c->cached_with_image = use_img;
-  c->host_next_pos = T;
-  c->have_logits = true;
+  sh.cached_ids.assign(ids, ids + T);
+  sh.cached_with_image = use_img;
+  sh.host_next_pos = T;
+  sh.have_logits = true;
   // a new prefill starts a new generation: reset the draw counter of the sampler
   return DTK_OK;
 }
 
-int dtk_set_sampling(dtk_ctx* c, const dtk_sampling* sp) {
+int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
+  if (!c) return DTK_ERR_ARG;
+  return prefill_impl(c, c->seq0, c->kv, c->logits, c->st, true, ids, T, pixels, image_key, flags, logits_out);
+}
+
+int dtk_prefill_slot(dtk_ctx* c, int slot, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
+  if (!c || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_prefill_slot: slot %d of %d", slot, c ? c->nb : 0);
+  return prefill_impl(c, c->bseq[(size_t)slot], c->kvb + (size_t)slot * c->kv_slot_stride, c->logits_b + (size_t)slot * c->V,
+                      c->st_b + slot, false, ids, T, pixels, image_key, flags, logits_out);
+}
+
+static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp_dst, DecState* st_dst, bool is_single) {
   if (!c || !sp) return fail(c, DTK_ERR_ARG, "dtk_set_sampling: null argument");
   if (sp->n_bad < 0 || sp->n_bad > 8 || sp->n_begin_suppress < 0 || sp->n_begin_suppress > 8 ||
       sp->n_always_suppress < 0 || sp->n_always_suppress > 8)
@@ -804,12 +926,96 @@ int dtk_set_sampling(dtk_ctx* c, const dtk_sampling* sp) {
     dv.bad_ids[i] = sp->bad_ids[i]; dv.begin_ids[i] = sp->begin_suppress_ids[i]; dv.always_ids[i] = sp->always_suppress_ids[i];
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->sp, &dv, sizeof dv, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(sp_dst, &dv, sizeof dv, hipMemcpyHostToDevice));
   const uint32_t zero = 0;
-  HIPCHK(c, hipMemcpy(&c->st->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
-  c->sampling = *sp;
-  c->launched = c->waited = 0;
+  HIPCHK(c, hipMemcpy(&st_dst->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
+  if (is_single) { c->sampling = *sp; c->launched = c->waited = 0; }
   return DTK_OK;
+}
+
+int dtk_set_sampling(dtk_ctx* c, const dtk_sampling* sp) {
+  if (!c) return DTK_ERR_ARG;
+  return set_sampling_impl(c, sp, c->sp, c->st, true);
+}
+
+int dtk_set_sampling_slot(dtk_ctx* c, int slot, const dtk_sampling* sp) {
+  if (!c || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_set_sampling_slot: slot %d of %d", slot, c ? c->nb : 0);
+  return set_sampling_impl(c, sp, c->sp_b + slot, c->st_b + slot, false);
+}
+
+int dtk_num_slots(const dtk_ctx* c) { return c ? c->nb : 0; }
+
+// One batched decode step for the slots with active[slot] != 0 (every one must have been prefilled).
+int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
+  if (!c || !active) return fail(c, DTK_ERR_ARG, "dtk_decode_batch_launch: null argument");
+  if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "context was created without batch slots");
+  if (c->blaunched - c->bwaited >= DTK_MAX_INFLIGHT) return fail(c, DTK_ERR_STATE, "too many batch steps in flight");
+  int n_active = 0;
+  for (int j = 0; j < 16; ++j) {
+    if (!active[j]) continue;
+    if (j >= c->nb) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    const SeqHost& sh = c->bseq[(size_t)j];
+    if (!sh.have_logits) return fail(c, DTK_ERR_STATE, "slot %d: decode before prefill", j);
+    if (sh.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "slot %d: context length %d reached max_positions", j, sh.host_next_pos);
+    ++n_active;
+  }
+  if (!n_active) return fail(c, DTK_ERR_ARG, "no active slot");
+  HIPCHK(c, hipSetDevice(c->device));
+  BatchState* hb = c->bs_host + (c->blaunched % DTK_MAX_INFLIGHT);
+  for (int j = 0; j < 16; ++j) hb->active[j] = active[j] ? 1 : 0;
+  hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
+  HIPCHK(c, hipMemcpyAsync(c->bs_dev, hb, sizeof(BatchState), hipMemcpyHostToDevice, c->stream));
+  if (c->use_graph) {
+    int rc = ensure_batch_graph(c);
+    if (rc) return rc;
+    HIPCHK(c, hipGraphLaunch(c->bgraph_exec, c->stream));
+  } else {
+    batch_step_launches(c);
+    HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
+  c->blaunched++;
+  c->stats.decode_steps++;
+  for (int j = 0; j < 16; ++j)
+    if (active[j]) { c->bseq[(size_t)j].host_next_pos++; c->bseq[(size_t)j].cached_ids.push_back(-1); }
+  return DTK_OK;
+}
+
+// tokens_out[16]: the token sampled for every slot that was active in the oldest un-read step (-1 otherwise)
+int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
+  if (!c || !tokens_out) return fail(c, DTK_ERR_ARG, "dtk_decode_batch_wait: null argument");
+  if (c->bwaited >= c->blaunched) return fail(c, DTK_ERR_STATE, "no batch step in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t k = c->bwaited;
+  const int ring = (int)(k % DTK_MAX_INFLIGHT);
+  HIPCHK(c, hipEventSynchronize(c->bstep_done[ring]));
+  const BatchState* hb = c->bs_host + ring;
+  // how many steps were launched after step k for each slot (their cached ids are still -1)
+  for (int j = 0; j < 16; ++j) {
+    tokens_out[j] = -1;
+    if (!hb->active[j]) continue;
+    const int64_t tok = ((volatile int64_t*)c->tokb_host)[(size_t)ring * 16 + j];
+    tokens_out[j] = tok;
+    SeqHost& sh = c->bseq[(size_t)j];
+    size_t later = 0;
+    for (uint64_t q = k + 1; q < c->blaunched; ++q) later += c->bs_host[q % DTK_MAX_INFLIGHT].active[j] ? 1 : 0;
+    if (sh.cached_ids.size() > later) sh.cached_ids[sh.cached_ids.size() - 1 - later] = tok;
+  }
+  c->bwaited++;
+  return DTK_OK;
+}
+
+int dtk_get_logits_slot(dtk_ctx* c, int slot, float* out) {
+  if (!c || !out || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_get_logits_slot: bad argument");
+  if (!c->bseq[(size_t)slot].have_logits) return fail(c, DTK_ERR_STATE, "no logits yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->logits_b + (size_t)slot * c->V, (size_t)c->V * 4, hipMemcpyDeviceToHost));
+  return DTK_OK;
+}
+
+int dtk_context_len_slot(const dtk_ctx* c, int slot) {
+  return (c && slot >= 0 && slot < c->nb) ? c->bseq[(size_t)slot].host_next_pos : -1;
 }
 
 int dtk_set_graph_mode(dtk_ctx* c, int enabled) {
@@ -821,9 +1027,9 @@ int dtk_set_graph_mode(dtk_ctx* c, int enabled) {
 
 int dtk_decode_launch(dtk_ctx* c) {
   if (!c) return DTK_ERR_ARG;
-  if (!c->have_logits) return fail(c, DTK_ERR_STATE, "dtk_decode before dtk_prefill");
+  if (!c->seq0.have_logits) return fail(c, DTK_ERR_STATE, "dtk_decode before dtk_prefill");
   if (c->launched - c->waited >= DTK_MAX_INFLIGHT) return fail(c, DTK_ERR_STATE, "too many decode steps in flight");
-  if (c->host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "context length %d reached max_positions", c->host_next_pos);
+  if (c->seq0.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "context length %d reached max_positions", c->seq0.host_next_pos);
   HIPCHK(c, hipSetDevice(c->device));
   if (c->use_graph) {
     int rc = ensure_graph(c);
@@ -846,9 +1052,9 @@ int dtk_decode_launch(dtk_ctx* c) {
   }
   HIPCHK(c, hipEventRecord(c->step_done[c->launched % DTK_MAX_INFLIGHT], c->stream));
   c->launched++;
-  c->host_next_pos++;
+  c->seq0.host_next_pos++;
   c->stats.decode_steps++;
-  c->cached_ids.push_back(-1);  // filled in by dtk_decode_wait
+  c->seq0.cached_ids.push_back(-1);  // filled in by dtk_decode_wait
   return DTK_OK;
 }
 
@@ -862,8 +1068,8 @@ int dtk_decode_wait(dtk_ctx* c, int64_t* token_out) {
   // been launched yet; later copies of the whole ring rewrite it with the same value
   const int64_t tok = ((volatile int64_t*)c->tok_ring_host)[k % DTK_MAX_INFLIGHT];
   *token_out = tok;
-  const size_t idx = c->cached_ids.size() - (size_t)(c->launched - k);
-  c->cached_ids[idx] = tok;
+  const size_t idx = c->seq0.cached_ids.size() - (size_t)(c->launched - k);
+  c->seq0.cached_ids[idx] = tok;
   c->waited++;
   return DTK_OK;
 }
@@ -876,14 +1082,14 @@ int dtk_decode(dtk_ctx* c, int64_t* token_out) {
 
 int dtk_get_logits(dtk_ctx* c, float* out) {
   if (!c || !out) return fail(c, DTK_ERR_ARG, "dtk_get_logits: null argument");
-  if (!c->have_logits) return fail(c, DTK_ERR_STATE, "no logits yet");
+  if (!c->seq0.have_logits) return fail(c, DTK_ERR_STATE, "no logits yet");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost));
   return DTK_OK;
 }
 
-int dtk_context_len(const dtk_ctx* c) { return c ? c->host_next_pos : -1; }
+int dtk_context_len(const dtk_ctx* c) { return c ? c->seq0.host_next_pos : -1; }
 
 int dtk_synchronize(dtk_ctx* c) {
   if (!c) return DTK_ERR_ARG;
@@ -930,7 +1136,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
   *avg_us = ms * 1e3f / (float)(reps * c->L);
-  c->have_logits = false;
+  c->seq0.have_logits = false;
   return DTK_OK;
 }
 
@@ -1047,7 +1253,7 @@ int dtk_op_sample(dtk_ctx* c, const float* logits, int V, int step, int64_t* tok
   SampleArgs sa;
   sa.logits = dl; sa.V = V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed; sa.x = c->x; sa.d = c->d;
   sa.tok_ring = dtok; sa.ring = 1; sa.probs_out = probs_out ? c->probs_dev : nullptr; sa.advance = 0;
-  sa.step_override = step;
+  sa.step_override = step; sa.bs = nullptr; sa.logits_stride = 0;
   launch_sample(sa, s);
   HIPCHK(c, hipMemcpyAsync(token_out, dtok, 8, hipMemcpyDeviceToHost, s));
   if (probs_out) HIPCHK(c, hipMemcpyAsync(probs_out, c->probs_dev, (size_t)V * 4, hipMemcpyDeviceToHost, s));

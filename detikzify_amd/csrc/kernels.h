@@ -62,8 +62,38 @@ struct SampleArgs {
   float* probs_out;      // optional (tests): filtered, renormalised distribution [V]
   int advance;           // 1: product path (advance DecState, gather embedding)
   int step_override;     // >=0: use as draw index (tests)
+  const BatchState* bs;  // batched mode: block = slot, inactive slots return; pointers are slot 0's
+  int logits_stride;     // elements between slots' logits (batched mode)
 };
+void launch_sample_b(const SampleArgs& a, hipStream_t s);
 void launch_sample(const SampleArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- batched decode (16 slots share W)
+struct GemvBArgs {
+  const bf16_t* W; int N; int K;       // weight [N][K]
+  const bf16_t* X; int ldx;            // inputs [16][ldx] (slot-major)
+  bf16_t* Y; int ldy;                  // RESID: residual streams [16][ldy]; SWIGLU: act [16][ldy]; STORE
+  float* logits;                       // LOGITS: [16][N]
+  const BatchState* bs;
+  const DecState* st;                  // [16]
+  bf16_t* q_out;                       // QKV: [16][d]
+  bf16_t* kcache; bf16_t* vcache;      // this layer's caches of slot 0; slot s at + s*kv_slot_stride
+  size_t kv_slot_stride;
+  const bf16_t* rope_cos; const bf16_t* rope_sin;
+  int T_max; int d; int ff;
+};
+void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
+void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
+                      const BatchState* bs, hipStream_t s);
+struct AttnDecBArgs {
+  const bf16_t* q;                     // [16][d]
+  const bf16_t* kcache; const bf16_t* vcache; size_t kv_slot_stride;
+  const DecState* st; const BatchState* bs;
+  float* pm; float* pl; float* po;     // [slots][H][S], ..., [slots][H][S][128]
+  bf16_t* out;                         // [16][d]
+  int H; int S; int T_max; int d; float scale;
+};
+void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- batched (prefill / ViT) kernels
 #define GEMM_BIAS 1

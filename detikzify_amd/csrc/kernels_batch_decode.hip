@@ -1,0 +1,331 @@
+// kernels_batch_decode.hip — one decode step for up to 16 independent sequences ("slots") that
+// share ONE pass over the weights: the MCTS rollouts/sec kernel set (independent
+// rollouts of one GPU are batched so W is read once for b sequences; bytes/step = W + sum_b K*t_b).
+//
+// k_gemv_b: Y[slot][n] = W[n][:] . X[slot][:] as a skinny GEMM on v_mfma_f32_16x16x32_bf16 with the
+// 16 slots as the MFMA N dimension: the A fragment of a wave is a 16-row x 32-k tile of W loaded
+// straight from HBM (non-temporal, lane l -> row l&15, 16 bytes at k = (l>>4)*8: the fragment layout IS
+// the global layout, no LDS), the B fragment is X[slot = l&15][k..k+8) from L2.  A block owns 16*T weight
+// rows; its 8 waves split K (each wave streams a contiguous K slice of those rows, 4 k-steps in
+// flight) and reduce their 16x16 partials through LDS.  Inactive slots are computed and discarded
+// (columns are independent), so the captured graph is identical for every active set.
+// Epilogues as in kernels_decode.hip (same HF rounding points), applied per active slot.
+#include "kernels.h"
+
+#define GB_WAVES 8
+#define GB_THREADS (GB_WAVES * 64)
+#define GB_KSTEP 32
+#define GB_UNROLL 4
+
+// rows of tile t of a block for the paired epilogues: QKV -> (i, i+64) RoPE partners; SWIGLU -> (gate, up)
+template <int EPI, int T>
+__device__ __forceinline__ int gb_tile_row0(const GemvBArgs& a, int blk, int t) {
+  if (EPI == EPI_QKV) {  // block = 16 dims i0..i0+15 (< 64) of one head of one section
+    const int per_sec = a.d >> 5;                 // (d/128 heads) * 4 sub-blocks
+    const int sec = blk / per_sec, rem = blk - sec * per_sec;
+    const int head = rem >> 2, i0 = (rem & 3) * 16;
+    return sec * a.d + head * 128 + i0 + t * 64;
+  }
+  if (EPI == EPI_SWIGLU) return blk * 16 + t * a.ff;
+  return (blk * T + t) * 16;
+}
+
+template <int EPI, int T>
+__global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
+  __shared__ float red[GB_WAVES][T][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int K = a.K;
+  // K slice of this wave, in k-steps of 32 (the last step may be partial: K % 8 == 0)
+  const int nsteps = (K + GB_KSTEP - 1) / GB_KSTEP;
+  const int per = (nsteps + GB_WAVES - 1) / GB_WAVES;
+  const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+
+  const int arow = lane & 15, koff = (lane >> 4) * 8;
+  const bf16_t* wrow[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int r = gb_tile_row0<EPI, T>(a, blk, t) + arow;
+    if (r >= a.N) r = a.N - 1;
+    wrow[t] = a.W + (size_t)r * K;
+  }
+  const bf16_t* xrow = a.X + (size_t)arow * a.ldx;  // B fragment: slot = lane & 15
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int s = s0; s < s1; s += GB_UNROLL) {
+    u32x4 wv[T][GB_UNROLL], xv[GB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < GB_UNROLL; ++u) {
+      int k = (s + u) * GB_KSTEP + koff;
+      const bool ok = (s + u < s1) && (k < K);
+      if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
+#pragma unroll
+      for (int t = 0; t < T; ++t) wv[t][u] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + k));
+      xv[u] = *reinterpret_cast<const u32x4*>(xrow + k);
+      if (!ok) xv[u] = (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < GB_UNROLL; ++u)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[t][u]),
+                                                         __builtin_bit_cast(bf16x8_t, xv[u]), acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+  __syncthreads();
+  if (tid >= 256) return;
+  // thread -> (m, n) of the 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
+  const int l2 = tid >> 2, r2 = tid & 3;
+  const int n = l2 & 15;             // slot
+  const int m = (l2 >> 4) * 4 + r2;  // row inside the tile
+  float v[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < GB_WAVES; ++w) sum += red[w][t][tid];
+    v[t] = sum;
+  }
+  if (!a.bs->active[n]) return;
+  if (EPI == EPI_RESID) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+      if (row < a.N) {
+        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
+        *y = f2bf(bf2f(*y) + rbf(v[t]));
+      }
+    }
+  } else if (EPI == EPI_LOGITS) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+      if (row < a.N) a.logits[(size_t)n * a.N + row] = rbf(v[t]);
+    }
+  } else if (EPI == EPI_STORE) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+      if (row < a.N) a.Y[(size_t)n * a.ldy + row] = f2bf(v[t]);
+    }
+  } else if (EPI == EPI_SWIGLU) {
+    const int i = blk * 16 + m;
+    if (i < a.ff) {
+      const float gte = rbf(v[0]), up = rbf(v[T - 1]);
+      const float sl = rbf(gte / (1.f + expf(-gte)));
+      a.Y[(size_t)n * a.ldy + i] = f2bf(sl * up);
+    }
+  } else if (EPI == EPI_QKV) {
+    const int per_sec = a.d >> 5;
+    const int sec = blk / per_sec, rem = blk - sec * per_sec;
+    const int head = rem >> 2, i = (rem & 3) * 16 + m;
+    const int pos = a.st[n].pos;
+    const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
+    const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+    if (sec == 2) {
+      bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
+      dst[i] = f2bf(x1);
+      dst[i + 64] = f2bf(x2);
+    } else {
+      const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+      const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+      const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+      const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+      bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                               : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
+      dst[i] = f2bf(o1);
+      dst[i + 64] = f2bf(o2);
+    }
+  }
+}
+
+void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (epi == EPI_QKV) {
+    const int grid = 3 * (a.d >> 5);
+    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2>), dim3(grid), dim3(GB_THREADS), 0, s, a);
+  } else if (epi == EPI_SWIGLU) {
+    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
+  } else if (epi == EPI_RESID) {
+    hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+  } else if (epi == EPI_LOGITS) {
+    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+  }
+}
+
+// RMSNorm of the active slots' vectors: grid = 16 slots, one block each (HF LlamaRMSNorm rounding).
+__global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y,
+                                                   int ldy, int D, float eps, const BatchState* bs) {
+  const int slot = blockIdx.x;
+  if (!bs->active[slot]) return;
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D8 = D >> 3;
+  const u32x4* x4 = reinterpret_cast<const u32x4*>(X + (size_t)slot * ldx);
+  float ss = 0.f;
+  for (int c = tid; c < D8; c += 256) {
+    const u32x4 v = x4[c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = pk_lo(v[e]), hi = pk_hi(v[e]);
+      ss += lo * lo;
+      ss += hi * hi;
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+  const u32x4* w4 = reinterpret_cast<const u32x4*>(w);
+  u32x4* y4 = reinterpret_cast<u32x4*>(Y + (size_t)slot * ldy);
+  for (int c = tid; c < D8; c += 256) {
+    const u32x4 v = x4[c], g = w4[c];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2(pk_lo(g[e]) * rbf(pk_lo(v[e]) * inv), pk_hi(g[e]) * rbf(pk_hi(v[e]) * inv));
+    y4[c] = o;
+  }
+}
+void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
+                      const BatchState* bs, hipStream_t s) {
+  hipLaunchKernelGGL(k_rmsnorm_b, dim3(16), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs);
+}
+
+// Split-K decode attention per slot: grid (H, S, 16); same algorithm as k_attn_decode.
+__global__ __launch_bounds__(256) void k_attn_decode_b(AttnDecBArgs a) {
+  const int h = blockIdx.x, sp = blockIdx.y, slot = blockIdx.z;
+  if (!a.bs->active[slot]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int n = a.st[slot].pos + 1;
+  int chunk = (n + a.S - 1) / a.S;
+  chunk = (chunk + 15) & ~15;
+  const int j_begin = sp * chunk;
+  const int j_end = min(n, j_begin + chunk);
+  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + h * 128)[sub];
+  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)h * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)h * a.T_max * 128;
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+    u32x4 kv[4], vv[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i * 16 + wave * 4 + grp;
+      ok[i] = j < j_end;
+      const int jj = ok[i] ? j : j_begin;
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = dot8(qv, kv[i], 0.f);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s *= a.scale;
+      if (ok[i]) {
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn);
+        const float p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[i][e]);
+          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[i][e]);
+        }
+        m = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64);
+    const float l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * c1 + o2 * c2;
+    }
+    m = mn;
+  }
+  __shared__ float sm_m[4][16], sm_l[4][16], sm_o[4][16][8];
+  if (grp == 0) {
+    sm_m[wave][sub] = m;
+    sm_l[wave][sub] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float M = sm_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_m[w][tid]);
+    float L = 0.f;
+    float oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = __expf(sm_m[w][tid] - M);
+      L += c * sm_l[w][tid];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+    }
+    const size_t slot_i = ((size_t)slot * a.H + h) * a.S + sp;
+    float* dst = a.po + slot_i * 128 + tid * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = oo[e];
+    if (tid == 0) {
+      a.pm[slot_i] = M;
+      a.pl[slot_i] = L;
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
+  const int h = blockIdx.x, slot = blockIdx.y, t = threadIdx.x;
+  if (!a.bs->active[slot]) return;
+  const int S = a.S;
+  const size_t base = ((size_t)slot * a.H + h) * S;
+  float pm[16], pl[16], po[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const bool ok = s < S;
+    const int ss = ok ? s : 0;
+    pm[s] = ok ? a.pm[base + ss] : -1e30f;
+    pl[s] = ok ? a.pl[base + ss] : 0.f;
+    po[s] = ok ? a.po[(base + ss) * 128 + t] : 0.f;
+  }
+  float M = -1e30f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) M = fmaxf(M, pm[s]);
+  float L = 0.f, o = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float w = __expf(pm[s] - M);
+    L += w * pl[s];
+    o += w * po[s];
+  }
+  a.out[(size_t)slot * a.d + h * 128 + t] = f2bf(o / L);
+}
+
+void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, 16), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, 16), dim3(128), 0, s, a);
+}

@@ -578,6 +578,17 @@ __device__ __forceinline__ bool is_banned(const SamplingDev* sp, int i, bool fir
 }
 
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
+  if (a.bs) {  // batched decode: one block per slot, same code on that slot's buffers
+    const int slot = blockIdx.x;
+    if (!a.bs->active[slot]) return;
+    a.logits += (size_t)slot * a.logits_stride;
+    a.sp += slot;
+    a.st += slot;
+    a.x += (size_t)slot * a.d;
+    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * 16 + slot;
+    a.ring = 1;        // the ring index was applied above
+    a.step_override = -1;
+  }
   __shared__ float s_f[16];
   __shared__ int s_i[16];
   __shared__ unsigned long long s_q[16];
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
 
   const int tok = s_token;
   if (tid == 0) {
-    a.tok_ring[draw % (uint32_t)a.ring] = (int64_t)tok;
+    a.tok_ring[a.bs ? 0u : draw % (uint32_t)a.ring] = (int64_t)tok;
     if (a.advance) {
       a.st->token = tok;
       a.st->pos = a.st->next_pos;
@@ -778,4 +789,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
 
 void launch_sample(const SampleArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_sample, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
+}
+void launch_sample_b(const SampleArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sample, dim3(16), dim3(SAMPLE_THREADS), 0, s, a);
 }

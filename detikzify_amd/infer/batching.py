@@ -1,0 +1,149 @@
+"""
+Batched decode of independent rollouts on ONE GPU (north-star: "independent rollouts
+... as embarrassingly-parallel batched decodes").  The reference's tree search is sequential, so what
+can be batched without touching its semantics are *independent trees* (root parallelisation, the same
+divergence as sharding trees across GPUs): every tree runs the reference's logic unchanged in its own
+thread (DetikzifyGenerator.rollout already generates in a worker thread, infer/generate.py:248-258), and
+whenever those threads ask for their next token the BatchEngine issues ONE dtk_decode_batch step for all
+of them: the weights are streamed once per step for up to 16 sequences (bytes/step = W + sum_b K*t_b).
+
+BatchEngine      lock-step scheduler over the C ABI's slots (dtk_prefill_slot / dtk_decode_batch_*)
+simulate_parallel  B independent DetikzifyGenerator trees on one image, results as they complete
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from contextlib import contextmanager
+from typing import Any, Dict, Iterator, List, Optional, Tuple
+
+
+class _Sequence:
+    def __init__(self, engine: "BatchEngine", slot: int):
+        self.engine, self.slot = engine, slot
+
+    def next_token(self) -> int:
+        return self.engine._next_token(self.slot)
+
+
+class BatchEngine:
+    """All methods are thread-safe; one engine per model.  A sequence is 'active' from the end of its
+    prefill until it leaves; a decode step runs as soon as every active sequence waits for a token."""
+
+    def __init__(self, model, max_batch: Optional[int] = None):
+        n = model.num_slots()
+        if n <= 0:
+            raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
+        self.model = model
+        self.capacity = min(n, max_batch or n)
+        self.cv = threading.Condition()
+        self.free: List[int] = list(range(self.capacity))
+        self.active: set = set()
+        self.ready: set = set()
+        self.tokens: Dict[int, int] = {}
+        self.generation = 0
+        self.error: Optional[BaseException] = None
+        self.steps = 0
+        self.tokens_out = 0
+        model.batch_engine = self
+
+    def close(self):
+        self.model.batch_engine = None
+
+    @contextmanager
+    def sequence(self, ids, pixel_values, sampling: Dict[str, Any]) -> Iterator[_Sequence]:
+        with self.cv:
+            while not self.free:
+                self.cv.wait()
+            slot = self.free.pop()
+        joined = False
+        try:
+            with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
+                self.model.set_sampling(slot=slot, **sampling)
+                self.model.prefill(ids, pixel_values, slot=slot)
+                self.active.add(slot)
+                joined = True
+            yield _Sequence(self, slot)
+        finally:
+            with self.cv:
+                if joined:
+                    self.active.discard(slot)
+                    self.ready.discard(slot)
+                    self._maybe_step()          # the others may all be waiting on this one
+                self.free.append(slot)
+                self.cv.notify_all()
+
+    # -- called with self.cv held ---------------------------------------------------------------------
+    def _maybe_step(self):
+        if not self.active or self.ready != self.active or self.error is not None:
+            return
+        try:
+            slots = sorted(self.active)
+            self.model.decode_batch_launch(slots)
+            toks = self.model.decode_batch_wait()
+            for s in slots:
+                self.tokens[s] = toks[s]
+            self.steps += 1
+            self.tokens_out += len(slots)
+        except BaseException as e:  # surface in every waiting thread
+            self.error = e
+        self.ready.clear()
+        self.generation += 1
+        self.cv.notify_all()
+
+    def _next_token(self, slot: int) -> int:
+        with self.cv:
+            if self.error is not None:
+                raise self.error
+            self.ready.add(slot)
+            gen = self.generation
+            self._maybe_step()
+            while self.generation == gen and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise self.error
+            return self.tokens[slot]
+
+
+def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
+                      **gen_kwargs) -> Iterator[Tuple[float, Any]]:
+    """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (thread t uses
+    torch seed seed_base + t for its sampling seeds) decoded as one batch.  Yields (score, document)
+    pairs in completion order.  trees == 1 is the unmodified sequential search."""
+    import torch
+    engine = BatchEngine(pipeline.model, max_batch=trees) if trees > 1 else None
+    out: "queue.Queue" = queue.Queue()
+    img = pipeline.load(image)
+
+    def worker(t: int):
+        try:
+            gen = torch.Generator().manual_seed(seed_base + t)
+            seeds = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
+            g = pipeline._generator(img, None, False, metric=pipeline.metric, **gen_kwargs)
+            base_generate = g.generate
+            g.generate = lambda input_ids, **kw: base_generate(input_ids, seed=next(seeds), **kw)   # per-tree RNG stream
+            for item in g.simulate(expansions=expansions_per_tree):
+                out.put(item)
+        except BaseException as e:
+            out.put(e)
+        finally:
+            out.put(None)
+
+    threads = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(trees)]
+    for th in threads:
+        th.start()
+    done = 0
+    try:
+        while done < trees:
+            item = out.get()
+            if item is None:
+                done += 1
+            elif isinstance(item, BaseException):
+                raise item
+            else:
+                yield item
+    finally:
+        for th in threads:
+            th.join(timeout=60)
+        if engine is not None:
+            engine.close()

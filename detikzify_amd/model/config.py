@@ -42,6 +42,7 @@ class DetikzifyConfig:
     concat_patches: int = 3
     patch_token_id: int = 32013      # == BOS (v1/__init__.py:49)
     attn_splits: int = 8
+    batch_slots: int = 0             # KV slots for batched decode of independent rollouts (0 = none)
     model_type: str = "detikzify"
     name_or_path: str = ""
     vision_tower: str = "vit_so400m_patch14_siglip_384.webli"

@@ -13,6 +13,7 @@ There is no CPU fallback: constructing the model without the HIP library or a GP
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import hashlib
 from types import SimpleNamespace
@@ -79,6 +80,7 @@ class DetikzifyForCausalLM:
         self.hip_device = int(device_index)
         kd = config.kernel_dict()
         cc = _lib.DtkConfig(**kd)
+        cc.reserved[0] = int(getattr(config, "batch_slots", 0) or 0)
         ctx = C.c_void_p()
         rc = self.lib.dtk_create(C.byref(cc), self.hip_device, C.byref(ctx))
         if rc != 0:
@@ -92,6 +94,7 @@ class DetikzifyForCausalLM:
         self.name_or_path = config.name_or_path
         self.model = SimpleNamespace(vision_model=DetikzifyVisionModel(self))
         self.reuse_prefix = False     # output-identical KV/image reuse across rollouts
+        self.batch_engine = None      # set by infer.batching.BatchEngine: generate() then decodes in a slot
         self._weights_ready = False
 
     # ---- HF-shaped attributes ---------------------------------------------------------------
@@ -188,16 +191,20 @@ class DetikzifyForCausalLM:
         n = (c.vit_image // c.vit_patch) ** 2
         feats = np.empty((B, n, c.vit_dim), dtype=np.uint16)
         pooled = np.empty((B, c.vit_dim), dtype=np.uint16)
-        self._check(self.lib.dtk_vit_encode(
-            self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p),
-            pooled.ctypes.data_as(C.c_void_p) if want_pooled else None), "dtk_vit_encode")
+        # a context is driven by one thread at a time: with a batch engine, take its lock (the SelfSim
+        # reward of one tree runs while other trees decode)
+        guard = self.batch_engine.cv if self.batch_engine is not None else contextlib.nullcontext()
+        with guard:
+            self._check(self.lib.dtk_vit_encode(
+                self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p),
+                pooled.ctypes.data_as(C.c_void_p) if want_pooled else None), "dtk_vit_encode")
         f = _bf16_tensor_from_bits(feats.reshape(-1)).view(B, n, c.vit_dim)
         p = _bf16_tensor_from_bits(pooled.reshape(-1)).view(B, c.vit_dim) if want_pooled else None
         return f, p
 
     # ---- decoder ------------------------------------------------------------------------------
     def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor] = None,
-                return_logits: bool = False, reuse: Optional[bool] = None) -> Optional[torch.Tensor]:
+                return_logits: bool = False, reuse: Optional[bool] = None, slot: Optional[int] = None) -> Optional[torch.Tensor]:
         ids = input_ids.detach().to("cpu", torch.int64).reshape(-1).contiguous()
         T = ids.numel()
         px_ptr, key = None, 0
@@ -213,14 +220,18 @@ class DetikzifyForCausalLM:
         reuse = self.reuse_prefix if reuse is None else reuse
         flags = (_lib.DTK_PREFILL_REUSE_PREFIX | _lib.DTK_PREFILL_REUSE_IMAGE) if reuse else 0
         logits = np.empty(self.config.vocab, dtype=np.float32) if return_logits else None
-        self._check(self.lib.dtk_prefill(
-            self._ctx, ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr, C.c_uint64(key), flags,
-            logits.ctypes.data_as(C.c_void_p) if return_logits else None), "dtk_prefill")
+        lp = logits.ctypes.data_as(C.c_void_p) if return_logits else None
+        if slot is None:
+            self._check(self.lib.dtk_prefill(self._ctx, ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
+                                             C.c_uint64(key), flags, lp), "dtk_prefill")
+        else:
+            self._check(self.lib.dtk_prefill_slot(self._ctx, int(slot), ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
+                                                  C.c_uint64(key), flags, lp), "dtk_prefill_slot")
         return torch.from_numpy(logits) if return_logits else None
 
     def set_sampling(self, do_sample=False, temperature=1.0, top_p=1.0, top_k=0, seed=0,
                      bad_ids: Iterable[int] = (), begin_suppress_ids: Iterable[int] = (),
-                     always_suppress_ids: Iterable[int] = ()):
+                     always_suppress_ids: Iterable[int] = (), slot: Optional[int] = None):
         s = _lib.DtkSampling()
         s.do_sample, s.temperature, s.top_p, s.top_k = int(bool(do_sample)), float(temperature), float(top_p), int(top_k or 0)
         s.seed = int(seed) & ((1 << 64) - 1)
@@ -233,7 +244,30 @@ class DetikzifyForCausalLM:
             arr = getattr(s, field)
             for i, v in enumerate(vals):
                 arr[i] = v
-        self._check(self.lib.dtk_set_sampling(self._ctx, C.byref(s)), "dtk_set_sampling")
+        if slot is None:
+            self._check(self.lib.dtk_set_sampling(self._ctx, C.byref(s)), "dtk_set_sampling")
+        else:
+            self._check(self.lib.dtk_set_sampling_slot(self._ctx, int(slot), C.byref(s)), "dtk_set_sampling_slot")
+
+    # ---- batched decode (independent rollouts share one pass over the weights) -----------------------
+    def num_slots(self) -> int:
+        return int(self.lib.dtk_num_slots(self._ctx))
+
+    def decode_batch_launch(self, active_slots: Iterable[int]):
+        arr = (C.c_int32 * 16)()
+        for j in active_slots:
+            arr[int(j)] = 1
+        self._check(self.lib.dtk_decode_batch_launch(self._ctx, arr), "dtk_decode_batch_launch")
+
+    def decode_batch_wait(self) -> List[int]:
+        out = (C.c_int64 * 16)()
+        self._check(self.lib.dtk_decode_batch_wait(self._ctx, out), "dtk_decode_batch_wait")
+        return [int(v) for v in out]
+
+    def get_logits_slot(self, slot: int) -> torch.Tensor:
+        out = np.empty(self.config.vocab, dtype=np.float32)
+        self._check(self.lib.dtk_get_logits_slot(self._ctx, int(slot), out.ctypes.data_as(C.c_void_p)), "dtk_get_logits_slot")
+        return torch.from_numpy(out)
 
     def decode_launch(self):
         self._check(self.lib.dtk_decode_launch(self._ctx), "dtk_decode_launch")
@@ -314,7 +348,26 @@ class DetikzifyForCausalLM:
         buf = torch.empty((1, max(max_length, T)), dtype=torch.int64)
         buf[0, :T] = ids[0]
         cur = T
-        if n_new_max > 0:
+        engine = self.batch_engine
+        if n_new_max > 0 and engine is not None:
+            # batched mode: this sequence decodes in a KV slot, in lock-step with the other threads'
+            # sequences (infer/batching.py); one pass over the weights serves all of them
+            with engine.sequence(ids[0], pixel_values, dict(
+                    do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k, seed=seed, bad_ids=bad,
+                    begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ())) as seq:
+                while True:
+                    tok = seq.next_token()
+                    buf[0, cur] = tok
+                    cur += 1
+                    if streamer is not None:
+                        streamer.put(torch.tensor([tok], dtype=torch.int64))
+                    stop = tok in eos_set or cur >= max_length
+                    for crit in criteria:
+                        r = crit(buf[:, :cur], None)
+                        stop = stop or bool(r.all() if isinstance(r, torch.Tensor) else r)
+                    if stop:
+                        break
+        elif n_new_max > 0:
             self.set_sampling(do_sample, temperature, top_p, top_k, seed, bad,
                               begin_suppress_tokens or (), suppress_tokens or ())
             self.prefill(ids[0], pixel_values)

@@ -68,7 +68,7 @@ typedef struct dtk_config {
   int32_t concat_patches;  /* 3  (modeling_detikzify.py:101)       */
   int32_t image_token_id;  /* == BOS for v1 (v1/__init__.py:49)    */
   int32_t attn_splits;     /* split-K factor of decode attention; 0 = default */
-  int32_t reserved[7];
+  int32_t reserved[7];     /* [0] = batch slots for dtk_decode_batch_* (0 = none)       */
 } dtk_config;
 
 /* Per-generation sampling state: the HF logits processors + sampler that
@@ -166,6 +166,19 @@ int  dtk_context_len(const dtk_ctx* ctx);
 int  dtk_set_graph_mode(dtk_ctx* ctx, int enabled);
 int  dtk_synchronize(dtk_ctx* ctx);
 int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
+
+/* Batched decode for independent rollouts of one GPU: dtk_config.reserved[0] = number
+ * of slots (<= 16), each with its own KV cache, sampling state and logits.  One dtk_decode_batch_*
+ * step = one _sample iteration for every active slot with ONE pass over the weights (bytes/step =
+ * W + sum_b K*t_b).  The image embeddings cache is shared (DTK_PREFILL_REUSE_IMAGE). */
+int  dtk_num_slots(const dtk_ctx* ctx);
+int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const float* pixels,
+                      uint64_t image_key, int flags, float* logits_last_out);
+int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
+int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active16);
+int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out16);
+int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
+int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
 
 /* Tuning aids (tools/, bench): time one decode GEMV role (0 qkv, 1 o_proj, 2 gate/up, 3 down,
  * 4 lm_head) in kernel variant `variant` over all layers with HIP events (clobbers the decode

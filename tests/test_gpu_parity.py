@@ -483,3 +483,103 @@ def test_rccl_coexists_with_the_library(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------ batched decode
+@pytest.fixture(scope="module")
+def tiny_batched():
+    from detikzify_amd.model import load
+    return load("detikzify-tiny", synthetic=1234, batch_slots=5)
+
+
+def _batch_prompts(proc):
+    out = []
+    for k, extra in enumerate(([], [70, 300, 41], [9] * 17)):
+        enc = proc(images=sketch_image(10 + k, 96), return_tensors="pt")
+        out.append((torch.cat([enc.input_ids[0], torch.tensor(extra, dtype=torch.long)]), enc.pixel_values))
+    return out
+
+
+def test_batched_decode_tracks_oracle_and_is_batch_invariant(tiny_batched):
+    """dtk_decode_batch_*: three sequences of different lengths/images in one step.  (1) per-slot logits
+    follow the oracle (teacher forced, same bounds as the single path); (2) a slot's logits are
+    bit-identical whether it decodes alone or next to other slots (MFMA columns are independent)."""
+    model, proc = tiny_batched
+    oracle = DetikzifyOracle(TINY_CFG, weights_from_device(model, TINY_CFG), precision="bf16")
+    prompts = _batch_prompts(proc)
+    n_steps = 12
+    for s, (ids, px) in enumerate(prompts):
+        model.set_sampling(do_sample=False, bad_ids=[1], begin_suppress_ids=[2], slot=s)
+        model.prefill(ids, px, slot=s)
+    toks = [[] for _ in prompts]
+    logit_log = [[] for _ in prompts]
+    for step in range(n_steps):
+        active = [0, 1, 2] if step < 8 else [0, 2]       # slot 1 leaves after 8 tokens
+        model.decode_batch_launch(active)
+        out = model.decode_batch_wait()
+        for s in active:
+            toks[s].append(out[s])
+            logit_log[s].append(model.get_logits_slot(s))
+        assert all(out[j] == -1 for j in range(16) if j not in active)
+    worst, flips = 0.0, 0
+    for s, (ids, px) in enumerate(prompts):
+        logits = oracle.prefill(ids, px[0])
+        for i, t in enumerate(toks[s]):
+            rt = sampling.greedy(logits, [1], [2], i == 0)
+            if rt != t:
+                top2 = torch.topk(sampling.mask_scores(logits, [1], [2], i == 0), 2)[0]
+                assert float(top2[0] - top2[1]) <= 2 * float(top2[0].abs()) * 2.0 ** -7 + 1e-6, (s, i, t, rt)
+                flips += 1
+            logits = oracle.step(t)
+            worst = max(worst, rel_l2(logit_log[s][i], logits))
+    print(f"batched decode: worst logits rel_l2 {worst:.2e}, {flips} near-tie flips")
+    assert worst < 1e-2 and flips <= 3
+    # batch invariance: slot 2 alone reproduces its tokens and logits bit for bit
+    ids, px = prompts[2]
+    model.set_sampling(do_sample=False, bad_ids=[1], begin_suppress_ids=[2], slot=2)
+    model.prefill(ids, px, slot=2)
+    for i in range(n_steps):
+        model.decode_batch_launch([2])
+        assert model.decode_batch_wait()[2] == toks[2][i]
+        assert torch.equal(model.get_logits_slot(2), logit_log[2][i])
+
+
+def test_batch_engine_threads_match_slot_alone(tiny_batched):
+    """model.generate() from several threads through the BatchEngine == each prompt generated alone"""
+    import threading
+    from detikzify_amd.infer.batching import BatchEngine
+    model, proc = tiny_batched
+    prompts = _batch_prompts(proc)
+    kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=24, bad_words_ids=[[1]],
+              begin_suppress_tokens=[2], eos_token_id=-1)
+    engine = BatchEngine(model)
+    try:
+        alone = [model.generate(input_ids=ids[None], pixel_values=px, seed=50 + i, **kw)[0].tolist()
+                 for i, (ids, px) in enumerate(prompts)]
+        res = [None] * len(prompts)
+
+        def run(i):
+            ids, px = prompts[i]
+            res[i] = model.generate(input_ids=ids[None], pixel_values=px, seed=50 + i, **kw)[0].tolist()
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(len(prompts))]
+        [t.start() for t in ths]
+        [t.join(timeout=120) for t in ths]
+        assert res == alone
+        assert engine.steps < 3 * 24            # steps were shared between the three sequences
+    finally:
+        engine.close()
+    # single-sequence path is unaffected by the engine having existed
+    ids, px = prompts[0]
+    single = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=8,
+                            bad_words_ids=[[1]], eos_token_id=-1)
+    assert single.shape[1] == ids.numel() + 8
+
+
+def test_simulate_parallel_trees(tiny_batched):
+    from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
+    from detikzify_amd.infer.batching import simulate_parallel
+    model, proc = tiny_batched
+    pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument, max_length=70)
+    res = list(simulate_parallel(pipe, sketch_image(8, 128), trees=4, expansions_per_tree=3))
+    assert len(res) == 12 and all(-1.0 <= s <= 1.0 + 1e-6 for s, _ in res)
+    assert model.batch_engine is None
