@@ -1112,6 +1112,28 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   if (!c || !avg_us || reps < 1) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  if (role == 5) {  // batched gate/up kernel, experiment modes (variant = mode)
+    if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
+    BatchState hb{}; for (int j = 0; j < c->nb; ++j) hb.active[j] = 1;
+    HIPCHK(c, hipMemcpy(c->bs_dev, &hb, sizeof hb, hipMemcpyHostToDevice));
+    auto pass = [&]() {
+      for (int l = 0; l < c->L; ++l) {
+        GemvBArgs g{};
+        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+        g.W = c->layers[l].wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
+        launch_gemv_b_mode(variant, g, s);
+      }
+    };
+    pass();
+    HIPCHK(c, hipEventRecord(c->ev_a, s));
+    for (int r = 0; r < reps; ++r) pass();
+    HIPCHK(c, hipEventRecord(c->ev_b, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+    *avg_us = ms * 1e3f / (float)(reps * c->L);
+    return DTK_OK;
+  }
   const bool same_layer = (variant & 0x100) != 0;  // every launch re-reads layer 0 (Infinity Cache probe)
   variant &= 0xff;
   auto one_pass = [&]() {

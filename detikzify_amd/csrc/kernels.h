@@ -83,6 +83,7 @@ struct GemvBArgs {
   int T_max; int d; int ff;
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
+void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
                       const BatchState* bs, hipStream_t s);
 struct AttnDecBArgs {

@@ -30,7 +30,7 @@ __device__ __forceinline__ int gb_tile_row0(const GemvBArgs& a, int blk, int t) 
   return (blk * T + t) * 16;
 }
 
-template <int EPI, int T>
+template <int EPI, int T, int MODE = 0>
 __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
   __shared__ float red[GB_WAVES][T][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
   const int per = (nsteps + GB_WAVES - 1) / GB_WAVES;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
 
-  const int arow = lane & 15, koff = (lane >> 4) * 8;
+  // MODE (timing experiments only): 1 = no x loads, 2 = lane-contiguous W loads (4 lanes = 64 B of a row), 3 = both
+  const int arow = (MODE & 2) ? (lane >> 2) : (lane & 15), koff = (MODE & 2) ? (lane & 3) * 8 : (lane >> 4) * 8;
   const bf16_t* wrow[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
       if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
 #pragma unroll
       for (int t = 0; t < T; ++t) wv[t][u] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + k));
-      xv[u] = *reinterpret_cast<const u32x4*>(xrow + k);
+      if (MODE & 1) xv[u] = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      else xv[u] = *reinterpret_cast<const u32x4*>(xrow + k);
       if (!ok) xv[u] = (u32x4){0u, 0u, 0u, 0u};
     }
 #pragma unroll
@@ -143,6 +145,14 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
       dst[i + 64] = f2bf(o2);
     }
   }
+}
+
+void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
+  const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
+  if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 2>), g, b, 0, s, a);
+  else if (mode == 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 3>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0>), g, b, 0, s, a);
 }
 
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {

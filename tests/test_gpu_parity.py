@@ -557,6 +557,7 @@ def test_batch_engine_threads_match_slot_alone(tiny_batched):
         alone = [model.generate(input_ids=ids[None], pixel_values=px, seed=50 + i, **kw)[0].tolist()
                  for i, (ids, px) in enumerate(prompts)]
         res = [None] * len(prompts)
+        steps_alone = engine.steps
 
         def run(i):
             ids, px = prompts[i]
@@ -565,7 +566,7 @@ def test_batch_engine_threads_match_slot_alone(tiny_batched):
         [t.start() for t in ths]
         [t.join(timeout=120) for t in ths]
         assert res == alone
-        assert engine.steps < 3 * 24            # steps were shared between the three sequences
+        assert engine.steps - steps_alone < 2 * 24      # the three sequences shared their decode steps
     finally:
         engine.close()
     # single-sequence path is unaffected by the engine having existed
