@@ -45,6 +45,7 @@ struct SeqHost {   // host-side mirror of one sequence's decode state
 
 struct LayerW {
   bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
+  bf16_t *t_wqkv = nullptr, *t_wo = nullptr, *t_wgu = nullptr, *t_wdown = nullptr;  // fragment-major copies (batched decode)
 };
 struct VitBlockW {
   bf16_t *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
@@ -115,6 +116,8 @@ struct dtk_ctx {
   DecState* st_b = nullptr;          // [16]
   SamplingDev* sp_b = nullptr;       // [16]
   BatchState* bs_dev = nullptr;
+  bf16_t* t_lm_head = nullptr;       // fragment-major copy of lm_head
+  bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
   int64_t* tokb_dev = nullptr;       // [DTK_MAX_INFLIGHT][16]
   int64_t* tokb_host = nullptr;      // pinned mirror
@@ -363,6 +366,14 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->st_b = P.take<DecState>(16);
     c->sp_b = P.take<SamplingDev>(16);
     c->bs_dev = P.take<BatchState>(1);
+    for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
+      bf16_t* a1 = P.take<bf16_t>(tiled_elems(3 * d, d));
+      bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
+      bf16_t* a3 = P.take<bf16_t>(tiled_elems(2 * ff, d));
+      bf16_t* a4 = P.take<bf16_t>(tiled_elems(d, ff));
+      if (reg) { c->layers[i].t_wqkv = a1; c->layers[i].t_wo = a2; c->layers[i].t_wgu = a3; c->layers[i].t_wdown = a4; }
+    }
+    c->t_lm_head = P.take<bf16_t>(tiled_elems(V, d));
     c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * 16);
   }
   c->scratch_bytes = (size_t)64 << 20;
@@ -505,26 +516,39 @@ void batch_step_launches(dtk_ctx* c) {
     g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
     launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
-    g.W = w.wqkv; g.N = 3 * d; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    g.W = w.t_wqkv; g.N = 3 * d; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
-    g.W = w.wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
+    g.W = w.t_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
     launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
-    g.W = w.wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
+    g.W = w.t_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
     launch_gemv_b(EPI_SWIGLU, g, s);
-    g.W = w.wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
+    g.W = w.t_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
   }
   launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
   GemvBArgs g{};
-  g.bs = c->bs_dev; g.st = c->st_b; g.W = c->lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
+  g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
   g.d = d; g.ff = ff;
   launch_gemv_b(EPI_LOGITS, g, s);
+}
+
+void ensure_tiled_weights(dtk_ctx* c) {
+  if (c->tiled_ready || c->nb <= 0) return;
+  for (int l = 0; l < c->L; ++l) {
+    LayerW& w = c->layers[l];
+    launch_retile(w.wqkv, w.t_wqkv, 3 * c->d, c->d, c->stream);
+    launch_retile(w.wo, w.t_wo, c->d, c->d, c->stream);
+    launch_retile(w.wgu, w.t_wgu, 2 * c->ff, c->d, c->stream);
+    launch_retile(w.wdown, w.t_wdown, c->d, c->ff, c->stream);
+  }
+  launch_retile(c->lm_head, c->t_lm_head, c->V, c->d, c->stream);
+  c->tiled_ready = true;
 }
 
 int ensure_batch_graph(dtk_ctx* c) {
@@ -734,6 +758,7 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   c->have_image = false;
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
+  c->tiled_ready = false;
   return DTK_OK;
 }
 
@@ -768,6 +793,7 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
   c->have_image = false;
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
+  c->tiled_ready = false;
   return DTK_OK;
 }
 
@@ -961,6 +987,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   }
   if (!n_active) return fail(c, DTK_ERR_ARG, "no active slot");
   HIPCHK(c, hipSetDevice(c->device));
+  ensure_tiled_weights(c);
   BatchState* hb = c->bs_host + (c->blaunched % DTK_MAX_INFLIGHT);
   for (int j = 0; j < 16; ++j) hb->active[j] = active[j] ? 1 : 0;
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
@@ -1114,13 +1141,14 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   hipStream_t s = c->stream;
   if (role == 5) {  // batched gate/up kernel, experiment modes (variant = mode)
     if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
+    ensure_tiled_weights(c);
     BatchState hb{}; for (int j = 0; j < c->nb; ++j) hb.active[j] = 1;
     HIPCHK(c, hipMemcpy(c->bs_dev, &hb, sizeof hb, hipMemcpyHostToDevice));
     auto pass = [&]() {
       for (int l = 0; l < c->L; ++l) {
         GemvBArgs g{};
         g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
-        g.W = c->layers[l].wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
+        g.W = c->layers[l].t_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
         launch_gemv_b_mode(variant, g, s);
       }
     };

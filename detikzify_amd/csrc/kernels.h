@@ -70,7 +70,7 @@ void launch_sample(const SampleArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- batched decode (16 slots share W)
 struct GemvBArgs {
-  const bf16_t* W; int N; int K;       // weight [N][K]
+  const bf16_t* W; int N; int K;       // weight [N][K] in the fragment-major (tiled) copy
   const bf16_t* X; int ldx;            // inputs [16][ldx] (slot-major)
   bf16_t* Y; int ldy;                  // RESID: residual streams [16][ldy]; SWIGLU: act [16][ldy]; STORE
   float* logits;                       // LOGITS: [16][N]
@@ -84,6 +84,8 @@ struct GemvBArgs {
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
+void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
+static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 31) >> 5) * 512; }
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
                       const BatchState* bs, hipStream_t s);
 struct AttnDecBArgs {

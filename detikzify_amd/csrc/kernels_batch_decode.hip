@@ -3,9 +3,11 @@
 // rollouts of one GPU are batched so W is read once for b sequences; bytes/step = W + sum_b K*t_b).
 //
 // k_gemv_b: Y[slot][n] = W[n][:] . X[slot][:] as a skinny GEMM on v_mfma_f32_16x16x32_bf16 with the
-// 16 slots as the MFMA N dimension: the A fragment of a wave is a 16-row x 32-k tile of W loaded
-// straight from HBM (non-temporal, lane l -> row l&15, 16 bytes at k = (l>>4)*8: the fragment layout IS
-// the global layout, no LDS), the B fragment is X[slot = l&15][k..k+8) from L2.  A block owns 16*T weight
+// 16 slots as the MFMA N dimension.  The weights are read from a FRAGMENT-MAJOR ("tiled") copy built
+// once by k_retile: tile (n/16, k/32) is 1 KiB stored in MFMA A-operand lane order (lane = (k%32/8)*16
+// + n%16, 8 bf16 per lane), so one wave-load is 1 KiB CONTIGUOUS and lands directly in the operand
+// registers (row-major weights would make every wave-load touch 16 rows x 64 B: measured 3.5 TB/s).
+// The B fragment is X[slot = l&15][k..k+8) from L2.  A block owns 16*T weight
 // rows; its 8 waves split K (each wave streams a contiguous K slice of those rows, 4 k-steps in
 // flight) and reduce their 16x16 partials through LDS.  Inactive slots are computed and discarded
 // (columns are independent), so the captured graph is identical for every active set.
@@ -41,14 +43,15 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
   const int per = (nsteps + GB_WAVES - 1) / GB_WAVES;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
 
-  // MODE (timing experiments only): 1 = no x loads, 2 = lane-contiguous W loads (4 lanes = 64 B of a row), 3 = both
-  const int arow = (MODE & 2) ? (lane >> 2) : (lane & 15), koff = (MODE & 2) ? (lane & 3) * 8 : (lane >> 4) * 8;
-  const bf16_t* wrow[T];
+  // MODE (timing experiments only): 1 = no x loads
+  const int arow = lane & 15, koff = (lane >> 4) * 8;
+  const bf16_t* wrow[T];  // tile row of this block's t-th row tile in the fragment-major copy, + this lane's 16 B
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    int r = gb_tile_row0<EPI, T>(a, blk, t) + arow;
-    if (r >= a.N) r = a.N - 1;
-    wrow[t] = a.W + (size_t)r * K;
+    int tn = gb_tile_row0<EPI, T>(a, blk, t) >> 4;
+    const int tn_max = ((a.N + 15) >> 4) - 1;
+    if (tn > tn_max) tn = tn_max;
+    wrow[t] = a.W + (size_t)tn * nsteps * 512 + lane * 8;
   }
   const bf16_t* xrow = a.X + (size_t)arow * a.ldx;  // B fragment: slot = lane & 15
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
       const bool ok = (s + u < s1) && (k < K);
       if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
 #pragma unroll
-      for (int t = 0; t < T; ++t) wv[t][u] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + k));
+      for (int t = 0; t < T; ++t) wv[t][u] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)(ok ? s + u : s) * 512));
       if (MODE & 1) xv[u] = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
       else xv[u] = *reinterpret_cast<const u32x4*>(xrow + k);
       if (!ok) xv[u] = (u32x4){0u, 0u, 0u, 0u};
@@ -150,8 +153,6 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
   if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
-  else if (mode == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 2>), g, b, 0, s, a);
-  else if (mode == 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 3>), g, b, 0, s, a);
   else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0>), g, b, 0, s, a);
 }
 
@@ -338,4 +339,25 @@ __global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, 16), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, 16), dim3(128), 0, s, a);
+}
+
+// Row-major [N][K] bf16 -> fragment-major tiles (see the header): storage = ceil(N/16)*ceil(K/32) tiles
+// of 512 elements, zero padded.  One thread per 16-byte lane slot.
+__global__ void k_retile(const bf16_t* src, bf16_t* dst, int N, int K) {
+  const int K32 = (K + 31) >> 5, N16 = (N + 15) >> 4;
+  const long total = (long)N16 * K32 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long tile = i >> 6;
+    const int tk = (int)(tile % K32), tn = (int)(tile / K32);
+    const int n = tn * 16 + (lane & 15), k = tk * 32 + (lane >> 4) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * K + k);
+    reinterpret_cast<u32x4*>(dst)[i] = v;
+  }
+}
+void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s) {
+  const long total = (long)((N + 15) >> 4) * ((K + 31) >> 5) * 64;
+  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, N, K);
 }
