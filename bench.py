@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
     ap.add_argument("--probe-tokens", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=8, help="independent rollouts decoded as one batch per GPU in the "
+    ap.add_argument("--batch", type=int, default=16, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     return ap.parse_args()
 

@@ -80,6 +80,7 @@ SYMBOLS = {
     "dtk_context_len_slot": (C.c_int, [_P, C.c_int]),
     "dtk_bench_gemv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "dtk_set_gemv_variant": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dtk_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "dtk_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

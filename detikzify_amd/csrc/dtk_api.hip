@@ -133,8 +133,9 @@ struct dtk_ctx {
   hipEvent_t probe_a = nullptr, probe_b = nullptr;
   bool use_graph = true;
   bool graph_ready = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr, graph_short = nullptr;
+  hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
+  int attn_full_max = 1024;          // contexts below this use the one-block-per-head attention
   bool gemm_naive = false;
   int probe = 0;
   bool probe_pending = false;
@@ -452,7 +453,7 @@ void project_image(dtk_ctx* c) {
 }
 
 // launches of one decoded token (captured into the graph, or issued directly)
-void decode_step_launches(dtk_ctx* c, bool with_probe) {
+void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
   hipStream_t s = c->stream;
   SampleArgs sa;
   sa.logits = c->logits; sa.V = c->V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed;
@@ -475,7 +476,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe) {
     ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
     ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax;
     ad.scale = scale;
-    ad.combine = c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
+    ad.combine = (short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.N = c->d; g.K = c->d; g.y = c->x;
@@ -565,12 +566,16 @@ int ensure_batch_graph(dtk_ctx* c) {
 
 int ensure_graph(dtk_ctx* c) {
   if (c->graph_ready) return DTK_OK;
-  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  decode_step_launches(c, false);
-  HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT,
-                           hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
-  HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+  // two captures of the same step: split-K attention (any context) and the one-block-per-head
+  // attention used while the context is short; the host picks per step (it knows the position)
+  for (int v = 0; v < 2; ++v) {
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    decode_step_launches(c, false, v == 1);
+    HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamEndCapture(c->stream, v ? &c->graph_short : &c->graph));
+    HIPCHK(c, hipGraphInstantiate(v ? &c->graph_short_exec : &c->graph_exec, v ? c->graph_short : c->graph, nullptr, nullptr, 0));
+  }
   c->graph_ready = true;
   return DTK_OK;
 }
@@ -641,6 +646,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   const char* ac = getenv("DTK_ATTN_COMBINE");
   c->attn_combine = !ac ? 2 : (!strcmp(ac, "consumer") ? 0 : (!strcmp(ac, "inkernel") ? 1 : 2));
   if (c->S > 16) c->S = 16;
+  if (const char* fm = getenv("DTK_ATTN_FULL_MAX")) c->attn_full_max = atoi(fm);
   if (const char* gv = getenv("DTK_GEMV_VARIANTS")) {  // "epi:variant,epi:variant" (tuning aid)
     int e = 0, v = 0;
     const char* p = gv;
@@ -702,6 +708,8 @@ void dtk_destroy(dtk_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->graph_short_exec) (void)hipGraphExecDestroy(c->graph_short_exec);
+  if (c->graph_short) (void)hipGraphDestroy(c->graph_short);
   if (c->bgraph_exec) (void)hipGraphExecDestroy(c->bgraph_exec);
   if (c->bgraph) (void)hipGraphDestroy(c->bgraph);
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->bstep_done[i]) (void)hipEventDestroy(c->bstep_done[i]);
@@ -1061,7 +1069,8 @@ int dtk_decode_launch(dtk_ctx* c) {
   if (c->use_graph) {
     int rc = ensure_graph(c);
     if (rc) return rc;
-    HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+    const bool short_ctx = c->seq0.host_next_pos < c->attn_full_max;
+    HIPCHK(c, hipGraphLaunch(short_ctx ? c->graph_short_exec : c->graph_exec, c->stream));
   } else {
     if (c->probe && c->launched > c->waited) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->probe && c->probe_pending) {  // read the previous step's pair before re-recording it
@@ -1073,7 +1082,7 @@ int dtk_decode_launch(dtk_ctx* c) {
       }
       c->probe_pending = false;
     }
-    decode_step_launches(c, c->probe != 0);
+    decode_step_launches(c, c->probe != 0, c->seq0.host_next_pos < c->attn_full_max);
     if (c->probe) c->probe_pending = true;
     HIPCHK(c, hipMemcpyAsync(c->tok_ring_host, c->tok_ring_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT, hipMemcpyDeviceToHost, c->stream));
   }
@@ -1190,10 +1199,31 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   return DTK_OK;
 }
 
+// Runtime options (tests / tuning): "attn_full_max" = contexts below this use the one-block-per-head
+// decode attention (0 = always split-K); "attn_combine" = 0 consumer | 1 in-kernel | 2 own kernel.
+int dtk_set_option(dtk_ctx* c, const char* name, int value) {
+  if (!c || !name) return DTK_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
+  else if (!strcmp(name, "attn_combine")) {
+    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_combine must be 0..2");
+    c->attn_combine = value;
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_short_exec) { (void)hipGraphExecDestroy(c->graph_short_exec); c->graph_short_exec = nullptr; }
+    if (c->graph_short) { (void)hipGraphDestroy(c->graph_short); c->graph_short = nullptr; }
+    c->graph_ready = false;
+  } else return fail(c, DTK_ERR_ARG, "unknown option '%s'", name);
+  return DTK_OK;
+}
+
 int dtk_set_gemv_variant(dtk_ctx* c, int epi, int variant) {
   if (!c) return DTK_ERR_ARG;
   if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
   if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  if (c->graph_short_exec) { (void)hipGraphExecDestroy(c->graph_short_exec); c->graph_short_exec = nullptr; }
+  if (c->graph_short) { (void)hipGraphDestroy(c->graph_short); c->graph_short = nullptr; }
   c->graph_ready = false;
   set_gemv_default_variant(epi, variant);
   return DTK_OK;

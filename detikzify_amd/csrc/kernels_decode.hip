@@ -545,7 +545,105 @@ __global__ __launch_bounds__(128) void k_attn_combine(AttnDecArgs a) {
   a.out[h * 128 + t] = f2bf(o / L);
 }
 
+// Short-context variant: ONE 1024-thread block per head scans all keys (16 waves x 4 row-groups, 4 rows
+// each in flight = 256 rows per iteration), merges its 64 online-softmax streams through shuffles + LDS
+// and writes the normalised bf16 head output itself: no split-K partials, no combine kernel (2 launches
+// and ~4 us per layer less below ~1k tokens of context; above that the split-K grid wins on bandwidth).
+__global__ __launch_bounds__(1024) void k_attn_decode_head(AttnDecArgs a) {
+  const int h = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int n = a.st->pos + 1;
+  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + h * 128)[sub];
+  const bf16_t* kbase = a.kcache + (size_t)h * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)h * a.T_max * 128;
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    u32x4 kv[4], vv[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i * 64 + wave * 4 + grp;
+      ok[i] = j < n;
+      const int jj = ok[i] ? j : 0;
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = dot8(qv, kv[i], 0.f);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s *= a.scale;
+      if (ok[i]) {
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn);
+        const float p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[i][e]);
+          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[i][e]);
+        }
+        m = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64);
+    const float l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * c1 + o2 * c2;
+    }
+    m = mn;
+  }
+  __shared__ float sm_m[16][16], sm_l[16][16], sm_o[16][16][8];
+  if (grp == 0) {
+    sm_m[wave][sub] = m;
+    sm_l[wave][sub] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float M = sm_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, sm_m[w][tid]);
+    float L = 0.f;
+    float oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const float c = __expf(sm_m[w][tid] - M);
+      L += c * sm_l[w][tid];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+    }
+    const float invL = 1.f / L;
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack2(oo[2 * e] * invL, oo[2 * e + 1] * invL);
+    reinterpret_cast<u32x4*>(a.out + h * 128)[tid] = ov;
+  }
+}
+
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s) {
+  if (a.combine == 3) {  // one block per head, output written directly
+    hipLaunchKernelGGL(k_attn_decode_head, dim3(a.H), dim3(1024), 0, s, a);
+    return;
+  }
   hipLaunchKernelGGL(k_attn_decode, dim3(a.H, a.S), dim3(256), 0, s, a);
   if (a.combine == 2) hipLaunchKernelGGL(k_attn_combine, dim3(a.H), dim3(128), 0, s, a);
 }
@@ -611,13 +709,40 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
   const bool sampling = sp->do_sample != 0;
   const float invT = sampling ? 1.f / sp->temperature : 1.f;
 
-  // ---- pass 1: masked (scaled) max and first argmax
+  // ---- pass 1: masked (scaled) max and first argmax.  16-byte loads, four per thread in flight
+  // (the greedy path is one memory round trip + the block reduction)
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int i = tid; i < V; i += SAMPLE_THREADS) {
-    float z = a.logits[i] * invT;
-    if (is_banned(sp, i, first)) z = -INFINITY;
-    if (z > best || (z == best && i < besti)) { best = z; besti = i; }
+  const bool vec = ((V & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0);
+  if (vec) {
+    const int V4 = V >> 2;
+    const f32x4* l4 = reinterpret_cast<const f32x4*>(a.logits);
+    for (int base = tid; base < V4; base += 4 * SAMPLE_THREADS) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i4 = base + u * SAMPLE_THREADS;
+        v[u] = (i4 < V4) ? l4[i4] : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i4 = base + u * SAMPLE_THREADS;
+        if (i4 >= V4) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = i4 * 4 + e;
+          float z = v[u][e] * invT;
+          if (is_banned(sp, i, first)) z = -INFINITY;
+          if (z > best || (z == best && i < besti)) { best = z; besti = i; }
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < V; i += SAMPLE_THREADS) {
+      float z = a.logits[i] * invT;
+      if (is_banned(sp, i, first)) z = -INFINITY;
+      if (z > best || (z == best && i < besti)) { best = z; besti = i; }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

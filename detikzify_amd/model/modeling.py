@@ -288,6 +288,9 @@ class DetikzifyForCausalLM:
     def set_graph_mode(self, mode: int):
         self._check(self.lib.dtk_set_graph_mode(self._ctx, int(mode)), "dtk_set_graph_mode")
 
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.dtk_set_option(self._ctx, name.encode(), int(value)), f"dtk_set_option({name})")
+
     def synchronize(self):
         self._check(self.lib.dtk_synchronize(self._ctx), "dtk_synchronize")
 

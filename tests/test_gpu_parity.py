@@ -301,6 +301,28 @@ def test_graph_replay_equals_plain_launches(tiny):
     assert a == b
 
 
+def test_attention_variants_agree(tiny):
+    """decode attention: one-block-per-head (short contexts) vs split-K + combine kernel vs split-K with
+    consumer-side / in-kernel combine — identical greedy tokens, logits within the single-op bound"""
+    model, proc = tiny
+    enc = proc(images=sketch_image(9, 96), return_tensors="pt")
+    ids, px = enc.input_ids[0], enc.pixel_values
+    outs, logs = {}, {}
+    try:
+        for name, opts in (("head", dict(attn_full_max=4096, attn_combine=2)), ("split", dict(attn_full_max=0, attn_combine=2)),
+                           ("consumer", dict(attn_full_max=0, attn_combine=0)), ("inkernel", dict(attn_full_max=0, attn_combine=1))):
+            for k, v in opts.items():
+                model.set_option(k, v)
+            outs[name] = run_greedy(model, ids, px, 40)
+            logs[name] = model.get_logits()
+    finally:
+        model.set_option("attn_combine", 2)
+        model.set_option("attn_full_max", 1024)
+    for name in ("split", "consumer", "inkernel"):
+        assert outs[name] == outs["head"], name
+        assert rel_l2(logs[name], logs["head"]) < 5e-3, name
+
+
 def test_prefix_and_image_reuse_is_output_identical(tiny):
     model, proc = tiny
     enc = proc(images=sketch_image(5, 96), return_tensors="pt")
