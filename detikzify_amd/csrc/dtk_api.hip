@@ -135,7 +135,7 @@ struct dtk_ctx {
   bool graph_ready = false;
   hipGraph_t graph = nullptr, graph_short = nullptr;
   hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
-  int attn_full_max = 1024;          // contexts below this use the one-block-per-head attention
+  int attn_full_max = 0;             // contexts below this use the one-block-per-head attention (measured slower: off)
   bool gemm_naive = false;
   int probe = 0;
   bool probe_pending = false;

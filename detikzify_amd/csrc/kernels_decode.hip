@@ -703,7 +703,11 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = a.V;
-  const SamplingDev* sp = a.sp;
+  // the sampling configuration is read once into LDS (is_banned runs for every vocabulary entry)
+  __shared__ SamplingDev s_sp;
+  if (tid < (int)(sizeof(SamplingDev) / 4)) reinterpret_cast<uint32_t*>(&s_sp)[tid] = reinterpret_cast<const uint32_t*>(a.sp)[tid];
+  __syncthreads();
+  const SamplingDev* sp = &s_sp;
   const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
   const bool first = (draw == 0);
   const bool sampling = sp->do_sample != 0;
