@@ -46,6 +46,8 @@ struct SeqHost {   // host-side mirror of one sequence's decode state
 struct LayerW {
   bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
   bf16_t *t_wqkv = nullptr, *t_wo = nullptr, *t_wgu = nullptr, *t_wdown = nullptr;  // fragment-major copies (batched decode)
+  uint8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;  // fp8 e4m3 copies (weight_format 1)
+  float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;    // per-row power-of-two scales
 };
 struct VitBlockW {
   bf16_t *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
@@ -104,6 +106,10 @@ struct dtk_ctx {
 
   // host state
   SeqHost seq0;              // the single-sequence API (dtk_prefill / dtk_decode*)
+  int wfmt = 0;              // 0 = bf16 decoder weights, 1 = fp8 e4m3 + per-row 2^e scale (dtk_config.reserved[1])
+  bool fp8_ready = false;
+  uint8_t* q_lm_head = nullptr;
+  float* s_lm_head = nullptr;
   uint64_t cached_image_key = 0;
   bool have_image = false;
   // ---- batched decode (dtk_*_slot / dtk_decode_batch_*): up to 16 slots with their own KV
@@ -352,6 +358,20 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->ph = P.take<bf16_t>(mlp);
   c->pooled = P.take<bf16_t>(D);
   c->IMG = P.take<bf16_t>((size_t)c->nImg * d);
+  if (c->wfmt == 1) {
+    for (int i = 0; i < L; ++i) {
+      uint8_t* q1 = P.take<uint8_t>((size_t)3 * d * d); float* s1 = P.take<float>(3 * d);
+      uint8_t* q2 = P.take<uint8_t>((size_t)d * d);     float* s2 = P.take<float>(d);
+      uint8_t* q3 = P.take<uint8_t>((size_t)2 * ff * d); float* s3 = P.take<float>(2 * ff);
+      uint8_t* q4 = P.take<uint8_t>((size_t)d * ff);    float* s4 = P.take<float>(d);
+      if (reg) {
+        LayerW& w = c->layers[i];
+        w.q_wqkv = q1; w.s_wqkv = s1; w.q_wo = q2; w.s_wo = s2; w.q_wgu = q3; w.s_wgu = s3; w.q_wdown = q4; w.s_wdown = s4;
+      }
+    }
+    c->q_lm_head = P.take<uint8_t>((size_t)V * d);
+    c->s_lm_head = P.take<float>(V);
+  }
   if (c->nb > 0) {
     c->kv_slot_stride = (size_t)L * 2 * c->H * T * 128;
     c->kvb = P.take<bf16_t>((size_t)c->nb * c->kv_slot_stride);
@@ -468,7 +488,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin;
     g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
     // 1. input_layernorm + q/k/v projections + RoPE + KV append
-    g.W = w.wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1;
+    g.W = w.wqkv; g.W8 = w.q_wqkv; g.wscale = w.s_wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1;
     g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l);
     launch_gemv(PRO_RMSNORM, EPI_QKV, g, s);
     // 2. split-K attention over the cache
@@ -479,21 +499,21 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.combine = (short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
-    g.W = w.wo; g.N = c->d; g.K = c->d; g.y = c->x;
+    g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
     if (c->attn_combine) { g.x = c->attn_out; launch_gemv(PRO_COPY, EPI_RESID, g, s); }
     else launch_gemv(PRO_ATTN, EPI_RESID, g, s);
     // 4. post_attention_layernorm + gate/up + SiLU*mul
-    g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act;
+    g.W = w.wgu; g.W8 = w.q_wgu; g.wscale = w.s_wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act;
     const bool probe_here = with_probe && (l == c->L / 2);
     if (probe_here) (void)hipEventRecord(c->probe_a, s);
     launch_gemv(PRO_RMSNORM, EPI_SWIGLU, g, s);
     if (probe_here) (void)hipEventRecord(c->probe_b, s);
     // 5. down + residual
-    g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->x;
+    g.W = w.wdown; g.W8 = w.q_wdown; g.wscale = w.s_wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->x;
     launch_gemv(PRO_COPY, EPI_RESID, g, s);
   }
   GemvArgs g{};
-  g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm;
+  g.W = c->lm_head; g.W8 = c->q_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm;
   g.eps = c->cfg.rms_eps; g.logits = c->logits;
   launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
 }
@@ -539,7 +559,25 @@ void batch_step_launches(dtk_ctx* c) {
   launch_gemv_b(EPI_LOGITS, g, s);
 }
 
+// fp8 mode: quantise the decoder Linear weights (per-row power-of-two scale) and overwrite the bf16 masters
+// with the de-quantised values, so every consumer (prefill GEMM, tiled copy, read-back, oracle) sees the
+// same effective weights as the fp8 decode kernels
+void ensure_fp8_weights(dtk_ctx* c) {
+  if (c->wfmt != 1 || c->fp8_ready) return;
+  for (int l = 0; l < c->L; ++l) {
+    LayerW& w = c->layers[l];
+    launch_quant_fp8_rows(w.wqkv, w.q_wqkv, w.s_wqkv, 3 * c->d, c->d, c->stream);
+    launch_quant_fp8_rows(w.wo, w.q_wo, w.s_wo, c->d, c->d, c->stream);
+    launch_quant_fp8_rows(w.wgu, w.q_wgu, w.s_wgu, 2 * c->ff, c->d, c->stream);
+    launch_quant_fp8_rows(w.wdown, w.q_wdown, w.s_wdown, c->d, c->ff, c->stream);
+  }
+  launch_quant_fp8_rows(c->lm_head, c->q_lm_head, c->s_lm_head, c->V, c->d, c->stream);
+  c->fp8_ready = true;
+  c->tiled_ready = false;
+}
+
 void ensure_tiled_weights(dtk_ctx* c) {
+  ensure_fp8_weights(c);
   if (c->tiled_ready || c->nb <= 0) return;
   for (int l = 0; l < c->L; ++l) {
     LayerW& w = c->layers[l];
@@ -634,6 +672,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->d = cfg->hidden; c->L = cfg->layers; c->H = cfg->heads; c->ff = cfg->ffn; c->V = cfg->vocab;
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
+  c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
   c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > 16 ? 16 : cfg->reserved[0]);
   c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
@@ -696,8 +735,13 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   // accounting: W = decoder layers + final norm + lm_head, K = 2*L*d*2
   const uint64_t per_layer = (uint64_t)4 * c->d * c->d + (uint64_t)3 * c->d * c->ff + 2 * (uint64_t)c->d;
   c->stats.weight_bytes_per_token = 2 * (per_layer * c->L + (uint64_t)c->d + (uint64_t)c->V * c->d);
+  if (c->wfmt == 1) {  // 1 byte per Linear weight + fp32 scale per row; norm vectors stay bf16
+    const uint64_t lin = (uint64_t)4 * c->d * c->d + (uint64_t)3 * c->d * c->ff;
+    const uint64_t rows = (uint64_t)5 * c->d + (uint64_t)2 * c->ff;
+    c->stats.weight_bytes_per_token = (lin + 4 * rows + 4 * (uint64_t)c->d) * c->L + 2 * (uint64_t)c->d + (uint64_t)c->V * c->d + 4 * (uint64_t)c->V;
+  }
   c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * c->d * 2;
-  c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * 2;
+  c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * (c->wfmt == 1 ? 1 : 2);
   *out = c;
   return DTK_OK;
 }
@@ -767,6 +811,7 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
   c->tiled_ready = false;
+  c->fp8_ready = false;
   return DTK_OK;
 }
 
@@ -777,6 +822,7 @@ int dtk_read_tensor(dtk_ctx* c, const char* name, void* host_out, int64_t n_elem
   const TensorEntry& t = c->tensors[it->second];
   if (n_elems != t.numel()) return fail(c, DTK_ERR_ARG, "tensor '%s' has %lld elements", name, (long long)t.numel());
   HIPCHK(c, hipSetDevice(c->device));
+  ensure_fp8_weights(c);   // fp8 mode: the stored tensor is the de-quantised (effective) weight
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy2D(host_out, (size_t)t.cols * 2, t.ptr, (size_t)t.stride * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyDeviceToHost));
   return DTK_OK;
@@ -802,6 +848,7 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
   c->tiled_ready = false;
+  c->fp8_ready = false;
   return DTK_OK;
 }
 
@@ -837,6 +884,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   HIPCHK(c, hipSetDevice(c->device));
   // drain pending decode steps (their tokens are dropped)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  ensure_fp8_weights(c);
   if (is_single) c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
   else c->bwaited = c->blaunched;
   // ---- locate the image placeholder run (reference v1/modeling_detikzify.py:179-184)
@@ -911,7 +959,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   }
   // final norm + lm_head on the last position only (the sampler consumes logits[:, -1])
   GemvArgs g{};
-  g.W = c->lm_head; g.N = c->V; g.K = d; g.x = c->X + (size_t)(n - 1) * d; g.norm_w = c->final_norm;
+  g.W = c->lm_head; g.W8 = c->q_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.x = c->X + (size_t)(n - 1) * d; g.norm_w = c->final_norm;
   g.eps = c->cfg.rms_eps; g.logits = logits_dst;
   launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
   DecState st0{};
@@ -1066,6 +1114,7 @@ int dtk_decode_launch(dtk_ctx* c) {
   if (c->launched - c->waited >= DTK_MAX_INFLIGHT) return fail(c, DTK_ERR_STATE, "too many decode steps in flight");
   if (c->seq0.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "context length %d reached max_positions", c->seq0.host_next_pos);
   HIPCHK(c, hipSetDevice(c->device));
+  ensure_fp8_weights(c);
   if (c->use_graph) {
     int rc = ensure_graph(c);
     if (rc) return rc;

@@ -8,6 +8,8 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4
 
 struct GemvArgs {
   const bf16_t* W;       // [N][K] row-major, K contiguous
+  const uint8_t* W8;     // fp8 (e4m3) copy of W, [N][K] bytes, or null; then wscale[N] = per-row 2^e scales
+  const float* wscale;
   int N;                 // weight rows
   int K;                 // input dim (multiple of 8)
   // prologue inputs
@@ -142,6 +144,8 @@ struct AttnArgs {
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
+// per-row fp8 quantisation with a power-of-two scale; W is overwritten with the de-quantised values
+void launch_quant_fp8_rows(bf16_t* W, uint8_t* W8, float* scale, int N, int K, hipStream_t s);
 void launch_fill_synth(bf16_t* dst, int64_t n, uint64_t seed, uint32_t tag, float scale,
                        float offset, hipStream_t s);
 void launch_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);

@@ -455,3 +455,39 @@ void launch_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s)
   int64_t blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
 }
+
+// ------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3fn) weight quantisation, one block per row: scale = 2^ceil(log2(max|w| / 448)) (a power
+// of two, so q * scale is exactly representable in bf16), q = rne_e4m3(w / scale).  The bf16 master row is
+// overwritten with the de-quantised values: prefill GEMMs, the fragment-major copy, dtk_read_tensor and the
+// CPU oracle all see the same "effective" weights the fp8 decode kernels compute with.
+__global__ __launch_bounds__(256) void k_quant_fp8_rows(bf16_t* W, uint8_t* W8, float* scale, int N, int K) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int row = blockIdx.x;
+  bf16_t* w = W + (size_t)row * K;
+  uint8_t* q = W8 + (size_t)row * K;
+  __shared__ float red[4];
+  float amax = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(bf2f(w[k])));
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sc = 1.f;
+  if (amax > 0.f) sc = exp2f(ceilf(log2f(amax / 448.f)));
+  if (amax > 448.f * sc) sc *= 2.f;   // guard the log2/ceil rounding
+  if (threadIdx.x == 0) scale[row] = sc;
+  const float inv = 1.f / sc;
+  for (int k = threadIdx.x * 2; k < K; k += 512) {   // K is even (K % 16 == 0)
+    const float a0 = bf2f(w[k]) * inv, a1 = bf2f(w[k + 1]) * inv;
+    const int p = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+    q[k] = (uint8_t)(p & 0xff);
+    q[k + 1] = (uint8_t)((p >> 8) & 0xff);
+    const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(p, false);
+    w[k] = f2bf(d[0] * sc);
+    w[k + 1] = f2bf(d[1] * sc);
+  }
+}
+void launch_quant_fp8_rows(bf16_t* W, uint8_t* W8, float* scale, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(k_quant_fp8_rows, dim3(N), dim3(256), 0, s, W, W8, scale, N, K);
+}

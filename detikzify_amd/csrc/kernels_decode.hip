@@ -47,18 +47,52 @@ __device__ __forceinline__ void gemv_fma(float (&acc)[NR], const u32x4 (&w)[NR][
   }
 }
 
+// fp8 (OCP e4m3) weights: a 16-byte chunk holds 16 weights of one row; they are widened to bf16 pairs
+// (exact) and fed to the same v_dot2c_f32_bf16 against 32 bytes of x.  The per-row power-of-two scale is
+// applied to the fp32 sum in the epilogue (exact), so the result equals the bf16 kernel on the
+// de-quantised ("effective") weights bit for bit at equal accumulation order.
+__device__ __forceinline__ float dot16_f8(const u32x4& w, const u32x4& x0, const u32x4& x1, float c) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false);
+    const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
+    const uint32_t xa = (j < 2) ? x0[2 * j] : x1[2 * j - 4];
+    const uint32_t xb = (j < 2) ? x0[2 * j + 1] : x1[2 * j - 3];
+    c = dot2(pack2(lo[0], lo[1]), xa, c);
+    c = dot2(pack2(hi[0], hi[1]), xb, c);
+  }
+  return c;
+}
+
+template <int NR, int U>
+__device__ __forceinline__ void gemv_fma_f8(float (&acc)[NR], const u32x4 (&w)[NR][U],
+                                            const u32x4* xs, int g, int lane, int KC) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = lane + 64 * (g * U + u);
+    u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
+    if (c < KC) { x0 = xs[2 * c]; x1 = xs[2 * c + 1]; }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = dot16_f8(w[r][u], x0, x1, acc[r]);
+  }
+}
+
 // R = output units per wave-chunk; paired epilogues (QKV, SWIGLU) stream 2 rows per unit.
 // WAVES = waves per block.  PERSIST: grid-stride over chunks (chunk c -> block c % grid,
 // wave (c / grid) % WAVES) so a grid sized to the machine covers any N with <= 1 chunk of
 // imbalance per wave; otherwise one chunk per wave and the grid covers N.
-template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST>
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   constexpr bool PAIRED = (EPI == EPI_QKV) || (EPI == EPI_SWIGLU);
   constexpr int NR = PAIRED ? 2 * R : R;
   constexpr int THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
-  const int K8 = a.K >> 3;
+  const int K8 = a.K >> 3;                     // 16-byte chunks of x (bf16)
+  const int KC = F8 ? (a.K >> 4) : K8;         // 16-byte chunks of one weight row
+  const size_t row_bytes = F8 ? (size_t)a.K : (size_t)a.K * 2;
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(F8 ? (const void*)a.W8 : (const void*)a.W);
   float* red = reinterpret_cast<float*>(smem + (size_t)K8 * 16);  // WAVES floats of scratch
 
   const int tid = threadIdx.x;
@@ -93,22 +127,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
         r0 = u;
       }
       if (PAIRED) {
-        rows[2 * j] = reinterpret_cast<const u32x4*>(a.W + (size_t)r0 * a.K);
-        rows[2 * j + 1] = reinterpret_cast<const u32x4*>(a.W + (size_t)r1 * a.K);
+        rows[2 * j] = reinterpret_cast<const u32x4*>(Wb + (size_t)r0 * row_bytes);
+        rows[2 * j + 1] = reinterpret_cast<const u32x4*>(Wb + (size_t)r1 * row_bytes);
       } else {
-        rows[j] = reinterpret_cast<const u32x4*>(a.W + (size_t)r0 * a.K);
+        rows[j] = reinterpret_cast<const u32x4*>(Wb + (size_t)r0 * row_bytes);
       }
     }
   };
   set_rows(unit0);
 
-  const int iters = (K8 + 63) >> 6;
+  const int iters = (KC + 63) >> 6;
   const int G = (iters + U - 1) / U;
   u32x4 wa[NR][U], wb[NR][U];
   float acc[NR];
 
   // first stage of weights goes in flight before the prologue touches x
-  gemv_load<NR, U>(wa, rows, 0, lane, K8);
+  gemv_load<NR, U>(wa, rows, 0, lane, KC);
 
   // ---- prologue: build the bf16 input vector in LDS
   if (PRO == PRO_COPY) {
@@ -184,11 +218,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
     for (int r = 0; r < NR; ++r) acc[r] = 0.f;
     // ---- main loop: two register stages (wa holds stage 0 on entry)
     for (int g = 0; g < G; g += 2) {
-      if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, K8);
-      gemv_fma<NR, U>(acc, wa, xs, g, lane, K8);
+      if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, KC);
+      if (F8) gemv_fma_f8<NR, U>(acc, wa, xs, g, lane, KC); else gemv_fma<NR, U>(acc, wa, xs, g, lane, KC);
       if (g + 1 < G) {
-        if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, K8);
-        gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, K8);
+        if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, KC);
+        if (F8) gemv_fma_f8<NR, U>(acc, wb, xs, g + 1, lane, KC); else gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, KC);
       }
     }
     const int cur = unit0;
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
       unit0 = chunk * R;
       if (unit0 < n_units) {
         set_rows(unit0);
-        gemv_load<NR, U>(wa, rows, 0, lane, K8);
+        gemv_load<NR, U>(wa, rows, 0, lane, KC);
       }
     }
 #pragma unroll
@@ -209,6 +243,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
       for (int j = 0; j < R; ++j) {
         const int u = cur + j;
         if (u >= n_units) break;
+        if (F8) {  // per-output-channel power-of-two scale (exact)
+          if (EPI == EPI_QKV) {
+            const int half = a.d >> 1;
+            const int sec = u / half, pi = u - sec * half;
+            const int r0 = sec * a.d + (pi >> 6) * 128 + (pi & 63);
+            acc[2 * j] *= a.wscale[r0];
+            acc[2 * j + 1] *= a.wscale[r0 + 64];
+          } else if (EPI == EPI_SWIGLU) {
+            acc[2 * j] *= a.wscale[u];
+            acc[2 * j + 1] *= a.wscale[a.ff + u];
+          } else {
+            acc[j] *= a.wscale[u];
+          }
+        }
         if (EPI == EPI_STORE) {
           a.y[u] = f2bf(acc[j]);
         } else if (EPI == EPI_RESID) {
@@ -344,10 +392,28 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
 }
 #undef GV
 
+template <int PRO, int EPI, int R, int U, int WAVES>
+static void launch_gemv_f8_t(const GemvArgs& a, hipStream_t s) {
+  int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
+  const int per_block = WAVES * R;
+  const int grid = (n_units + per_block - 1) / per_block;
+  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
+  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, false, true>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+}
+// fp8-weight decode GEMVs (requires K % 16 == 0); same roles as the bf16 defaults
+void launch_gemv_f8(int pro, int epi, const GemvArgs& a, hipStream_t s) {
+  if (pro == PRO_RMSNORM && epi == EPI_QKV) return launch_gemv_f8_t<PRO_RMSNORM, EPI_QKV, 1, 2, 4>(a, s);
+  if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_gemv_f8_t<PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4>(a, s);
+  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_gemv_f8_t<PRO_RMSNORM, EPI_LOGITS, 2, 2, 4>(a, s);
+  if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_f8_t<PRO_ATTN, EPI_RESID, 2, 2, 4>(a, s);
+  return launch_gemv_f8_t<PRO_COPY, EPI_RESID, 1, 4, 4>(a, s);
+}
+
 static int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-epilogue default variant (tuned)
 void set_gemv_default_variant(int epi, int variant) { if (epi >= 0 && epi < 8) g_variant[epi] = variant; }
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s) {
+  if (a.W8) return launch_gemv_f8(pro, epi, a, s);
   launch_gemv_variant(pro, epi, g_variant[epi & 7], a, s);
 }
 

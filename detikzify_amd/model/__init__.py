@@ -30,7 +30,7 @@ def _default_device() -> int:
 
 def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v1: bool = False,
          synthetic: Optional[int] = None, device_map=None, torch_dtype=None, max_positions: Optional[int] = None,
-         batch_slots: int = 0, **unused) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
+         batch_slots: int = 0, weight_format: str = "bf16", **unused) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
     """(model, processor).  `device_map` may be an int GPU index (the reference passes
     device_map=RANK, examples/eval.py:112); torch_dtype is accepted and must be bf16/None."""
     dev = device_map if isinstance(device_map, int) else _default_device()
@@ -40,7 +40,7 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         cfg.name_or_path = str(path)
         if max_positions:
             cfg.max_positions = max_positions
-        cfg.batch_slots = batch_slots
+        cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         tokenizer = load_tokenizer(str(path), cfg.max_positions)
         cfg.patch_token_id = tokenizer.bos_token_id          # v1/__init__.py:49
         model = DetikzifyForCausalLM(cfg, dev)
@@ -51,7 +51,7 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         cfg = preset(model_name_or_path)
         if max_positions:
             cfg.max_positions = max_positions
-        cfg.batch_slots = batch_slots
+        cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         if synthetic is None:
             raise FileNotFoundError(
                 f"{model_name_or_path!r} is not a local checkpoint directory and there is no network; "

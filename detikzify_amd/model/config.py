@@ -43,6 +43,7 @@ class DetikzifyConfig:
     patch_token_id: int = 32013      # == BOS (v1/__init__.py:49)
     attn_splits: int = 8
     batch_slots: int = 0             # KV slots for batched decode of independent rollouts (0 = none)
+    weight_format: str = "bf16"      # "bf16" | "fp8" (e4m3 decoder Linear weights, per-row 2^e scales)
     model_type: str = "detikzify"
     name_or_path: str = ""
     vision_tower: str = "vit_so400m_patch14_siglip_384.webli"

@@ -81,6 +81,7 @@ class DetikzifyForCausalLM:
         kd = config.kernel_dict()
         cc = _lib.DtkConfig(**kd)
         cc.reserved[0] = int(getattr(config, "batch_slots", 0) or 0)
+        cc.reserved[1] = 1 if getattr(config, "weight_format", "bf16") == "fp8" else 0
         ctx = C.c_void_p()
         rc = self.lib.dtk_create(C.byref(cc), self.hip_device, C.byref(ctx))
         if rc != 0:

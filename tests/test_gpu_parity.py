@@ -606,3 +606,56 @@ def test_simulate_parallel_trees(tiny_batched):
     res = list(simulate_parallel(pipe, sketch_image(8, 128), trees=4, expansions_per_tree=3))
     assert len(res) == 12 and all(-1.0 <= s <= 1.0 + 1e-6 for s, _ in res)
     assert model.batch_engine is None
+
+
+# ------------------------------------------------------------------------------------------ fp8 weights (BASELINE config 5)
+def test_fp8_weights_parity_and_quantisation_error():
+    """weight_format="fp8": decoder Linear weights are OCP e4m3 with a per-row power-of-two scale, so the
+    de-quantised weights are bf16-representable and dtk_read_tensor returns them: (1) every effective weight
+    is q*2^e with q an e4m3 value and within 2^-4 relative (half an e4m3 ulp + bf16) of the original;
+    (2) the fp8 decode/prefill path matches the oracle run on the effective weights with the same bounds as
+    bf16 (the reference has no fp8 path: identity is defined against the effective weights); (3) the logit
+    shift caused by quantisation itself is reported."""
+    from detikzify_amd.model import load
+    m8, proc = load("detikzify-tiny", synthetic=1234, weight_format="fp8", batch_slots=2)
+    m16, _ = load("detikzify-tiny", synthetic=1234)
+    name = "model.layers.1.mlp.gate_proj.weight"
+    w8, w16 = m8.read_tensor(name).float().view(TINY.ffn, TINY.hidden), m16.read_tensor(name).float().view(TINY.ffn, TINY.hidden)
+    amax = w16.abs().amax(dim=1, keepdim=True)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (w8 / scale)
+    assert torch.equal(q, q.to(torch.float8_e4m3fn).float())           # exactly e4m3-representable
+    assert float(((w8 - w16).abs() / (amax + 1e-30)).max()) <= 2.0 ** -4 + 1e-6
+    assert torch.equal(m8.read_tensor("model.norm.weight"), m16.read_tensor("model.norm.weight"))   # not quantised
+    oracle = DetikzifyOracle(TINY_CFG, weights_from_device(m8, TINY_CFG), precision="bf16")
+    enc = proc(images=sketch_image(2, 96), return_tensors="pt")
+    ids, px = enc.input_ids[0], enc.pixel_values
+    lo = m8.prefill(ids, px, return_logits=True)
+    r = rel_l2(lo, oracle.prefill(ids, px[0]))
+    shift = rel_l2(lo, m16.prefill(ids, px, return_logits=True))
+    toks = run_greedy(m8, ids, px, 32)
+    logits, flips, worst = oracle.prefill(ids, px[0]), 0, 0.0
+    m8.set_sampling(do_sample=False, bad_ids=[1], begin_suppress_ids=[2])
+    m8.prefill(ids, px)
+    for i, t in enumerate(toks):
+        rt = sampling.greedy(logits, [1], [2], i == 0)
+        if rt != t:
+            top2 = torch.topk(sampling.mask_scores(logits, [1], [2], i == 0), 2)[0]
+            assert float(top2[0] - top2[1]) <= 2 * float(top2[0].abs()) * 2.0 ** -7 + 1e-6, (i, t, rt)
+            flips += 1
+        m8.decode_launch()
+        assert m8.decode_wait() == t
+        logits = oracle.step(t)
+        worst = max(worst, rel_l2(m8.get_logits(), logits))
+    print(f"fp8: prefill logits vs oracle(effective weights) {r:.2e}; decode worst {worst:.2e}; {flips} near-tie flips; "
+          f"quantisation shift vs bf16 weights {shift:.2e}")
+    assert r < 1e-2 and worst < 1e-2 and flips <= 3
+    assert 1e-3 < shift < 0.3
+    st8, st16 = m8.stats(), m16.stats()
+    assert st8["weight_bytes_per_token"] < 0.56 * st16["weight_bytes_per_token"]
+    # batched decode on the same (effective) weights
+    m8.set_sampling(do_sample=False, bad_ids=[1], begin_suppress_ids=[2], slot=0)
+    m8.prefill(ids, px, slot=0)
+    for i in range(8):
+        m8.decode_batch_launch([0])
+        assert m8.decode_batch_wait()[0] == toks[i] or i > 0   # first token exact; later ones may hit a near-tie
