@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
     ap.add_argument("--probe-tokens", type=int, default=64)
+    ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
     ap.add_argument("--batch", type=int, default=16, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     return ap.parse_args()
@@ -112,7 +114,8 @@ def main():
         torch.cuda.set_device(local_rank)
         ddist.init_process_group("nccl", timeout_s=1800)
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=max(0, min(16, args.batch)))
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=max(0, min(16, args.batch)),
+                       weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config
     img = sketch_image(0, 224)
@@ -173,7 +176,8 @@ def main():
     result = {
         "metric": "tikz_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.weight_format == "bf16" else "fp8-e4m3 weights / bf16 activations", "data": "synthetic",
         "config": {"workload": f"{args.model} (synthetic weights, seed 1234), 1 image 224x224->384x384, 243-token prefix, "
                                f"{'sampling T=.8 p=.95' if args.sample else 'greedy'} decode of {n_new} tokens per rollout, "
                                f"batch 1 per GPU, hipGraph per token" + (", image/prefix reuse" if args.reuse else ""),

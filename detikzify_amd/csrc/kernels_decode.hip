@@ -22,6 +22,15 @@
 template <int NR, int U>
 __device__ __forceinline__ void gemv_load(u32x4 (&w)[NR][U], const u32x4* (&rows)[NR],
                                           int g, int lane, int K8) {
+  if (64 * (g * U + U) <= K8) {  // wave-uniform: the whole group is inside the row -> no predication
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = lane + 64 * (g * U + u);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) w[r][u] = ld_nt(rows[r] + c);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int c = lane + 64 * (g * U + u);
@@ -37,11 +46,12 @@ __device__ __forceinline__ void gemv_load(u32x4 (&w)[NR][U], const u32x4* (&rows
 template <int NR, int U>
 __device__ __forceinline__ void gemv_fma(float (&acc)[NR], const u32x4 (&w)[NR][U],
                                          const u32x4* xs, int g, int lane, int K8) {
+  const bool full = 64 * (g * U + U) <= K8;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int c = lane + 64 * (g * U + u);
     u32x4 xv = {0u, 0u, 0u, 0u};
-    if (c < K8) xv = xs[c];
+    if (full || c < K8) xv = xs[c];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xv, acc[r]);
   }
@@ -52,15 +62,15 @@ __device__ __forceinline__ void gemv_fma(float (&acc)[NR], const u32x4 (&w)[NR][
 // applied to the fp32 sum in the epilogue (exact), so the result equals the bf16 kernel on the
 // de-quantised ("effective") weights bit for bit at equal accumulation order.
 __device__ __forceinline__ float dot16_f8(const u32x4& w, const u32x4& x0, const u32x4& x1, float c) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // v_cvt_scalef32_pk_bf16_fp8: two e4m3 bytes -> packed bf16 pair in ONE instruction (exact, scale 1)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false);
-    const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
+    const bf16x2_t lo = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j], 1.0f, false);
+    const bf16x2_t hi = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j], 1.0f, true);
     const uint32_t xa = (j < 2) ? x0[2 * j] : x1[2 * j - 4];
     const uint32_t xb = (j < 2) ? x0[2 * j + 1] : x1[2 * j - 3];
-    c = dot2(pack2(lo[0], lo[1]), xa, c);
-    c = dot2(pack2(hi[0], hi[1]), xb, c);
+    c = __builtin_amdgcn_fdot2_f32_bf16(lo, __builtin_bit_cast(bf16x2_t, xa), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(hi, __builtin_bit_cast(bf16x2_t, xb), c, false);
   }
   return c;
 }
@@ -72,7 +82,7 @@ __device__ __forceinline__ void gemv_fma_f8(float (&acc)[NR], const u32x4 (&w)[N
   for (int u = 0; u < U; ++u) {
     const int c = lane + 64 * (g * U + u);
     u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
-    if (c < KC) { x0 = xs[2 * c]; x1 = xs[2 * c + 1]; }
+    if (64 * (g * U + U) <= KC || c < KC) { x0 = xs[2 * c]; x1 = xs[2 * c + 1]; }
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = dot16_f8(w[r][u], x0, x1, acc[r]);
   }
@@ -392,22 +402,53 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
 }
 #undef GV
 
-template <int PRO, int EPI, int R, int U, int WAVES>
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST = false, int BPC = 4>
 static void launch_gemv_f8_t(const GemvArgs& a, hipStream_t s) {
   int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
   const int per_block = WAVES * R;
-  const int grid = (n_units + per_block - 1) / per_block;
+  int grid = (n_units + per_block - 1) / per_block;
+  if (PERSIST && grid > num_cus() * BPC) grid = num_cus() * BPC;
   const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
-  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, false, true>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, PERSIST, true>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
-// fp8-weight decode GEMVs (requires K % 16 == 0); same roles as the bf16 defaults
+// fp8-weight decode GEMVs (requires K % 16 == 0); same roles as the bf16 defaults.  An fp8 row is half
+// the bytes, so more rows per wave (R=2) amortise the prologue / reduction; DTK_F8_VARIANT sweeps the choice.
+static int f8_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DTK_F8_VARIANT"); v = e ? atoi(e) : 8; }
+  return v;
+}
+#define F8(PRO, EPI, R, U, W) return launch_gemv_f8_t<PRO, EPI, R, U, W>(a, s)
+#define F8P(PRO, EPI, R, U, W, BPC) return launch_gemv_f8_t<PRO, EPI, R, U, W, true, BPC>(a, s)
 void launch_gemv_f8(int pro, int epi, const GemvArgs& a, hipStream_t s) {
-  if (pro == PRO_RMSNORM && epi == EPI_QKV) return launch_gemv_f8_t<PRO_RMSNORM, EPI_QKV, 1, 2, 4>(a, s);
-  if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_gemv_f8_t<PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4>(a, s);
-  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_gemv_f8_t<PRO_RMSNORM, EPI_LOGITS, 2, 2, 4>(a, s);
-  if (pro == PRO_ATTN && epi == EPI_RESID) return launch_gemv_f8_t<PRO_ATTN, EPI_RESID, 2, 2, 4>(a, s);
-  return launch_gemv_f8_t<PRO_COPY, EPI_RESID, 1, 4, 4>(a, s);
+  const int v = f8_variant();
+  if (pro == PRO_RMSNORM && (epi == EPI_QKV || epi == EPI_SWIGLU)) {
+    if (epi == EPI_QKV) {
+      switch (v) { default: F8(PRO_RMSNORM, EPI_QKV, 2, 2, 4); case 0: F8(PRO_RMSNORM, EPI_QKV, 1, 2, 4);
+                   case 2: F8(PRO_RMSNORM, EPI_QKV, 2, 4, 4); case 3: F8(PRO_RMSNORM, EPI_QKV, 4, 2, 4);
+                   case 4: F8(PRO_RMSNORM, EPI_QKV, 2, 2, 8); case 5: F8(PRO_RMSNORM, EPI_QKV, 1, 4, 4);
+                   case 6: F8P(PRO_RMSNORM, EPI_QKV, 1, 2, 4, 4); case 7: F8P(PRO_RMSNORM, EPI_QKV, 2, 2, 4, 4);
+                   case 8: F8P(PRO_RMSNORM, EPI_QKV, 1, 2, 8, 2); case 9: F8P(PRO_RMSNORM, EPI_QKV, 1, 4, 4, 4); }
+    }
+    switch (v) { default: F8(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4); case 0: F8(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4);
+                 case 2: F8(PRO_RMSNORM, EPI_SWIGLU, 2, 4, 4); case 3: F8(PRO_RMSNORM, EPI_SWIGLU, 4, 2, 4);
+                 case 4: F8(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 8); case 5: F8(PRO_RMSNORM, EPI_SWIGLU, 1, 4, 4);
+                 case 6: F8P(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 4, 4); case 7: F8P(PRO_RMSNORM, EPI_SWIGLU, 2, 2, 4, 4);
+                 case 8: F8P(PRO_RMSNORM, EPI_SWIGLU, 1, 2, 8, 2); case 9: F8P(PRO_RMSNORM, EPI_SWIGLU, 1, 4, 4, 4); }
+  }
+  if (pro == PRO_RMSNORM && epi == EPI_LOGITS) {
+    switch (v) { default: F8(PRO_RMSNORM, EPI_LOGITS, 4, 2, 4); case 0: F8(PRO_RMSNORM, EPI_LOGITS, 2, 2, 4);
+                 case 2: F8(PRO_RMSNORM, EPI_LOGITS, 4, 4, 4); case 3: F8(PRO_RMSNORM, EPI_LOGITS, 8, 2, 4); }
+  }
+  if (pro == PRO_ATTN && epi == EPI_RESID) F8(PRO_ATTN, EPI_RESID, 2, 2, 4);
+  switch (v) { default: F8(PRO_COPY, EPI_RESID, 2, 4, 4); case 0: F8(PRO_COPY, EPI_RESID, 1, 4, 4);
+               case 2: F8(PRO_COPY, EPI_RESID, 2, 8, 4); case 3: F8(PRO_COPY, EPI_RESID, 4, 4, 4);
+               case 4: F8(PRO_COPY, EPI_RESID, 2, 4, 8); case 5: F8(PRO_COPY, EPI_RESID, 1, 8, 4);
+               case 6: F8P(PRO_COPY, EPI_RESID, 1, 4, 4, 4); case 7: F8P(PRO_COPY, EPI_RESID, 2, 4, 4, 4);
+               case 8: F8P(PRO_COPY, EPI_RESID, 1, 4, 8, 2); case 9: F8P(PRO_COPY, EPI_RESID, 1, 8, 4, 4); }
 }
+#undef F8
+#undef F8P
 
 static int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-epilogue default variant (tuned)
 void set_gemv_default_variant(int epi, int variant) { if (epi >= 0 && epi < 8) g_variant[epi] = variant; }
