@@ -110,9 +110,15 @@ def main():
     from detikzify_amd.util import expand
     from tests.helpers import sketch_image
 
+    backend = os.environ.get("DTK_DIST_BACKEND", "nccl")     # "gloo": control-flow test of N ranks on one GPU
+    n_dev = max(1, torch.cuda.device_count())
     if world > 1:
+        if local_rank >= n_dev and backend == "nccl":
+            raise SystemExit(f"rank {rank}: local_rank {local_rank} but only {n_dev} GPUs")
+        local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
-        ddist.init_process_group("nccl", timeout_s=1800)
+        ddist.init_process_group(backend, timeout_s=1800)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=max(0, min(16, args.batch)),
                        weight_format=args.weight_format)
@@ -161,7 +167,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -208,7 +214,7 @@ def main():
                 fence()
                 tb = time.perf_counter() - tb
             if world > 1:
-                t = torch.tensor([tb], dtype=torch.float64, device="cuda")
+                t = torch.tensor([tb], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 tb = float(t.item())
             mean_ctx_b = T0 + (n_new - 1) / 2.0

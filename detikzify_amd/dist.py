@@ -39,7 +39,7 @@ def init_process_group(backend: str = None, timeout_s: int = 3 * 24 * 3600):
         return
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
 
 
