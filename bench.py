@@ -120,7 +120,7 @@ def main():
         ddist.init_process_group(backend, timeout_s=1800)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=max(0, min(16, args.batch)),
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=(min(16, args.batch) + 1) if args.batch > 1 else 0,   # + the prefix-cache slot
                        weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config
@@ -223,8 +223,10 @@ def main():
                 "batch_per_gpu": args.batch, "rollouts_per_sec": world * args.batch / tb,
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
-                "note": "B independent rollouts (own KV slot, seed, prefill incl. ViT) per GPU through model.generate "
-                        "from B threads; one dtk_decode_batch step serves all of them"}
+                "prefix_sharing": bool(engine.share_prefix),
+                "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
+                        "dtk_decode_batch step serves all of them; the 243-token image prefix is encoded once and its "
+                        "KV forked into each slot (bit-identical to a full prefill, SURVEY f1)"}
         except Exception as e:
             result["batched_rollouts"] = {"error": repr(e)}
         finally:

@@ -384,8 +384,8 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pmb = P.take<float>((size_t)c->nb * c->H * c->S);
     c->plb = P.take<float>((size_t)c->nb * c->H * c->S);
     c->pob = P.take<float>((size_t)c->nb * c->H * c->S * 128);
-    c->st_b = P.take<DecState>(16);
-    c->sp_b = P.take<SamplingDev>(16);
+    c->st_b = P.take<DecState>(17);
+    c->sp_b = P.take<SamplingDev>(17);
     c->bs_dev = P.take<BatchState>(1);
     for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
       bf16_t* a1 = P.take<bf16_t>(tiled_elems(3 * d, d));
@@ -673,7 +673,8 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
-  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > 16 ? 16 : cfg->reserved[0]);
+  // up to 16 decoding slots (the MFMA N dimension) + 1 slot that is only ever prefilled / forked (prefix cache)
+  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > 17 ? 17 : cfg->reserved[0]);
   c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
   c->vMlp = cfg->vit_mlp; c->vN = np * np;
@@ -1035,7 +1036,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   int n_active = 0;
   for (int j = 0; j < 16; ++j) {
     if (!active[j]) continue;
-    if (j >= c->nb) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    if (j >= c->nb || j >= 16) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
     const SeqHost& sh = c->bseq[(size_t)j];
     if (!sh.have_logits) return fail(c, DTK_ERR_STATE, "slot %d: decode before prefill", j);
     if (sh.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "slot %d: context length %d reached max_positions", j, sh.host_next_pos);
@@ -1085,6 +1086,31 @@ int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
     if (sh.cached_ids.size() > later) sh.cached_ids[sh.cached_ids.size() - 1 - later] = tok;
   }
   c->bwaited++;
+  return DTK_OK;
+}
+
+// Copy the KV of the first n_tokens positions of slot src into slot dst (SURVEY §8 f1 / the proposed
+// dtk_kv_fork): rollouts that share a prefix (always: the 243 image tokens) reuse its KV bit for bit instead
+// of re-running ViT + prefill.  dst then needs a dtk_prefill_slot(..., DTK_PREFILL_REUSE_PREFIX) of the full
+// prompt, which only processes what lies beyond the common prefix (at least the last token).
+int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
+  if (!c || src < 0 || dst < 0 || src >= c->nb || dst >= c->nb || src == dst)
+    return fail(c, DTK_ERR_ARG, "dtk_kv_fork: bad slots %d -> %d of %d", src, dst, c ? c->nb : 0);
+  SeqHost& a = c->bseq[(size_t)src];
+  if (n_tokens < 1 || (size_t)n_tokens > a.cached_ids.size() || n_tokens > c->Tmax)
+    return fail(c, DTK_ERR_ARG, "dtk_kv_fork: %d tokens but slot %d holds %zu", n_tokens, src, a.cached_ids.size());
+  for (int i = 0; i < n_tokens; ++i)
+    if (a.cached_ids[(size_t)i] < 0) return fail(c, DTK_ERR_STATE, "dtk_kv_fork: source has un-read tokens");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t pitch = (size_t)c->Tmax * 128 * 2;           // one (layer, k|v, head) plane
+  const size_t rows = (size_t)c->L * 2 * c->H;
+  HIPCHK(c, hipMemcpy2DAsync(c->kvb + (size_t)dst * c->kv_slot_stride, pitch, c->kvb + (size_t)src * c->kv_slot_stride, pitch,
+                             (size_t)n_tokens * 128 * 2, rows, hipMemcpyDeviceToDevice, c->stream));
+  SeqHost& b = c->bseq[(size_t)dst];
+  b.cached_ids.assign(a.cached_ids.begin(), a.cached_ids.begin() + n_tokens);
+  b.cached_with_image = a.cached_with_image;
+  b.host_next_pos = n_tokens;
+  b.have_logits = false;
   return DTK_OK;
 }
 

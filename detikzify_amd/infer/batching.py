@@ -30,12 +30,19 @@ class BatchEngine:
     """All methods are thread-safe; one engine per model.  A sequence is 'active' from the end of its
     prefill until it leaves; a decode step runs as soon as every active sequence waits for a token."""
 
-    def __init__(self, model, max_batch: Optional[int] = None):
+    def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True):
         n = model.num_slots()
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
         self.model = model
-        self.capacity = min(n, max_batch or n)
+        # one slot is set aside as the prefix cache: it holds the KV of the image prefix ([image_token]*n
+        # + pixels) of the current image; sequences fork it (bit-identical KV, SURVEY §8 f1) and only
+        # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
+        self.share_prefix = share_prefix and n >= 2 and (max_batch is None or max_batch < n)
+        self.prefix_slot = n - 1 if self.share_prefix else None
+        self.prefix_key = None
+        self.prefix_ids = None
+        self.capacity = min(n - (1 if self.share_prefix else 0), max_batch or n)
         self.cv = threading.Condition()
         self.free: List[int] = list(range(self.capacity))
         self.active: set = set()
@@ -60,7 +67,10 @@ class BatchEngine:
         try:
             with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
                 self.model.set_sampling(slot=slot, **sampling)
-                self.model.prefill(ids, pixel_values, slot=slot)
+                if self.share_prefix and pixel_values is not None and self._fork_prefix(slot, ids, pixel_values):
+                    self.model.prefill(ids, pixel_values, slot=slot, reuse=True)    # only the tail beyond the prefix
+                else:
+                    self.model.prefill(ids, pixel_values, slot=slot)
                 self.active.add(slot)
                 joined = True
             yield _Sequence(self, slot)
@@ -74,6 +84,21 @@ class BatchEngine:
                 self.cv.notify_all()
 
     # -- called with self.cv held ---------------------------------------------------------------------
+    def _fork_prefix(self, slot: int, ids, pixel_values) -> bool:
+        import torch
+        tok = self.model.config.image_token_id
+        ids = ids.reshape(-1)
+        n_img = int((ids == tok).sum())
+        if n_img == 0 or not bool((ids[:n_img] == tok).all()):
+            return False                      # the image run is not a leading prefix: no sharing
+        key = self.model.image_key(pixel_values)
+        if self.prefix_key != key or self.prefix_ids is None or self.prefix_ids.numel() != n_img:
+            self.model.set_sampling(slot=self.prefix_slot, do_sample=False)
+            self.model.prefill(ids[:n_img], pixel_values, slot=self.prefix_slot)
+            self.prefix_key, self.prefix_ids = key, ids[:n_img].clone()
+        self.model.kv_fork(self.prefix_slot, slot, n_img)
+        return True
+
     def _maybe_step(self):
         if not self.active or self.ready != self.active or self.error is not None:
             return

@@ -265,6 +265,14 @@ class DetikzifyForCausalLM:
         self._check(self.lib.dtk_decode_batch_wait(self._ctx, out), "dtk_decode_batch_wait")
         return [int(v) for v in out]
 
+    def kv_fork(self, src_slot: int, dst_slot: int, n_tokens: int):
+        self._check(self.lib.dtk_kv_fork(self._ctx, int(src_slot), int(dst_slot), int(n_tokens)), "dtk_kv_fork")
+
+    @staticmethod
+    def image_key(pixel_values: torch.Tensor) -> int:
+        px = pixel_values.detach().to("cpu", torch.float32).contiguous()
+        return int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
+
     def get_logits_slot(self, slot: int) -> torch.Tensor:
         out = np.empty(self.config.vocab, dtype=np.float32)
         self._check(self.lib.dtk_get_logits_slot(self._ctx, int(slot), out.ctypes.data_as(C.c_void_p)), "dtk_get_logits_slot")

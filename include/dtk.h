@@ -177,6 +177,7 @@ int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const f
 int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
 int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active16);
 int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out16);
+int  dtk_kv_fork(dtk_ctx* ctx, int src_slot, int dst_slot, int n_tokens);   /* share a prefix's KV (f1) */
 int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
 int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
 

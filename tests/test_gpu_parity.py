@@ -598,6 +598,44 @@ def test_batch_engine_threads_match_slot_alone(tiny_batched):
     assert single.shape[1] == ids.numel() + 8
 
 
+def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched):
+    """dtk_kv_fork + tail prefill == full prefill, bit for bit (logits and the tokens that follow), and the
+    BatchEngine's prefix cache gives the same generations as share_prefix=False"""
+    import threading
+    from detikzify_amd.infer.batching import BatchEngine
+    model, proc = tiny_batched
+    (ids, px), (ids_b, px_b), _ = _batch_prompts(proc)
+    long_ids = torch.cat([ids, torch.tensor([70, 300, 41, 9, 9])])
+    model.set_sampling(do_sample=False, bad_ids=[1], slot=0)
+    full = model.prefill(long_ids, px, slot=0, return_logits=True)
+    model.set_sampling(do_sample=False, bad_ids=[1], slot=3)
+    model.prefill(ids, px, slot=3)                       # prefix only
+    model.kv_fork(3, 1, ids.numel())
+    model.set_sampling(do_sample=False, bad_ids=[1], slot=1)
+    forked = model.prefill(long_ids, px, slot=1, return_logits=True, reuse=True)
+    assert torch.equal(full, forked)
+    for _ in range(6):
+        model.decode_batch_launch([0, 1])
+        out = model.decode_batch_wait()
+        assert out[0] == out[1]
+    kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=20, bad_words_ids=[[1]],
+              begin_suppress_tokens=[2], eos_token_id=-1)
+    results = {}
+    for share in (False, True):
+        engine = BatchEngine(model, max_batch=3, share_prefix=share)
+        assert engine.share_prefix == share
+        res = [None] * 3
+        def run(i):
+            res[i] = model.generate(input_ids=(ids if i < 2 else ids_b)[None], pixel_values=(px if i < 2 else px_b), seed=70 + i, **kw)[0].tolist()
+        try:
+            ths = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+            [t.start() for t in ths]; [t.join(timeout=120) for t in ths]
+        finally:
+            engine.close()
+        results[share] = res
+    assert results[True] == results[False]
+
+
 def test_simulate_parallel_trees(tiny_batched):
     from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
     from detikzify_amd.infer.batching import simulate_parallel
