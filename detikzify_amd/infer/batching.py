@@ -28,9 +28,12 @@ class _Sequence:
 
 class BatchEngine:
     """All methods are thread-safe; one engine per model.  A sequence is 'active' from the end of its
-    prefill until it leaves; a decode step runs as soon as every active sequence waits for a token."""
+    prefill until it leaves.  Steps are pipelined one deep: as soon as the tokens of step k are handed
+    out, step k+1 is launched for the same slots, so the threads' per-token host work (streamer,
+    stopping criteria, Python) runs under the GPU's next step; a sequence that stops after token k just
+    discards its token of step k+1 (its slot is recycled once that step has completed)."""
 
-    def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True):
+    def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True):
         n = model.num_slots()
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
@@ -38,23 +41,28 @@ class BatchEngine:
         # one slot is set aside as the prefix cache: it holds the KV of the image prefix ([image_token]*n
         # + pixels) of the current image; sequences fork it (bit-identical KV) and only
         # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
-        self.share_prefix = share_prefix and n >= 2 and (max_batch is None or max_batch < n)
+        dec = min(n, 16)
+        self.share_prefix = share_prefix and n >= 2 and (n > 16 or max_batch is None or max_batch < n)
         self.prefix_slot = n - 1 if self.share_prefix else None
         self.prefix_key = None
         self.prefix_ids = None
-        self.capacity = min(n - (1 if self.share_prefix else 0), max_batch or n)
+        self.capacity = min(dec - (1 if self.share_prefix and n <= 16 else 0), max_batch or dec)
+        self.pipeline = pipeline
         self.cv = threading.Condition()
         self.free: List[int] = list(range(self.capacity))
         self.active: set = set()
         self.ready: set = set()
-        self.tokens: Dict[int, int] = {}
-        self.generation = 0
+        self.pending: Dict[int, List[int]] = {}
+        self.inflight: Optional[List[int]] = None      # slots of the launched, not yet collected step
+        self.zombies: set = set()                      # left while in flight: freed when that step completes
         self.error: Optional[BaseException] = None
         self.steps = 0
         self.tokens_out = 0
         model.batch_engine = self
 
     def close(self):
+        with self.cv:
+            self._collect()
         self.model.batch_engine = None
 
     @contextmanager
@@ -66,11 +74,13 @@ class BatchEngine:
         joined = False
         try:
             with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
+                self._collect()     # a prefill drops un-collected steps on the C side: collect first
                 self.model.set_sampling(slot=slot, **sampling)
                 if self.share_prefix and pixel_values is not None and self._fork_prefix(slot, ids, pixel_values):
                     self.model.prefill(ids, pixel_values, slot=slot, reuse=True)    # only the tail beyond the prefix
                 else:
                     self.model.prefill(ids, pixel_values, slot=slot)
+                self.pending[slot] = []
                 self.active.add(slot)
                 joined = True
             yield _Sequence(self, slot)
@@ -79,13 +89,21 @@ class BatchEngine:
                 if joined:
                     self.active.discard(slot)
                     self.ready.discard(slot)
-                    self._maybe_step()          # the others may all be waiting on this one
-                self.free.append(slot)
+                    self.pending.pop(slot, None)
+                    if self.inflight is not None and slot in self.inflight:
+                        self.zombies.add(slot)      # recycled by _collect()
+                    else:
+                        self.free.append(slot)
+                    if self.active:
+                        self._maybe_step()          # the others may all be waiting on this one
+                    else:
+                        self._collect()             # nobody left to collect the speculative step
+                else:
+                    self.free.append(slot)
                 self.cv.notify_all()
 
     # -- called with self.cv held ---------------------------------------------------------------------
     def _fork_prefix(self, slot: int, ids, pixel_values) -> bool:
-        import torch
         tok = self.model.config.image_token_id
         ids = ids.reshape(-1)
         n_img = int((ids == tok).sum())
@@ -99,35 +117,68 @@ class BatchEngine:
         self.model.kv_fork(self.prefix_slot, slot, n_img)
         return True
 
-    def _maybe_step(self):
-        if not self.active or self.ready != self.active or self.error is not None:
+    def _launch(self):
+        # a slot whose context is full cannot take another (speculative) step; its sequence is at max_length
+        lim = self.model.config.max_positions
+        slots = [s for s in sorted(self.active) if self.model.lib.dtk_context_len_slot(self.model._ctx, s) < lim]
+        if not slots or self.error is not None:
             return
         try:
-            slots = sorted(self.active)
             self.model.decode_batch_launch(slots)
-            toks = self.model.decode_batch_wait()
-            for s in slots:
-                self.tokens[s] = toks[s]
-            self.steps += 1
-            self.tokens_out += len(slots)
-        except BaseException as e:  # surface in every waiting thread
+            self.inflight = slots
+        except BaseException as e:
             self.error = e
-        self.ready.clear()
-        self.generation += 1
+            self.cv.notify_all()
+
+    def _collect(self):
+        """wait for the in-flight step, hand its tokens to the sequences that are still active"""
+        if self.inflight is None:
+            return
+        try:
+            toks = self.model.decode_batch_wait()
+            for s in self.inflight:
+                if s in self.active:
+                    self.pending[s].append(toks[s])
+                    self.tokens_out += 1
+            self.steps += 1
+        except BaseException as e:
+            self.error = e
+        for s in self.inflight:
+            if s in self.zombies:
+                self.zombies.discard(s)
+                self.free.append(s)
+        self.inflight = None
         self.cv.notify_all()
+
+    def _maybe_step(self):
+        """every active sequence waits for a token -> collect the step in flight (launch it first if there
+        is none) and immediately launch the next one"""
+        if not self.active or self.error is not None or not (self.ready >= self.active):
+            return
+        if self.inflight is None:
+            self._launch()
+        self._collect()
+        self.ready.clear()
+        if self.pipeline:
+            self._launch()
 
     def _next_token(self, slot: int) -> int:
         with self.cv:
-            if self.error is not None:
-                raise self.error
-            self.ready.add(slot)
-            gen = self.generation
-            self._maybe_step()
-            while self.generation == gen and self.error is None:
+            while True:
+                if self.error is not None:
+                    raise self.error
+                q = self.pending.get(slot)
+                if q:
+                    return q.pop(0)
+                self.ready.add(slot)
+                self._maybe_step()
+                q = self.pending.get(slot)
+                if q:
+                    self.ready.discard(slot)
+                    return q.pop(0)
+                if self.error is not None:
+                    raise self.error
                 self.cv.wait()
-            if self.error is not None:
-                raise self.error
-            return self.tokens[slot]
 
 
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
