@@ -224,6 +224,7 @@ def main():
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
                 "prefix_sharing": bool(engine.share_prefix),
+                "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3)},
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
                         "dtk_decode_batch step serves all of them; the 243-token image prefix is encoded once and its "
                         "KV forked into each slot (bit-identical to a full prefill, SURVEY f1)"}

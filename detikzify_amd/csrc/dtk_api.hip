@@ -1111,6 +1111,18 @@ int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
   b.cached_with_image = a.cached_with_image;
   b.host_next_pos = n_tokens;
   b.have_logits = false;
+  // a fork of the WHOLE source sequence also inherits its next-token logits: the destination can decode at
+  // once (a rollout from the MCTS root needs no prefill at all).  The source must not have decoded since its
+  // prefill (its logits buffer would belong to a later position).
+  if ((size_t)n_tokens == a.cached_ids.size() && a.have_logits && a.host_next_pos == n_tokens) {
+    HIPCHK(c, hipMemcpyAsync(c->logits_b + (size_t)dst * c->V, c->logits_b + (size_t)src * c->V, (size_t)c->V * 4,
+                             hipMemcpyDeviceToDevice, c->stream));
+    DecState st0{};
+    st0.pos = n_tokens - 1; st0.next_pos = n_tokens; st0.token = (int32_t)a.cached_ids[(size_t)n_tokens - 1]; st0.draw = 0;
+    HIPCHK(c, hipMemcpyAsync(c->st_b + dst, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // st0 lives on this stack frame
+    b.have_logits = true;
+  }
   return DTK_OK;
 }
 

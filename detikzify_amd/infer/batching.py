@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import time
 from contextlib import contextmanager
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
@@ -58,6 +59,7 @@ class BatchEngine:
         self.error: Optional[BaseException] = None
         self.steps = 0
         self.tokens_out = 0
+        self.t_wait = self.t_launch = self.t_prefill = 0.0     # seconds inside the native calls (diagnostics)
         model.batch_engine = self
 
     def close(self):
@@ -75,11 +77,16 @@ class BatchEngine:
         try:
             with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
                 self._collect()     # a prefill drops un-collected steps on the C side: collect first
+                t0 = time.perf_counter()
                 self.model.set_sampling(slot=slot, **sampling)
-                if self.share_prefix and pixel_values is not None and self._fork_prefix(slot, ids, pixel_values):
+                forked = self.share_prefix and pixel_values is not None and self._fork_prefix(slot, ids, pixel_values)
+                if forked and ids.numel() == self.prefix_ids.numel():
+                    pass    # the prompt IS the prefix (rollout from the root): KV and logits were forked, nothing to run
+                elif forked:
                     self.model.prefill(ids, pixel_values, slot=slot, reuse=True)    # only the tail beyond the prefix
                 else:
                     self.model.prefill(ids, pixel_values, slot=slot)
+                self.t_prefill += time.perf_counter() - t0
                 self.pending[slot] = []
                 self.active.add(slot)
                 joined = True
@@ -124,7 +131,9 @@ class BatchEngine:
         if not slots or self.error is not None:
             return
         try:
+            t0 = time.perf_counter()
             self.model.decode_batch_launch(slots)
+            self.t_launch += time.perf_counter() - t0
             self.inflight = slots
         except BaseException as e:
             self.error = e
@@ -135,7 +144,9 @@ class BatchEngine:
         if self.inflight is None:
             return
         try:
+            t0 = time.perf_counter()
             toks = self.model.decode_batch_wait()
+            self.t_wait += time.perf_counter() - t0
             for s in self.inflight:
                 if s in self.active:
                     self.pending[s].append(toks[s])

@@ -614,6 +614,16 @@ def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched):
     model.set_sampling(do_sample=False, bad_ids=[1], slot=1)
     forked = model.prefill(long_ids, px, slot=1, return_logits=True, reuse=True)
     assert torch.equal(full, forked)
+    # a fork of the whole source also inherits its logits: decode straight away, identical to a full prefill
+    model.set_sampling(do_sample=False, bad_ids=[1], slot=2)
+    model.prefill(ids, px, slot=2)
+    model.set_sampling(do_sample=False, bad_ids=[1], slot=4)
+    model.kv_fork(3, 4, ids.numel())
+    assert torch.equal(model.get_logits_slot(4), model.get_logits_slot(2))
+    for _ in range(5):
+        model.decode_batch_launch([2, 4])
+        out = model.decode_batch_wait()
+        assert out[2] == out[4]
     for _ in range(6):
         model.decode_batch_launch([0, 1])
         out = model.decode_batch_wait()
