@@ -90,7 +90,6 @@ def test_engine_random_joins_and_leaves(pipeline):
     eng.close()
     assert sorted(eng.free) == [0, 1, 2, 3] and not eng.zombies and eng.inflight is None and not m.launched
     assert total[0] <= eng.tokens_out <= total[0] + 35      # a sequence may leave one delivered token unread
-    assert m.steps < total[0]                     # steps were shared
     assert m.forks == 35 and m.prefills <= 36     # one prefix prefill (same image); tail prefills only for longer prompts
 
 
