@@ -203,8 +203,11 @@ def main():
         from detikzify_amd.infer.batching import BatchEngine
         engine = BatchEngine(model, max_batch=args.batch)
         try:
+            # MCTS rollouts sample with the pipeline's defaults (temperature .8, top-p .95: generate.py:362-364)
+            mcts_kw = {**gen_kw, "do_sample": True, "temperature": 0.8, "top_p": 0.95, "top_k": 0}
+
             def one(i):
-                model.generate(input_ids=ids, seed=5000 + rank * 100 + i, **gen_kw)
+                model.generate(input_ids=ids, seed=5000 + rank * 100 + i, **mcts_kw)
             for rep_i in range(2):          # first pass warms the batch graph up
                 fence()
                 tb = time.perf_counter()
@@ -225,6 +228,7 @@ def main():
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
                 "prefix_sharing": bool(engine.share_prefix),
                 "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3)},
+                "decode": "sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), 512 tokens, EOS suppressed",
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
                         "dtk_decode_batch step serves all of them; the 243-token image prefix is encoded once and its "
                         "KV forked into each slot (bit-identical to a full prefill, SURVEY f1)"}

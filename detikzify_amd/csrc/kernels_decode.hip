@@ -17,6 +17,8 @@
 // Each wave owns NR weight rows for the full K, lanes stride K in 16-byte chunks
 // (64 lanes x 16 B = 1 KiB per row per load instruction), two register stages so the
 // next stage's loads are in flight while the current one is consumed by v_dot2c_f32_bf16.
+#include <cstdlib>
+#include <cstring>
 #include "kernels.h"
 
 template <int NR, int U>
@@ -873,12 +875,12 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
   const float zmax = s_max;
 
   if (sampling) {
-    // fixed-point mass q_i = floor(exp(z_i - zmax) * 2^32)  (exact integer sums)
+    // fixed-point mass q_i = floor(exp(z_i - zmax) * 2^31)  (fits 32 bits; exact integer sums)
     auto mass = [&](int i, float& z) -> unsigned long long {
       z = a.logits[i] * invT;
       if (is_banned(sp, i, first)) z = -INFINITY;
       const float e = expf(z - zmax);
-      return (unsigned long long)((double)e * 4294967296.0);
+      return (unsigned long long)((double)e * 2147483648.0);
     };
     // ---- radix descent for the keep-threshold key.  Top-k then top-p, as HF orders the
     // warpers: top-k keeps keys >= (k-th largest); top-p then works on the softmax of the
@@ -1023,9 +1025,263 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident sampler for vocabularies up to 32 768 (every v1 model): thread t owns the 32
+// CONSECUTIVE logits [32t, 32t+32) — one 128-byte line, read once with 16-byte loads — and keeps their keys
+// and integer masses in registers through every pass (argmax, top-k / top-p radix descent, inverse-CDF
+// scan), so the whole sampler is ONE pass over the logits.  Histogram updates are run-length
+// aggregated per thread (neighbouring logits mostly share the high key byte), which removes the
+// same-address LDS-atomic serialisation that dominated k_sample (190 us -> measured in profiles/).
+// Same integer semantics as k_sample / oracle/sampling.py (bit-exact kept set and draws).
+#define SF_PER 32
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
+  if (a.bs) {
+    const int slot = blockIdx.x;
+    if (!a.bs->active[slot]) return;
+    a.logits += (size_t)slot * a.logits_stride;
+    a.sp += slot;
+    a.st += slot;
+    a.x += (size_t)slot * a.d;
+    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * 16 + slot;
+    a.ring = 1;
+    a.step_override = -1;
+  }
+  __shared__ SamplingDev s_sp;
+  __shared__ float s_f[16];
+  __shared__ int s_i[16];
+  __shared__ unsigned long long s_q[16];
+  __shared__ unsigned long long h_mass[256];
+  __shared__ unsigned int h_cnt[256];
+  __shared__ unsigned long long sc_above_q;
+  __shared__ unsigned int sc_above_c, sc_bin;
+  __shared__ unsigned long long scan[SAMPLE_THREADS];
+  __shared__ int s_token;
+  __shared__ float s_max;
+  __shared__ unsigned long long s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V;
+  if (tid < (int)(sizeof(SamplingDev) / 4)) reinterpret_cast<uint32_t*>(&s_sp)[tid] = reinterpret_cast<const uint32_t*>(a.sp)[tid];
+  __syncthreads();
+  const SamplingDev* sp = &s_sp;
+  const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
+  const bool first = (draw == 0);
+  const bool sampling = sp->do_sample != 0;
+  const float invT = sampling ? 1.f / sp->temperature : 1.f;
+  const int i0 = tid * SF_PER;
+
+  // ---- the one pass over the logits
+  float z[SF_PER];
+  const bool vec = ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0) && (i0 + SF_PER <= V);
+  if (vec) {
+    const f32x4* l4 = reinterpret_cast<const f32x4*>(a.logits + i0);
+#pragma unroll
+    for (int k = 0; k < SF_PER / 4; ++k) {
+      const f32x4 v = l4[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[4 * k + e] = v[e] * invT;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SF_PER; ++k) z[k] = (i0 + k < V) ? a.logits[i0 + k] * invT : -INFINITY;
+  }
+  // bans: a handful of ids, each owned by exactly one thread (static register index via the unrolled compare)
+  {
+    const int nb = sp->n_bad, na = sp->n_always, ng = first ? sp->n_begin : 0;
+    for (int j = 0; j < nb + na + ng; ++j) {
+      const int id = j < nb ? sp->bad_ids[j] : (j < nb + na ? sp->always_ids[j - nb] : sp->begin_ids[j - nb - na]);
+      const int rel = id - i0;
+      if (rel >= 0 && rel < SF_PER) {
+#pragma unroll
+        for (int k = 0; k < SF_PER; ++k) if (k == rel) z[k] = -INFINITY;
+      }
+    }
+  }
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < SF_PER; ++k)
+    if (i0 + k < V && (z[k] > best || (z[k] == best && i0 + k < besti))) { best = z[k]; besti = i0 + k; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(besti, off, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) { s_f[wave] = best; s_i[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    float b = s_f[0]; int bi = s_i[0];
+    for (int w = 1; w < 16; ++w)
+      if (s_f[w] > b || (s_f[w] == b && s_i[w] < bi)) { b = s_f[w]; bi = s_i[w]; }
+    s_max = b; s_token = bi;
+  }
+  __syncthreads();
+  const float zmax = s_max;
+
+  if (sampling) {
+    uint32_t q[SF_PER];   // floor(exp(z - zmax) * 2^31) <= 2^31
+#pragma unroll
+    for (int k = 0; k < SF_PER; ++k) {
+      const bool in = i0 + k < V;
+      const float zz = z[k];
+      q[k] = in ? (uint32_t)((double)expf(zz - zmax) * 2147483648.0) : 0u;
+      z[k] = __uint_as_float(in ? fkey(zz) : 0u);   // the slot now holds the order-preserving key
+    }
+#define key(k) __float_as_uint(z[k])
+    // radix descent helper state: run-length aggregated histogram update
+    uint32_t thr_k = 0;
+    if (sp->top_k > 0 && sp->top_k < V) {
+      uint32_t prefix = 0; unsigned int above = 0;
+      for (int level = 3; level >= 0; --level) {
+        const int shift = level * 8;
+        for (int b = tid; b < 256; b += SAMPLE_THREADS) h_cnt[b] = 0;
+        __syncthreads();
+        uint32_t cur = 0xffffffffu, cc = 0;
+#pragma unroll
+        for (int k = 0; k < SF_PER; ++k) {
+          if (i0 + k >= V) continue;
+          const bool match = (level == 3) || ((key(k) >> (shift + 8)) == (prefix >> (shift + 8)));
+          if (!match) continue;
+          const uint32_t bin = (key(k) >> shift) & 255u;
+          if (bin != cur) { if (cc) atomicAdd(&h_cnt[cur], cc); cur = bin; cc = 0; }
+          ++cc;
+        }
+        if (cc) atomicAdd(&h_cnt[cur], cc);
+        __syncthreads();
+        if (tid == 0) {
+          unsigned int ab = above; int bsel = 0;
+          for (int b = 255; b >= 0; --b) {
+            if (h_cnt[b] == 0) continue;
+            if (ab + h_cnt[b] >= (unsigned)sp->top_k) { bsel = b; break; }
+            ab += h_cnt[b];
+          }
+          sc_above_c = ab; sc_bin = bsel;
+        }
+        __syncthreads();
+        above = sc_above_c;
+        prefix |= (sc_bin << shift);
+        __syncthreads();
+      }
+      thr_k = prefix;
+    }
+    unsigned long long loc = 0;
+#pragma unroll
+    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr_k) loc += q[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loc += __shfl_xor(loc, off, 64);
+    if (lane == 0) s_q[wave] = loc;
+    __syncthreads();
+    if (tid == 0) { unsigned long long t = 0; for (int w = 0; w < 16; ++w) t += s_q[w]; s_total = t; }
+    __syncthreads();
+    const unsigned long long total_k = s_total;
+
+    uint32_t thr = thr_k;
+    if (sp->top_p < 1.0f) {
+      const unsigned long long pq = (unsigned long long)((double)sp->top_p * (double)total_k);
+      uint32_t prefix = 0; unsigned long long above = 0;
+      for (int level = 3; level >= 0; --level) {
+        const int shift = level * 8;
+        for (int b = tid; b < 256; b += SAMPLE_THREADS) { h_mass[b] = 0; h_cnt[b] = 0; }
+        __syncthreads();
+        uint32_t cur = 0xffffffffu, cc = 0;
+        unsigned long long cm = 0;
+#pragma unroll
+        for (int k = 0; k < SF_PER; ++k) {
+          if (i0 + k >= V || key(k) < thr_k) continue;
+          const bool match = (level == 3) || ((key(k) >> (shift + 8)) == (prefix >> (shift + 8)));
+          if (!match) continue;
+          const uint32_t bin = (key(k) >> shift) & 255u;
+          if (bin != cur) {
+            if (cc) { atomicAdd(&h_mass[cur], cm); atomicAdd(&h_cnt[cur], cc); }
+            cur = bin; cc = 0; cm = 0;
+          }
+          ++cc; cm += q[k];
+        }
+        if (cc) { atomicAdd(&h_mass[cur], cm); atomicAdd(&h_cnt[cur], cc); }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned long long ab = above; int bsel = -1; unsigned long long ab_sel = above;
+          for (int b = 255; b >= 0; --b) {
+            if (h_cnt[b] == 0) continue;
+            if (ab < pq || bsel < 0) { bsel = b; ab_sel = ab; } else break;
+            ab += h_mass[b];
+          }
+          sc_above_q = ab_sel; sc_bin = (unsigned)bsel;
+        }
+        __syncthreads();
+        above = sc_above_q;
+        prefix |= (sc_bin << shift);
+        __syncthreads();
+      }
+      thr = prefix > thr_k ? prefix : thr_k;
+    }
+    // kept mass + inverse-CDF draw in index order (thread t's range is contiguous: a plain block scan)
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr) mine += q[k];
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < SAMPLE_THREADS; off <<= 1) {
+      unsigned long long v = 0;
+      if (tid >= off) v = scan[tid - off];
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const unsigned long long kept = scan[SAMPLE_THREADS - 1];
+    const uint64_t r = splitmix64(sp->seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(draw + 1))) >> 32;
+    const unsigned long long target = __umul64hi(kept, r << 32);
+    const unsigned long long excl = scan[tid] - mine;
+    if (mine > 0 && target >= excl && target < excl + mine) {
+      unsigned long long run = excl;
+      bool done = false;
+#pragma unroll
+      for (int k = 0; k < SF_PER; ++k) {
+        if (!done && i0 + k < V && key(k) >= thr) {
+          if (target < run + q[k]) { s_token = i0 + k; done = true; }
+          run += q[k];
+        }
+      }
+    }
+    if (a.probs_out) {
+#pragma unroll
+      for (int k = 0; k < SF_PER; ++k)
+        if (i0 + k < V) a.probs_out[i0 + k] = (key(k) >= thr) ? (float)((double)q[k] / (double)kept) : 0.f;
+    }
+    __syncthreads();
+  } else if (a.probs_out) {
+#pragma unroll
+    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V) a.probs_out[i0 + k] = (i0 + k == s_token) ? 1.f : 0.f;
+  }
+
+  const int tok = s_token;
+  if (tid == 0) {
+    a.tok_ring[a.bs ? 0u : draw % (uint32_t)a.ring] = (int64_t)tok;
+    if (a.advance) {
+      a.st->token = tok;
+      a.st->pos = a.st->next_pos;
+      a.st->next_pos = a.st->next_pos + 1;
+      a.st->draw = draw + 1;
+    }
+  }
+  if (a.advance) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)tok * a.d);
+    u32x4* dst = reinterpret_cast<u32x4*>(a.x);
+    for (int c = tid; c < (a.d >> 3); c += SAMPLE_THREADS) dst[c] = src[c];
+  }
+}
+#undef key
+
+static bool sample_fast_ok(const SampleArgs& a) {
+  static int force_generic = -1;
+  if (force_generic < 0) { const char* e = getenv("DTK_SAMPLER"); force_generic = (e && !strcmp(e, "generic")) ? 1 : 0; }
+  return !force_generic && a.V <= SF_PER * SAMPLE_THREADS;
+}
 void launch_sample(const SampleArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_sample, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
+  if (sample_fast_ok(a)) hipLaunchKernelGGL(k_sample_fast, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(k_sample, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
 }
 void launch_sample_b(const SampleArgs& a, hipStream_t s) {
+  if (sample_fast_ok(a)) { hipLaunchKernelGGL(k_sample_fast, dim3(16), dim3(SAMPLE_THREADS), 0, s, a); return; }
   hipLaunchKernelGGL(k_sample, dim3(16), dim3(SAMPLE_THREADS), 0, s, a);
 }

@@ -14,7 +14,7 @@ temperature/top_p/top_k, do_sample):
 `processed_scores` is the literal HF algorithm (sort + cumsum in fp32).  `draw` is the
 deterministic inverse-CDF draw the HIP sampler implements (torch.multinomial's RNG stream cannot
 be reproduced on a different device, so token parity under sampling is defined against this
-counter-based draw): integer probability mass q_i = floor(exp(z_i - zmax) * 2^32), kept set
+counter-based draw): integer probability mass q_i = floor(exp(z_i - zmax) * 2^31), kept set
 = {i : mass strictly above z_i < top_p * total}, target = floor(kept_total * r / 2^32) with
 r = splitmix64(seed ^ C*(n+1)) >> 32, first index whose running mass exceeds target.
 """
@@ -78,7 +78,7 @@ def integer_masses(logits, temperature, bad=(), begin=(), first=False, always=()
     z = (z * np.float32(1.0 / np.float32(temperature))).float()   # device multiplies by 1/T
     zmax = z.max()
     e = torch.exp(z - zmax).double()
-    q = torch.floor(e * 4294967296.0).to(torch.int64)
+    q = torch.floor(e * 2147483648.0).to(torch.int64)
     return z, q
 
 
