@@ -41,8 +41,14 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         if max_positions:
             cfg.max_positions = max_positions
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
-        tokenizer = load_tokenizer(str(path), cfg.max_positions)
-        cfg.patch_token_id = tokenizer.bos_token_id          # v1/__init__.py:49
+        try:
+            tokenizer = load_tokenizer(str(path), cfg.max_positions)
+            cfg.patch_token_id = tokenizer.bos_token_id          # v1/__init__.py:49
+        except Exception as e:   # checkpoint directory without tokenizer files (synthetic fixtures)
+            import warnings
+            warnings.warn(f"no usable tokenizer under {path} ({e!r}); using SyntheticTokenizer")
+            tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
+                                           pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions)
         model = DetikzifyForCausalLM(cfg, dev)
         _load_safetensors_dir(model, path)
         if modality_projector:

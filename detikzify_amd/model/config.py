@@ -108,7 +108,13 @@ class DetikzifyConfig:
             patch_token_id=j.get("patch_token_id", j.get("bos_token_id", 1)),
             concat_patches=j.get("concat_patches", 3),
             vit_feature_layer=j.get("feature_layer", 26),
+            max_positions=j.get("model_max_length", 2048),
         )
+        # optional vision-tower description (written by our own fixtures; real v1 checkpoints use the defaults)
+        for src, dst in (("vit_dim", "vit_dim"), ("vit_depth", "vit_depth"), ("vit_heads", "vit_heads"), ("vit_mlp", "vit_mlp"),
+                         ("vit_patch", "vit_patch"), ("vit_image", "vit_image"), ("vit_gelu_tanh", "vit_gelu_tanh")):
+            if src in j:
+                setattr(c, dst, j[src])
         if j.get("num_key_value_heads", c.heads) != c.heads:
             raise NotImplementedError("GQA checkpoints (v2 models) are not supported by this build")
         return c

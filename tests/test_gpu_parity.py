@@ -707,3 +707,37 @@ def test_fp8_weights_parity_and_quantisation_error():
     for i in range(8):
         m8.decode_batch_launch([0])
         assert m8.decode_batch_wait()[0] == toks[i] or i > 0   # first token exact; later ones may hit a near-tie
+
+
+# ------------------------------------------------------------------------------------------ checkpoint loader (f4)
+def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
+    """load(<HF-layout dir>): config.json + *.safetensors (decoder keys, mm_projector, timm tower under
+    vision_model., and the tower alone in vision_tower.safetensors with bare timm names) reproduces the
+    synthetic-fill model bit for bit (weights and greedy tokens)."""
+    import json
+    from safetensors.torch import save_file
+    from detikzify_amd.model import load
+    from oracle.synth import make_weights
+    w = {k: v.to(torch.bfloat16) for k, v in make_weights(TINY_CFG, 1234).items()}
+    dec = {k: v for k, v in w.items() if not k.startswith("vision_model.")}
+    vit = {k[len("vision_model."):]: v for k, v in w.items() if k.startswith("vision_model.")}
+    save_file(dec, str(tmp_path / "model.safetensors"))
+    save_file(vit, str(tmp_path / "vision_tower.safetensors"))
+    cfgj = dict(hidden_size=TINY.hidden, num_hidden_layers=TINY.layers, num_attention_heads=TINY.heads,
+                num_key_value_heads=TINY.heads, intermediate_size=TINY.ffn, vocab_size=TINY.vocab, rms_norm_eps=TINY.rms_eps,
+                rope_theta=TINY.rope_theta, rope_scaling={"type": "linear", "factor": TINY.rope_factor}, bos_token_id=1,
+                eos_token_id=2, pad_token_id=0, patch_token_id=1, concat_patches=3, feature_layer=TINY.vit_feature_layer,
+                model_max_length=TINY.max_positions, vit_dim=TINY.vit_dim, vit_depth=TINY.vit_depth, vit_heads=TINY.vit_heads,
+                vit_mlp=TINY.vit_mlp, vit_patch=TINY.vit_patch, vit_image=TINY.vit_image)
+    (tmp_path / "config.json").write_text(json.dumps(cfgj))
+    with pytest.warns(UserWarning):
+        model, proc = load(str(tmp_path))
+    ref, _ = tiny
+    for name in ("model.layers.1.self_attn.k_proj.weight", "vision_model.blocks.0.attn.qkv.weight",
+                 "vision_model.patch_embed.proj.weight", "model.mm_projector.bias", "lm_head.weight"):
+        assert torch.equal(model.read_tensor(name), ref.read_tensor(name)), name
+    enc = proc(images=sketch_image(4, 96), return_tensors="pt")
+    assert run_greedy(model, enc.input_ids[0], enc.pixel_values, 24) == run_greedy(ref, enc.input_ids[0], enc.pixel_values, 24)
+    with pytest.raises(KeyError):
+        (tmp_path / "vision_tower.safetensors").unlink()
+        load(str(tmp_path))
