@@ -112,7 +112,8 @@ class DetikzifyConfig:
         )
         # optional vision-tower description (written by our own fixtures; real v1 checkpoints use the defaults)
         for src, dst in (("vit_dim", "vit_dim"), ("vit_depth", "vit_depth"), ("vit_heads", "vit_heads"), ("vit_mlp", "vit_mlp"),
-                         ("vit_patch", "vit_patch"), ("vit_image", "vit_image"), ("vit_gelu_tanh", "vit_gelu_tanh")):
+                         ("vit_patch", "vit_patch"), ("vit_image", "vit_image"), ("vit_gelu_tanh", "vit_gelu_tanh"),
+                         ("attn_splits", "attn_splits")):
             if src in j:
                 setattr(c, dst, j[src])
         if j.get("num_key_value_heads", c.heads) != c.heads:

@@ -728,7 +728,7 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
                 rope_theta=TINY.rope_theta, rope_scaling={"type": "linear", "factor": TINY.rope_factor}, bos_token_id=1,
                 eos_token_id=2, pad_token_id=0, patch_token_id=1, concat_patches=3, feature_layer=TINY.vit_feature_layer,
                 model_max_length=TINY.max_positions, vit_dim=TINY.vit_dim, vit_depth=TINY.vit_depth, vit_heads=TINY.vit_heads,
-                vit_mlp=TINY.vit_mlp, vit_patch=TINY.vit_patch, vit_image=TINY.vit_image)
+                vit_mlp=TINY.vit_mlp, vit_patch=TINY.vit_patch, vit_image=TINY.vit_image, attn_splits=TINY.attn_splits)
     (tmp_path / "config.json").write_text(json.dumps(cfgj))
     with pytest.warns(UserWarning):
         model, proc = load(str(tmp_path))
@@ -738,6 +738,6 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
         assert torch.equal(model.read_tensor(name), ref.read_tensor(name)), name
     enc = proc(images=sketch_image(4, 96), return_tensors="pt")
     assert run_greedy(model, enc.input_ids[0], enc.pixel_values, 24) == run_greedy(ref, enc.input_ids[0], enc.pixel_values, 24)
-    with pytest.raises(KeyError):
-        (tmp_path / "vision_tower.safetensors").unlink()
+    (tmp_path / "vision_tower.safetensors").unlink()
+    with pytest.raises(KeyError), pytest.warns(UserWarning):
         load(str(tmp_path))
