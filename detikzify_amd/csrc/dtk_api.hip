@@ -142,6 +142,7 @@ struct dtk_ctx {
   hipGraph_t graph = nullptr, graph_short = nullptr;
   hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
   int attn_full_max = 0;             // contexts below this use the one-block-per-head attention (measured slower: off)
+  int attn_impl = 0;                 // prefill / ViT attention kernel: 0 auto, 1 VALU, 2 MFMA flash (dtk_set_option "attn_impl")
   bool gemm_naive = false;
   int probe = 0;
   bool probe_pending = false;
@@ -435,7 +436,7 @@ void vit_forward(dtk_ctx* c, bool want_pooled) {
     a.K = c->VQKV + D; a.k_sh = hd; a.k_st = 3 * D;
     a.V = c->VQKV + 2 * D; a.v_sh = hd; a.v_st = 3 * D;
     a.O = c->VAO; a.o_sh = hd; a.o_st = D;
-    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale;
+    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl;
     launch_attention(a, s);
     gemm(c, c->VAO, D, w.projw, D, w.projb, c->VX, D, c->VX, D, N, D, D, GEMM_BIAS | GEMM_RESIDUAL);
     launch_layernorm_rows(c->VX, D, w.n2w, w.n2b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
@@ -458,7 +459,7 @@ void vit_forward(dtk_ctx* c, bool want_pooled) {
   a.K = c->pkv; a.k_sh = hd; a.k_st = 2 * D;
   a.V = c->pkv + D; a.v_sh = hd; a.v_st = 2 * D;
   a.O = c->pao; a.o_sh = hd; a.o_st = D;
-  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale;
+  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl;
   launch_attention(a, s);
   gemm(c, c->pao, D, c->ap_pw, D, c->ap_pb, nullptr, 0, c->px, D, 1, D, D, GEMM_BIAS);
   launch_layernorm_rows(c->px, D, c->ap_nw, c->ap_nb, c->pn, D, 1, D, c->cfg.vit_ln_eps, s);
@@ -950,7 +951,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     a.K = kc(l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
     a.V = vc(l); a.v_sh = (long)c->Tmax * 128; a.v_st = 128;
     a.O = c->AO; a.o_sh = 128; a.o_st = d;
-    a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale;
+    a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl;
     launch_attention(a, s);
     gemm(c, c->AO, d, w.wo, d, nullptr, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL);
     launch_rmsnorm_rows(c->X, d, w.ln2, c->Xn, d, n, d, c->cfg.rms_eps, s);
@@ -1293,6 +1294,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
+  else if (!strcmp(name, "attn_impl")) {   // prefill / ViT attention: 0 auto, 1 VALU kernel, 2 MFMA flash kernel
+    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_impl must be 0..2");
+    c->attn_impl = value;
+  }
   else if (!strcmp(name, "attn_combine")) {
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_combine must be 0..2");
     c->attn_combine = value;
@@ -1386,7 +1391,7 @@ int dtk_op_attention(dtk_ctx* c, const uint16_t* Q, const uint16_t* K, const uin
   a.V = dV; a.v_sh = (long)Tk * hd; a.v_st = hd;
   a.O = dO; a.o_sh = (long)Tq * hd; a.o_st = hd;
   a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.causal = causal; a.q_offset = q_offset;
-  a.scale = 1.0f / sqrtf((float)hd);
+  a.scale = 1.0f / sqrtf((float)hd); a.impl = c->attn_impl;
   launch_attention(a, s);
   HIPCHK(c, hipMemcpyAsync(O, dO, (size_t)H * Tq * hd * 2, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

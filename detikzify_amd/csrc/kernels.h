@@ -141,6 +141,7 @@ struct AttnArgs {
   int H, Tq, Tk, hd;
   int causal; int q_offset;   // query i sits at absolute position q_offset + i
   float scale;
+  int impl;   // 0 auto (MFMA flash kernel when hd is 72/128 and Tq >= 16), 1 VALU kernel, 2 MFMA kernel
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -406,7 +406,188 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   }
 }
 
+// MFMA flash attention for the ViT (hd 72, 729 x 729, bidirectional) and the decoder prefill (hd 128, causal).
+// One block = 4 waves = 64 queries, a wave owns 16 queries; key tiles of 64 staged through LDS (register
+// prefetch of the next tile under the MFMAs).  Everything is computed TRANSPOSED so that a lane's MFMA
+// column is always "its" query (lane & 15):
+//   S^T[key][q] = K . Q^T   A = K rows from LDS (16-byte reads), B = Q rows (registers, loaded once)
+//   O^T[d][q]   = V^T . P^T A = V^T gathered from the row-major LDS tile (8 ds_read_u16 per fragment),
+//                           B = P^T = the lane's own probabilities: the k index of the MFMA is a free
+//                           permutation, so k = (lane group g, element e) is mapped to key g*4+e of key
+//                           sub-tile 2s (e < 4) / 2s+1 (e >= 4) — exactly the keys whose scores the lane holds
+//                           in its S^T accumulators.  P never goes through LDS, V is never transposed.
+// Row max / sum: 16 in-lane values + two xor-shuffles (lane groups 16/32 apart).  fp32 scores, fp32 running
+// max/sum, probabilities fed to the P.V MFMA as a bf16 hi + lo pair (~fp32-probability semantics, the same
+// as the VALU kernel and the oracle), fp32 O, one bf16 rounding of the output.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attention_mfma(AttnArgs a) {
+  constexpr int CH = HD / 8;                           // 16-byte chunks per row
+  constexpr int KS = (HD + 31) / 32;                   // k-steps over d for S^T
+  constexpr int DT = (HD + 15) / 16;                   // 16-row tiles of O^T
+  constexpr int HDP = (HD % 64 == 0) ? HD + 8 : HD;    // row stride (elements): 72 -> 36 dwords, 128 -> 68 dwords
+  constexpr int NLD = (64 * CH + 255) / 256;           // 16-byte chunks a thread stages per operand
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * HDP + 32];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * HDP + 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y;
+  const int myq = blockIdx.x * 64 + wave * 16 + lq;
+  const int qrow = myq < a.Tq ? myq : a.Tq - 1;
+
+  bf16x8_t qf[KS];
+  {
+    const bf16_t* qp = a.Q + (size_t)h * a.q_sh + (size_t)qrow * a.q_st;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 4 + g;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (c < CH) v = *reinterpret_cast<const u32x4*>(qp + c * 8);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  const int klim = a.causal ? min(a.Tk, a.q_offset + qrow + 1) : a.Tk;   // keys visible to this lane's query
+  int kmax = a.Tk;                                                        // keys this block needs
+  if (a.causal) kmax = min(a.Tk, a.q_offset + min(a.Tq - 1, (int)blockIdx.x * 64 + 63) + 1);
+
+  float m = -1e30f, l = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rk[NLD], rv[NLD];
+  auto tile_load = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 64 * CH) {
+        const int r = idx / CH, c = idx - r * CH;
+        int j = j0 + r; if (j >= a.Tk) j = a.Tk - 1;
+        rk[i] = *reinterpret_cast<const u32x4*>(a.K + (size_t)h * a.k_sh + (size_t)j * a.k_st + c * 8);
+        rv[i] = *reinterpret_cast<const u32x4*>(a.V + (size_t)h * a.v_sh + (size_t)j * a.v_st + c * 8);
+      }
+    }
+  };
+  auto tile_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 64 * CH) {
+        const int r = idx / CH, c = idx - r * CH;
+        *reinterpret_cast<u32x4*>(&Ks[r * HDP + c * 8]) = rk[i];
+        *reinterpret_cast<u32x4*>(&Vs[r * HDP + c * 8]) = rv[i];
+      }
+    }
+  };
+
+  tile_load(0);
+  for (int j0 = 0; j0 < kmax; j0 += 64) {
+    __syncthreads();   // the previous tile's fragment reads are done
+    tile_write();
+    __syncthreads();
+    if (j0 + 64 < kmax) tile_load(j0 + 64);
+
+    // ---- S^T = K . Q^T : s[t][r] = score(key j0 + t*16 + g*4 + r, query lq)
+    f32x4 sc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 4 + g;
+        u32x4 kv = *reinterpret_cast<const u32x4*>(&Ks[(t * 16 + lq) * HDP + c * 8]);
+        if ((HD % 32) != 0 && ks == KS - 1 && c >= CH) kv = (u32x4){0u, 0u, 0u, 0u};
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kv), qf[ks], sc[t], 0, 0, 0);
+      }
+    }
+    float tmax = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + t * 16 + g * 4 + r;
+        const float v = key < klim ? sc[t][r] * a.scale : -1e30f;
+        sc[t][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m, tmax);
+    const float corr = __expf(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + t * 16 + g * 4 + r;
+        const float p = key < klim ? __expf(sc[t][r] - mn) : 0.f;
+        sc[t][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * corr + psum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] *= corr;
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // p = hi + lo with hi = bf16(p), lo = bf16(p - hi): two MFMAs on the same V^T fragment keep ~16
+      // mantissa bits of the fp32 probabilities (a single bf16 P costs ~2e-3 relative L2 on the output)
+      u32x4 pw, pl;
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const float p0 = sc[2 * s2 + half][2 * pr], p1 = sc[2 * s2 + half][2 * pr + 1];
+          const uint32_t hi = pack2(p0, p1);
+          pw[half * 2 + pr] = hi;
+          pl[half * 2 + pr] = pack2(p0 - pk_lo(hi), p1 - pk_hi(hi));
+        }
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+      const bf16x8_t pfl = __builtin_bit_cast(bf16x8_t, pl);
+      const bf16_t* v0 = Vs + ((2 * s2) * 16 + g * 4) * HDP + lq;       // keys of sub-tile 2*s2
+      const bf16_t* v1 = v0 + 16 * HDP;                                  // keys of sub-tile 2*s2 + 1
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        u32x4 vw;
+        vw[0] = (uint32_t)v0[dt * 16] | ((uint32_t)v0[dt * 16 + HDP] << 16);
+        vw[1] = (uint32_t)v0[dt * 16 + 2 * HDP] | ((uint32_t)v0[dt * 16 + 3 * HDP] << 16);
+        vw[2] = (uint32_t)v1[dt * 16] | ((uint32_t)v1[dt * 16 + HDP] << 16);
+        vw[3] = (uint32_t)v1[dt * 16 + 2 * HDP] | ((uint32_t)v1[dt * 16 + 3 * HDP] << 16);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vw);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (myq < a.Tq) {
+    const float inv = 1.f / l;
+    bf16_t* op = a.O + (size_t)h * a.o_sh + (size_t)myq * a.o_st;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (d < HD) {   // HD % 4 == 0: a group of 4 is fully in or fully out
+        u32x2 w;
+        w[0] = pack2(o[dt][0] * inv, o[dt][1] * inv);
+        w[1] = pack2(o[dt][2] * inv, o[dt][3] * inv);
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+    }
+  }
+}
+
 void launch_attention(const AttnArgs& a, hipStream_t s) {
+  const bool can_mfma = (a.hd == 72 || a.hd == 128) && (a.q_st % 8 == 0) && (a.k_st % 8 == 0) && (a.v_st % 8 == 0) &&
+                        (a.o_st % 4 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) && (a.v_sh % 8 == 0) && (a.o_sh % 4 == 0);
+  const bool mfma = can_mfma && (a.impl == 2 || (a.impl == 0 && a.Tq >= 16));
+  if (mfma) {
+    dim3 grid((a.Tq + 63) / 64, a.H);
+    if (a.hd == 72) hipLaunchKernelGGL((k_attention_mfma<72>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_attention_mfma<128>), grid, dim3(256), 0, s, a);
+    return;
+  }
   dim3 grid((a.Tq + 3) / 4, a.H);
   if (a.hd == 72) hipLaunchKernelGGL((k_attention<72>), grid, dim3(256), 0, s, a);
   else if (a.hd == 128) hipLaunchKernelGGL((k_attention<128>), grid, dim3(256), 0, s, a);

@@ -135,9 +135,14 @@ def test_op_gemv(tiny, N, K, mode):
 
 
 @pytest.mark.parametrize("H,Tq,Tk,hd,causal,qoff", [(2, 36, 36, 72, 0, 0), (2, 1, 36, 72, 0, 0), (3, 5, 19, 128, 1, 14),
-                                                    (2, 70, 70, 128, 1, 0), (2, 130, 200, 128, 1, 70), (1, 729, 729, 72, 0, 0)])
-def test_op_attention(tiny, H, Tq, Tk, hd, causal, qoff):
+                                                    (2, 70, 70, 128, 1, 0), (2, 130, 200, 128, 1, 70), (1, 729, 729, 72, 0, 0),
+                                                    (2, 300, 300, 128, 1, 0), (2, 100, 257, 72, 0, 0)])
+@pytest.mark.parametrize("impl", [1, 2])
+def test_op_attention(tiny, H, Tq, Tk, hd, causal, qoff, impl):
+    """impl 1 = VALU kernel (fp32 probabilities), impl 2 = MFMA flash kernel (probabilities as a bf16 hi+lo
+    pair in the P.V MFMA); both against the fp32-probability oracle."""
     model, _ = tiny
+    model.set_option("attn_impl", impl)
     g = torch.Generator().manual_seed(H * 7 + Tq + Tk)
     q = rb(torch.randn(H, Tq, hd, generator=g)); k = rb(torch.randn(H, Tk, hd, generator=g)); v = rb(torch.randn(H, Tk, hd, generator=g))
     ref = attention(q, k, v, hd ** -0.5, qoff if causal else None)
@@ -146,7 +151,8 @@ def test_op_attention(tiny, H, Tq, Tk, hd, causal, qoff):
     qb, kb, vb = bf16_bits(q), bf16_bits(k), bf16_bits(v)
     model._check(model.lib.dtk_op_attention(model._ctx, p(qb), p(kb), p(vb), H, Tq, Tk, hd, causal, qoff, p(out)), "dtk_op_attention")
     frac, ulps, rl2 = ulp_report(out, ref)
-    print(f"attention H{H} {Tq}x{Tk} hd{hd} causal={causal}: differing {frac:.4f} max_ulp {ulps:.2f} rel_l2 {rl2:.2e}")
+    model.set_option("attn_impl", 0)
+    print(f"attention impl{impl} H{H} {Tq}x{Tk} hd{hd} causal={causal}: differing {frac:.4f} max_ulp {ulps:.2f} rel_l2 {rl2:.2e}")
     assert rl2 < 2e-3 and ulps <= 4.01
 
 
