@@ -9,6 +9,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
+DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
 DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
 DTK_MAX_INFLIGHT = 4
 DTK_EPI_BIAS, DTK_EPI_GELU, DTK_EPI_RESIDUAL, DTK_GEMM_NAIVE = 1, 2, 4, 256

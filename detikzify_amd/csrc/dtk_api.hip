@@ -113,6 +113,8 @@ struct dtk_ctx {
   uint64_t cached_image_key = 0;
   bool have_image = false;
   // ---- batched decode (dtk_*_slot / dtk_decode_batch_*): up to 16 slots with their own KV
+  int KVH = 0;                       // key/value heads (dtk_config.reserved[2]; 0 -> heads)
+  bool proj_bias = true;             // mm_projector has a bias (v1) / bias-free connector (v2)
   int nb = 0;                        // number of batch slots (dtk_config.reserved[0])
   std::vector<SeqHost> bseq;
   bf16_t* kvb = nullptr;             // [nb][L][2][H][Tmax][128]
@@ -218,6 +220,7 @@ void add_tensor(dtk_ctx* c, const std::string& name, bf16_t* ptr, int64_t rows, 
 // Lays out every device buffer.  Called twice (size pass with base == nullptr, then for real).
 void plan(dtk_ctx* c, Planner& P, bool reg) {
   const int d = c->d, L = c->L, ff = c->ff, V = c->V, T = c->Tmax;
+  const int kvd = c->KVH * 128, qkvn = d + 2 * kvd;   // fused QKV rows: [H q heads | KVH k heads | KVH v heads] x 128
   const int D = c->vD, N = c->vN, mlp = c->vMlp;
   const float ws = 0.02f;
   auto R = [&](const std::string& n, bf16_t* p, int64_t r, int64_t cl, int64_t st, float sc,
@@ -229,7 +232,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   for (int i = 0; i < L; ++i) {
     LayerW w;
     w.ln1 = P.take<bf16_t>(d);
-    w.wqkv = P.take<bf16_t>((size_t)3 * d * d);
+    w.wqkv = P.take<bf16_t>((size_t)qkvn * d);
     w.wo = P.take<bf16_t>((size_t)d * d);
     w.ln2 = P.take<bf16_t>(d);
     w.wgu = P.take<bf16_t>((size_t)2 * ff * d);
@@ -239,8 +242,8 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
       const std::string p = "model.layers." + std::to_string(i) + ".";
       R(p + "input_layernorm.weight", w.ln1, 1, d, d, 0.1f, 1.f);
       R(p + "self_attn.q_proj.weight", w.wqkv, d, d, d, ws, 0.f);
-      R(p + "self_attn.k_proj.weight", w.wqkv + (size_t)d * d, d, d, d, ws, 0.f);
-      R(p + "self_attn.v_proj.weight", w.wqkv + (size_t)2 * d * d, d, d, d, ws, 0.f);
+      R(p + "self_attn.k_proj.weight", w.wqkv + (size_t)d * d, kvd, d, d, ws, 0.f);
+      R(p + "self_attn.v_proj.weight", w.wqkv + (size_t)(d + kvd) * d, kvd, d, d, ws, 0.f);
       R(p + "self_attn.o_proj.weight", w.wo, d, d, d, ws, 0.f);
       R(p + "post_attention_layernorm.weight", w.ln2, 1, d, d, 0.1f, 1.f);
       R(p + "mlp.gate_proj.weight", w.wgu, ff, d, d, ws, 0.f);
@@ -256,7 +259,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->mm_b = P.take<bf16_t>(d);
   R("model.mm_projector.weight", c->mm_w, d, (int64_t)c->cfg.concat_patches * D,
     (int64_t)c->cfg.concat_patches * D, ws, 0.f);
-  R("model.mm_projector.bias", c->mm_b, 1, d, d, 0.01f, 0.f);
+  if (c->proj_bias) R("model.mm_projector.bias", c->mm_b, 1, d, d, 0.01f, 0.f);   // v2 connector is bias-free
   c->rope_cos = P.take<bf16_t>((size_t)T * 64);
   c->rope_sin = P.take<bf16_t>((size_t)T * 64);
   R("rope.cos", c->rope_cos, T, 64, 64, 0.f, 0.f);
@@ -320,10 +323,10 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   R(vp + "attn_pool.mlp.fc2.bias", c->ap_f2b, 1, D, D, 0.01f, 0.f);
 
   // ---- KV cache + activations
-  c->kv = P.take<bf16_t>((size_t)L * 2 * c->H * T * 128);
+  c->kv = P.take<bf16_t>((size_t)L * 2 * c->KVH * T * 128);
   c->X = P.take<bf16_t>((size_t)T * d);
   c->Xn = P.take<bf16_t>((size_t)T * d);
-  c->QKV = P.take<bf16_t>((size_t)T * 3 * d);
+  c->QKV = P.take<bf16_t>((size_t)T * qkvn);
   c->Qh = P.take<bf16_t>((size_t)T * d);
   c->AO = P.take<bf16_t>((size_t)T * d);
   c->GU = P.take<bf16_t>((size_t)T * 2 * ff);
@@ -361,7 +364,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->IMG = P.take<bf16_t>((size_t)c->nImg * d);
   if (c->wfmt == 1) {
     for (int i = 0; i < L; ++i) {
-      uint8_t* q1 = P.take<uint8_t>((size_t)3 * d * d); float* s1 = P.take<float>(3 * d);
+      uint8_t* q1 = P.take<uint8_t>((size_t)qkvn * d); float* s1 = P.take<float>(qkvn);
       uint8_t* q2 = P.take<uint8_t>((size_t)d * d);     float* s2 = P.take<float>(d);
       uint8_t* q3 = P.take<uint8_t>((size_t)2 * ff * d); float* s3 = P.take<float>(2 * ff);
       uint8_t* q4 = P.take<uint8_t>((size_t)d * ff);    float* s4 = P.take<float>(d);
@@ -374,7 +377,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->s_lm_head = P.take<float>(V);
   }
   if (c->nb > 0) {
-    c->kv_slot_stride = (size_t)L * 2 * c->H * T * 128;
+    c->kv_slot_stride = (size_t)L * 2 * c->KVH * T * 128;
     c->kvb = P.take<bf16_t>((size_t)c->nb * c->kv_slot_stride);
     c->xb = P.take<bf16_t>((size_t)16 * d);
     c->xnb = P.take<bf16_t>((size_t)16 * (d > ff ? d : ff));
@@ -389,7 +392,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->sp_b = P.take<SamplingDev>(17);
     c->bs_dev = P.take<BatchState>(1);
     for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
-      bf16_t* a1 = P.take<bf16_t>(tiled_elems(3 * d, d));
+      bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
       bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
       bf16_t* a3 = P.take<bf16_t>(tiled_elems(2 * ff, d));
       bf16_t* a4 = P.take<bf16_t>(tiled_elems(d, ff));
@@ -413,8 +416,8 @@ void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 
 int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
 
-bf16_t* kcache(dtk_ctx* c, int layer) { return c->kv + (size_t)layer * 2 * c->H * c->Tmax * 128; }
-bf16_t* vcache(dtk_ctx* c, int layer) { return kcache(c, layer) + (size_t)c->H * c->Tmax * 128; }
+bf16_t* kcache(dtk_ctx* c, int layer) { return c->kv + (size_t)layer * 2 * c->KVH * c->Tmax * 128; }
+bf16_t* vcache(dtk_ctx* c, int layer) { return kcache(c, layer) + (size_t)c->KVH * c->Tmax * 128; }
 
 // ViT trunk + (optionally) MAP head for the image already in pixels_dev.
 void vit_forward(dtk_ctx* c, bool want_pooled) {
@@ -436,7 +439,7 @@ void vit_forward(dtk_ctx* c, bool want_pooled) {
     a.K = c->VQKV + D; a.k_sh = hd; a.k_st = 3 * D;
     a.V = c->VQKV + 2 * D; a.v_sh = hd; a.v_st = 3 * D;
     a.O = c->VAO; a.o_sh = hd; a.o_st = D;
-    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl;
+    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
     launch_attention(a, s);
     gemm(c, c->VAO, D, w.projw, D, w.projb, c->VX, D, c->VX, D, N, D, D, GEMM_BIAS | GEMM_RESIDUAL);
     launch_layernorm_rows(c->VX, D, w.n2w, w.n2b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
@@ -459,7 +462,7 @@ void vit_forward(dtk_ctx* c, bool want_pooled) {
   a.K = c->pkv; a.k_sh = hd; a.k_st = 2 * D;
   a.V = c->pkv + D; a.v_sh = hd; a.v_st = 2 * D;
   a.O = c->pao; a.o_sh = hd; a.o_st = D;
-  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl;
+  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
   launch_attention(a, s);
   gemm(c, c->pao, D, c->ap_pw, D, c->ap_pb, nullptr, 0, c->px, D, 1, D, D, GEMM_BIAS);
   launch_layernorm_rows(c->px, D, c->ap_nw, c->ap_nb, c->pn, D, 1, D, c->cfg.vit_ln_eps, s);
@@ -470,7 +473,8 @@ void vit_forward(dtk_ctx* c, bool want_pooled) {
 void project_image(dtk_ctx* c) {
   // feats [N][D] viewed as [N/concat][concat*D] (3 consecutive patch tokens), Linear with bias
   const int K = c->cfg.concat_patches * c->vD;
-  gemm(c, c->feats, K, c->mm_w, K, c->mm_b, nullptr, 0, c->IMG, c->d, c->nImg, c->d, K, GEMM_BIAS);
+  gemm(c, c->feats, K, c->mm_w, K, c->proj_bias ? c->mm_b : nullptr, nullptr, 0, c->IMG, c->d, c->nImg, c->d, K,
+       c->proj_bias ? GEMM_BIAS : 0);
 }
 
 // launches of one decoded token (captured into the graph, or issued directly)
@@ -485,17 +489,17 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
     GemvArgs g{};
-    g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+    g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin;
     g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
     // 1. input_layernorm + q/k/v projections + RoPE + KV append
-    g.W = w.wqkv; g.W8 = w.q_wqkv; g.wscale = w.s_wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1;
+    g.W = w.wqkv; g.W8 = w.q_wqkv; g.wscale = w.s_wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1;
     g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l);
     launch_gemv(PRO_RMSNORM, EPI_QKV, g, s);
     // 2. split-K attention over the cache
     AttnDecArgs ad;
     ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
-    ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax;
+    ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.G = c->H / c->KVH;
     ad.scale = scale;
     ad.combine = (short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     launch_attn_decode(ad, s);
@@ -529,20 +533,20 @@ void batch_step_launches(dtk_ctx* c) {
   sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V;
   launch_sample_b(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
-  const size_t kv_layer = (size_t)2 * c->H * c->Tmax * 128;
+  const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
     bf16_t* kc = c->kvb + (size_t)l * kv_layer;
-    bf16_t* vc = kc + (size_t)c->H * c->Tmax * 128;
+    bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
     GemvBArgs g{};
-    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff;
+    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
     launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
-    g.W = w.t_wqkv; g.N = 3 * d; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    g.W = w.t_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
@@ -567,7 +571,7 @@ void ensure_fp8_weights(dtk_ctx* c) {
   if (c->wfmt != 1 || c->fp8_ready) return;
   for (int l = 0; l < c->L; ++l) {
     LayerW& w = c->layers[l];
-    launch_quant_fp8_rows(w.wqkv, w.q_wqkv, w.s_wqkv, 3 * c->d, c->d, c->stream);
+    launch_quant_fp8_rows(w.wqkv, w.q_wqkv, w.s_wqkv, c->d + 2 * c->KVH * 128, c->d, c->stream);
     launch_quant_fp8_rows(w.wo, w.q_wo, w.s_wo, c->d, c->d, c->stream);
     launch_quant_fp8_rows(w.wgu, w.q_wgu, w.s_wgu, 2 * c->ff, c->d, c->stream);
     launch_quant_fp8_rows(w.wdown, w.q_wdown, w.s_wdown, c->d, c->ff, c->stream);
@@ -582,7 +586,7 @@ void ensure_tiled_weights(dtk_ctx* c) {
   if (c->tiled_ready || c->nb <= 0) return;
   for (int l = 0; l < c->L; ++l) {
     LayerW& w = c->layers[l];
-    launch_retile(w.wqkv, w.t_wqkv, 3 * c->d, c->d, c->stream);
+    launch_retile(w.wqkv, w.t_wqkv, c->d + 2 * c->KVH * 128, c->d, c->stream);
     launch_retile(w.wo, w.t_wo, c->d, c->d, c->stream);
     launch_retile(w.wgu, w.t_wgu, 2 * c->ff, c->d, c->stream);
     launch_retile(w.wdown, w.t_wdown, c->d, c->ff, c->stream);
@@ -650,6 +654,8 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   if (cfg->head_dim != 128) return fail(nullptr, DTK_ERR_ARG, "head_dim must be 128 (got %d)", cfg->head_dim);
   if (cfg->hidden != cfg->heads * cfg->head_dim)
     return fail(nullptr, DTK_ERR_ARG, "hidden (%d) != heads*head_dim", cfg->hidden);
+  if (cfg->reserved[2] < 0 || (cfg->reserved[2] > 0 && cfg->heads % cfg->reserved[2] != 0))
+    return fail(nullptr, DTK_ERR_ARG, "kv_heads (%d) must divide heads (%d)", cfg->reserved[2], cfg->heads);
   if (cfg->hidden % 8 || cfg->ffn % 8 || cfg->vit_dim % 8 || cfg->vit_mlp % 8)
     return fail(nullptr, DTK_ERR_ARG, "dims must be multiples of 8");
   if (cfg->vit_dim % cfg->vit_heads) return fail(nullptr, DTK_ERR_ARG, "vit_dim %% vit_heads != 0");
@@ -671,6 +677,8 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->cfg = *cfg;
   c->device = device;
   c->d = cfg->hidden; c->L = cfg->layers; c->H = cfg->heads; c->ff = cfg->ffn; c->V = cfg->vocab;
+  c->KVH = cfg->reserved[2] > 0 ? cfg->reserved[2] : cfg->heads;      // GQA (v2: LLaMA-3.1, 32 / 8)
+  c->proj_bias = (cfg->reserved[3] & DTK_ARCH_PROJ_NO_BIAS) == 0;     // v2 connector: Linear(3*D -> d, bias=False)
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
@@ -735,14 +743,16 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   CCHK(hipStreamSynchronize(c->stream));
 #undef CCHK
   // accounting: W = decoder layers + final norm + lm_head, K = 2*L*d*2
-  const uint64_t per_layer = (uint64_t)4 * c->d * c->d + (uint64_t)3 * c->d * c->ff + 2 * (uint64_t)c->d;
+  const uint64_t kvd = (uint64_t)c->KVH * 128;
+  const uint64_t attn_lin = (uint64_t)2 * c->d * c->d + 2 * kvd * c->d;   // q, o: d x d; k, v: kvd x d
+  const uint64_t per_layer = attn_lin + (uint64_t)3 * c->d * c->ff + 2 * (uint64_t)c->d;
   c->stats.weight_bytes_per_token = 2 * (per_layer * c->L + (uint64_t)c->d + (uint64_t)c->V * c->d);
   if (c->wfmt == 1) {  // 1 byte per Linear weight + fp32 scale per row; norm vectors stay bf16
-    const uint64_t lin = (uint64_t)4 * c->d * c->d + (uint64_t)3 * c->d * c->ff;
-    const uint64_t rows = (uint64_t)5 * c->d + (uint64_t)2 * c->ff;
+    const uint64_t lin = attn_lin + (uint64_t)3 * c->d * c->ff;
+    const uint64_t rows = (uint64_t)3 * c->d + 2 * kvd + (uint64_t)2 * c->ff;
     c->stats.weight_bytes_per_token = (lin + 4 * rows + 4 * (uint64_t)c->d) * c->L + 2 * (uint64_t)c->d + (uint64_t)c->V * c->d + 4 * (uint64_t)c->V;
   }
-  c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * c->d * 2;
+  c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * kvd * 2;
   c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * (c->wfmt == 1 ? 1 : 2);
   *out = c;
   return DTK_OK;
@@ -878,9 +888,9 @@ int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, 
 
 static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_dst, DecState* st_dst, bool is_single,
                         const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
-  const size_t kv_layer = (size_t)2 * c->H * c->Tmax * 128;
+  const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
   auto kc = [&](int l) { return kvbase + (size_t)l * kv_layer; };
-  auto vc = [&](int l) { return kvbase + (size_t)l * kv_layer + (size_t)c->H * c->Tmax * 128; };
+  auto vc = [&](int l) { return kvbase + (size_t)l * kv_layer + (size_t)c->KVH * c->Tmax * 128; };
   if (!c || !ids || T < 1) return fail(c, DTK_ERR_ARG, "dtk_prefill: bad argument");
   if (T > c->Tmax) return fail(c, DTK_ERR_RANGE, "prompt of %d tokens exceeds max_positions %d", T, c->Tmax);
   HIPCHK(c, hipSetDevice(c->device));
@@ -944,14 +954,15 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
     launch_rmsnorm_rows(c->X, d, w.ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
-    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, 3 * d, n, 3 * d, d, 0);
-    launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->Tmax, s);
+    const int qkvn = d + 2 * c->KVH * 128;
+    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0);
+    launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
     AttnArgs a;
     a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
     a.K = kc(l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
     a.V = vc(l); a.v_sh = (long)c->Tmax * 128; a.v_st = 128;
     a.O = c->AO; a.o_sh = 128; a.o_st = d;
-    a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl;
+    a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl; a.kv_group = c->H / c->KVH;
     launch_attention(a, s);
     gemm(c, c->AO, d, w.wo, d, nullptr, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL);
     launch_rmsnorm_rows(c->X, d, w.ln2, c->Xn, d, n, d, c->cfg.rms_eps, s);
@@ -1104,7 +1115,7 @@ int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
     if (a.cached_ids[(size_t)i] < 0) return fail(c, DTK_ERR_STATE, "dtk_kv_fork: source has un-read tokens");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t pitch = (size_t)c->Tmax * 128 * 2;           // one (layer, k|v, head) plane
-  const size_t rows = (size_t)c->L * 2 * c->H;
+  const size_t rows = (size_t)c->L * 2 * c->KVH;
   HIPCHK(c, hipMemcpy2DAsync(c->kvb + (size_t)dst * c->kv_slot_stride, pitch, c->kvb + (size_t)src * c->kv_slot_stride, pitch,
                              (size_t)n_tokens * 128 * 2, rows, hipMemcpyDeviceToDevice, c->stream));
   SeqHost& b = c->bseq[(size_t)dst];
@@ -1244,7 +1255,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
     auto pass = [&]() {
       for (int l = 0; l < c->L; ++l) {
         GemvBArgs g{};
-        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
         g.W = c->layers[l].t_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
         launch_gemv_b_mode(variant, g, s);
       }
@@ -1265,9 +1276,9 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
     for (int l = 0; l < c->L; ++l) {
       const LayerW& w = c->layers[same_layer ? 0 : l];
       GemvArgs g{};
-      g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff;
+      g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
       g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
-      if (role == 0) { g.W = w.wqkv; g.N = 3 * c->d; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch_gemv_variant(PRO_RMSNORM, EPI_QKV, variant, g, s); }
+      if (role == 0) { g.W = w.wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch_gemv_variant(PRO_RMSNORM, EPI_QKV, variant, g, s); }
       else if (role == 1) { g.W = w.wo; g.N = c->d; g.K = c->d; g.x = c->attn_out; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
       else if (role == 2) { g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act; launch_gemv_variant(PRO_RMSNORM, EPI_SWIGLU, variant, g, s); }
       else if (role == 3) { g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
@@ -1391,7 +1402,7 @@ int dtk_op_attention(dtk_ctx* c, const uint16_t* Q, const uint16_t* K, const uin
   a.V = dV; a.v_sh = (long)Tk * hd; a.v_st = hd;
   a.O = dO; a.o_sh = (long)Tq * hd; a.o_st = hd;
   a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.causal = causal; a.q_offset = q_offset;
-  a.scale = 1.0f / sqrtf((float)hd); a.impl = c->attn_impl;
+  a.scale = 1.0f / sqrtf((float)hd); a.impl = c->attn_impl; a.kv_group = 1;
   launch_attention(a, s);
   HIPCHK(c, hipMemcpyAsync(O, dO, (size_t)H * Tq * hd * 2, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

@@ -31,8 +31,10 @@ struct GemvArgs {
   const bf16_t* rope_sin;
   const DecState* st;
   int T_max;
-  int d;                 // hidden (QKV: N == 3*d)
+  int d;                 // hidden (== H*128)
   int ff;                // EPI_SWIGLU: N == 2*ff
+  int H;                 // EPI_QKV: query heads; rows = [H q heads | KVH k heads | KVH v heads] x 128, N == (H + 2*KVH)*128
+  int KVH;               //          key/value heads (GQA: H % KVH == 0; MHA: KVH == H)
 };
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s);
@@ -41,7 +43,7 @@ void set_gemv_default_variant(int epi, int variant);
 
 struct AttnDecArgs {
   const bf16_t* q;       // [H*128] (RoPE applied)
-  const bf16_t* kcache;  // [H][T_max][128]
+  const bf16_t* kcache;  // [KVH][T_max][128]; query head h reads kv head h / G
   const bf16_t* vcache;
   const DecState* st;    // keys 0..st->pos
   float* pm; float* pl; float* po;   // [H][S], [H][S], [H][S][130] (130 = 128 o + m + l when combine)
@@ -49,6 +51,7 @@ struct AttnDecArgs {
   int combine;           // 1: the last-arriving split of a head writes the bf16 head output
   bf16_t* out;           // [H*128] attention output (combine)
   unsigned* counters;    // [H] arrival tickets, zero between launches
+  int G;                 // query heads per kv head (1 = MHA)
 };
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s);
 
@@ -83,6 +86,7 @@ struct GemvBArgs {
   size_t kv_slot_stride;
   const bf16_t* rope_cos; const bf16_t* rope_sin;
   int T_max; int d; int ff;
+  int H; int KVH;                      // QKV: head counts (rows = [H | KVH | KVH] x 128)
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
@@ -97,6 +101,7 @@ struct AttnDecBArgs {
   float* pm; float* pl; float* po;     // [slots][H][S], ..., [slots][H][S][128]
   bf16_t* out;                         // [16][d]
   int H; int S; int T_max; int d; float scale;
+  int G;                               // query heads per kv head (1 = MHA)
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 
@@ -131,7 +136,7 @@ void launch_im2col(const float* pixels, bf16_t* patches, int image, int patch, i
 // q,k RoPE + scatter of one prefill chunk: QKV [T][3d] -> Qh [H][T][128], caches at start_pos+t
 void launch_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
                          const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos,
-                         int H, int T_max, hipStream_t s);
+                         int H, int KVH, int T_max, hipStream_t s);
 
 struct AttnArgs {
   const bf16_t* Q; long q_sh; long q_st;   // element strides: head, token
@@ -141,6 +146,7 @@ struct AttnArgs {
   int H, Tq, Tk, hd;
   int causal; int q_offset;   // query i sits at absolute position q_offset + i
   float scale;
+  int kv_group;  // query heads per K/V head (GQA): head h reads K/V head h / kv_group; 0 or 1 = one K/V head per query head
   int impl;   // 0 auto (MFMA flash kernel when hd is 72/128 and Tq >= 16), 1 VALU kernel, 2 MFMA kernel
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);

@@ -22,12 +22,8 @@
 // rows of tile t of a block for the paired epilogues: QKV -> (i, i+64) RoPE partners; SWIGLU -> (gate, up)
 template <int EPI, int T>
 __device__ __forceinline__ int gb_tile_row0(const GemvBArgs& a, int blk, int t) {
-  if (EPI == EPI_QKV) {  // block = 16 dims i0..i0+15 (< 64) of one head of one section
-    const int per_sec = a.d >> 5;                 // (d/128 heads) * 4 sub-blocks
-    const int sec = blk / per_sec, rem = blk - sec * per_sec;
-    const int head = rem >> 2, i0 = (rem & 3) * 16;
-    return sec * a.d + head * 128 + i0 + t * 64;
-  }
+  if (EPI == EPI_QKV)    // block = 16 dims i0..i0+15 (< 64) of head block blk/4 over [H q | KVH k | KVH v]
+    return (blk >> 2) * 128 + (blk & 3) * 16 + t * 64;
   if (EPI == EPI_SWIGLU) return blk * 16 + t * a.ff;
   return (blk * T + t) * 16;
 }
@@ -127,9 +123,9 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
       a.Y[(size_t)n * a.ldy + i] = f2bf(sl * up);
     }
   } else if (EPI == EPI_QKV) {
-    const int per_sec = a.d >> 5;
-    const int sec = blk / per_sec, rem = blk - sec * per_sec;
-    const int head = rem >> 2, i = (rem & 3) * 16 + m;
+    const int hb = blk >> 2, i = (blk & 3) * 16 + m;
+    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
     const int pos = a.st[n].pos;
     const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
     const size_t slot_kv = (size_t)n * a.kv_slot_stride;
@@ -158,7 +154,7 @@ void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGL
 
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
   if (epi == EPI_QKV) {
-    const int grid = 3 * (a.d >> 5);
+    const int grid = (a.H + 2 * a.KVH) * 4;   // 4 blocks of 16 RoPE pairs per head block
     hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2>), dim3(grid), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_SWIGLU) {
     hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
@@ -222,8 +218,9 @@ __global__ __launch_bounds__(256) void k_attn_decode_b(AttnDecBArgs a) {
   const int j_begin = sp * chunk;
   const int j_end = min(n, j_begin + chunk);
   const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + h * 128)[sub];
-  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)h * a.T_max * 128;
-  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)h * a.T_max * 128;
+  const int kvh = h / a.G;
+  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   float m = -1e30f, l = 0.f;
   float o[8];
 #pragma unroll

@@ -294,14 +294,15 @@ void launch_im2col(const float* pixels, bf16_t* patches, int image, int patch, i
   hipLaunchKernelGGL(k_im2col, dim3(np * np), dim3(256), 0, s, pixels, patches, image, patch, ldp);
 }
 
-// grid (T, H), 64 threads: thread i owns the RoPE pair (i, i+64) of q and k, and copies v.
+// grid (T, H), 64 threads: thread i owns the RoPE pair (i, i+64) of q head h; blocks h < KVH also rotate k head h
+// and copy v head h.  QKV row layout: [H q heads | KVH k heads | KVH v heads] x 128.
 __global__ void k_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
                                const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos,
-                               int H, int T_max) {
+                               int H, int KVH, int T_max) {
   const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
-  const int d = H * 128;
+  const int qd = H * 128, kvd = KVH * 128;
   const int pos = start_pos + t;
-  const bf16_t* row = QKV + (size_t)t * 3 * d;
+  const bf16_t* row = QKV + (size_t)t * (qd + 2 * kvd);
   const float c = bf2f(cos_t[(size_t)pos * 64 + i]);
   const float s = bf2f(sin_t[(size_t)pos * 64 + i]);
   {
@@ -310,23 +311,24 @@ __global__ void k_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf
     dst[i] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
     dst[i + 64] = f2bf(rbf(x2 * c) + rbf(x1 * s));
   }
+  if (h >= KVH) return;
   {
-    const float x1 = bf2f(row[d + h * 128 + i]), x2 = bf2f(row[d + h * 128 + i + 64]);
+    const float x1 = bf2f(row[qd + h * 128 + i]), x2 = bf2f(row[qd + h * 128 + i + 64]);
     bf16_t* dst = kcache + ((size_t)h * T_max + pos) * 128;
     dst[i] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
     dst[i + 64] = f2bf(rbf(x2 * c) + rbf(x1 * s));
   }
   {
     bf16_t* dst = vcache + ((size_t)h * T_max + pos) * 128;
-    dst[i] = row[2 * d + h * 128 + i];
-    dst[i + 64] = row[2 * d + h * 128 + i + 64];
+    dst[i] = row[qd + kvd + h * 128 + i];
+    dst[i + 64] = row[qd + kvd + h * 128 + i + 64];
   }
 }
 void launch_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
-                         const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H,
+                         const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H, int KVH,
                          int T_max, hipStream_t s) {
   hipLaunchKernelGGL(k_rope_scatter, dim3(T, H), dim3(64), 0, s, QKV, Qh, kcache, vcache, cos_t,
-                     sin_t, T, start_pos, H, T_max);
+                     sin_t, T, start_pos, H, KVH, T_max);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   __shared__ uint32_t Vs[64 * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y;
+  const int hk = a.kv_group > 1 ? h / a.kv_group : h;   // GQA
   const int qi = blockIdx.x * 4 + wave;
   const bool qok = qi < a.Tq;
   const int qrow = qok ? qi : a.Tq - 1;
@@ -372,8 +375,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     for (int idx = tid; idx < 64 * HD2; idx += 256) {
       const int r = idx / HD2, c = idx - r * HD2;
       int j = j0 + r; if (j >= a.Tk) j = a.Tk - 1;
-      Ks[r * RS + c] = reinterpret_cast<const uint32_t*>(a.K + (size_t)h * a.k_sh + (size_t)j * a.k_st)[c];
-      Vs[r * RS + c] = reinterpret_cast<const uint32_t*>(a.V + (size_t)h * a.v_sh + (size_t)j * a.v_st)[c];
+      Ks[r * RS + c] = reinterpret_cast<const uint32_t*>(a.K + (size_t)hk * a.k_sh + (size_t)j * a.k_st)[c];
+      Vs[r * RS + c] = reinterpret_cast<const uint32_t*>(a.V + (size_t)hk * a.v_sh + (size_t)j * a.v_st)[c];
     }
     __syncthreads();
     // scores: lane = key
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int h = blockIdx.y;
+  const int hk = a.kv_group > 1 ? h / a.kv_group : h;   // GQA
   const int myq = blockIdx.x * 64 + wave * 16 + lq;
   const int qrow = myq < a.Tq ? myq : a.Tq - 1;
 
@@ -462,8 +466,8 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnArgs a) {
       if (idx < 64 * CH) {
         const int r = idx / CH, c = idx - r * CH;
         int j = j0 + r; if (j >= a.Tk) j = a.Tk - 1;
-        rk[i] = *reinterpret_cast<const u32x4*>(a.K + (size_t)h * a.k_sh + (size_t)j * a.k_st + c * 8);
-        rv[i] = *reinterpret_cast<const u32x4*>(a.V + (size_t)h * a.v_sh + (size_t)j * a.v_st + c * 8);
+        rk[i] = *reinterpret_cast<const u32x4*>(a.K + (size_t)hk * a.k_sh + (size_t)j * a.k_st + c * 8);
+        rv[i] = *reinterpret_cast<const u32x4*>(a.V + (size_t)hk * a.v_sh + (size_t)j * a.v_st + c * 8);
       }
     }
   };

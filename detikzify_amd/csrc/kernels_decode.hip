@@ -126,11 +126,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
       int u = u0 + j;
       if (u >= n_units) u = n_units - 1;  // clamped: inactive tails never fault
       int r0, r1 = 0;
-      if (EPI == EPI_QKV) {
-        const int half = a.d >> 1;
-        const int sec = u / half;
-        const int pi = u - sec * half;
-        r0 = sec * a.d + (pi >> 6) * 128 + (pi & 63);
+      if (EPI == EPI_QKV) {   // unit = RoPE pair (i, i+64) of head block hb over [H q | KVH k | KVH v]
+        r0 = (u >> 6) * 128 + (u & 63);
         r1 = r0 + 64;
       } else if (EPI == EPI_SWIGLU) {
         r0 = u;
@@ -257,9 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
         if (u >= n_units) break;
         if (F8) {  // per-output-channel power-of-two scale (exact)
           if (EPI == EPI_QKV) {
-            const int half = a.d >> 1;
-            const int sec = u / half, pi = u - sec * half;
-            const int r0 = sec * a.d + (pi >> 6) * 128 + (pi & 63);
+            const int r0 = (u >> 6) * 128 + (u & 63);
             acc[2 * j] *= a.wscale[r0];
             acc[2 * j + 1] *= a.wscale[r0 + 64];
           } else if (EPI == EPI_SWIGLU) {
@@ -282,10 +277,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
           const float sl = rbf(gte / (1.f + expf(-gte)));
           a.y[u] = f2bf(sl * up);
         } else if (EPI == EPI_QKV) {
-          const int half = a.d >> 1;
-          const int sec = u / half;
-          const int pi = u - sec * half;
-          const int head = pi >> 6, i = pi & 63;
+          const int hb = u >> 6, i = u & 63;
+          const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+          const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
           const int pos = a.st->pos;
           const float x1 = rbf(acc[2 * j]);      // dim i
           const float x2 = rbf(acc[2 * j + 1]);  // dim i + 64
@@ -480,8 +474,9 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecArgs a) {
 
   // q piece of this lane: dims sub*8 .. sub*8+7 as packed bf16
   const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + h * 128)[sub];
-  const bf16_t* kbase = a.kcache + (size_t)h * a.T_max * 128;
-  const bf16_t* vbase = a.vcache + (size_t)h * a.T_max * 128;
+  const int kvh = h / a.G;   // GQA: G query heads share one kv head
+  const bf16_t* kbase = a.kcache + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)kvh * a.T_max * 128;
 
   float m = -1e30f, l = 0.f;
   float o[8];
@@ -664,8 +659,9 @@ __global__ __launch_bounds__(1024) void k_attn_decode_head(AttnDecArgs a) {
   const int sub = lane & 15, grp = lane >> 4;
   const int n = a.st->pos + 1;
   const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + h * 128)[sub];
-  const bf16_t* kbase = a.kcache + (size_t)h * a.T_max * 128;
-  const bf16_t* vbase = a.vcache + (size_t)h * a.T_max * 128;
+  const int kvh = h / a.G;   // GQA: G query heads share one kv head
+  const bf16_t* kbase = a.kcache + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)kvh * a.T_max * 128;
   float m = -1e30f, l = 0.f;
   float o[8];
 #pragma unroll

@@ -4,7 +4,11 @@ outputs for (rendered image, input image).  Same behaviour as reference
 detikzify/evaluate/imagesim.py:21-147 for the v1 models, whose config reports pooling_mode "cos"
 (v1/configuration_detikzify.py:11-13): each image -> load -> expand(trim) -> image processor ->
 vision_model(pixel_values).pooler_output -> cosine in float64 (:91-125).  `cos_avg` (mean of the
-patch features) is kept; `emd` (v2 models, POT solver) is out of scope for this build.
+patch features) is kept.  `emd` (the v2 default, :63,:118-123): patch features of both images -> pairwise
+cosine distances in float64 -> earth mover's distance with uniform marginals -> 2*tanh(-emd)+1.  The reference
+calls POT's `ot.emd2(a=[], b=[], M)` (absent here); with uniform marginals over two equally sized patch sets
+the transport polytope's vertices are permutation matrices (Birkhoff), so the exact optimum is the minimum-cost
+assignment divided by n — solved with scipy.optimize.linear_sum_assignment.
 torchmetrics is absent here: update/compute/reset are restated with plain attributes (the
 reference disables metric state sync on this path anyway, infer/generate.py:373).
 
@@ -15,6 +19,9 @@ from __future__ import annotations
 
 from typing import Dict, List, Literal, Optional, Union
 
+import math
+
+import numpy as np
 import torch
 import torch.nn.functional as F
 from PIL import Image
@@ -22,13 +29,39 @@ from PIL import Image
 from ..util import expand, load, unwrap_processor
 
 
+def pairwise_cosine_distance(a: torch.Tensor, b: torch.Tensor) -> np.ndarray:
+    """1 - torchmetrics.functional.pairwise_cosine_similarity(a, b): rows are L2-normalised, then a @ b.T"""
+    an = a / a.norm(dim=1, keepdim=True)
+    bn = b / b.norm(dim=1, keepdim=True)
+    return (1.0 - an @ bn.T).cpu().numpy()
+
+
+def emd2_uniform(M: np.ndarray) -> float:
+    """ot.emd2(a=[], b=[], M): optimal-transport cost between two uniform distributions.  Equal sizes: the
+    optimum is a permutation (exact); unequal sizes fall back to the LP (scipy linprog / HiGHS)."""
+    n, m = M.shape
+    if n == m:
+        from scipy.optimize import linear_sum_assignment
+        r, c = linear_sum_assignment(M)
+        return float(M[r, c].sum() / n)
+    from scipy.optimize import linprog
+    A_eq = np.zeros((n + m, n * m))
+    for i in range(n):
+        A_eq[i, i * m:(i + 1) * m] = 1.0
+    for j in range(m):
+        A_eq[n + j, j::m] = 1.0
+    b_eq = np.concatenate([np.full(n, 1.0 / n), np.full(m, 1.0 / m)])
+    res = linprog(M.reshape(-1), A_eq=A_eq, b_eq=b_eq, bounds=(0, None), method="highs")
+    return float(res.fun)
+
+
 class ImageSim:
     higher_is_better = True
 
-    def __init__(self, model=None, processor=None, mode: Literal["cos", "cos_avg"] = "cos",
+    def __init__(self, model=None, processor=None, mode: Literal["cos", "cos_avg", "emd"] = "cos",
                  preprocess: bool = True, cache_reference: bool = False, **_):
-        if mode not in ("cos", "cos_avg"):
-            raise NotImplementedError(f"mode {mode!r}: only the v1 'cos' / 'cos_avg' poolings are built")
+        if mode not in ("cos", "cos_avg", "emd"):
+            raise ValueError(f"unknown pooling mode {mode!r}")
         self.model, self.processor = model, processor
         self.mode, self.preprocess = mode, preprocess
         self.cache_reference = cache_reference
@@ -55,7 +88,9 @@ class ImageSim:
             out = self.model(**enc)
             if self.mode == "cos":
                 return out.pooler_output.squeeze()
-            return out.last_hidden_state.squeeze().mean(dim=0)
+            if self.mode == "cos_avg":
+                return out.last_hidden_state.squeeze().mean(dim=0)
+            return out.last_hidden_state.squeeze()
 
     def _reference_features(self, image) -> torch.Tensor:
         if not self.cache_reference or not isinstance(image, Image.Image):
@@ -68,6 +103,8 @@ class ImageSim:
     def get_similarity(self, img1=None, img2=None, **_) -> float:
         f1 = self.get_vision_features(img1)
         f2 = self._reference_features(img2)
+        if f1.ndim > 1:   # patch features: earth mover's distance over pairwise cosine distances (:118-123)
+            return 2.0 * math.tanh(-emd2_uniform(pairwise_cosine_distance(f1.double(), f2.double()))) + 1.0
         return F.cosine_similarity(f1.double(), f2.double(), dim=0).item()
 
     # ---- metric protocol (update / compute / reset) ---------------------------------------------

@@ -22,6 +22,9 @@ from .tokenizer import SyntheticTokenizer, load_tokenizer
 
 # names the reference resolves to its v1 loader (detikzify/model/v1/__init__.py:10-15)
 v1_models = ["nllg/detikzify-ds-1.3b", "nllg/detikzify-ds-7b", "nllg/detikzify-tl-1.1b", "nllg/detikzify-cl-7b"]
+# the current upstream default family (README.md:21-30): HF SigLIP-420 + LLaMA-3.1-8B (GQA), loaded through the
+# same entry point (detikzify/model/__init__.py:44-61)
+v2_models = ["nllg/detikzify-v2-8b", "nllg/detikzify-v2.5-8b"]
 
 
 def _default_device() -> int:
@@ -43,12 +46,14 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         try:
             tokenizer = load_tokenizer(str(path), cfg.max_positions)
-            cfg.patch_token_id = tokenizer.bos_token_id          # v1/__init__.py:49
+            if cfg.arch == "v1":
+                cfg.patch_token_id = tokenizer.bos_token_id      # v1/__init__.py:49
         except Exception as e:   # checkpoint directory without tokenizer files (synthetic fixtures)
             import warnings
             warnings.warn(f"no usable tokenizer under {path} ({e!r}); using SyntheticTokenizer")
             tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
-                                           pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions)
+                                           pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions,
+                                           image_token_id=cfg.patch_token_id)
         model = DetikzifyForCausalLM(cfg, dev)
         _load_safetensors_dir(model, path)
         if modality_projector:
@@ -63,7 +68,8 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
                 f"{model_name_or_path!r} is not a local checkpoint directory and there is no network; "
                 "pass synthetic=<seed> for seeded synthetic weights at this preset's shapes")
         tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
-                                       pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions)
+                                       pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions,
+                                           image_token_id=cfg.patch_token_id)
         model = DetikzifyForCausalLM(cfg, dev)
         model.fill_synthetic(int(synthetic))
     model.generation_config.pad_token_id = tokenizer.pad_token_id     # v1/__init__.py:41
@@ -80,8 +86,10 @@ def _load_safetensors_dir(model: DetikzifyForCausalLM, path: Path):
     inside the same files under "vision_model." / "model.vision_model.model.0." or as
     vision_tower.safetensors with bare timm names."""
     from safetensors import safe_open
+    from .convert import V2Converter, is_v2_key
     known = set(model.tensor_names())
     seen = set()
+    conv = V2Converter()
     files = sorted(path.glob("*.safetensors"))
     if not files:
         raise FileNotFoundError(f"no *.safetensors under {path}")
@@ -89,16 +97,24 @@ def _load_safetensors_dir(model: DetikzifyForCausalLM, path: Path):
         bare_timm = f.name == "vision_tower.safetensors"
         with safe_open(str(f), framework="pt") as sf:
             for k in sf.keys():
-                name = k
-                if bare_timm:
-                    name = "vision_model." + k
-                for pre in ("model.vision_model.model.0.", "model.vision_model."):
-                    if k.startswith(pre):
-                        name = "vision_model." + k[len(pre):]
-                if name in known:
-                    model.load_tensor(name, sf.get_tensor(k))
-                    seen.add(name)
-    missing = [k for k in known if k not in seen and not k.startswith("rope.")]
+                if not bare_timm and (is_v2_key(k) or (model.config.arch == "v2" and k == "lm_head.weight")):
+                    pairs = conv.feed(k, sf.get_tensor(k))         # v2 checkpoint names (model/convert.py)
+                else:
+                    name = k
+                    if bare_timm:
+                        name = "vision_model." + k
+                    for pre in ("model.vision_model.model.0.", "model.vision_model."):
+                        if k.startswith(pre):
+                            name = "vision_model." + k[len(pre):]
+                    pairs = [(name, None)]
+                for name, t in pairs:
+                    if name in known:
+                        model.load_tensor(name, sf.get_tensor(k) if t is None else t)
+                        seen.add(name)
+    conv.finish()
+    # a v2 checkpoint may ship without the (unused: SelfSim is "emd" there) SigLIP pooling head
+    optional = "vision_model.attn_pool." if model.config.arch == "v2" else "\0"
+    missing = [k for k in known if k not in seen and not k.startswith("rope.") and not k.startswith(optional)]
     if missing:
         raise KeyError(f"checkpoint {path} lacks {len(missing)} tensors, e.g. {missing[:4]}")
     model._install_rope_tables()
@@ -114,4 +130,4 @@ def _load_projector(model: DetikzifyForCausalLM, filename: str):
 
 __all__ = ["load", "DetikzifyConfig", "DetikzifyForCausalLM", "DetikzifyVisionModel", "DetikzifyProcessor",
            "DetikzifyImageProcessor", "BatchFeature", "SyntheticTokenizer", "GenerationConfig", "PRESETS",
-           "preset", "v1_models"]
+           "preset", "v1_models", "v2_models"]

@@ -14,6 +14,7 @@ There is no CPU fallback: constructing the model without the HIP library or a GP
 from __future__ import annotations
 
 import contextlib
+import math
 import ctypes as C
 import hashlib
 from types import SimpleNamespace
@@ -82,6 +83,8 @@ class DetikzifyForCausalLM:
         cc = _lib.DtkConfig(**kd)
         cc.reserved[0] = int(getattr(config, "batch_slots", 0) or 0)
         cc.reserved[1] = 1 if getattr(config, "weight_format", "bf16") == "fp8" else 0
+        cc.reserved[2] = int(getattr(config, "kv_heads", 0) or 0)                       # GQA (v2)
+        cc.reserved[3] = 0 if getattr(config, "proj_bias", True) else _lib.DTK_ARCH_PROJ_NO_BIAS
         ctx = C.c_void_p()
         rc = self.lib.dtk_create(C.byref(cc), self.hip_device, C.byref(ctx))
         if rc != 0:
@@ -173,10 +176,19 @@ class DetikzifyForCausalLM:
 
     def _install_rope_tables(self):
         """cos/sin exactly as HF LlamaRotaryEmbedding computes them (modeling_llama.py:108-140):
-        fp32 inv_freq (linear scaling: / factor), fp32 pos*inv_freq, cos/sin cast to bf16."""
+        fp32 inv_freq (linear scaling: / factor; "llama3": modeling_rope_utils._compute_llama3_parameters),
+        fp32 pos*inv_freq, cos/sin cast to bf16."""
         c = self.config
         inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.int64).float() / c.head_dim))
-        if c.rope_factor and c.rope_factor != 1.0:
+        if getattr(c, "rope_type", "linear") == "llama3":
+            low_wl = c.rope_original_max_position / c.rope_low_freq_factor
+            high_wl = c.rope_original_max_position / c.rope_high_freq_factor
+            wavelen = 2 * math.pi / inv
+            scaled = torch.where(wavelen > low_wl, inv / c.rope_factor, inv)
+            smooth = (c.rope_original_max_position / wavelen - c.rope_low_freq_factor) / (c.rope_high_freq_factor - c.rope_low_freq_factor)
+            mid = (1 - smooth) * scaled / c.rope_factor + smooth * scaled
+            inv = torch.where((wavelen <= low_wl) & (wavelen >= high_wl), mid, scaled)
+        elif c.rope_factor and c.rope_factor != 1.0:
             inv = inv / c.rope_factor
         freqs = torch.arange(c.max_positions, dtype=torch.float32)[:, None] * inv[None, :]
         self.load_tensor("rope.cos", freqs.cos().to(torch.bfloat16))

@@ -20,7 +20,7 @@ class SyntheticTokenizer:
              "rectangle ", "\\fill", "thick", "->", "\n", "%\n", "\\documentclass{standalone}\n"]
 
     def __init__(self, vocab_size: int, bos_token_id: int = 1, eos_token_id: int = 2,
-                 pad_token_id: int = 0, model_max_length: int = 2048):
+                 pad_token_id: int = 0, model_max_length: int = 2048, image_token_id: int = None):
         self.vocab_size = vocab_size
         self.bos_token_id, self.eos_token_id, self.pad_token_id = bos_token_id, eos_token_id, pad_token_id
         self.bos_token, self.eos_token, self.pad_token = "<s>", "</s>", "<pad>"
@@ -28,6 +28,11 @@ class SyntheticTokenizer:
         self.padding_side = "right"
         self.init_kwargs: dict = {}
         special = {pad_token_id: self.pad_token, bos_token_id: self.bos_token, eos_token_id: self.eos_token}
+        # v2: a dedicated image token (reference processing_detikzify.py:52 "<|reserved_special_token_2|>"); v1 reuses BOS
+        self.image_token = "<|reserved_special_token_2|>"
+        self.image_token_id = image_token_id if image_token_id not in special else None
+        if self.image_token_id is not None:
+            special[self.image_token_id] = self.image_token
         self.all_special_ids = sorted(special)
         self._id2tok: List[str] = []
         free = [i for i in range(vocab_size) if i not in special]
@@ -80,6 +85,8 @@ class SyntheticTokenizer:
         i = 0
         specials = [(self.bos_token, self.bos_token_id), (self.eos_token, self.eos_token_id),
                     (self.pad_token, self.pad_token_id)]
+        if self.image_token_id is not None:
+            specials.append((self.image_token, self.image_token_id))
         while i < len(text):
             for s, sid in specials:
                 if text.startswith(s, i):

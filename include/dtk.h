@@ -46,7 +46,7 @@ typedef struct dtk_config {
   /* LLaMA decoder */
   int32_t hidden;          /* d                                   */
   int32_t layers;          /* L                                   */
-  int32_t heads;           /* H (MHA: kv_heads == heads)          */
+  int32_t heads;           /* H query heads (kv heads: reserved[2]) */
   int32_t head_dim;        /* hd (must be 128)                    */
   int32_t ffn;             /* intermediate_size                   */
   int32_t vocab;           /* V                                   */
@@ -68,8 +68,13 @@ typedef struct dtk_config {
   int32_t concat_patches;  /* 3  (modeling_detikzify.py:101)       */
   int32_t image_token_id;  /* == BOS for v1 (v1/__init__.py:49)    */
   int32_t attn_splits;     /* split-K factor of decode attention; 0 = default */
-  int32_t reserved[7];     /* [0] = batch slots for dtk_decode_batch_* (0 = none)       */
+  int32_t reserved[7];     /* [0] = batch slots for dtk_decode_batch_* (0 = none)
+                            * [1] = 1: fp8 e4m3 decoder weights
+                            * [2] = key/value heads (GQA, num_key_value_heads); 0 = heads (MHA, all v1 models)
+                            * [3] = architecture flags, DTK_ARCH_*                        */
 } dtk_config;
+/* v2 connector (reference detikzify/model/modeling_detikzify.py:62-70): Linear(concat*D -> d, bias=False) */
+#define DTK_ARCH_PROJ_NO_BIAS 1
 
 /* Per-generation sampling state: the HF logits processors + sampler that
  * DetikzifyGenerator.generate configures (generate.py:218-227; HF

@@ -38,6 +38,28 @@ def rope_tables(head_dim: int, theta: float, factor: float, max_pos: int, precis
     return rb(freqs.cos(), precision), rb(freqs.sin(), precision)
 
 
+def llama3_inv_freq(head_dim: int, theta: float, factor: float = 8.0, low_freq_factor: float = 1.0,
+                    high_freq_factor: float = 4.0, original_max_position: int = 8192) -> torch.Tensor:
+    """rope_type "llama3" (LLaMA-3.1, the v2 text model): transformers/modeling_rope_utils.py
+    _compute_llama3_parameters — wavelengths above original/low_freq_factor are divided by `factor`,
+    those below original/high_freq_factor are kept, the band in between is interpolated."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    low_freq_wavelen = original_max_position / low_freq_factor
+    high_freq_wavelen = original_max_position / high_freq_factor
+    wavelen = 2 * math.pi / inv_freq
+    inv_llama = torch.where(wavelen > low_freq_wavelen, inv_freq / factor, inv_freq)
+    smooth = (original_max_position / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor)
+    smoothed = (1 - smooth) * inv_llama / factor + smooth * inv_llama
+    is_medium = ~(wavelen < high_freq_wavelen) * ~(wavelen > low_freq_wavelen)
+    return torch.where(is_medium, smoothed, inv_llama)
+
+
+def rope_tables_from_inv_freq(inv_freq: torch.Tensor, max_pos: int, precision="bf16"):
+    pos = torch.arange(max_pos, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :].float()
+    return rb(freqs.cos(), precision), rb(freqs.sin(), precision)
+
+
 def apply_rope(x, cos, sin, precision="bf16"):
     """x [H, T, hd]; cos/sin [T, hd/2].  q*cos + rotate_half(q)*sin, each product a bf16 tensor."""
     h = x.shape[-1] // 2
@@ -48,7 +70,11 @@ def apply_rope(x, cos, sin, precision="bf16"):
 
 
 def attention(q, k, v, scale, causal_offset: Optional[int] = None, precision="bf16"):
-    """q [H,Tq,hd], k/v [H,Tk,hd].  causal_offset = absolute position of query 0 (None = full)."""
+    """q [H,Tq,hd], k/v [H,Tk,hd] (or [KVH,Tk,hd] with H % KVH == 0: GQA, HF repeat_kv).
+    causal_offset = absolute position of query 0 (None = full)."""
+    if k.shape[0] != q.shape[0]:
+        rep = q.shape[0] // k.shape[0]
+        k, v = k.repeat_interleave(rep, dim=0), v.repeat_interleave(rep, dim=0)
     s = (q @ k.transpose(-1, -2)) * scale
     if causal_offset is not None:
         Tq, Tk = q.shape[1], k.shape[1]
@@ -66,9 +92,15 @@ class LlamaOracle:
         self.cfg, self.w, self.precision = cfg, weights, precision
         self.d, self.L, self.H = cfg["hidden"], cfg["layers"], cfg["heads"]
         self.hd = cfg["head_dim"]
+        self.KVH = cfg.get("kv_heads") or self.H
         self.scale = 1.0 / math.sqrt(self.hd)
         if "rope.cos" in weights:
             self.cos, self.sin = weights["rope.cos"], weights["rope.sin"]
+        elif cfg.get("rope_type") == "llama3":
+            self.cos, self.sin = rope_tables_from_inv_freq(
+                llama3_inv_freq(self.hd, cfg["rope_theta"], cfg.get("rope_factor", 8.0), cfg.get("rope_low_freq_factor", 1.0),
+                                cfg.get("rope_high_freq_factor", 4.0), cfg.get("rope_original_max_position", 8192)),
+                cfg["max_positions"], precision)
         else:
             self.cos, self.sin = rope_tables(self.hd, cfg["rope_theta"], cfg["rope_factor"],
                                              cfg["max_positions"], precision)
@@ -101,8 +133,8 @@ class LlamaOracle:
             k = linear(h, self.w[p + "self_attn.k_proj.weight"], None, P)
             v = linear(h, self.w[p + "self_attn.v_proj.weight"], None, P)
             q = q.view(T, self.H, self.hd).transpose(0, 1)
-            k = k.view(T, self.H, self.hd).transpose(0, 1)
-            v = v.view(T, self.H, self.hd).transpose(0, 1)
+            k = k.view(T, self.KVH, self.hd).transpose(0, 1)
+            v = v.view(T, self.KVH, self.hd).transpose(0, 1)
             q, k = apply_rope(q, cos, sin, P), apply_rope(k, cos, sin, P)
             self.k[i] = k if self.k[i] is None else torch.cat([self.k[i], k], dim=1)
             self.v[i] = v if self.v[i] is None else torch.cat([self.v[i], v], dim=1)

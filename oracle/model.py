@@ -1,5 +1,7 @@
 """
-DeTikZify v1 model glue restated on CPU (test infrastructure, see oracle/__init__.py).
+DeTikZify model glue restated on CPU (test infrastructure, see oracle/__init__.py).  Written against v1; the
+v2 model (detikzify/model/modeling_detikzify.py:119-271) differs only in configuration here: GQA + rope "llama3"
+in the decoder (oracle/llama.py), bias-free connector, HF SigLIP naming of the same ViT, a dedicated image token.
 
 reference detikzify/model/v1/modeling_detikzify.py:
   get_vision_features   :132-137   feats[:, -n*c:].reshape(-1, n, D*c)  (3 consecutive patches)
@@ -38,8 +40,9 @@ class DetikzifyOracle:
         return feats[-n * c:].reshape(n, feats.shape[-1] * c)
 
     def image_embeds(self, pixels: torch.Tensor) -> torch.Tensor:
+        # v1: nn.Linear(3D, d) with bias; v2 connector (modeling_detikzify.py:62-86): reshape(seq // 3, 3D) + bias-free Linear
         return linear(self.vision_features(pixels), self.w["model.mm_projector.weight"],
-                      self.w["model.mm_projector.bias"], self.P)
+                      self.w.get("model.mm_projector.bias"), self.P)
 
     # -- decoder -----------------------------------------------------------------------------
     def input_embeds(self, ids: torch.Tensor, pixels: Optional[torch.Tensor]) -> torch.Tensor:

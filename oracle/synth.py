@@ -25,6 +25,7 @@ def tensor_specs(cfg: dict) -> List[Tuple[str, Tuple[int, ...], float, float]]:
     D, depth, mlp, p = cfg["vit_dim"], cfg["vit_depth"], cfg["vit_mlp"], cfg["vit_patch"]
     N = (cfg["vit_image"] // p) ** 2
     cc = cfg["concat_patches"]
+    kvd = (cfg.get("kv_heads") or cfg["heads"]) * cfg["head_dim"]
     s: List[Tuple[str, Tuple[int, ...], float, float]] = []
     s.append(("model.embed_tokens.weight", (V, d), WS, 0.0))
     for i in range(L):
@@ -32,8 +33,8 @@ def tensor_specs(cfg: dict) -> List[Tuple[str, Tuple[int, ...], float, float]]:
         s += [
             (q + "input_layernorm.weight", (d,), NS, 1.0),
             (q + "self_attn.q_proj.weight", (d, d), WS, 0.0),
-            (q + "self_attn.k_proj.weight", (d, d), WS, 0.0),
-            (q + "self_attn.v_proj.weight", (d, d), WS, 0.0),
+            (q + "self_attn.k_proj.weight", (kvd, d), WS, 0.0),
+            (q + "self_attn.v_proj.weight", (kvd, d), WS, 0.0),
             (q + "self_attn.o_proj.weight", (d, d), WS, 0.0),
             (q + "post_attention_layernorm.weight", (d,), NS, 1.0),
             (q + "mlp.gate_proj.weight", (ff, d), WS, 0.0),
@@ -44,7 +45,10 @@ def tensor_specs(cfg: dict) -> List[Tuple[str, Tuple[int, ...], float, float]]:
         ("model.norm.weight", (d,), NS, 1.0),
         ("lm_head.weight", (V, d), WS, 0.0),
         ("model.mm_projector.weight", (d, cc * D), WS, 0.0),
-        ("model.mm_projector.bias", (d,), BS, 0.0),
+    ]
+    if cfg.get("proj_bias", True):   # the v2 connector is bias-free: the tensor does not exist (nor its tag)
+        s.append(("model.mm_projector.bias", (d,), BS, 0.0))
+    s += [
         ("rope.cos", (T, 64), 0.0, 0.0),   # not synthesised (computed), keeps the index aligned
         ("rope.sin", (T, 64), 0.0, 0.0),
     ]

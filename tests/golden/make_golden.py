@@ -39,7 +39,7 @@ OUT = Path(__file__).resolve().parent
 REF = Path("/root/reference")
 
 from oracle.synth import make_weights  # noqa: E402
-from tests.helpers import TINY_CFG, FakeModel, fake_processor, sketch_image  # noqa: E402
+from tests.helpers import TINY_CFG, TINY_V2_CFG, FakeModel, fake_processor, sketch_image  # noqa: E402
 
 
 # ------------------------------------------------------------------------------------- A: Llama
@@ -74,6 +74,42 @@ def golden_llama():
             out[f"logits_ids_{tag}"] = model(input_ids=ids).logits[0, -1].float().numpy()
     np.savez_compressed(OUT / "llama_tiny.npz", **out)
     print("llama_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+def golden_llama_gqa():
+    """the v2 decoder differences: GQA (4 query / 2 kv heads) and rope_type "llama3" (HF LlamaForCausalLM)"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = TINY_V2_CFG
+    w = make_weights(cfg, 4321)
+    hf_cfg = LlamaConfig(
+        hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"], num_hidden_layers=cfg["layers"],
+        num_attention_heads=cfg["heads"], num_key_value_heads=cfg["kv_heads"], head_dim=cfg["head_dim"],
+        vocab_size=cfg["vocab"], rms_norm_eps=cfg["rms_eps"], max_position_embeddings=cfg["max_positions"],
+        rope_theta=cfg["rope_theta"],
+        rope_scaling={"rope_type": "llama3", "factor": cfg["rope_factor"], "low_freq_factor": cfg["rope_low_freq_factor"],
+                      "high_freq_factor": cfg["rope_high_freq_factor"],
+                      "original_max_position_embeddings": cfg["rope_original_max_position"]},
+        attention_bias=False, tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    T = 90      # beyond original_max_position (64): every llama3 frequency band is exercised
+    embeds = (torch.randn(T, cfg["hidden"], generator=g) * 0.5).to(torch.bfloat16).float()
+    ids = torch.randint(6, cfg["vocab"], (1, 12), generator=g)
+    out["embeds"], out["ids"] = embeds.numpy(), ids.numpy()
+    for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        model = LlamaForCausalLM(hf_cfg).eval()
+        model.load_state_dict({k: w[k] for k in model.state_dict().keys()})
+        model = model.to(dtype)
+        with torch.no_grad():
+            out[f"logits_embeds_{tag}"] = model(inputs_embeds=embeds[None].to(dtype)).logits[0].float().numpy()
+            gen = model.generate(input_ids=ids, do_sample=False, max_new_tokens=24, bad_words_ids=[[5]],
+                                 begin_suppress_tokens=[2], pad_token_id=0)
+            out[f"greedy_{tag}"] = gen[0, ids.shape[1]:].numpy()
+            out[f"logits_ids_{tag}"] = model(input_ids=ids).logits[0, -1].float().numpy()
+        if tag == "fp32":
+            out["inv_freq"] = model.model.rotary_emb.inv_freq.float().numpy()
+    np.savez_compressed(OUT / "llama_tiny_gqa.npz", **out)
+    print("llama_tiny_gqa.npz", {k: v.shape for k, v in out.items()})
 
 
 # ------------------------------------------------------------------------------------- B: SigLIP
@@ -312,6 +348,7 @@ def golden_generator():
 
 if __name__ == "__main__":
     golden_llama()
+    golden_llama_gqa()
     golden_siglip()
     golden_processors()
     golden_mcts()

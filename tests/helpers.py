@@ -15,6 +15,8 @@ from detikzify_amd.model.tokenizer import SyntheticTokenizer
 
 TINY = preset("detikzify-tiny")
 TINY_CFG = TINY.kernel_dict()
+TINY_V2 = preset("detikzify-tiny-v2")          # GQA 4/2, rope "llama3", bias-free connector, tanh GELU, dedicated image token
+TINY_V2_CFG = TINY_V2.oracle_dict()
 
 
 def sketch_image(seed: int = 0, size: int = 224) -> Image.Image:

@@ -24,7 +24,7 @@ from oracle.ops import bits_to_f32, f32_to_bits, linear, rb
 from oracle.synth import synth_bits, tensor_specs
 from oracle.vit import layernorm
 from oracle.llama import attention, rmsnorm
-from tests.helpers import TINY, TINY_CFG, rel_l2, sketch_image
+from tests.helpers import TINY, TINY_CFG, TINY_V2, TINY_V2_CFG, rel_l2, sketch_image
 
 
 @pytest.fixture(scope="module")
@@ -747,3 +747,161 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
     (tmp_path / "vision_tower.safetensors").unlink()
     with pytest.raises(KeyError), pytest.warns(UserWarning):
         load(str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------ v2 models (f2)
+# GQA decoder + rope "llama3" + bias-free connector + tanh-GELU SigLIP + dedicated image token, at toy size.
+@pytest.fixture(scope="module")
+def tiny_v2():
+    from detikzify_amd.model import load
+    model, proc = load("detikzify-tiny-v2", synthetic=4321, batch_slots=5)
+    return model, proc
+
+
+@pytest.fixture(scope="module")
+def tiny_v2_oracle(tiny_v2):
+    model, _ = tiny_v2
+    return DetikzifyOracle(TINY_V2_CFG, weights_from_device(model, TINY_V2_CFG), precision="bf16")
+
+
+def test_v2_weights_and_rope_tables(tiny_v2):
+    model, _ = tiny_v2
+    names = set(model.tensor_names())
+    assert "model.mm_projector.bias" not in names
+    for tag, (name, shape, scale, offset) in enumerate(tensor_specs(TINY_V2_CFG)):
+        if name.startswith("rope."):
+            continue
+        got = f32_to_bits(model.read_tensor(name).float())
+        assert np.array_equal(got, synth_bits(4321, tag, int(np.prod(shape)), scale, offset)), name
+    from oracle.llama import llama3_inv_freq, rope_tables_from_inv_freq
+    c = TINY_V2_CFG
+    cos, sin = rope_tables_from_inv_freq(llama3_inv_freq(128, c["rope_theta"], c["rope_factor"], c["rope_low_freq_factor"],
+                                                         c["rope_high_freq_factor"], c["rope_original_max_position"]), c["max_positions"])
+    assert torch.equal(model.read_tensor("rope.cos").float().view(-1, 64), cos)
+    assert torch.equal(model.read_tensor("rope.sin").float().view(-1, 64), sin)
+
+
+def test_v2_prefill_logits_and_greedy(tiny_v2, tiny_v2_oracle):
+    model, proc = tiny_v2
+    enc = proc(images=sketch_image(1, 96), return_tensors="pt")
+    assert enc.input_ids.shape[1] == 12 and int(enc.input_ids[0, 0]) == TINY_V2.image_token_id
+    ids = torch.cat([enc.input_ids[0], torch.tensor([70, 300, 41, 7, 600, 9])])
+    lo = model.prefill(ids, enc.pixel_values, return_logits=True)
+    ref = tiny_v2_oracle.prefill(ids, enc.pixel_values[0])
+    truth = DetikzifyOracle(TINY_V2_CFG, tiny_v2_oracle.w, precision="fp32").prefill(ids, enc.pixel_values[0])
+    r, e_dev, e_orc = rel_l2(lo, ref), rel_l2(lo, truth), rel_l2(ref, truth)
+    print(f"v2 prefill logits rel_l2 {r:.2e}; vs fp32 oracle: device {e_dev:.2e}, bf16 oracle {e_orc:.2e}")
+    assert r < 1e-2 and e_dev < 1.5 * e_orc + 2e-3
+    # greedy decode with teacher forcing (same near-tie rule as the v1 test), 100 tokens: positions cross
+    # rope_original_max_position (64) so every llama3 band is used by the decode-step RoPE epilogue
+    ids, px = enc.input_ids[0], enc.pixel_values
+    n = 100
+    bad = [TINY_V2.image_token_id]
+    model.set_graph_mode(1)
+    out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=n,
+                         bad_words_ids=[bad], begin_suppress_tokens=[2], eos_token_id=-1)
+    toks = out[0, ids.numel():].tolist()
+    logits = tiny_v2_oracle.prefill(ids, px[0])
+    flips, worst = 0, 0.0
+    for i, t in enumerate(toks):
+        ref_t = sampling.greedy(logits, bad, [2], i == 0)
+        if ref_t != t:
+            top2 = torch.topk(sampling.mask_scores(logits, bad, [2], i == 0), 2)[0]
+            gap, ulp = float(top2[0] - top2[1]), float(top2[0].abs()) * 2.0 ** -7
+            assert gap <= 2 * ulp + 1e-6, f"step {i}: token {t} vs {ref_t} with decisive gap {gap} (ulp {ulp})"
+            flips += 1
+        logits = tiny_v2_oracle.step(t)
+    print(f"v2 greedy: {flips} near-tie flips in {n} tokens")
+    assert flips <= 6
+    # graph replay == plain launches, incremental logits track the oracle
+    model.set_graph_mode(0)
+    out0 = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=n,
+                          bad_words_ids=[bad], begin_suppress_tokens=[2], eos_token_id=-1)
+    model.set_graph_mode(1)
+    assert out0[0].tolist() == out[0].tolist()
+
+
+def test_v2_batched_decode_and_fork_are_bit_identical_to_alone(tiny_v2):
+    """GQA through the MFMA batched path: 4 slots decoded together == each decoded alone; a forked slot == a prefilled one"""
+    model, proc = tiny_v2
+    encs = [proc(images=sketch_image(10 + i, 96), return_tensors="pt") for i in range(3)]
+    prompts = [torch.cat([e.input_ids[0], torch.tensor([20 + i, 33, 7 * i + 8])]) for i, e in enumerate(encs)]
+    bad = [TINY_V2.image_token_id]
+    n = 30
+
+    def alone(slot, ids, px):
+        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=100 + slot, bad_ids=bad, begin_suppress_ids=[2], slot=slot)
+        model.prefill(ids, px, slot=slot)
+        toks = []
+        for _ in range(n):
+            model.decode_batch_launch([slot])
+            toks.append(model.decode_batch_wait()[slot])
+        return toks
+
+    ref = [alone(i, prompts[i], encs[i].pixel_values) for i in range(3)]
+    for i in range(3):
+        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=100 + i, bad_ids=bad, begin_suppress_ids=[2], slot=i)
+        model.prefill(prompts[i], encs[i].pixel_values, slot=i)
+    model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=100, bad_ids=bad, begin_suppress_ids=[2], slot=3)
+    model.kv_fork(0, 3, prompts[0].numel())          # slot 3 = a second rollout from slot 0's prompt (same seed -> same tokens)
+    got = [[] for _ in range(4)]
+    for _ in range(n):
+        model.decode_batch_launch([0, 1, 2, 3])
+        t = model.decode_batch_wait()
+        for sl in range(4):
+            got[sl].append(t[sl])
+    assert got[:3] == ref
+    assert got[3] == ref[0]
+
+
+def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
+    """synthetic weights written under the v2 checkpoint names (HF SigLIP / text_model / connector) + composite
+    config.json -> load() -> same weights, same greedy tokens; SelfSim falls back to "emd" for a v2 config"""
+    import json
+    from safetensors.torch import save_file
+    from detikzify_amd.evaluate.imagesim import ImageSim
+    from detikzify_amd.model import load
+    from detikzify_amd.model.convert import registry_to_v2
+    from oracle.synth import make_weights
+    ref, rproc = tiny_v2
+    c = TINY_V2
+    w = {k: v.to(torch.bfloat16) for k, v in make_weights(TINY_V2_CFG, 4321).items()}
+    sd, inproj = {}, {}
+    for name, t in w.items():
+        for k, piece in registry_to_v2(name, t, c.vit_dim):
+            (inproj if k.startswith("__inproj__") else sd)[k] = piece.contiguous()
+    for kind in ("weight", "bias"):
+        sd[f"model.vision_model.vision_model.head.attention.in_proj_{kind}"] = torch.cat(
+            [inproj[f"__inproj__.q.{kind}"], inproj[f"__inproj__.kv.{kind}"]], 0).contiguous()
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[::2]}, str(tmp_path / "model-00001-of-00002.safetensors"))    # q/k/v split across shards
+    save_file({k: sd[k] for k in keys[1::2]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    cfgj = {"model_type": "detikzify", "image_token_id": c.image_token_id, "concat_factor": 3, "pad_token_id": 0,
+            "model_max_length": c.max_positions, "attn_splits": c.attn_splits,
+            "text_config": {"hidden_size": c.hidden, "num_hidden_layers": c.layers, "num_attention_heads": c.heads,
+                            "num_key_value_heads": c.kv_heads, "intermediate_size": c.ffn, "vocab_size": c.vocab,
+                            "rms_norm_eps": c.rms_eps, "rope_theta": c.rope_theta, "bos_token_id": 1, "eos_token_id": 2,
+                            "rope_scaling": {"rope_type": "llama3", "factor": c.rope_factor, "low_freq_factor": 1.0,
+                                             "high_freq_factor": 4.0, "original_max_position_embeddings": c.rope_original_max_position}},
+            "vision_config": {"hidden_size": c.vit_dim, "intermediate_size": c.vit_mlp, "num_hidden_layers": c.vit_depth,
+                              "num_attention_heads": c.vit_heads, "image_size": c.vit_image, "patch_size": c.vit_patch,
+                              "hidden_act": "gelu_pytorch_tanh"}}
+    (tmp_path / "config.json").write_text(json.dumps(cfgj))
+    with pytest.warns(UserWarning):
+        model, proc = load(str(tmp_path))
+    assert model.config.arch == "v2" and model.config.num_kv_heads == 2 and not model.config.proj_bias
+    for name in ("model.layers.1.self_attn.v_proj.weight", "vision_model.blocks.1.attn.qkv.weight", "vision_model.attn_pool.kv.bias",
+                 "vision_model.pos_embed", "model.mm_projector.weight", "lm_head.weight", "rope.cos"):
+        assert torch.equal(model.read_tensor(name), ref.read_tensor(name)), name
+    enc = proc(images=sketch_image(4, 96), return_tensors="pt")
+    kw = dict(do_sample=False, max_new_tokens=24, bad_words_ids=[[c.image_token_id]], begin_suppress_tokens=[2], eos_token_id=-1)
+    a = model.generate(input_ids=enc.input_ids, pixel_values=enc.pixel_values, **kw)
+    b = ref.generate(input_ids=enc.input_ids, pixel_values=enc.pixel_values, **kw)
+    assert a.tolist() == b.tolist()
+    # SelfSim: v2 config -> "emd" over patch features; identical images score 1, different ones less
+    sim = ImageSim.from_detikzify(model, proc)
+    assert sim.mode == "emd"
+    img, other = sketch_image(5, 96), sketch_image(6, 96)
+    s_same, s_diff = sim.get_similarity(img, img), sim.get_similarity(img, other)
+    print(f"emd SelfSim: same {s_same:.6f} different {s_diff:.6f}")
+    assert abs(s_same - 1.0) < 1e-9 and s_diff < s_same

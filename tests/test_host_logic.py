@@ -165,3 +165,91 @@ def test_model_requires_gpu_and_fails_loudly():
         load("detikzify-tiny", synthetic=1)
     with pytest.raises(FileNotFoundError):
         load("nllg/detikzify-ds-7b", device_map=0)
+
+
+# ------------------------------------------------------------------------------------------ v2 checkpoints (f2/f4)
+def test_v2_checkpoint_names_convert_to_the_registry():
+    """every key of a v2 state dict (HF SiglipVisionModel + LlamaModel + connector, as
+    DetikzifyForConditionalGeneration nests them, modeling_detikzify.py:119-135,274-285) lands on a registry
+    tensor of the right shape; the fused qkv / attn_pool splits invert exactly"""
+    import torch
+    from transformers import LlamaConfig, LlamaModel, SiglipVisionConfig, SiglipVisionModel
+    from detikzify_amd.model.convert import V2Converter, is_v2_key, registry_to_v2
+    from oracle.synth import make_weights, tensor_specs
+    from tests.helpers import TINY_V2_CFG as c
+    specs = {n: tuple(sh) for n, sh, _, _ in tensor_specs(c) if not n.startswith("rope.")}
+    assert "model.mm_projector.bias" not in specs                      # bias-free connector
+    assert specs["model.layers.0.self_attn.k_proj.weight"] == (c["kv_heads"] * 128, c["hidden"])
+    vis = SiglipVisionModel(SiglipVisionConfig(hidden_size=c["vit_dim"], intermediate_size=c["vit_mlp"],
+                                               num_hidden_layers=c["vit_depth"], num_attention_heads=c["vit_heads"],
+                                               image_size=c["vit_image"], patch_size=c["vit_patch"]))
+    txt = LlamaModel(LlamaConfig(hidden_size=c["hidden"], intermediate_size=c["ffn"], num_hidden_layers=c["layers"],
+                                 num_attention_heads=c["heads"], num_key_value_heads=c["kv_heads"], head_dim=128,
+                                 vocab_size=c["vocab"]))
+    sd = {"model.vision_model." + k: v for k, v in vis.state_dict().items()}
+    sd.update({"model.text_model." + k: v for k, v in txt.state_dict().items()})
+    sd["model.connector.modality_projection.proj.weight"] = torch.zeros(c["hidden"], 3 * c["vit_dim"])
+    sd["lm_head.weight"] = torch.zeros(c["vocab"], c["hidden"])
+    conv, got = V2Converter(), {}
+    for k, v in sd.items():
+        assert is_v2_key(k) or k == "lm_head.weight"
+        for name, t in conv.feed(k, v):
+            got[name] = t
+    conv.finish()
+    assert set(got) == set(specs), (sorted(set(specs) - set(got))[:5], sorted(set(got) - set(specs))[:5])
+    for n, t in got.items():
+        assert int(np.prod(t.shape)) == int(np.prod(specs[n])), n
+    # exact inverse on values: registry -> v2 names -> registry
+    w = make_weights(c, 7)
+    v2, inproj = {}, {}
+    for n, t in w.items():
+        for k, piece in registry_to_v2(n, t, c["vit_dim"]):
+            (inproj if k.startswith("__inproj__") else v2)[k] = piece
+    for kind in ("weight", "bias"):
+        v2[f"model.vision_model.vision_model.head.attention.in_proj_{kind}"] = torch.cat(
+            [inproj[f"__inproj__.q.{kind}"], inproj[f"__inproj__.kv.{kind}"]], 0)
+    conv, back = V2Converter(), {}
+    for k in sorted(v2, reverse=True):                                  # order must not matter
+        for name, t in conv.feed(k, v2[k]):
+            back[name] = t
+    conv.finish()
+    assert set(back) == set(w)
+    for n in w:
+        assert torch.equal(back[n].reshape(-1), w[n].reshape(-1)), n
+
+
+def test_v2_config_json_and_presets(tmp_path):
+    import json
+    from detikzify_amd.model.config import DetikzifyConfig, preset
+    c = preset("nllg/detikzify-v2-8b")
+    assert (c.num_kv_heads, c.num_patches, c.vocab, c.proj_bias, c.pooling_mode, c.image_token_id) == (8, 300, 128256, False, "emd", 128005)
+    j = {"model_type": "detikzify", "image_token_id": 128005, "concat_factor": 3, "pad_token_id": 128004,
+         "text_config": {"hidden_size": 4096, "num_hidden_layers": 32, "num_attention_heads": 32, "num_key_value_heads": 8,
+                         "intermediate_size": 14336, "vocab_size": 128256, "rms_norm_eps": 1e-5, "rope_theta": 500000.0,
+                         "rope_scaling": {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                          "original_max_position_embeddings": 8192},
+                         "bos_token_id": 128000, "eos_token_id": [128001, 128008]},
+         "vision_config": {"hidden_size": 1152, "intermediate_size": 4304, "num_hidden_layers": 27, "num_attention_heads": 16,
+                           "image_size": 420, "patch_size": 14, "hidden_act": "gelu_pytorch_tanh"}}
+    (tmp_path / "config.json").write_text(json.dumps(j))
+    r = DetikzifyConfig.from_hf_json(str(tmp_path / "config.json"))
+    for f in ("hidden", "layers", "heads", "kv_heads", "ffn", "vocab", "rope_type", "rope_factor", "rope_theta", "vit_image",
+              "vit_gelu_tanh", "vit_feature_layer", "proj_bias", "arch", "patch_token_id", "pad_token_id", "eos_token_id"):
+        assert getattr(r, f) == getattr(c, f), f
+    assert preset("detikzify-ds-7b").num_kv_heads == 32 and preset("detikzify-ds-7b").pooling_mode == "cos"
+
+
+def test_emd_selfsim_matches_the_transport_lp():
+    from scipy.optimize import linprog
+    from detikzify_amd.evaluate.imagesim import emd2_uniform, pairwise_cosine_distance
+    import torch
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(9, 16, generator=g).double(), torch.randn(9, 16, generator=g).double()
+    M = pairwise_cosine_distance(a, b)
+    n = 9
+    A = np.zeros((2 * n, n * n))
+    for i in range(n):
+        A[i, i * n:(i + 1) * n] = 1; A[n + i, i::n] = 1
+    lp = linprog(M.reshape(-1), A_eq=A, b_eq=np.full(2 * n, 1 / n), bounds=(0, None), method="highs").fun
+    assert abs(emd2_uniform(M) - lp) < 1e-9
+    assert abs(emd2_uniform(pairwise_cosine_distance(a, a))) < 1e-12       # identical patch sets: distance 0 -> score 1

@@ -8,7 +8,7 @@ from oracle.llama import LlamaOracle
 from oracle.model import DetikzifyOracle
 from oracle.synth import make_weights
 from oracle.vit import VitOracle
-from tests.helpers import TINY_CFG, rel_l2
+from tests.helpers import TINY_CFG, TINY_V2_CFG, rel_l2
 
 
 def test_llama_fp32_matches_hf(golden_dir):
@@ -41,6 +41,29 @@ def test_greedy_tokens_match_hf_generate(golden_dir):
     w = make_weights(TINY_CFG, 1234)
     o = DetikzifyOracle(TINY_CFG, w, precision="fp32")
     toks = o.generate(torch.from_numpy(g["ids"][0]), None, 24, bad=[1], begin=[2], eos=2)
+    ref = g["greedy_fp32"].tolist()
+    assert toks == ref[: len(toks)] and len(toks) >= min(24, len(ref))
+
+
+def test_llama_gqa_llama3_rope_matches_hf(golden_dir):
+    """the v2 decoder: GQA 4/2 + rope_type "llama3" vs HF LlamaForCausalLM, 90 positions with
+    original_max_position 64 so every frequency band of the llama3 scaling is exercised"""
+    from oracle.llama import llama3_inv_freq
+    g = np.load(golden_dir / "llama_tiny_gqa.npz")
+    c = TINY_V2_CFG
+    inv = llama3_inv_freq(c["head_dim"], c["rope_theta"], c["rope_factor"], c["rope_low_freq_factor"],
+                          c["rope_high_freq_factor"], c["rope_original_max_position"])
+    assert np.allclose(inv.numpy(), g["inv_freq"], rtol=1e-6, atol=0)
+    assert len({float(x) for x in (inv * (c["rope_theta"] ** (torch.arange(0, 128, 2).float() / 128)))}) > 3   # bands differ
+    w = make_weights(c, 4321)
+    llm = LlamaOracle(c, w, precision="fp32")
+    logits = llm.logits(llm.forward(torch.from_numpy(g["embeds"])))
+    assert rel_l2(logits, g["logits_embeds_fp32"]) < 2e-5
+    llm16 = LlamaOracle(c, w, precision="bf16")
+    l16 = llm16.logits(llm16.forward(torch.from_numpy(g["embeds"])))
+    assert rel_l2(l16, g["logits_embeds_bf16"]) < 2e-2 and rel_l2(l16, g["logits_embeds_fp32"]) < 2e-2
+    o = DetikzifyOracle(c, w, precision="fp32")
+    toks = o.generate(torch.from_numpy(g["ids"][0]), None, 24, bad=[5], begin=[2], eos=2)
     ref = g["greedy_fp32"].tolist()
     assert toks == ref[: len(toks)] and len(toks) >= min(24, len(ref))
 
