@@ -48,6 +48,7 @@ struct LayerW {
   bf16_t *t_wqkv = nullptr, *t_wo = nullptr, *t_wgu = nullptr, *t_wdown = nullptr;  // fragment-major copies (batched decode)
   uint8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;  // fp8 e4m3 copies (weight_format 1)
   float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;    // per-row power-of-two scales
+  uint8_t *t8_wqkv = nullptr, *t8_wo = nullptr, *t8_wgu = nullptr, *t8_wdown = nullptr;  // fp8 pair-tiled copies (batched decode, fp8)
 };
 struct VitBlockW {
   bf16_t *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
@@ -125,6 +126,7 @@ struct dtk_ctx {
   SamplingDev* sp_b = nullptr;       // [16]
   BatchState* bs_dev = nullptr;
   bf16_t* t_lm_head = nullptr;       // fragment-major copy of lm_head
+  uint8_t* t8_lm_head = nullptr;     // fp8 pair-tiled copy of lm_head (weight_format fp8)
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
   int64_t* tokb_dev = nullptr;       // [DTK_MAX_INFLIGHT][16]
@@ -391,14 +393,25 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->st_b = P.take<DecState>(17);
     c->sp_b = P.take<SamplingDev>(17);
     c->bs_dev = P.take<BatchState>(1);
-    for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
-      bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
-      bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
-      bf16_t* a3 = P.take<bf16_t>(tiled_elems(2 * ff, d));
-      bf16_t* a4 = P.take<bf16_t>(tiled_elems(d, ff));
-      if (reg) { c->layers[i].t_wqkv = a1; c->layers[i].t_wo = a2; c->layers[i].t_wgu = a3; c->layers[i].t_wdown = a4; }
+    if (c->wfmt == 1) {             // fp8: pair-tiled fp8 copies (+6.6 GB for cl-7b), no bf16 tiles
+      for (int i = 0; i < L; ++i) {
+        uint8_t* a1 = P.take<uint8_t>(tiled_bytes_f8(qkvn, d));
+        uint8_t* a2 = P.take<uint8_t>(tiled_bytes_f8(d, d));
+        uint8_t* a3 = P.take<uint8_t>(tiled_bytes_f8(2 * ff, d));
+        uint8_t* a4 = P.take<uint8_t>(tiled_bytes_f8(d, ff));
+        if (reg) { c->layers[i].t8_wqkv = a1; c->layers[i].t8_wo = a2; c->layers[i].t8_wgu = a3; c->layers[i].t8_wdown = a4; }
+      }
+      c->t8_lm_head = P.take<uint8_t>(tiled_bytes_f8(V, d));
+    } else {
+      for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
+        bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
+        bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
+        bf16_t* a3 = P.take<bf16_t>(tiled_elems(2 * ff, d));
+        bf16_t* a4 = P.take<bf16_t>(tiled_elems(d, ff));
+        if (reg) { c->layers[i].t_wqkv = a1; c->layers[i].t_wo = a2; c->layers[i].t_wgu = a3; c->layers[i].t_wdown = a4; }
+      }
+      c->t_lm_head = P.take<bf16_t>(tiled_elems(V, d));
     }
-    c->t_lm_head = P.take<bf16_t>(tiled_elems(V, d));
     c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * 16);
   }
   c->scratch_bytes = (size_t)64 << 20;
@@ -542,24 +555,24 @@ void batch_step_launches(dtk_ctx* c) {
     g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
     launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
-    g.W = w.t_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    g.W = w.t_wqkv; g.W8 = w.t8_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
-    g.W = w.t_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
+    g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
     launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
-    g.W = w.t_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
+    g.W = w.t_wgu; g.W8 = w.t8_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
     launch_gemv_b(EPI_SWIGLU, g, s);
-    g.W = w.t_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
+    g.W = w.t_wdown; g.W8 = w.t8_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
   }
   launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
   GemvBArgs g{};
-  g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
+  g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.W8 = c->t8_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
   g.d = d; g.ff = ff;
   launch_gemv_b(EPI_LOGITS, g, s);
 }
@@ -584,6 +597,19 @@ void ensure_fp8_weights(dtk_ctx* c) {
 void ensure_tiled_weights(dtk_ctx* c) {
   ensure_fp8_weights(c);
   if (c->tiled_ready || c->nb <= 0) return;
+  if (c->wfmt == 1) {
+    const int qkvn = c->d + 2 * c->KVH * 128;
+    for (int l = 0; l < c->L; ++l) {
+      LayerW& w = c->layers[l];
+      launch_retile_f8(w.q_wqkv, w.t8_wqkv, qkvn, c->d, c->stream);
+      launch_retile_f8(w.q_wo, w.t8_wo, c->d, c->d, c->stream);
+      launch_retile_f8(w.q_wgu, w.t8_wgu, 2 * c->ff, c->d, c->stream);
+      launch_retile_f8(w.q_wdown, w.t8_wdown, c->d, c->ff, c->stream);
+    }
+    launch_retile_f8(c->q_lm_head, c->t8_lm_head, c->V, c->d, c->stream);
+    c->tiled_ready = true;
+    return;
+  }
   for (int l = 0; l < c->L; ++l) {
     LayerW& w = c->layers[l];
     launch_retile(w.wqkv, w.t_wqkv, c->d + 2 * c->KVH * 128, c->d, c->stream);
@@ -1256,7 +1282,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
       for (int l = 0; l < c->L; ++l) {
         GemvBArgs g{};
         g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
-        g.W = c->layers[l].t_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
+        g.W = c->layers[l].t_wgu; g.W8 = c->layers[l].t8_wgu; g.wscale = c->layers[l].s_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
         launch_gemv_b_mode(variant, g, s);
       }
     };

@@ -87,11 +87,17 @@ struct GemvBArgs {
   const bf16_t* rope_cos; const bf16_t* rope_sin;
   int T_max; int d; int ff;
   int H; int KVH;                      // QKV: head counts (rows = [H | KVH | KVH] x 128)
+  const uint8_t* W8;                   // fp8 (e4m3) pair-tiled copy of the weights, or null; then wscale[N] = per-row 2^e scales
+  const float* wscale;
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
 static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 31) >> 5) * 512; }
+// fp8: a 1 KiB tile covers 16 rows x 64 k (two MFMA k-steps): lane l holds row l&15, bytes 0..7 = k0 + (l>>4)*8 + 0..7,
+// bytes 8..15 = the same columns of the next k-step (k0 + 32 + ...)
+void launch_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K, hipStream_t s);
+static inline size_t tiled_bytes_f8(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 63) >> 6) * 1024; }
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
                       const BatchState* bs, hipStream_t s);
 struct AttnDecBArgs {

@@ -13,6 +13,7 @@
 // (columns are independent), so the captured graph is identical for every active set.
 // Epilogues as in kernels_decode.hip (same HF rounding points), applied per active slot.
 #include "kernels.h"
+#include <stdlib.h>
 
 #define GB_WAVES 8
 #define GB_THREADS (GB_WAVES * 64)
@@ -28,26 +29,42 @@ __device__ __forceinline__ int gb_tile_row0(const GemvBArgs& a, int blk, int t) 
   return (blk * T + t) * 16;
 }
 
-template <int EPI, int T, int MODE = 0>
-__global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
-  __shared__ float red[GB_WAVES][T][256];
+// two e4m3 words (8 weights of one row) -> the bf16 A fragment of one k-step (exact)
+__device__ __forceinline__ bf16x8_t f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
+  u32x4 o;
+  o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false));
+  o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, true));
+  o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, false));
+  o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, true));
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+
+// F8: the weights come from the fp8 pair-tiled copy (half the bytes); they are widened to bf16 in registers and
+// fed to the same bf16 MFMA in the same k order, the per-row power-of-two scale multiplies the reduced fp32
+// sum — bit-identical to the bf16 kernel on the de-quantised weights.
+template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
+  __shared__ float red[WAVES][T][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
   const int K = a.K;
   // K slice of this wave, in k-steps of 32 (the last step may be partial: K % 8 == 0)
   const int nsteps = (K + GB_KSTEP - 1) / GB_KSTEP;
-  const int per = (nsteps + GB_WAVES - 1) / GB_WAVES;
-  const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+  const int per = (nsteps + WAVES - 1) / WAVES;
+  const int s0 = min(nsteps, wave * per), s1 = min(nsteps, s0 + per);
 
   // MODE (timing experiments only): 1 = no x loads
   const int arow = lane & 15, koff = (lane >> 4) * 8;
-  const bf16_t* wrow[T];  // tile row of this block's t-th row tile in the fragment-major copy, + this lane's 16 B
+  // this lane's 16 bytes of tile 0 of the block's t-th row tile.  bf16: 1 KiB tile = one k-step; fp8: 1 KiB
+  // pair tile = two k-steps.  A load "unit" below is one such tile.
+  const int units_per_row = F8 ? (nsteps + 1) >> 1 : nsteps;
+  const unsigned char* wrow[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     int tn = gb_tile_row0<EPI, T>(a, blk, t) >> 4;
     const int tn_max = ((a.N + 15) >> 4) - 1;
     if (tn > tn_max) tn = tn_max;
-    wrow[t] = a.W + (size_t)tn * nsteps * 512 + lane * 8;
+    wrow[t] = (F8 ? a.W8 : reinterpret_cast<const unsigned char*>(a.W)) + ((size_t)tn * units_per_row * 64 + lane) * 16;
   }
   const bf16_t* xrow = a.X + (size_t)arow * a.ldx;  // B fragment: slot = lane & 15
 
@@ -55,25 +72,60 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int s = s0; s < s1; s += GB_UNROLL) {
-    u32x4 wv[T][GB_UNROLL], xv[GB_UNROLL];
+  // A stage = 4 k-steps of weights + x fragments in registers.
+  // fp8: the same K slice [s0, s1) as the bf16 kernel; a pair tile that straddles a slice boundary is loaded by
+  // both neighbours and the foreign k-step is masked (x fragment = 0), so the k order per accumulator is the same.
+  constexpr int U = F8 ? 2 : 4;   // tiles per stage
+  constexpr int XN = 4;           // x fragments (k-steps) per stage
+  const int u0 = F8 ? (s0 >> 1) : s0, u1 = F8 ? ((s1 + 1) >> 1) : s1;
+  auto load = [&](u32x4 (&w)[T][U], u32x4 (&x)[XN], int u) {
 #pragma unroll
-    for (int u = 0; u < GB_UNROLL; ++u) {
-      int k = (s + u) * GB_KSTEP + koff;
-      const bool ok = (s + u < s1) && (k < K);
-      if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
+    for (int i = 0; i < U; ++i) {
+      const bool okp = u + i < u1;
+      const int uu = okp ? u + i : u;
 #pragma unroll
-      for (int t = 0; t < T; ++t) wv[t][u] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)(ok ? s + u : s) * 512));
-      if (MODE & 1) xv[u] = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      else xv[u] = *reinterpret_cast<const u32x4*>(xrow + k);
-      if (!ok) xv[u] = (u32x4){0u, 0u, 0u, 0u};
+      for (int t = 0; t < T; ++t) w[t][i] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)uu * 1024));
+#pragma unroll
+      for (int h = 0; h < (F8 ? 2 : 1); ++h) {
+        const int st = F8 ? 2 * (u + i) + h : u + i;
+        int k = st * GB_KSTEP + koff;
+        const bool ok = okp && st >= s0 && st < s1 && k < K;
+        if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
+        u32x4 xv;
+        if (MODE & 1) xv = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        else xv = *reinterpret_cast<const u32x4*>(xrow + k);
+        if (!ok) xv = (u32x4){0u, 0u, 0u, 0u};
+        x[F8 ? 2 * i + h : i] = xv;
+      }
     }
+  };
+  auto mma = [&](const u32x4 (&w)[T][U], const u32x4 (&x)[XN]) {
 #pragma unroll
-    for (int u = 0; u < GB_UNROLL; ++u)
+    for (int i = 0; i < U; ++i)
 #pragma unroll
-      for (int t = 0; t < T; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[t][u]),
-                                                         __builtin_bit_cast(bf16x8_t, xv[u]), acc[t], 0, 0, 0);
+      for (int h = 0; h < (F8 ? 2 : 1); ++h)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const bf16x8_t af = F8 ? f8x8_to_bf16x8(w[t][i][2 * h], w[t][i][2 * h + 1]) : __builtin_bit_cast(bf16x8_t, w[t][i]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, x[F8 ? 2 * i + h : i]), acc[t], 0, 0, 0);
+        }
+  };
+  if (F8) {   // two stages in flight (measured: fp8 step 3.24 -> 2.99 ms at B=16)
+    u32x4 wA[T][U], xA[XN], wB[T][U], xB[XN];
+    if (u0 < u1) load(wA, xA, u0);
+    for (int u = u0; u < u1; u += 2 * U) {
+      const bool hb = u + U < u1;
+      if (hb) load(wB, xB, u + U);
+      mma(wA, xA);
+      if (u + 2 * U < u1) load(wA, xA, u + 2 * U);
+      if (hb) mma(wB, xB);
+    }
+  } else {    // bf16: one stage (the second stage costs 128 VGPRs and measured 2 % slower: 3.90 -> 3.99 ms)
+    u32x4 wA[T][U], xA[XN];
+    for (int u = u0; u < u1; u += U) {
+      load(wA, xA, u);
+      mma(wA, xA);
+    }
   }
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -90,7 +142,12 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
   for (int t = 0; t < T; ++t) {
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < GB_WAVES; ++w) sum += red[w][t][tid];
+    for (int w = 0; w < WAVES; ++w) sum += red[w][t][tid];
+    if (F8) {
+      int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+      if (row >= a.N) row = a.N - 1;
+      sum *= a.wscale[row];   // power of two: exact
+    }
     v[t] = sum;
   }
   if (!a.bs->active[n]) return;
@@ -148,23 +205,36 @@ __global__ __launch_bounds__(GB_THREADS) void k_gemv_b(GemvBArgs a) {
 
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
-  if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
+  if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true>), g, b, 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
   else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0>), g, b, 0, s, a);
 }
 
-void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
+// waves per block of the N = d kernels (o_proj, down: only N/16 = 256 blocks, so the K split is what fills a CU)
+static int resid_waves() {
+  static int w = 0;
+  if (!w) { const char* e = getenv("DTK_GB_RESID_WAVES"); w = (e && atoi(e) == 16) ? 16 : 8; }   // measured: 8 and 16 within 1-2 % (DTK_GB_RESID_WAVES=16 to try)
+  return w;
+}
+template <bool F8>
+static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (epi == EPI_QKV) {
     const int grid = (a.H + 2 * a.KVH) * 4;   // 4 blocks of 16 RoPE pairs per head block
-    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2>), dim3(grid), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2, 0, F8>), dim3(grid), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_SWIGLU) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_RESID) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    if (resid_waves() == 16) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_LOGITS) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
+}
+void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (a.W8) launch_gemv_b_impl<true>(epi, a, s);
+  else launch_gemv_b_impl<false>(epi, a, s);
 }
 
 // RMSNorm of the active slots' vectors: grid = 16 slots, one block each (HF LlamaRMSNorm rounding).
@@ -352,6 +422,28 @@ __global__ void k_retile(const bf16_t* src, bf16_t* dst, int N, int K) {
     if (n < N && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * K + k);
     reinterpret_cast<u32x4*>(dst)[i] = v;
   }
+}
+// Row-major fp8 [N][K] -> pair tiles (kernels.h): one thread per 16-byte lane slot.
+__global__ void k_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K) {
+  const int K64 = (K + 63) >> 6, N16 = (N + 15) >> 4;
+  const long total = (long)N16 * K64 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long tile = i >> 6;
+    const int tk = (int)(tile % K64), tn = (int)(tile / K64);
+    const int n = tn * 16 + (lane & 15), k = tk * 64 + (lane >> 4) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N) {   // K % 8 == 0: an 8-byte group is fully in or fully out
+      if (k < K) { const u32x2 lo = *reinterpret_cast<const u32x2*>(src + (size_t)n * K + k); v[0] = lo[0]; v[1] = lo[1]; }
+      if (k + 32 < K) { const u32x2 hi = *reinterpret_cast<const u32x2*>(src + (size_t)n * K + k + 32); v[2] = hi[0]; v[3] = hi[1]; }
+    }
+    reinterpret_cast<u32x4*>(dst)[i] = v;
+  }
+}
+void launch_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K, hipStream_t s) {
+  const long total = (long)((N + 15) >> 4) * ((K + 63) >> 6) * 64;
+  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_retile_f8, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, N, K);
 }
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s) {
   const long total = (long)((N + 15) >> 4) * ((K + 31) >> 5) * 64;

@@ -17,8 +17,9 @@ ap.add_argument("--model", default="detikzify-ds-7b")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--weight-format", default="bf16")
 args = ap.parse_args()
-model, proc = load(args.model, synthetic=1234, batch_slots=args.batch)
+model, proc = load(args.model, synthetic=1234, batch_slots=args.batch, weight_format=args.weight_format)
 model.set_graph_mode(args.graph)
 enc = proc(images=sketch_image(0, 224), return_tensors="pt")
 ids, px = enc.input_ids[0], enc.pixel_values
