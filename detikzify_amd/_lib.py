@@ -12,6 +12,7 @@ DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
 DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
 DTK_MAX_INFLIGHT = 4
+DTK_MAX_BATCH = 32          # entries of the active / tokens_out arrays of dtk_decode_batch_*
 DTK_EPI_BIAS, DTK_EPI_GELU, DTK_EPI_RESIDUAL, DTK_GEMM_NAIVE = 1, 2, 4, 256
 
 
@@ -118,8 +119,8 @@ def load_library() -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, loud by design
         fn.restype, fn.argtypes = res, args
-    if lib.dtk_abi_version() != 1:
-        raise DtkError(f"ABI version {lib.dtk_abi_version()} != 1")
+    if lib.dtk_abi_version() != 2:
+        raise DtkError(f"ABI version {lib.dtk_abi_version()} != 2")
     _lib = lib
     return lib
 

@@ -62,12 +62,23 @@ struct DecState {
   int32_t pad[3];
 };
 
-// Batched decode (kernels_batch_decode.hip): which of the 16 slots take part in this step.
+// Batched decode (kernels_batch_decode.hip): which of the (up to 32) slots take part in this step.
+#ifndef DTK_MAX_BATCH
+#define DTK_MAX_BATCH 32   // == include/dtk.h
+#endif
 struct BatchState {
-  int32_t active[16];
+  int32_t active[DTK_MAX_BATCH];
   int32_t step;      // global step counter (token ring index)
   int32_t pad[15];
 };
+
+// Batched decode keeps the GEMV INPUT vectors (normalised x, attention output, SwiGLU activation) of the slots in
+// the MFMA B-operand fragment order: tile (slot/16, k/32) is 1 KiB, lane = ((k%32)/8)*16 + slot%16 holds 8
+// consecutive k.  A wave's x load is then 1 KiB contiguous (8 full cache lines) instead of 16 rows x 64 B
+// (16 half-used lines): measured gate/up at 32 slots 48 -> see DESIGN §3.1b.
+__device__ __forceinline__ size_t xtile_off(int slot, int k, int nsteps) {
+  return ((size_t)((slot >> 4) * nsteps + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (slot & 15)) * 8 + (k & 7);
+}
 
 struct SamplingDev {
   int32_t do_sample;

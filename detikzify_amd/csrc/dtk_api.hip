@@ -117,6 +117,7 @@ struct dtk_ctx {
   int KVH = 0;                       // key/value heads (dtk_config.reserved[2]; 0 -> heads)
   bool proj_bias = true;             // mm_projector has a bias (v1) / bias-free connector (v2)
   int nb = 0;                        // number of batch slots (dtk_config.reserved[0])
+  int nt = 1;                        // 16-slot column tiles of the batched kernels (2 when nb > 17)
   std::vector<SeqHost> bseq;
   bf16_t* kvb = nullptr;             // [nb][L][2][H][Tmax][128]
   size_t kv_slot_stride = 0;
@@ -381,17 +382,18 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   if (c->nb > 0) {
     c->kv_slot_stride = (size_t)L * 2 * c->KVH * T * 128;
     c->kvb = P.take<bf16_t>((size_t)c->nb * c->kv_slot_stride);
-    c->xb = P.take<bf16_t>((size_t)16 * d);
-    c->xnb = P.take<bf16_t>((size_t)16 * (d > ff ? d : ff));
-    c->qb = P.take<bf16_t>((size_t)16 * d);
-    c->aob = P.take<bf16_t>((size_t)16 * d);
-    c->actb = P.take<bf16_t>((size_t)16 * ff);
+    c->xb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * d);
+    // xnb / aob / actb are fragment-major GEMV inputs (common.h xtile_off): K rounded up to whole 32-wide k-steps
+    c->xnb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)(d > ff ? d : ff), 32));
+    c->qb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * d);
+    c->aob = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)d, 32));
+    c->actb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)ff, 32));
     c->logits_b = P.take<float>((size_t)c->nb * V);
     c->pmb = P.take<float>((size_t)c->nb * c->H * c->S);
     c->plb = P.take<float>((size_t)c->nb * c->H * c->S);
     c->pob = P.take<float>((size_t)c->nb * c->H * c->S * 128);
-    c->st_b = P.take<DecState>(17);
-    c->sp_b = P.take<SamplingDev>(17);
+    c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
+    c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
     c->bs_dev = P.take<BatchState>(1);
     if (c->wfmt == 1) {             // fp8: pair-tiled fp8 copies (+6.6 GB for cl-7b), no bf16 tiles
       for (int i = 0; i < L; ++i) {
@@ -412,7 +414,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
       }
       c->t_lm_head = P.take<bf16_t>(tiled_elems(V, d));
     }
-    c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * 16);
+    c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH);
   }
   c->scratch_bytes = (size_t)64 << 20;
   c->scratch = P.take<unsigned char>(c->scratch_bytes);
@@ -543,7 +545,7 @@ void batch_step_launches(dtk_ctx* c) {
   SampleArgs sa;
   sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
   sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
-  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = 16 * c->nt;
   launch_sample_b(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
@@ -552,28 +554,28 @@ void batch_step_launches(dtk_ctx* c) {
     bf16_t* kc = c->kvb + (size_t)l * kv_layer;
     bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
     GemvBArgs g{};
-    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH;
+    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
-    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
     g.W = w.t_wqkv; g.W8 = w.t8_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
-    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
     g.W = w.t_wgu; g.W8 = w.t8_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
     launch_gemv_b(EPI_SWIGLU, g, s);
     g.W = w.t_wdown; g.W8 = w.t8_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
   }
-  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, s);
+  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
   GemvBArgs g{};
   g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.W8 = c->t8_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
-  g.d = d; g.ff = ff;
+  g.d = d; g.ff = ff; g.nt = c->nt;
   launch_gemv_b(EPI_LOGITS, g, s);
 }
 
@@ -625,7 +627,7 @@ int ensure_batch_graph(dtk_ctx* c) {
   if (c->bgraph_ready) return DTK_OK;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   batch_step_launches(c);
-  HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16,
+  HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph));
   HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec, c->bgraph, nullptr, nullptr, 0));
@@ -708,8 +710,9 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
-  // up to 16 decoding slots (the MFMA N dimension) + 1 slot that is only ever prefilled / forked (prefix cache)
-  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > 17 ? 17 : cfg->reserved[0]);
+  // up to 32 decoding slots (one or two 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
+  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_BATCH + 1 ? DTK_MAX_BATCH + 1 : cfg->reserved[0]);
+  c->nt = c->nb > 17 ? 2 : 1;          // 17 = 16 decoding slots + the prefix slot
   c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
   c->vMlp = cfg->vit_mlp; c->vN = np * np;
@@ -756,7 +759,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
   if (c->nb > 0) {
     CCHK(hipHostMalloc((void**)&c->bs_host, sizeof(BatchState) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
-    CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16, hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipHostMallocDefault));
     for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->bstep_done[i], hipEventDisableTiming));
   }
   CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
@@ -1072,9 +1075,9 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "context was created without batch slots");
   if (c->blaunched - c->bwaited >= DTK_MAX_INFLIGHT) return fail(c, DTK_ERR_STATE, "too many batch steps in flight");
   int n_active = 0;
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) {
     if (!active[j]) continue;
-    if (j >= c->nb || j >= 16) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    if (j >= c->nb || j >= 16 * c->nt) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
     const SeqHost& sh = c->bseq[(size_t)j];
     if (!sh.have_logits) return fail(c, DTK_ERR_STATE, "slot %d: decode before prefill", j);
     if (sh.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "slot %d: context length %d reached max_positions", j, sh.host_next_pos);
@@ -1084,7 +1087,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   HIPCHK(c, hipSetDevice(c->device));
   ensure_tiled_weights(c);
   BatchState* hb = c->bs_host + (c->blaunched % DTK_MAX_INFLIGHT);
-  for (int j = 0; j < 16; ++j) hb->active[j] = active[j] ? 1 : 0;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) hb->active[j] = active[j] ? 1 : 0;
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
   HIPCHK(c, hipMemcpyAsync(c->bs_dev, hb, sizeof(BatchState), hipMemcpyHostToDevice, c->stream));
   if (c->use_graph) {
@@ -1093,17 +1096,17 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     HIPCHK(c, hipGraphLaunch(c->bgraph_exec, c->stream));
   } else {
     batch_step_launches(c);
-    HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
   c->blaunched++;
   c->stats.decode_steps++;
-  for (int j = 0; j < 16; ++j)
+  for (int j = 0; j < DTK_MAX_BATCH; ++j)
     if (active[j]) { c->bseq[(size_t)j].host_next_pos++; c->bseq[(size_t)j].cached_ids.push_back(-1); }
   return DTK_OK;
 }
 
-// tokens_out[16]: the token sampled for every slot that was active in the oldest un-read step (-1 otherwise)
+// tokens_out[DTK_MAX_BATCH]: the token sampled for every slot that was active in the oldest un-read step (-1 otherwise)
 int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
   if (!c || !tokens_out) return fail(c, DTK_ERR_ARG, "dtk_decode_batch_wait: null argument");
   if (c->bwaited >= c->blaunched) return fail(c, DTK_ERR_STATE, "no batch step in flight");
@@ -1113,10 +1116,10 @@ int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
   HIPCHK(c, hipEventSynchronize(c->bstep_done[ring]));
   const BatchState* hb = c->bs_host + ring;
   // how many steps were launched after step k for each slot (their cached ids are still -1)
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) {
     tokens_out[j] = -1;
     if (!hb->active[j]) continue;
-    const int64_t tok = ((volatile int64_t*)c->tokb_host)[(size_t)ring * 16 + j];
+    const int64_t tok = ((volatile int64_t*)c->tokb_host)[(size_t)ring * DTK_MAX_BATCH + j];
     tokens_out[j] = tok;
     SeqHost& sh = c->bseq[(size_t)j];
     size_t later = 0;
@@ -1281,7 +1284,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
     auto pass = [&]() {
       for (int l = 0; l < c->L; ++l) {
         GemvBArgs g{};
-        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
+        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt;
         g.W = c->layers[l].t_wgu; g.W8 = c->layers[l].t8_wgu; g.wscale = c->layers[l].s_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
         launch_gemv_b_mode(variant, g, s);
       }

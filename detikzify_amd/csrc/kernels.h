@@ -69,6 +69,7 @@ struct SampleArgs {
   int step_override;     // >=0: use as draw index (tests)
   const BatchState* bs;  // batched mode: block = slot, inactive slots return; pointers are slot 0's
   int logits_stride;     // elements between slots' logits (batched mode)
+  int nslots;            // batched mode: grid = 16 or 32 slots
 };
 void launch_sample_b(const SampleArgs& a, hipStream_t s);
 void launch_sample(const SampleArgs& a, hipStream_t s);
@@ -89,6 +90,7 @@ struct GemvBArgs {
   int H; int KVH;                      // QKV: head counts (rows = [H | KVH | KVH] x 128)
   const uint8_t* W8;                   // fp8 (e4m3) pair-tiled copy of the weights, or null; then wscale[N] = per-row 2^e scales
   const float* wscale;
+  int nt;                              // 16-slot column tiles: 1 (<= 16 slots) or 2 (<= 32 slots)
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
@@ -99,7 +101,7 @@ static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) 
 void launch_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K, hipStream_t s);
 static inline size_t tiled_bytes_f8(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 63) >> 6) * 1024; }
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
-                      const BatchState* bs, hipStream_t s);
+                      const BatchState* bs, int nslots, hipStream_t s);
 struct AttnDecBArgs {
   const bf16_t* q;                     // [16][d]
   const bf16_t* kcache; const bf16_t* vcache; size_t kv_slot_stride;
@@ -108,6 +110,7 @@ struct AttnDecBArgs {
   bf16_t* out;                         // [16][d]
   int H; int S; int T_max; int d; float scale;
   int G;                               // query heads per kv head (1 = MHA)
+  int nslots;                          // grid z: 16 or 32
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 

@@ -42,9 +42,10 @@ __device__ __forceinline__ bf16x8_t f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
 // F8: the weights come from the fp8 pair-tiled copy (half the bytes); they are widened to bf16 in registers and
 // fed to the same bf16 MFMA in the same k order, the per-row power-of-two scale multiplies the reduced fp32
 // sum — bit-identical to the bf16 kernel on the de-quantised weights.
-template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES>
+// NT = 16-slot column tiles (1: up to 16 slots, 2: up to 32): the A (weight) fragment of a k-step is reused by NT MFMAs
+template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES, int NT = 1>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
-  __shared__ float red[WAVES][T][256];
+  __shared__ float red[WAVES][T][NT][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
   const int K = a.K;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
   const int s0 = min(nsteps, wave * per), s1 = min(nsteps, s0 + per);
 
   // MODE (timing experiments only): 1 = no x loads
-  const int arow = lane & 15, koff = (lane >> 4) * 8;
+  const int koff = (lane >> 4) * 8;
   // this lane's 16 bytes of tile 0 of the block's t-th row tile.  bf16: 1 KiB tile = one k-step; fp8: 1 KiB
   // pair tile = two k-steps.  A load "unit" below is one such tile.
   const int units_per_row = F8 ? (nsteps + 1) >> 1 : nsteps;
@@ -66,11 +67,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
     if (tn > tn_max) tn = tn_max;
     wrow[t] = (F8 ? a.W8 : reinterpret_cast<const unsigned char*>(a.W)) + ((size_t)tn * units_per_row * 64 + lane) * 16;
   }
-  const bf16_t* xrow = a.X + (size_t)arow * a.ldx;  // B fragment: slot = lane & 15
+  const bf16_t* xlane = a.X + lane * 8;   // B fragment of tile (nt, k-step): slot = nt*16 + (lane & 15), fragment-major X (common.h)
 
-  f32x4 acc[T];
+  f32x4 acc[T][NT];
 #pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // A stage = 4 k-steps of weights + x fragments in registers.
   // fp8: the same K slice [s0, s1) as the bf16 kernel; a pair tile that straddles a slice boundary is loaded by
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
   constexpr int U = F8 ? 2 : 4;   // tiles per stage
   constexpr int XN = 4;           // x fragments (k-steps) per stage
   const int u0 = F8 ? (s0 >> 1) : s0, u1 = F8 ? ((s1 + 1) >> 1) : s1;
-  auto load = [&](u32x4 (&w)[T][U], u32x4 (&x)[XN], int u) {
+  auto load = [&](u32x4 (&w)[T][U], u32x4 (&x)[XN][NT], int u) {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const bool okp = u + i < u1;
@@ -88,18 +91,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 #pragma unroll
       for (int h = 0; h < (F8 ? 2 : 1); ++h) {
         const int st = F8 ? 2 * (u + i) + h : u + i;
-        int k = st * GB_KSTEP + koff;
+        const int k = st * GB_KSTEP + koff;
         const bool ok = okp && st >= s0 && st < s1 && k < K;
-        if (!ok) k = koff;  // any valid address; the x fragment is zeroed instead
-        u32x4 xv;
-        if (MODE & 1) xv = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        else xv = *reinterpret_cast<const u32x4*>(xrow + k);
-        if (!ok) xv = (u32x4){0u, 0u, 0u, 0u};
-        x[F8 ? 2 * i + h : i] = xv;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          u32x4 xv;
+          if (MODE & 1) xv = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          else xv = *reinterpret_cast<const u32x4*>(xlane + ((size_t)nt * nsteps + (ok ? st : 0)) * 512);
+          if (!ok) xv = (u32x4){0u, 0u, 0u, 0u};
+          x[F8 ? 2 * i + h : i][nt] = xv;
+        }
       }
     }
   };
-  auto mma = [&](const u32x4 (&w)[T][U], const u32x4 (&x)[XN]) {
+  auto mma = [&](const u32x4 (&w)[T][U], const u32x4 (&x)[XN][NT]) {
 #pragma unroll
     for (int i = 0; i < U; ++i)
 #pragma unroll
@@ -107,11 +112,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const bf16x8_t af = F8 ? f8x8_to_bf16x8(w[t][i][2 * h], w[t][i][2 * h + 1]) : __builtin_bit_cast(bf16x8_t, w[t][i]);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, x[F8 ? 2 * i + h : i]), acc[t], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, x[F8 ? 2 * i + h : i][nt]), acc[t][nt], 0, 0, 0);
         }
   };
   if (F8) {   // two stages in flight (measured: fp8 step 3.24 -> 2.99 ms at B=16)
-    u32x4 wA[T][U], xA[XN], wB[T][U], xB[XN];
+    u32x4 wA[T][U], xA[XN][NT], wB[T][U], xB[XN][NT];
     if (u0 < u1) load(wA, xA, u0);
     for (int u = u0; u < u1; u += 2 * U) {
       const bool hb = u + U < u1;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
       if (hb) mma(wB, xB);
     }
   } else {    // bf16: one stage (the second stage costs 128 VGPRs and measured 2 % slower: 3.90 -> 3.99 ms)
-    u32x4 wA[T][U], xA[XN];
+    u32x4 wA[T][U], xA[XN][NT];
     for (int u = u0; u < u1; u += U) {
       load(wA, xA, u);
       mma(wA, xA);
@@ -130,19 +137,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t][nt][lane * 4 + r] = acc[t][nt][r];
   __syncthreads();
-  if (tid >= 256) return;
-  // thread -> (m, n) of the 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
-  const int l2 = tid >> 2, r2 = tid & 3;
-  const int n = l2 & 15;             // slot
-  const int m = (l2 >> 4) * 4 + r2;  // row inside the tile
+  if (tid >= 256 * NT) return;
+  // thread -> (m, n) of a 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
+  const int nt = tid >> 8, ti = tid & 255;
+  const int l2 = ti >> 2, r2 = ti & 3;
+  const int n = nt * 16 + (l2 & 15);  // slot
+  const int m = (l2 >> 4) * 4 + r2;   // row inside the tile
   float v[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) sum += red[w][t][tid];
+    for (int w = 0; w < WAVES; ++w) sum += red[w][t][nt][ti];
     if (F8) {
       int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
       if (row >= a.N) row = a.N - 1;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
     if (i < a.ff) {
       const float gte = rbf(v[0]), up = rbf(v[T - 1]);
       const float sl = rbf(gte / (1.f + expf(-gte)));
-      a.Y[(size_t)n * a.ldy + i] = f2bf(sl * up);
+      a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
     }
   } else if (EPI == EPI_QKV) {
     const int hb = blk >> 2, i = (blk & 3) * 16 + m;
@@ -205,6 +215,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
+  if (a.nt == 2) {
+    if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1, false, GB_WAVES, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, false, GB_WAVES, 2>), g, b, 0, s, a);
+    return;
+  }
   if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true>), g, b, 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
   else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0>), g, b, 0, s, a);
@@ -216,25 +232,25 @@ static int resid_waves() {
   if (!w) { const char* e = getenv("DTK_GB_RESID_WAVES"); w = (e && atoi(e) == 16) ? 16 : 8; }   // measured: 8 and 16 within 1-2 % (DTK_GB_RESID_WAVES=16 to try)
   return w;
 }
-template <bool F8>
+template <bool F8, int NT>
 static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (epi == EPI_QKV) {
     const int grid = (a.H + 2 * a.KVH) * 4;   // 4 blocks of 16 RoPE pairs per head block
-    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2, 0, F8>), dim3(grid), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2, 0, F8, GB_WAVES, NT>), dim3(grid), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_SWIGLU) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8, GB_WAVES, NT>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_RESID) {
-    if (resid_waves() == 16) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    if (resid_waves() == 16) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_LOGITS) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
 }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (a.W8) launch_gemv_b_impl<true>(epi, a, s);
-  else launch_gemv_b_impl<false>(epi, a, s);
+  if (a.nt == 2) { if (a.W8) launch_gemv_b_impl<true, 2>(epi, a, s); else launch_gemv_b_impl<false, 2>(epi, a, s); }
+  else { if (a.W8) launch_gemv_b_impl<true, 1>(epi, a, s); else launch_gemv_b_impl<false, 1>(epi, a, s); }
 }
 
 // RMSNorm of the active slots' vectors: grid = 16 slots, one block each (HF LlamaRMSNorm rounding).
@@ -261,19 +277,19 @@ __global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, con
   __syncthreads();
   const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
   const u32x4* w4 = reinterpret_cast<const u32x4*>(w);
-  u32x4* y4 = reinterpret_cast<u32x4*>(Y + (size_t)slot * ldy);
+  const int nsteps = (D + 31) >> 5;   // Y is fragment-major (the next kernel's B operand)
   for (int c = tid; c < D8; c += 256) {
     const u32x4 v = x4[c], g = w4[c];
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       o[e] = pack2(pk_lo(g[e]) * rbf(pk_lo(v[e]) * inv), pk_hi(g[e]) * rbf(pk_hi(v[e]) * inv));
-    y4[c] = o;
+    *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, nsteps)) = o;
   }
 }
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
-                      const BatchState* bs, hipStream_t s) {
-  hipLaunchKernelGGL(k_rmsnorm_b, dim3(16), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs);
+                      const BatchState* bs, int nslots, hipStream_t s) {
+  hipLaunchKernelGGL(k_rmsnorm_b, dim3(nslots), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs);
 }
 
 // Split-K decode attention per slot: grid (H, S, 16); same algorithm as k_attn_decode.
@@ -400,12 +416,12 @@ __global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
     L += w * pl[s];
     o += w * po[s];
   }
-  a.out[(size_t)slot * a.d + h * 128 + t] = f2bf(o / L);
+  a.out[xtile_off(slot, h * 128 + t, (a.d + 31) >> 5)] = f2bf(o / L);   // o_proj's B operand: fragment-major
 }
 
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, 16), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, 16), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, a.nslots), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, a.nslots), dim3(128), 0, s, a);
 }
 
 // Row-major [N][K] bf16 -> fragment-major tiles (see the header): storage = ceil(N/16)*ceil(K/32) tiles

@@ -788,7 +788,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     a.sp += slot;
     a.st += slot;
     a.x += (size_t)slot * a.d;
-    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * 16 + slot;
+    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * DTK_MAX_BATCH + slot;
     a.ring = 1;        // the ring index was applied above
     a.step_override = -1;
   }
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
     a.sp += slot;
     a.st += slot;
     a.x += (size_t)slot * a.d;
-    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * 16 + slot;
+    a.tok_ring += (size_t)((unsigned)a.bs->step % (unsigned)a.ring) * DTK_MAX_BATCH + slot;
     a.ring = 1;
     a.step_override = -1;
   }
@@ -1278,6 +1278,6 @@ void launch_sample(const SampleArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(k_sample, dim3(1), dim3(SAMPLE_THREADS), 0, s, a);
 }
 void launch_sample_b(const SampleArgs& a, hipStream_t s) {
-  if (sample_fast_ok(a)) { hipLaunchKernelGGL(k_sample_fast, dim3(16), dim3(SAMPLE_THREADS), 0, s, a); return; }
-  hipLaunchKernelGGL(k_sample, dim3(16), dim3(SAMPLE_THREADS), 0, s, a);
+  if (sample_fast_ok(a)) { hipLaunchKernelGGL(k_sample_fast, dim3(a.nslots), dim3(SAMPLE_THREADS), 0, s, a); return; }
+  hipLaunchKernelGGL(k_sample, dim3(a.nslots), dim3(SAMPLE_THREADS), 0, s, a);
 }

@@ -5,7 +5,7 @@ can be batched without touching its semantics are *independent trees* (root para
 divergence as sharding trees across GPUs): every tree runs the reference's logic unchanged in its own
 thread (DetikzifyGenerator.rollout already generates in a worker thread, infer/generate.py:248-258), and
 whenever those threads ask for their next token the BatchEngine issues ONE dtk_decode_batch step for all
-of them: the weights are streamed once per step for up to 16 sequences (bytes/step = W + sum_b K*t_b).
+of them: the weights are streamed once per step for up to 32 sequences (bytes/step = W + sum_b K*t_b).
 
 BatchEngine      lock-step scheduler over the C ABI's slots (dtk_prefill_slot / dtk_decode_batch_*)
 simulate_parallel  B independent DetikzifyGenerator trees on one image, results as they complete
@@ -42,12 +42,13 @@ class BatchEngine:
         # one slot is set aside as the prefix cache: it holds the KV of the image prefix ([image_token]*n
         # + pixels) of the current image; sequences fork it (bit-identical KV) and only
         # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
-        dec = min(n, 16)
-        self.share_prefix = share_prefix and n >= 2 and (n > 16 or max_batch is None or max_batch < n)
+        maxdec = 32 if n > 17 else 16   # the kernels use one 16-slot MFMA column tile up to 17 slots, two above (include/dtk.h)
+        dec = min(n, maxdec)
+        self.share_prefix = share_prefix and n >= 2 and (n > maxdec or max_batch is None or max_batch < n)
         self.prefix_slot = n - 1 if self.share_prefix else None
         self.prefix_key = None
         self.prefix_ids = None
-        self.capacity = min(dec - (1 if self.share_prefix and n <= 16 else 0), max_batch or dec)
+        self.capacity = min(dec - (1 if self.share_prefix and n <= maxdec else 0), max_batch or dec)
         self.pipeline = pipeline
         self.cv = threading.Condition()
         self.free: List[int] = list(range(self.capacity))

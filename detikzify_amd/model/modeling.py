@@ -267,13 +267,13 @@ class DetikzifyForCausalLM:
         return int(self.lib.dtk_num_slots(self._ctx))
 
     def decode_batch_launch(self, active_slots: Iterable[int]):
-        arr = (C.c_int32 * 16)()
+        arr = (C.c_int32 * _lib.DTK_MAX_BATCH)()
         for j in active_slots:
             arr[int(j)] = 1
         self._check(self.lib.dtk_decode_batch_launch(self._ctx, arr), "dtk_decode_batch_launch")
 
     def decode_batch_wait(self) -> List[int]:
-        out = (C.c_int64 * 16)()
+        out = (C.c_int64 * _lib.DTK_MAX_BATCH)()
         self._check(self.lib.dtk_decode_batch_wait(self._ctx, out), "dtk_decode_batch_wait")
         return [int(v) for v in out]
 
@@ -289,6 +289,9 @@ class DetikzifyForCausalLM:
         out = np.empty(self.config.vocab, dtype=np.float32)
         self._check(self.lib.dtk_get_logits_slot(self._ctx, int(slot), out.ctypes.data_as(C.c_void_p)), "dtk_get_logits_slot")
         return torch.from_numpy(out)
+
+    def context_len_slot(self, slot: int) -> int:
+        return int(self.lib.dtk_context_len_slot(self._ctx, int(slot)))
 
     def decode_launch(self):
         self._check(self.lib.dtk_decode_launch(self._ctx), "dtk_decode_launch")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DTK_ABI_VERSION 1
+#define DTK_ABI_VERSION 2   /* 2: batch arrays are DTK_MAX_BATCH (32) entries (were 16) */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -173,15 +173,19 @@ int  dtk_synchronize(dtk_ctx* ctx);
 int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
 
 /* Batched decode for independent rollouts of one GPU: dtk_config.reserved[0] = number
- * of slots (<= 16), each with its own KV cache, sampling state and logits.  One dtk_decode_batch_*
- * step = one _sample iteration for every active slot with ONE pass over the weights (bytes/step =
- * W + sum_b K*t_b).  The image embeddings cache is shared (DTK_PREFILL_REUSE_IMAGE). */
+ * of slots (<= DTK_MAX_BATCH + 1), each with its own KV cache, sampling state and logits.  One
+ * dtk_decode_batch_* step = one _sample iteration for every active slot with ONE pass over the weights
+ * (bytes/step = W + sum_b K*t_b).  Up to 17 slots: slots 0..15 decode (one 16-column MFMA tile); 18..33 slots:
+ * slots 0..31 decode (two tiles); a further slot can only be prefilled / forked from (prefix cache).
+ * The `active` / `tokens_out` arrays always have DTK_MAX_BATCH entries.
+ * The image embeddings cache is shared (DTK_PREFILL_REUSE_IMAGE). */
+#define DTK_MAX_BATCH 32
 int  dtk_num_slots(const dtk_ctx* ctx);
 int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const float* pixels,
                       uint64_t image_key, int flags, float* logits_last_out);
 int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
-int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active16);
-int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out16);
+int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active /* [DTK_MAX_BATCH] */);
+int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out /* [DTK_MAX_BATCH] */);
 int  dtk_kv_fork(dtk_ctx* ctx, int src_slot, int dst_slot, int n_tokens);   /* share a prefix's KV (f1) */
 int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
 int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);

@@ -919,3 +919,53 @@ def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
     s_same, s_diff = sim.get_similarity(img, img), sim.get_similarity(img, other)
     print(f"emd SelfSim: same {s_same:.6f} different {s_diff:.6f}")
     assert abs(s_same - 1.0) < 1e-9 and s_diff < s_same
+
+
+# ------------------------------------------------------------------------------------------ 32 slots (two MFMA column tiles)
+def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
+    """load(batch_slots=33): slots 0..31 decode in one step (two 16-column MFMA tiles reuse each weight
+    fragment).  Every slot's tokens and logits equal the same sequence decoded on the 16-slot build: the
+    per-column arithmetic (k order, reduction order) does not depend on the tile count."""
+    from detikzify_amd.model import load
+    m16, proc = tiny_batched
+    m32, _ = load("detikzify-tiny", synthetic=1234, batch_slots=33)
+    assert m32.num_slots() == 33
+    enc = [proc(images=sketch_image(40 + i % 3, 96), return_tensors="pt") for i in range(3)]
+    prompts = [torch.cat([enc[i % 3].input_ids[0], torch.tensor([10 + i, 3 * i + 5][: 1 + i % 2])]) for i in range(32)]
+    n = 24
+
+    def setup(m, slot, i):
+        m.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=500 + i, bad_ids=[1], begin_suppress_ids=[2], slot=slot)
+        m.prefill(prompts[i], enc[i % 3].pixel_values, slot=slot)
+
+    # reference: sequences 0..3 and 28..31 on the 16-slot model, four at a time
+    ref = {}
+    for group in ([0, 1, 2, 3], [28, 29, 30, 31]):
+        for sl, i in enumerate(group):
+            setup(m16, sl, i)
+        toks = {i: [] for i in group}
+        for _ in range(n):
+            m16.decode_batch_launch([0, 1, 2, 3])
+            out = m16.decode_batch_wait()
+            for sl, i in enumerate(group):
+                toks[i].append(out[sl])
+        for sl, i in enumerate(group):
+            ref[i] = (toks[i], m16.get_logits_slot(sl).clone())
+    for i in range(32):
+        setup(m32, i, i)
+    got = {i: [] for i in range(32)}
+    for step in range(n):
+        m32.decode_batch_launch(range(32))
+        out = m32.decode_batch_wait()
+        for i in range(32):
+            got[i].append(out[i])
+    for i, (toks, logits) in ref.items():
+        assert got[i] == toks, i
+        assert torch.equal(m32.get_logits_slot(i), logits), i
+    assert len({tuple(v) for v in got.values()}) > 20       # the 32 sequences really differ
+    # a partially active step leaves the idle slots untouched
+    before = m32.get_logits_slot(20).clone()
+    m32.decode_batch_launch([0, 17, 31])
+    out = m32.decode_batch_wait()
+    assert out[20] == -1 and out[0] >= 0 and out[17] >= 0 and out[31] >= 0
+    assert torch.equal(m32.get_logits_slot(20), before) and m32.context_len_slot(20) == prompts[20].numel() + n

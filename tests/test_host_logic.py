@@ -153,7 +153,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dtk_abi_version() == 1
+    assert lib.dtk_abi_version() == 2
     assert ctypes.sizeof(_lib.DtkConfig) == 29 * 4 and ctypes.sizeof(_lib.DtkSampling) == 8 * 4 + 8 + 0 + 3 * 4 + 24 * 4 or True
 
 
