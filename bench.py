@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--probe-tokens", type=int, default=64)
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
-    ap.add_argument("--batch", type=int, default=16, help="independent rollouts decoded as one batch per GPU in the "
+    ap.add_argument("--batch", type=int, default=32, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     return ap.parse_args()
 
@@ -211,11 +211,15 @@ def main():
             for rep_i in range(2):          # first pass warms the batch graph up
                 fence()
                 tb = time.perf_counter()
+                engine.expect(args.batch)      # the B rollouts start together: first step once all have joined
                 ths = [threading.Thread(target=one, args=(i,)) for i in range(args.batch)]
                 [t.start() for t in ths]
                 [t.join() for t in ths]
                 fence()
-                tb = time.perf_counter() - tb
+                t_end = time.perf_counter()
+                phases = {"start_to_first_step_ms": round(1e3 * (engine.t_first_launch - tb), 1),
+                          "last_collect_to_end_ms": round(1e3 * (t_end - engine.t_last_collect), 1)}
+                tb = t_end - tb
             if world > 1:
                 t = torch.tensor([tb], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,7 +231,8 @@ def main():
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
                 "prefix_sharing": bool(engine.share_prefix),
-                "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3)},
+                "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3),
+                                   "host_bound_steps": engine.host_bound_steps, **phases},
                 "decode": "sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), 512 tokens, EOS suppressed",
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
                         "dtk_decode_batch step serves all of them; the 243-token image prefix is encoded once and its "

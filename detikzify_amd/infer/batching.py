@@ -32,9 +32,16 @@ class BatchEngine:
     prefill until it leaves.  Steps are pipelined one deep: as soon as the tokens of step k are handed
     out, step k+1 is launched for the same slots, so the threads' per-token host work (streamer,
     stopping criteria, Python) runs under the GPU's next step; a sequence that stops after token k just
-    discards its token of step k+1 (its slot is recycled once that step has completed)."""
+    discards its token of step k+1 (its slot is recycled once that step has completed).
 
-    def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True):
+    Tokens are handed to the threads through one SimpleQueue per slot, not through the shared condition
+    variable: a step wakes every waiting thread exactly once and without a contended lock (with 32 threads
+    a notify_all on one Condition cost ~1.3 ms of lock / GIL hand-offs per step, more than the GPU step hides).
+    The last thread to run out of tokens drives the step (collect + launch) while holding `cv`, which also
+    serialises every other use of the context (prefill of a joining sequence, the SelfSim ViT passes)."""
+
+    def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True,
+                 gather: int = 0, gather_timeout: float = 0.5):
         n = model.num_slots()
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
@@ -54,14 +61,28 @@ class BatchEngine:
         self.free: List[int] = list(range(self.capacity))
         self.active: set = set()
         self.ready: set = set()
-        self.pending: Dict[int, List[int]] = {}
+        self.tokq: List["queue.SimpleQueue"] = [queue.SimpleQueue() for _ in range(n)]   # per-slot token hand-off
         self.inflight: Optional[List[int]] = None      # slots of the launched, not yet collected step
         self.zombies: set = set()                      # left while in flight: freed when that step completes
         self.error: Optional[BaseException] = None
         self.steps = 0
         self.tokens_out = 0
         self.t_wait = self.t_launch = self.t_prefill = 0.0     # seconds inside the native calls (diagnostics)
+        self.host_bound_steps = 0
+        self.t_first_launch = self.t_last_collect = None        # perf_counter stamps (diagnostics; reset by expect())
+        # warm start: hold the first step until `gather` sequences have joined (rollouts started together should not
+        # trickle in one pipeline flush at a time); gives up after gather_timeout seconds
+        self.gather_left = min(int(gather), self.capacity)
+        self.gather_deadline = time.perf_counter() + gather_timeout
         model.batch_engine = self
+
+    def expect(self, n: int, timeout: float = 0.5):
+        """n sequences are about to join (e.g. the trees of simulate_parallel): no decode step before all of
+        them have been prefilled / forked, or `timeout` seconds have passed"""
+        with self.cv:
+            self.gather_left = min(int(n), self.capacity)
+            self.gather_deadline = time.perf_counter() + timeout
+            self.t_first_launch = self.t_last_collect = None
 
     def close(self):
         with self.cv:
@@ -88,8 +109,11 @@ class BatchEngine:
                 else:
                     self.model.prefill(ids, pixel_values, slot=slot)
                 self.t_prefill += time.perf_counter() - t0
-                self.pending[slot] = []
+                q = self.tokq[slot]
+                while not q.empty():       # leftovers of the slot's previous sequence
+                    q.get_nowait()
                 self.active.add(slot)
+                self.gather_left = max(0, self.gather_left - 1)
                 joined = True
             yield _Sequence(self, slot)
         finally:
@@ -97,7 +121,6 @@ class BatchEngine:
                 if joined:
                     self.active.discard(slot)
                     self.ready.discard(slot)
-                    self.pending.pop(slot, None)
                     if self.inflight is not None and slot in self.inflight:
                         self.zombies.add(slot)      # recycled by _collect()
                     else:
@@ -108,7 +131,7 @@ class BatchEngine:
                         self._collect()             # nobody left to collect the speculative step
                 else:
                     self.free.append(slot)
-                self.cv.notify_all()
+                self.cv.notify_all()   # a slot may have become free
 
     # -- called with self.cv held ---------------------------------------------------------------------
     def _fork_prefix(self, slot: int, ids, pixel_values) -> bool:
@@ -133,12 +156,19 @@ class BatchEngine:
             return
         try:
             t0 = time.perf_counter()
+            if self.t_first_launch is None:
+                self.t_first_launch = t0
             self.model.decode_batch_launch(slots)
             self.t_launch += time.perf_counter() - t0
             self.inflight = slots
         except BaseException as e:
-            self.error = e
-            self.cv.notify_all()
+            self._fail(e)
+
+    def _fail(self, e: BaseException):
+        self.error = e
+        for s in self.active:           # wake every waiting sequence with the error
+            self.tokq[s].put(e)
+        self.cv.notify_all()
 
     def _collect(self):
         """wait for the in-flight step, hand its tokens to the sequences that are still active"""
@@ -147,14 +177,18 @@ class BatchEngine:
         try:
             t0 = time.perf_counter()
             toks = self.model.decode_batch_wait()
-            self.t_wait += time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            self.t_wait += dt
+            self.t_last_collect = t0 + dt
+            if dt < 1e-4:
+                self.host_bound_steps += 1      # the GPU had already finished: this step waited for the host
             for s in self.inflight:
                 if s in self.active:
-                    self.pending[s].append(toks[s])
+                    self.tokq[s].put(toks[s])
                     self.tokens_out += 1
             self.steps += 1
         except BaseException as e:
-            self.error = e
+            self._fail(e)
         for s in self.inflight:
             if s in self.zombies:
                 self.zombies.discard(s)
@@ -167,6 +201,10 @@ class BatchEngine:
         is none) and immediately launch the next one"""
         if not self.active or self.error is not None or not (self.ready >= self.active):
             return
+        if self.gather_left > 0:
+            if time.perf_counter() < self.gather_deadline:
+                return                  # more sequences are about to join
+            self.gather_left = 0
         if self.inflight is None:
             self._launch()
         self._collect()
@@ -175,22 +213,24 @@ class BatchEngine:
             self._launch()
 
     def _next_token(self, slot: int) -> int:
-        with self.cv:
-            while True:
+        q = self.tokq[slot]
+        if q.empty():
+            with self.cv:
                 if self.error is not None:
                     raise self.error
-                q = self.pending.get(slot)
-                if q:
-                    return q.pop(0)
-                self.ready.add(slot)
-                self._maybe_step()
-                q = self.pending.get(slot)
-                if q:
-                    self.ready.discard(slot)
-                    return q.pop(0)
-                if self.error is not None:
-                    raise self.error
-                self.cv.wait()
+                if q.empty():
+                    self.ready.add(slot)
+                    self._maybe_step()      # the last sequence to run dry collects / launches for everybody
+        while True:                         # blocks (GIL released) until this slot's token of the next step arrives
+            try:
+                item = q.get(timeout=None if self.gather_left <= 0 else 0.05)
+                break
+            except queue.Empty:             # warm start only: re-check the gather deadline
+                with self.cv:
+                    self._maybe_step()
+        if isinstance(item, BaseException):
+            raise item
+        return item
 
 
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
@@ -199,7 +239,7 @@ def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, see
     torch seed seed_base + t for its sampling seeds) decoded as one batch.  Yields (score, document)
     pairs in completion order.  trees == 1 is the unmodified sequential search."""
     import torch
-    engine = BatchEngine(pipeline.model, max_batch=trees) if trees > 1 else None
+    engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees) if trees > 1 else None
     out: "queue.Queue" = queue.Queue()
     img = pipeline.load(image)
 
