@@ -1334,6 +1334,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
+  else if (!strcmp(name, "gemm_tile")) {   // MFMA GEMM block tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (process-wide)
+    if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..3");
+    set_gemm_tile(value);
+  }
   else if (!strcmp(name, "attn_impl")) {   // prefill / ViT attention: 0 auto, 1 VALU kernel, 2 MFMA flash kernel
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_impl must be 0..2");
     c->attn_impl = value;

@@ -8,9 +8,9 @@
 // tile's loads issued before the current tile's MFMAs (T14 split), padded LDS rows.
 // Epilogue fuses bias / GELU / residual exactly where timm / HF round to bf16.
 #include "kernels.h"
+#include <stdlib.h>
+#include <string.h>
 
-#define BM 64
-#define BN 64
 #define BK 64
 #define LDS_STRIDE 72  // bf16 elements per LDS row (64 + 8 pad -> 144 B, 16-byte aligned)
 
@@ -32,51 +32,67 @@ __device__ __forceinline__ float gemm_epilogue(float acc, int m, int n, const Ge
   return v;
 }
 
+// TBM x TBN block tile, 4 waves in a 2 x 2 grid, each wave (TBM/2) x (TBN/2) = TM x TN MFMA tiles: per 32-wide k-step a
+// wave reads TM + TN fragments from LDS for TM*TN MFMAs.  64x64 (2+2 reads per 4 MFMAs) is LDS-read-bound; 128x64 and
+// 128x128 (4+4 per 16) are not, but need M*N large enough to fill 256 CUs: launch_gemm_mfma picks per shape.  The k order
+// per output element is the same for every tile shape, so all variants (and the naive twin) round identically.
+template <int TBM, int TBN>
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDS_STRIDE];
+  constexpr int TM = TBM / 32, TN = TBN / 32;      // MFMA tiles per wave
+  constexpr int AI = TBM / 32, WI = TBN / 32;      // 16-byte staging chunks per thread per operand
+  __shared__ __attribute__((aligned(16))) bf16_t As[TBM * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[TBN * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware block -> tile map: consecutive block ids go round-robin over the 8 XCDs (each with its own L2), so
+  // the MB row-blocks that share one W tile are given ids with the same id % 8, adjacent in that XCD's dispatch order:
+  // the W tile is fetched from HBM once and re-used from that XCD's L2 (prefill: M = 243 -> 4 row-blocks; with the
+  // plain (n, m) grid every row-block re-read all weights: 4 x 13 GB per prefill).
+  const int MB = (a.M + TBM - 1) / TBM, NB = (a.N + TBN - 1) / TBN;
+  const int b = blockIdx.x;
+  const int nt = (b & 7) + 8 * ((b >> 3) / MB), mb = (b >> 3) % MB;
+  if (nt >= NB) return;
+  const int m0 = mb * TBM, n0 = nt * TBN;
 
-  // staging map: thread -> (row, 16-byte chunk); two rows per thread per operand
+  // staging map: thread -> (row, 16-byte chunk); rows srow + 32*i
   const int srow = tid >> 3;  // 0..31
   const int schk = tid & 7;   // 0..7 (8 bf16 each)
   const int K = a.K;
 
-  const bf16_t* Ag[2];
-  const bf16_t* Wg[2];
+  const bf16_t* Ag[AI];
+  const bf16_t* Wg[WI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < AI; ++i) {
     int am = m0 + srow + 32 * i; if (am >= a.M) am = a.M - 1;
-    int wn = n0 + srow + 32 * i; if (wn >= a.N) wn = a.N - 1;
     Ag[i] = a.A + (size_t)am * a.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int wn = n0 + srow + 32 * i; if (wn >= a.N) wn = a.N - 1;
     Wg[i] = a.W + (size_t)wn * a.ldw;
   }
 
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[2], rw[2];
+  u32x4 ra[AI], rw[WI];
   auto stage_load = [&](int k0) {
     const int k = k0 + schk * 8;
     const bool ok = k < K;  // K % 8 == 0: a chunk is fully in or fully out
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ra[i] = ok ? *reinterpret_cast<const u32x4*>(Ag[i] + k) : z;
-      rw[i] = ok ? *reinterpret_cast<const u32x4*>(Wg[i] + k) : z;
-    }
+    for (int i = 0; i < AI; ++i) ra[i] = ok ? *reinterpret_cast<const u32x4*>(Ag[i] + k) : z;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) rw[i] = ok ? *reinterpret_cast<const u32x4*>(Wg[i] + k) : z;
   };
   auto stage_write = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = ra[i];
-      *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = rw[i];
-    }
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = rw[i];
   };
 
   const int nk = (K + BK - 1) / BK;
@@ -88,39 +104,54 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
     if (t + 1 < nk) stage_load((t + 1) * BK);  // in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[2], bfr[2];
+      bf16x8_t af[TM], bfr[TN];
       const int kk = ks * 32 + (lane >> 4) * 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(
-            &As[(wr * 32 + i * 16 + (lane & 15)) * LDS_STRIDE + kk]);
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(
-            &Bs[(wc * 32 + i * 16 + (lane & 15)) * LDS_STRIDE + kk]);
-      }
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wr * (TBM / 2) + i * 16 + (lane & 15)) * LDS_STRIDE + kk]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wc * (TBN / 2) + j * 16 + (lane & 15)) * LDS_STRIDE + kk]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
-        const int n = n0 + wc * 32 + j * 16 + (lane & 15);
+        const int m = m0 + wr * (TBM / 2) + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wc * (TBN / 2) + j * 16 + (lane & 15);
         if (m < a.M && n < a.N)
           a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
       }
 }
 
+static int g_gemm_tile = -1;   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (dtk_set_option "gemm_tile" / DTK_GEMM_TILE)
+void set_gemm_tile(int v) { g_gemm_tile = v; }
+static int gemm_tile_override() {
+  if (g_gemm_tile < 0) {
+    const char* e = getenv("DTK_GEMM_TILE");
+    g_gemm_tile = !e ? 0 : (!strcmp(e, "64x64") ? 1 : (!strcmp(e, "128x64") ? 2 : (!strcmp(e, "128x128") ? 3 : 0)));
+  }
+  return g_gemm_tile;
+}
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-  hipLaunchKernelGGL(k_gemm_mfma, grid, dim3(256), 0, s, a);
+  auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  int tile = gemm_tile_override();
+  if (!tile) tile = 1;   // measured (ds-7b, M = 243 / 729): 64x64 17.1 / 4.6 ms, 128x64 18.7 / 5.5, 128x128 22.6 / 7.1 —
+                         // these GEMMs are latency- and tile-count-bound, not LDS-read-bound; the big tiles stay selectable
+  (void)blocks;
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
+  if (tile == 3) hipLaunchKernelGGL((k_gemm_mfma<128, 128>), grid(128, 128), dim3(256), 0, s, a);
+  else if (tile == 2) hipLaunchKernelGGL((k_gemm_mfma<128, 64>), grid(128, 64), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_gemm_mfma<64, 64>), grid(64, 64), dim3(256), 0, s, a);
 }
 
 // Plain one-thread-per-output GEMM: the obviously-correct twin of k_gemm_mfma (selected

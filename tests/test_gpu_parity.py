@@ -117,6 +117,31 @@ def test_op_gemm(tiny, M, N, K, flags, naive):
     assert rl2 < 1e-3 and ulps <= 2.01 and frac < 0.05
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(243, 512, 432, 5), (729, 400, 304, 3), (130, 77 * 8, 688, 0), (300, 1000, 1152, 1)])
+def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
+    """the 64x64 / 128x64 / 128x128 block tiles of k_gemm_mfma (chosen per shape by block count) keep the k order per
+    output element, so they agree bit for bit with each other and with the naive one-thread-per-output twin"""
+    from detikzify_amd import _lib
+    model, _ = tiny
+    g = torch.Generator().manual_seed(M + N + K)
+    A = rb(torch.randn(M, K, generator=g)); W = rb(torch.randn(N, K, generator=g) * 0.05)
+    b = rb(torch.randn(N, generator=g) * 0.1); R = rb(torch.randn(M, N, generator=g))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    Ab, Wb, bb, Rb = bf16_bits(A), bf16_bits(W), bf16_bits(b), bf16_bits(R)
+    outs = {}
+    for tile in (1, 2, 3, "naive"):
+        out = np.empty((M, N), dtype=np.uint16)
+        if tile != "naive":
+            model.set_option("gemm_tile", tile)
+        model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K,
+                                           flags | (_lib.DTK_GEMM_NAIVE if tile == "naive" else 0), p(out)), "dtk_op_gemm")
+        outs[tile] = out
+    model.set_option("gemm_tile", 0)
+    assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[3])
+    frac = float((outs[1] != outs["naive"]).mean())
+    assert frac < 2e-3     # fmaf chain vs MFMA tree inside a 32-wide k-step: rare 1-ulp flips only
+
+
 @pytest.mark.parametrize("N,K,mode", [(512, 256, 0), (256, 688, 0), (100, 2048, 1), (37, 4096, 1), (2048, 5504, 0)])
 def test_op_gemv(tiny, N, K, mode):
     model, _ = tiny
@@ -251,7 +276,7 @@ def test_bad_image_token_layout_raises(tiny):
 def run_greedy(model, ids, px, n, graph=1, **kw):
     model.set_graph_mode(graph)
     out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=n,
-                         bad_words_ids=[[1]], begin_suppress_tokens=[2], eos_token_id=-1, **kw)
+                         bad_words_ids=[[model.config.image_token_id]], begin_suppress_tokens=[2], eos_token_id=-1, **kw)
     model.set_graph_mode(1)
     return out[0, ids.numel():].tolist()
 
@@ -406,7 +431,7 @@ def test_pipeline_end_to_end_with_selfsim(tiny):
 
 
 # ------------------------------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("name", ["detikzify-ds-1.3b", "detikzify-ds-7b"])
+@pytest.mark.parametrize("name", ["detikzify-ds-1.3b", "detikzify-ds-7b", "detikzify-v2-8b"])
 def test_full_size_incremental_equals_batched(name):
     """BASELINE-size models, size-independent properties (no CPU oracle at this scale):
     (1) logits after prefill(T) == logits after prefill(T-1) + one decode step (batched MFMA path vs
@@ -418,7 +443,7 @@ def test_full_size_incremental_equals_batched(name):
     try:
         enc = proc(images=sketch_image(0, 224), return_tensors="pt")
         ids, px = enc.input_ids[0], enc.pixel_values
-        assert ids.numel() == 243
+        assert ids.numel() == model.config.num_patches == (300 if "v2" in name else 243)
         toks = run_greedy(model, ids, px, 24, graph=1)
         toks2 = run_greedy(model, ids, px, 24, graph=0)
         assert toks == toks2 and model.config.image_token_id not in toks
@@ -969,3 +994,66 @@ def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
     out = m32.decode_batch_wait()
     assert out[20] == -1 and out[0] >= 0 and out[17] >= 0 and out[31] >= 0
     assert torch.equal(m32.get_logits_slot(20), before) and m32.context_len_slot(20) == prompts[20].numel() + n
+
+
+# ------------------------------------------------------------------------------------------ edge cases of the boundary
+def test_context_limits_and_call_order_errors(tiny, tiny_oracle):
+    """maximum sizes and misuse: the library reports instead of corrupting memory (dtk.h error codes)"""
+    from detikzify_amd._lib import DtkError
+    from detikzify_amd.model import load
+    model, proc = tiny
+    enc = proc(images=sketch_image(1, 96), return_tensors="pt")
+    ids, px = enc.input_ids[0], enc.pixel_values
+    T = TINY.max_positions
+    # (1) generate() stops exactly at max_positions tokens (HF max_length criterion) and the context is then full
+    model.set_graph_mode(1)
+    out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_length=10 ** 6, bad_words_ids=[[1]],
+                         eos_token_id=-1)
+    assert out.shape[1] == T and model.context_len() <= T
+    # (2) the prompt may fill the whole context (no room to decode) ...
+    full = torch.cat([ids, torch.randint(3, TINY.vocab, (T - ids.numel(),), generator=torch.Generator().manual_seed(1))])
+    lo = model.prefill(full, px, return_logits=True)
+    ref = tiny_oracle.prefill(full, px[0])
+    assert rel_l2(lo, ref) < 1.5e-2 and model.context_len() == T
+    with pytest.raises(DtkError, match=r"\(-4\)"):
+        model.decode_launch()                     # DTK_ERR_RANGE
+    # ... but not exceed it
+    with pytest.raises(DtkError):
+        model.prefill(torch.cat([full, torch.tensor([7])]), px)
+    # (3) empty prompt, out-of-range token ids
+    with pytest.raises(DtkError):
+        model.prefill(torch.zeros(0, dtype=torch.int64), None)
+    with pytest.raises(DtkError):
+        model.prefill(torch.tensor([5, TINY.vocab + 3]), None)
+    # (4) a fresh context: decode / logits before any prefill -> DTK_ERR_STATE
+    fresh, _ = load("detikzify-tiny", synthetic=1, batch_slots=2)
+    with pytest.raises(DtkError, match=r"\(-3\)"):
+        fresh.decode_launch()
+    with pytest.raises(DtkError):
+        fresh.decode_batch_launch([0])
+    with pytest.raises(DtkError):
+        fresh.kv_fork(0, 1, 4)                    # nothing cached in the source slot
+    with pytest.raises(DtkError):
+        fresh.decode_batch_launch([5])            # slot out of range
+    with pytest.raises(DtkError):
+        fresh.set_option("no_such_option", 1)
+    with pytest.raises(KeyError):
+        fresh.read_tensor("model.layers.99.mlp.up_proj.weight")
+    # (5) a single text token prompt (T = 1 prefill takes the batched path with one row)
+    one = model.prefill(torch.tensor([9]), None, return_logits=True)
+    assert rel_l2(one, tiny_oracle.prefill(torch.tensor([9]), None)) < 1e-2
+
+
+def test_degenerate_sampling_settings_reduce_to_greedy(tiny):
+    """top_k = 1, top_p -> 0 and temperature -> 0+ all leave exactly the arg-max token (HF processors: TopK keeps the best,
+    TopP always keeps at least one token); the draw must then equal greedy for every seed"""
+    model, proc = tiny
+    enc = proc(images=sketch_image(7, 96), return_tensors="pt")
+    ids, px = enc.input_ids[0], enc.pixel_values
+    greedy = run_greedy(model, ids, px, 24)
+    for kw in (dict(top_k=1, temperature=0.8, top_p=1.0), dict(top_k=0, temperature=0.8, top_p=1e-6),
+               dict(top_k=0, temperature=1e-4, top_p=1.0), dict(top_k=1, temperature=1.3, top_p=0.5)):
+        for seed in (0, 12345):
+            out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=True, max_new_tokens=24, seed=seed,
+                                 bad_words_ids=[[1]], begin_suppress_tokens=[2], eos_token_id=-1, **kw)
+            assert out[0, ids.numel():].tolist() == greedy, (kw, seed)
