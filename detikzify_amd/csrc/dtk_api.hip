@@ -1338,6 +1338,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..3");
     set_gemm_tile(value);
   }
+  else if (!strcmp(name, "gemm_stages")) {
+    if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_stages must be 1..4");
+    set_gemm_stages(value);
+  }
   else if (!strcmp(name, "attn_impl")) {   // prefill / ViT attention: 0 auto, 1 VALU kernel, 2 MFMA flash kernel
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_impl must be 0..2");
     c->attn_impl = value;

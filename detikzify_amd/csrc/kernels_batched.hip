@@ -36,7 +36,7 @@ __device__ __forceinline__ float gemm_epilogue(float acc, int m, int n, const Ge
 // wave reads TM + TN fragments from LDS for TM*TN MFMAs.  64x64 (2+2 reads per 4 MFMAs) is LDS-read-bound; 128x64 and
 // 128x128 (4+4 per 16) are not, but need M*N large enough to fill 256 CUs: launch_gemm_mfma picks per shape.  The k order
 // per output element is the same for every tile shape, so all variants (and the naive twin) round identically.
-template <int TBM, int TBN>
+template <int TBM, int TBN, int D = 1>   // D = k-tiles of global loads kept in flight in registers
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
   constexpr int TM = TBM / 32, TN = TBN / 32;      // MFMA tiles per wave
   constexpr int AI = TBM / 32, WI = TBN / 32;      // 16-byte staging chunks per thread per operand
@@ -78,45 +78,55 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[AI], rw[WI];
-  auto stage_load = [&](int k0) {
+  // D register stages: the loads of k-tile t + D are issued as soon as stage t % D has been written to LDS, so D tiles
+  // of global-load latency overlap with the MFMAs (shapes with few blocks per CU — N = d GEMMs of the prefill, the
+  // N = 1152 GEMMs of the ViT — have nothing else to hide that latency behind).
+  u32x4 ra[D][AI], rw[D][WI];
+  auto stage_load = [&](u32x4 (&pa)[AI], u32x4 (&pw)[WI], int k0) {
     const int k = k0 + schk * 8;
     const bool ok = k < K;  // K % 8 == 0: a chunk is fully in or fully out
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = ok ? *reinterpret_cast<const u32x4*>(Ag[i] + k) : z;
+    for (int i = 0; i < AI; ++i) pa[i] = ok ? *reinterpret_cast<const u32x4*>(Ag[i] + k) : z;
 #pragma unroll
-    for (int i = 0; i < WI; ++i) rw[i] = ok ? *reinterpret_cast<const u32x4*>(Wg[i] + k) : z;
+    for (int i = 0; i < WI; ++i) pw[i] = ok ? *reinterpret_cast<const u32x4*>(Wg[i] + k) : z;
   };
-  auto stage_write = [&]() {
+  auto stage_write = [&](const u32x4 (&pa)[AI], const u32x4 (&pw)[WI]) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = ra[i];
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = pa[i];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = rw[i];
+    for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = pw[i];
   };
 
   const int nk = (K + BK - 1) / BK;
-  stage_load(0);
-  for (int t = 0; t < nk; ++t) {
-    __syncthreads();  // previous tile's fragment reads are done
-    stage_write();
-    __syncthreads();
-    if (t + 1 < nk) stage_load((t + 1) * BK);  // in flight under the MFMAs below
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[TM], bfr[TN];
-      const int kk = ks * 32 + (lane >> 4) * 8;
+  for (int d = 0; d < D; ++d)
+    if (d < nk) stage_load(ra[d], rw[d], d * BK);
+  for (int t0 = 0; t0 < nk; t0 += D) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wr * (TBM / 2) + i * 16 + (lane & 15)) * LDS_STRIDE + kk]);
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      if (t >= nk) break;
+      __syncthreads();  // previous tile's fragment reads are done
+      stage_write(ra[d], rw[d]);
+      __syncthreads();
+      if (t + D < nk) stage_load(ra[d], rw[d], (t + D) * BK);  // in flight under the next D tiles of MFMAs
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wc * (TBN / 2) + j * 16 + (lane & 15)) * LDS_STRIDE + kk]);
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[TM], bfr[TN];
+        const int kk = ks * 32 + (lane >> 4) * 8;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wr * (TBM / 2) + i * 16 + (lane & 15)) * LDS_STRIDE + kk]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          bfr[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wc * (TBN / 2) + j * 16 + (lane & 15)) * LDS_STRIDE + kk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -133,6 +143,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
       }
 }
 
+static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
+void set_gemm_stages(int v) { g_gemm_stages = v; }
 static int g_gemm_tile = -1;   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (dtk_set_option "gemm_tile" / DTK_GEMM_TILE)
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 static int gemm_tile_override() {
@@ -151,7 +163,15 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
   if (tile == 3) hipLaunchKernelGGL((k_gemm_mfma<128, 128>), grid(128, 128), dim3(256), 0, s, a);
   else if (tile == 2) hipLaunchKernelGGL((k_gemm_mfma<128, 64>), grid(128, 64), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_gemm_mfma<64, 64>), grid(64, 64), dim3(256), 0, s, a);
+  else {
+    if (g_gemm_stages < 0) { const char* e = getenv("DTK_GEMM_STAGES"); g_gemm_stages = e ? atoi(e) : 3; }
+    switch (g_gemm_stages) {
+      case 1: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 1>), grid(64, 64), dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 2>), grid(64, 64), dim3(256), 0, s, a); break;
+      case 4: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 4>), grid(64, 64), dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 3>), grid(64, 64), dim3(256), 0, s, a); break;
+    }
+  }
 }
 
 // Plain one-thread-per-output GEMM: the obviously-correct twin of k_gemm_mfma (selected
