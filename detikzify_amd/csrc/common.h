@@ -70,6 +70,11 @@ struct BatchState {
   int32_t active[DTK_MAX_BATCH];
   int32_t step;      // global step counter (token ring index)
   int32_t pad[15];
+  // forked slots (dtk_kv_fork) hold a bit-identical copy of their source's first share_len keys: attention reads those
+  // rows from the SOURCE slot's cache instead (-1 = none), so the 32 rollouts of one image stream the 243-key image
+  // prefix from HBM once per layer and hit the XCD's L2 afterwards
+  int32_t share_src[DTK_MAX_BATCH];
+  int32_t share_len[DTK_MAX_BATCH];
 };
 
 // Batched decode keeps the GEMV INPUT vectors (normalised x, attention output, SwiGLU activation) of the slots in

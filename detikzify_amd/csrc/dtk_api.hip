@@ -41,6 +41,9 @@ struct SeqHost {   // host-side mirror of one sequence's decode state
   bool cached_with_image = false;  // the cached KV was computed with image features spliced in
   int host_next_pos = 0;           // tokens with KV after all launched steps
   bool have_logits = false;
+  int share_src = -1;              // slot whose first share_len cached tokens are bit-identical to ours (dtk_kv_fork), or -1
+  int share_len = 0;
+  int last_reuse_start = 0;        // tokens of the previous cache the last prefill kept
 };
 
 struct LayerW {
@@ -117,6 +120,7 @@ struct dtk_ctx {
   int KVH = 0;                       // key/value heads (dtk_config.reserved[2]; 0 -> heads)
   bool proj_bias = true;             // mm_projector has a bias (v1) / bias-free connector (v2)
   int nb = 0;                        // number of batch slots (dtk_config.reserved[0])
+  bool share_reads = true;           // forked slots read their shared prefix from the source slot (dtk_set_option "share_prefix_reads")
   int nt = 1;                        // 16-slot column tiles of the batched kernels (2 when nb > 17)
   std::vector<SeqHost> bseq;
   bf16_t* kvb = nullptr;             // [nb][L][2][H][Tmax][128]
@@ -968,6 +972,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   }
   // KV computed with / without spliced image features never mixes
   if (has_img && sh.cached_with_image != use_img) start = 0;
+  sh.last_reuse_start = start;
   const int n = T - start;
   std::vector<int32_t> ids32((size_t)n);
   for (int t = 0; t < n; ++t) ids32[(size_t)t] = (int32_t)ids[start + t];
@@ -1030,8 +1035,17 @@ int dtk_prefill(dtk_ctx* c, const int64_t* ids, int T, const float* pixels, uint
 
 int dtk_prefill_slot(dtk_ctx* c, int slot, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags, float* logits_out) {
   if (!c || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_prefill_slot: slot %d of %d", slot, c ? c->nb : 0);
-  return prefill_impl(c, c->bseq[(size_t)slot], c->kvb + (size_t)slot * c->kv_slot_stride, c->logits_b + (size_t)slot * c->V,
-                      c->st_b + slot, false, ids, T, pixels, image_key, flags, logits_out);
+  SeqHost& sh = c->bseq[(size_t)slot];
+  sh.last_reuse_start = 0;
+  const int rc = prefill_impl(c, sh, c->kvb + (size_t)slot * c->kv_slot_stride, c->logits_b + (size_t)slot * c->V,
+                              c->st_b + slot, false, ids, T, pixels, image_key, flags, logits_out);
+  // positions >= kept of this slot were (or may have been) rewritten: shared-prefix reads stay valid only below that
+  const int kept = rc == DTK_OK ? sh.last_reuse_start : 0;
+  auto clip = [&](SeqHost& q) { q.share_len = std::min(q.share_len, kept); if (q.share_len <= 0) { q.share_src = -1; q.share_len = 0; } };
+  clip(sh);
+  for (int j = 0; j < c->nb; ++j)
+    if (j != slot && c->bseq[(size_t)j].share_src == slot) clip(c->bseq[(size_t)j]);
+  return rc;
 }
 
 static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp_dst, DecState* st_dst, bool is_single) {
@@ -1087,7 +1101,12 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   HIPCHK(c, hipSetDevice(c->device));
   ensure_tiled_weights(c);
   BatchState* hb = c->bs_host + (c->blaunched % DTK_MAX_INFLIGHT);
-  for (int j = 0; j < DTK_MAX_BATCH; ++j) hb->active[j] = active[j] ? 1 : 0;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) {
+    hb->active[j] = active[j] ? 1 : 0;
+    const bool sh_ok = c->share_reads && j < c->nb && c->bseq[(size_t)j].share_src >= 0;
+    hb->share_src[j] = sh_ok ? c->bseq[(size_t)j].share_src : -1;
+    hb->share_len[j] = sh_ok ? c->bseq[(size_t)j].share_len : 0;
+  }
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
   HIPCHK(c, hipMemcpyAsync(c->bs_dev, hb, sizeof(BatchState), hipMemcpyHostToDevice, c->stream));
   if (c->use_graph) {
@@ -1148,6 +1167,12 @@ int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
   HIPCHK(c, hipMemcpy2DAsync(c->kvb + (size_t)dst * c->kv_slot_stride, pitch, c->kvb + (size_t)src * c->kv_slot_stride, pitch,
                              (size_t)n_tokens * 128 * 2, rows, hipMemcpyDeviceToDevice, c->stream));
   SeqHost& b = c->bseq[(size_t)dst];
+  for (int j = 0; j < c->nb; ++j)          // whoever read its prefix from dst must stop: dst is being overwritten
+    if (c->bseq[(size_t)j].share_src == dst) { c->bseq[(size_t)j].share_src = -1; c->bseq[(size_t)j].share_len = 0; }
+  // dst now holds a bit-identical copy of src[0, n): its attention may read those rows from src (or from src's own
+  // source when src itself is a fork covering them), so all forks of one prefix stream the same memory
+  if (a.share_src >= 0 && a.share_src != dst && n_tokens <= a.share_len) { b.share_src = a.share_src; b.share_len = n_tokens; }
+  else { b.share_src = src; b.share_len = n_tokens; }
   b.cached_ids.assign(a.cached_ids.begin(), a.cached_ids.begin() + n_tokens);
   b.cached_with_image = a.cached_with_image;
   b.host_next_pos = n_tokens;
@@ -1280,6 +1305,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
     if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
     ensure_tiled_weights(c);
     BatchState hb{}; for (int j = 0; j < c->nb; ++j) hb.active[j] = 1;
+    for (int j = 0; j < DTK_MAX_BATCH; ++j) hb.share_src[j] = -1;
     HIPCHK(c, hipMemcpy(c->bs_dev, &hb, sizeof hb, hipMemcpyHostToDevice));
     auto pass = [&]() {
       for (int l = 0; l < c->L; ++l) {
@@ -1338,6 +1364,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..3");
     set_gemm_tile(value);
   }
+  else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;
   else if (!strcmp(name, "gemm_stages")) {
     if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_stages must be 1..4");
     set_gemm_stages(value);

@@ -307,6 +307,10 @@ __global__ __launch_bounds__(256) void k_attn_decode_b(AttnDecBArgs a) {
   const int kvh = h / a.G;
   const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  // shared prefix (BatchState): rows j < slen come from the source slot's cache (identical bits, one HBM stream for all forks)
+  const int ssrc = a.bs->share_src[slot];
+  const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
+  const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;   // wraps consistently (size_t)
   float m = -1e30f, l = 0.f;
   float o[8];
 #pragma unroll
@@ -319,8 +323,9 @@ __global__ __launch_bounds__(256) void k_attn_decode_b(AttnDecBArgs a) {
       const int j = j0 + i * 16 + wave * 4 + grp;
       ok[i] = j < j_end;
       const int jj = ok[i] ? j : j_begin;
-      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)jj * 128)[sub];
-      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)jj * 128)[sub];
+      const size_t off = (size_t)jj * 128 + (jj < slen ? sdelta : (size_t)0);
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + off)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + off)[sub];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

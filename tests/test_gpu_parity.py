@@ -1057,3 +1057,43 @@ def test_degenerate_sampling_settings_reduce_to_greedy(tiny):
             out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=True, max_new_tokens=24, seed=seed,
                                  bad_words_ids=[[1]], begin_suppress_tokens=[2], eos_token_id=-1, **kw)
             assert out[0, ids.numel():].tolist() == greedy, (kw, seed)
+
+
+def test_shared_prefix_reads_are_invisible_and_invalidate_correctly(tiny_batched):
+    """forked slots read their common prefix keys from the SOURCE slot's cache (one HBM stream for all rollouts of an
+    image).  (1) same tokens and logits with the optimisation off; (2) overwriting the source (new image in the prefix
+    slot, or a fork into it) must stop the dependents from reading it — they fall back to their own identical copy."""
+    model, proc = tiny_batched
+    (ids, px), (ids_b, px_b), _ = _batch_prompts(proc)
+    n = 20
+
+    def run(share, clobber):
+        model.set_option("share_prefix_reads", share)
+        model.set_sampling(do_sample=False, bad_ids=[1], slot=4)
+        model.prefill(ids, px, slot=4)                                   # slot 4 plays the prefix cache
+        for sl, seed in ((0, 11), (1, 12), (2, 13)):
+            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=seed, bad_ids=[1], begin_suppress_ids=[2], slot=sl)
+            model.kv_fork(4, sl, ids.numel())
+        model.kv_fork(0, 3, ids.numel())                                 # fork of a fork: chains to the root source
+        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=11, bad_ids=[1], begin_suppress_ids=[2], slot=3)
+        model.kv_fork(0, 3, ids.numel())
+        toks = [[] for _ in range(4)]
+        for step in range(n):
+            if clobber and step == 5:
+                model.prefill(ids_b, px_b, slot=4)                       # a different image lands in the prefix slot
+            if clobber and step == 9:
+                model.kv_fork(1, 4, 6)                                   # ... and then a fork overwrites it again
+            model.decode_batch_launch([0, 1, 2, 3])
+            out = model.decode_batch_wait()
+            for sl in range(4):
+                toks[sl].append(out[sl])
+        logits = [model.get_logits_slot(sl).clone() for sl in range(4)]
+        model.set_option("share_prefix_reads", 1)
+        return toks, logits
+
+    ref_t, ref_l = run(0, False)
+    assert ref_t[3] == ref_t[0]                                          # same prompt, same seed
+    for share, clobber in ((1, False), (1, True), (0, True)):
+        t, l = run(share, clobber)
+        assert t == ref_t, (share, clobber)
+        assert all(torch.equal(a, b) for a, b in zip(l, ref_l)), (share, clobber)
