@@ -43,7 +43,7 @@ __device__ __forceinline__ bf16x8_t f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
 // fed to the same bf16 MFMA in the same k order, the per-row power-of-two scale multiplies the reduced fp32
 // sum — bit-identical to the bf16 kernel on the de-quantised weights.
 // NT = 16-slot column tiles (1: up to 16 slots, 2: up to 32): the A (weight) fragment of a k-step is reused by NT MFMAs
-template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES, int NT = 1>
+template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES, int NT = 1, int KS = 4>   // KS = k-steps per register stage
 __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
   __shared__ float red[WAVES][T][NT][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
   // A stage = 4 k-steps of weights + x fragments in registers.
   // fp8: the same K slice [s0, s1) as the bf16 kernel; a pair tile that straddles a slice boundary is loaded by
   // both neighbours and the foreign k-step is masked (x fragment = 0), so the k order per accumulator is the same.
-  constexpr int U = F8 ? 2 : 4;   // tiles per stage
-  constexpr int XN = 4;           // x fragments (k-steps) per stage
+  constexpr int U = F8 ? KS / 2 : KS;   // tiles per stage
+  constexpr int XN = KS;                // x fragments (k-steps) per stage
   const int u0 = F8 ? (s0 >> 1) : s0, u1 = F8 ? ((s1 + 1) >> 1) : s1;
   auto load = [&](u32x4 (&w)[T][U], u32x4 (&x)[XN][NT], int u) {
 #pragma unroll
@@ -240,7 +240,13 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
   } else if (epi == EPI_SWIGLU) {
     hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8, GB_WAVES, NT>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_RESID) {
+    // N = d: only N/16 = 256 blocks of one 16-row tile.  Measured: 8 k-steps per stage (DTK_GB_RESID_KS=8) or 16 waves
+    // (DTK_GB_RESID_WAVES=16) change nothing (within 1-2 %) — with T = 1 these kernels read 2 KiB of x fragments from L2
+    // per KiB of weights at 32 slots, which is what bounds them (o_proj 9.3 us, down 26.8 us at B = 32)
+    static int ks = 0;
+    if (!ks) { const char* e = getenv("DTK_GB_RESID_KS"); ks = (e && atoi(e) == 8) ? 8 : 4; }
     if (resid_waves() == 16) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
+    else if (ks == 8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT, 8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_LOGITS) {
     hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
