@@ -39,6 +39,7 @@ struct TensorEntry {
 struct SeqHost {   // host-side mirror of one sequence's decode state
   std::vector<int64_t> cached_ids;
   bool cached_with_image = false;  // the cached KV was computed with image features spliced in
+  uint64_t image_key = 0;          // ... of the image with this caller-supplied key (0 = unknown: never reused across images)
   int host_next_pos = 0;           // tokens with KV after all launched steps
   bool have_logits = false;
   int share_src = -1;              // slot whose first share_len cached tokens are bit-identical to ours (dtk_kv_fork), or -1
@@ -948,8 +949,17 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
         return fail(c, DTK_ERR_ARG, "The image patch tokens should be consecutive.");
   }
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-  bool image_changed = false;
-  if (use_img) {
+  // ---- longest common prefix with the cached sequence (output-identical KV reuse).  The KV of the image positions
+  // depends on the image, not on the (all equal) placeholder ids: the cached sequence must have been computed with the
+  // same image key, and with / without spliced image features never mixes.
+  int start = 0;
+  const bool same_image = !has_img || (sh.cached_with_image == use_img && (!use_img || (image_key != 0 && sh.image_key == image_key)));
+  if ((flags & DTK_PREFILL_REUSE_PREFIX) && same_image && !sh.cached_ids.empty()) {
+    const int lim = (int)std::min<size_t>(sh.cached_ids.size(), (size_t)T - 1);
+    while (start < lim && sh.cached_ids[start] == ids[start]) ++start;
+  }
+  // ---- image features are needed only if an image position has to be recomputed
+  if (use_img && start < img_start + c->nImg) {
     const bool reuse = (flags & DTK_PREFILL_REUSE_IMAGE) && c->have_image && c->cached_image_key == image_key;
     if (!reuse) {
       if (!pixels) return fail(c, DTK_ERR_ARG, "pixels required (no cached image for this key)");
@@ -960,18 +970,9 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
       c->stats.vit_images++;
       c->have_image = true;
       c->cached_image_key = image_key;
-      image_changed = true;
     }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
-  // ---- longest common prefix with the cached sequence (output-identical KV reuse)
-  int start = 0;
-  if ((flags & DTK_PREFILL_REUSE_PREFIX) && !image_changed && !sh.cached_ids.empty()) {
-    const int lim = (int)std::min<size_t>(sh.cached_ids.size(), (size_t)T - 1);
-    while (start < lim && sh.cached_ids[start] == ids[start]) ++start;
-  }
-  // KV computed with / without spliced image features never mixes
-  if (has_img && sh.cached_with_image != use_img) start = 0;
   sh.last_reuse_start = start;
   const int n = T - start;
   std::vector<int32_t> ids32((size_t)n);
@@ -1022,6 +1023,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   c->stats.prefill_tokens += (uint64_t)n;
   sh.cached_ids.assign(ids, ids + T);
   sh.cached_with_image = use_img;
+  sh.image_key = use_img ? image_key : 0;
   sh.host_next_pos = T;
   sh.have_logits = true;
   // a new prefill starts a new generation: reset the draw counter of the sampler
@@ -1175,6 +1177,7 @@ int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
   else { b.share_src = src; b.share_len = n_tokens; }
   b.cached_ids.assign(a.cached_ids.begin(), a.cached_ids.begin() + n_tokens);
   b.cached_with_image = a.cached_with_image;
+  b.image_key = a.image_key;
   b.host_next_pos = n_tokens;
   b.have_logits = false;
   // a fork of the WHOLE source sequence also inherits its next-token logits: the destination can decode at

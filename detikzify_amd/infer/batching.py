@@ -55,6 +55,9 @@ class BatchEngine:
         self.prefix_slot = n - 1 if self.share_prefix else None
         self.prefix_key = None
         self.prefix_ids = None
+        self.slot_img: Dict[int, Tuple[int, int]] = {}      # slot -> (image key, prefix length) whose KV prefix it still holds
+        self.inplace_reuses = 0                              # joins that found their image prefix already in their slot
+        self.prefix_encodes = 0                              # ViT + prefix prefills run for the prefix cache (diagnostics)
         self.capacity = min(dec - (1 if self.share_prefix and n <= maxdec else 0), max_batch or dec)
         self.pipeline = pipeline
         self.cv = threading.Condition()
@@ -91,18 +94,28 @@ class BatchEngine:
 
     @contextmanager
     def sequence(self, ids, pixel_values, sampling: Dict[str, Any]) -> Iterator[_Sequence]:
+        want = self._prefix_key(ids, pixel_values) if (self.share_prefix and pixel_values is not None) else None
         with self.cv:
             while not self.free:
                 self.cv.wait()
-            slot = self.free.pop()
+            # slot choice: a free slot that holds no prefix worth keeping; else one that already holds THIS image's prefix
+            # (re-used in place); else evict the prefix of some other image
+            slot = next((f for f in reversed(self.free) if f not in self.slot_img), None)
+            if slot is None and want is not None:
+                slot = next((f for f in reversed(self.free) if self.slot_img.get(f) == want), None)
+            if slot is None:
+                slot = self.free[-1]
+            self.free.remove(slot)
         joined = False
         try:
             with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
                 self._collect()     # a prefill drops un-collected steps on the C side: collect first
                 t0 = time.perf_counter()
                 self.model.set_sampling(slot=slot, **sampling)
-                forked = self.share_prefix and pixel_values is not None and self._fork_prefix(slot, ids, pixel_values)
-                if forked and ids.numel() == self.prefix_ids.numel():
+                forked = self._fork_prefix(slot, ids, pixel_values, want) if want is not None else 0
+                if want is None:
+                    self.slot_img.pop(slot, None)
+                if forked == 2:
                     pass    # the prompt IS the prefix (rollout from the root): KV and logits were forked, nothing to run
                 elif forked:
                     self.model.prefill(ids, pixel_values, slot=slot, reuse=True)    # only the tail beyond the prefix
@@ -134,19 +147,38 @@ class BatchEngine:
                 self.cv.notify_all()   # a slot may have become free
 
     # -- called with self.cv held ---------------------------------------------------------------------
-    def _fork_prefix(self, slot: int, ids, pixel_values) -> bool:
+    def _prefix_key(self, ids, pixel_values):
+        """(image key, prefix length) if the prompt starts with its image-token run, else None"""
         tok = self.model.config.image_token_id
         ids = ids.reshape(-1)
         n_img = int((ids == tok).sum())
         if n_img == 0 or not bool((ids[:n_img] == tok).all()):
-            return False                      # the image run is not a leading prefix: no sharing
-        key = self.model.image_key(pixel_values)
-        if self.prefix_key != key or self.prefix_ids is None or self.prefix_ids.numel() != n_img:
+            return None                       # the image run is not a leading prefix: no sharing
+        return (self.model.image_key(pixel_values), n_img)
+
+    def _fork_prefix(self, slot: int, ids, pixel_values, key) -> int:
+        """Give `slot` the KV of its image prefix without running ViT + prefill again.  Returns 1 (prefix KV in place: the
+        caller prefills what follows with reuse) or 2 (prefix == whole prompt and the next-token logits were forked too).
+        Sources, in order: the slot itself if it still holds this image's prefix from its previous sequence; the
+        prefix-cache slot if it holds this image; any other slot that still holds this image's prefix (several images in
+        flight: a batch of 8 images x 4 rollouts encodes each image once); otherwise the prefix-cache slot is re-encoded."""
+        ids = ids.reshape(-1)
+        n_img = key[1]
+        if self.slot_img.get(slot) == key:
+            self.inplace_reuses += 1
+            return 1                                        # in place: dtk_prefill_slot(REUSE_PREFIX) keeps the prefix rows
+        self.slot_img[slot] = key
+        if self.prefix_key != key:
+            donor = next((s for s, k in self.slot_img.items() if k == key and s != slot), None)
+            if donor is not None:
+                self.model.kv_fork(donor, slot, n_img)      # the donor has decoded past the prefix: no logits to inherit
+                return 1
             self.model.set_sampling(slot=self.prefix_slot, do_sample=False)
             self.model.prefill(ids[:n_img], pixel_values, slot=self.prefix_slot)
             self.prefix_key, self.prefix_ids = key, ids[:n_img].clone()
+            self.prefix_encodes += 1
         self.model.kv_fork(self.prefix_slot, slot, n_img)
-        return True
+        return 2 if ids.numel() == n_img else 1
 
     def _launch(self):
         # a slot whose context is full cannot take another (speculative) step; its sequence is at max_length

@@ -90,7 +90,8 @@ def test_engine_random_joins_and_leaves(pipeline):
     eng.close()
     assert sorted(eng.free) == [0, 1, 2, 3] and not eng.zombies and eng.inflight is None and not m.launched
     assert total[0] <= eng.tokens_out <= total[0] + 35      # a sequence may leave one delivered token unread
-    assert m.forks == 35 and m.prefills <= 36     # one prefix prefill (same image); tail prefills only for longer prompts
+    # one prefix prefill (same image); every join either forks the prefix or finds it in its slot already
+    assert m.forks + eng.inplace_reuses == 35 and eng.prefix_encodes == 1 and m.prefills <= 36 + eng.inplace_reuses
 
 
 def test_engine_respects_context_limit_and_errors():
@@ -109,3 +110,29 @@ def test_engine_respects_context_limit_and_errors():
             seq.next_token()
     with pytest.raises(ValueError):
         BatchEngine(_FakeModel(0))
+
+
+def test_engine_shares_prefixes_of_several_images_in_flight():
+    """8 images x 3 rollouts through a 9-slot engine (one prefix-cache slot): every image is encoded once; later rollouts
+    of an image fork the prefix KV from any slot that still holds it, not from a re-encoded prefix cache"""
+    m = _FakeModel(9)
+    eng = BatchEngine(m, max_batch=8)
+    errs = []
+
+    def worker(i):
+        try:
+            px = torch.full((1,), float(i % 8))                 # image id
+            with eng.sequence(torch.tensor([1, 1, 1, 7, 9]), px, {}) as seq:
+                got = [seq.next_token() for _ in range(6 + i % 3)]
+                assert [g % 1000 for g in got] == list(range(len(got)))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    for wave in range(3):                                       # 3 rollouts per image, 8 images at a time
+        ths = [threading.Thread(target=worker, args=(wave * 8 + j,)) for j in range(8)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert not any(t.is_alive() for t in ths) and not errs, errs[:1]
+    eng.close()
+    assert eng.prefix_encodes == 8, eng.prefix_encodes          # not 24: waves 2 and 3 find a donor slot per image
+    assert m.forks + eng.inplace_reuses == 24

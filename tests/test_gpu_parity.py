@@ -11,6 +11,7 @@ oracle on the same seeded inputs.  Tolerances are stated where they are used:
     greedy tokens identical except at documented near-ties.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import pytest
@@ -1097,3 +1098,38 @@ def test_shared_prefix_reads_are_invisible_and_invalidate_correctly(tiny_batched
         t, l = run(share, clobber)
         assert t == ref_t, (share, clobber)
         assert all(torch.equal(a, b) for a, b in zip(l, ref_l)), (share, clobber)
+
+
+def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched):
+    """every way a sequence can obtain its image prefix in the BatchEngine — encode into the prefix cache + fork (with
+    logits), fork from another slot that still holds the image, re-use in place, eviction by another image — yields exactly
+    the tokens of a plain model.generate of the same prompt and seed"""
+    from detikzify_amd.infer.batching import BatchEngine
+    model, proc = tiny_batched
+    (ids, px), (ids_b, px_b), (ids_c, px_c) = _batch_prompts(proc)
+    kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=12, bad_words_ids=[[1]],
+              begin_suppress_tokens=[2], eos_token_id=-1)
+    jobs = [(ids, px, 1), (ids, px, 2), (ids_b, px_b, 3), (ids, px, 4), (ids_c, px_c, 5), (ids_b, px_b, 6), (ids, px, 7),
+            (ids_c, px_c, 8), (ids_c, px_c, 9), (ids, px, 10)]
+    assert model.batch_engine is None
+    ref = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
+    for max_batch in (1, 2):          # 1: strictly sequential joins (in-place re-use, eviction); 2: donors among live slots
+        engine = BatchEngine(model, max_batch=max_batch)
+        try:
+            got = [None] * len(jobs)
+
+            def run(k):
+                i, p, s = jobs[k]
+                got[k] = model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist()
+            if max_batch == 1:
+                for k in range(len(jobs)):
+                    run(k)
+            else:
+                for k0 in range(0, len(jobs), 2):
+                    ths = [threading.Thread(target=run, args=(k,)) for k in range(k0, min(k0 + 2, len(jobs)))]
+                    [t.start() for t in ths]; [t.join(timeout=120) for t in ths]
+        finally:
+            engine.close()
+        assert got == ref, max_batch
+        print(f"engine max_batch={max_batch}: prefix encodes {engine.prefix_encodes}, in-place {engine.inplace_reuses}")
+        assert engine.prefix_encodes < len(jobs)
