@@ -48,6 +48,9 @@ def parse():
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
     ap.add_argument("--batch", type=int, default=32, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
+    ap.add_argument("--mcts-trees", type=int, default=0, help="optional extra phase: root-parallel MCTS (reference search logic per "
+                    "tree, SelfSim reward on the device ViT, LaTeX replaced by the synthetic renderer) with this many trees per GPU")
+    ap.add_argument("--mcts-expansions", type=int, default=3, help="rollouts per tree in the --mcts-trees phase")
     return ap.parse_args()
 
 
@@ -235,12 +238,44 @@ def main():
                                    "host_bound_steps": engine.host_bound_steps, **phases},
                 "decode": "sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), 512 tokens, EOS suppressed",
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
-                        "dtk_decode_batch step serves all of them; the 243-token image prefix is encoded once and its "
-                        "KV forked into each slot (bit-identical to a full prefill, SURVEY f1)"}
+                        f"dtk_decode_batch step serves all of them; the {T0}-token image prefix is encoded once, its KV "
+                        "forked into each slot (bit-identical to a full prefill, SURVEY f1) and read from one copy"}
         except Exception as e:
             result["batched_rollouts"] = {"error": repr(e)}
         finally:
             engine.close()
+
+    # ---- optional phase: the MCTS loop itself (detikzify_amd.infer: DetikzifyGenerator per tree, unchanged reference
+    # semantics), `trees` independent trees per GPU decoded as one batch, reward = SelfSim on the device ViT of the
+    # SYNTHETIC renderer's image (no TeX offline: stub-reward number, never to be mixed with real-LaTeX numbers)
+    if args.mcts_trees > 1 and args.batch > 1:
+        try:
+            from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
+            from detikzify_amd.infer.batching import simulate_parallel
+            from tests.helpers import sketch_image as _sk
+            trees = min(args.mcts_trees, args.batch)
+            pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument,
+                                     max_length=T0 + min(n_new, 256))
+            pipe.metric.cache_reference = True           # f1: the reference image's features are computed once
+            img = _sk(0, 224)
+            vit_before = model.stats()["vit_images"]
+            fence()
+            tm = time.perf_counter()
+            res = list(simulate_parallel(pipe, img, trees=trees, expansions_per_tree=args.mcts_expansions))
+            fence()
+            tm = time.perf_counter() - tm
+            if world > 1:
+                t = torch.tensor([tm], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tm = float(t.item())
+            result["mcts_stub_reward"] = {
+                "trees_per_gpu": trees, "expansions_per_tree": args.mcts_expansions, "rollouts": world * len(res),
+                "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "max_length": T0 + min(n_new, 256),
+                "vit_passes": model.stats()["vit_images"] - vit_before,
+                "reward": "SelfSim (device ViT) of SyntheticTikzDocument renderings; LaTeX absent offline",
+                "scores_min_max": [float(min(s for s, _ in res)), float(max(s for s, _ in res))] if res else None}
+        except Exception as e:
+            result["mcts_stub_reward"] = {"error": repr(e)}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)

@@ -159,12 +159,12 @@ class BatchEngine:
     def _fork_prefix(self, slot: int, ids, pixel_values, key) -> int:
         """Give `slot` the KV of its image prefix without running ViT + prefill again.  Returns 1 (prefix KV in place: the
         caller prefills what follows with reuse) or 2 (prefix == whole prompt and the next-token logits were forked too).
-        Sources, in order: the slot itself if it still holds this image's prefix from its previous sequence; the
-        prefix-cache slot if it holds this image; any other slot that still holds this image's prefix (several images in
+        Sources, in order: the prefix-cache slot if it holds this image (its fork also carries the logits); the slot itself
+        if it still holds this image's prefix from its previous sequence; any other slot that still holds this image's prefix (several images in
         flight: a batch of 8 images x 4 rollouts encodes each image once); otherwise the prefix-cache slot is re-encoded."""
         ids = ids.reshape(-1)
         n_img = key[1]
-        if self.slot_img.get(slot) == key:
+        if self.prefix_key != key and self.slot_img.get(slot) == key:
             self.inplace_reuses += 1
             return 1                                        # in place: dtk_prefill_slot(REUSE_PREFIX) keeps the prefix rows
         self.slot_img[slot] = key
