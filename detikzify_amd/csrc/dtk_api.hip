@@ -1329,11 +1329,22 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
     return DTK_OK;
   }
   const bool same_layer = (variant & 0x100) != 0;  // every launch re-reads layer 0 (Infinity Cache probe)
+  const int plain = (variant >> 9) & 3;            // 0x200: same weights through PRO_COPY + EPI_STORE; 0x400: PRO_RMSNORM + EPI_STORE
   variant &= 0xff;
   auto one_pass = [&]() {
     for (int l = 0; l < c->L; ++l) {
       const LayerW& w = c->layers[same_layer ? 0 : l];
       GemvArgs g{};
+      if (plain) {   // cost of the fused prologue / epilogue = full role - this
+        g.eps = c->cfg.rms_eps; g.y = c->GU;
+        if (role == 0) { g.W = w.wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; }
+        else if (role == 1) { g.W = w.wo; g.N = c->d; g.K = c->d; g.x = c->attn_out; g.norm_w = w.ln1; }
+        else if (role == 2) { g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; }
+        else if (role == 3) { g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.norm_w = w.ln2; }
+        else { g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm; }
+        launch_gemv_variant(plain == 2 ? PRO_RMSNORM : PRO_COPY, EPI_STORE, variant, g, s);
+        continue;
+      }
       g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
       g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
       if (role == 0) { g.W = w.wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch_gemv_variant(PRO_RMSNORM, EPI_QKV, variant, g, s); }

@@ -90,6 +90,59 @@ __device__ __forceinline__ void gemv_fma_f8(float (&acc)[NR], const u32x4 (&w)[N
   }
 }
 
+// Epilogue of one output unit (one lane per wave): `a0` is the fp32 dot product of the unit's row (paired epilogues:
+// a0 / a1 = the two rows of the pair: RoPE partners i, i+64 or gate, up).  Same HF rounding points as the reference.
+template <int EPI, bool F8>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0, float a1) {
+    if (F8) {  // per-output-channel power-of-two scale (exact)
+      if (EPI == EPI_QKV) {
+        const int r0 = (u >> 6) * 128 + (u & 63);
+        a0 *= a.wscale[r0];
+        a1 *= a.wscale[r0 + 64];
+      } else if (EPI == EPI_SWIGLU) {
+        a0 *= a.wscale[u];
+        a1 *= a.wscale[a.ff + u];
+      } else {
+        a0 *= a.wscale[u];
+      }
+    }
+    if (EPI == EPI_STORE) {
+      a.y[u] = f2bf(a0);
+    } else if (EPI == EPI_RESID) {
+      // HF: hidden = residual + proj(x); proj output is a bf16 tensor
+      a.y[u] = f2bf(bf2f(a.y[u]) + rbf(a0));
+    } else if (EPI == EPI_LOGITS) {
+      a.logits[u] = rbf(a0);  // lm_head output is bf16, then .float()
+    } else if (EPI == EPI_SWIGLU) {
+      const float gte = rbf(a0);
+      const float up = rbf(a1);
+      const float sl = rbf(gte / (1.f + expf(-gte)));
+      a.y[u] = f2bf(sl * up);
+    } else if (EPI == EPI_QKV) {
+      const int hb = u >> 6, i = u & 63;
+      const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+      const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
+      const int pos = a.st->pos;
+      const float x1 = rbf(a0);      // dim i
+      const float x2 = rbf(a1);  // dim i + 64
+      if (sec == 2) {
+        bf16_t* dst = a.vcache + ((size_t)head * a.T_max + pos) * 128;
+        dst[i] = f2bf(x1);
+        dst[i + 64] = f2bf(x2);
+      } else {
+        // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
+        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+        const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+        const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+        bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
+                                 : (a.kcache + ((size_t)head * a.T_max + pos) * 128);
+        dst[i] = f2bf(o1);
+        dst[i + 64] = f2bf(o2);
+      }
+    }
+}
+
 // R = output units per wave-chunk; paired epilogues (QKV, SWIGLU) stream 2 rows per unit.
 // WAVES = waves per block.  PERSIST: grid-stride over chunks (chunk c -> block c % grid,
 // wave (c / grid) % WAVES) so a grid sized to the machine covers any N with <= 1 chunk of
@@ -252,53 +305,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
       for (int j = 0; j < R; ++j) {
         const int u = cur + j;
         if (u >= n_units) break;
-        if (F8) {  // per-output-channel power-of-two scale (exact)
-          if (EPI == EPI_QKV) {
-            const int r0 = (u >> 6) * 128 + (u & 63);
-            acc[2 * j] *= a.wscale[r0];
-            acc[2 * j + 1] *= a.wscale[r0 + 64];
-          } else if (EPI == EPI_SWIGLU) {
-            acc[2 * j] *= a.wscale[u];
-            acc[2 * j + 1] *= a.wscale[a.ff + u];
-          } else {
-            acc[j] *= a.wscale[u];
-          }
-        }
-        if (EPI == EPI_STORE) {
-          a.y[u] = f2bf(acc[j]);
-        } else if (EPI == EPI_RESID) {
-          // HF: hidden = residual + proj(x); proj output is a bf16 tensor
-          a.y[u] = f2bf(bf2f(a.y[u]) + rbf(acc[j]));
-        } else if (EPI == EPI_LOGITS) {
-          a.logits[u] = rbf(acc[j]);  // lm_head output is bf16, then .float()
-        } else if (EPI == EPI_SWIGLU) {
-          const float gte = rbf(acc[2 * j]);
-          const float up = rbf(acc[2 * j + 1]);
-          const float sl = rbf(gte / (1.f + expf(-gte)));
-          a.y[u] = f2bf(sl * up);
-        } else if (EPI == EPI_QKV) {
-          const int hb = u >> 6, i = u & 63;
-          const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
-          const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
-          const int pos = a.st->pos;
-          const float x1 = rbf(acc[2 * j]);      // dim i
-          const float x2 = rbf(acc[2 * j + 1]);  // dim i + 64
-          if (sec == 2) {
-            bf16_t* dst = a.vcache + ((size_t)head * a.T_max + pos) * 128;
-            dst[i] = f2bf(x1);
-            dst[i + 64] = f2bf(x2);
-          } else {
-            // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
-            const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-            const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
-            const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
-            const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
-            bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
-                                     : (a.kcache + ((size_t)head * a.T_max + pos) * 128);
-            dst[i] = f2bf(o1);
-            dst[i + 64] = f2bf(o2);
-          }
-        }
+        gemv_epilogue<EPI, F8>(a, u, PAIRED ? acc[2 * j] : acc[j], PAIRED ? acc[2 * j + 1] : 0.f);
       }
     }
     if (!PERSIST || unit0 >= n_units) break;
@@ -393,7 +400,12 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
       case 4: GV(PRO_RMSNORM, EPI_LOGITS, 1, 8, 4, false, 0);
     }
   }
-  if (pro == PRO_RMSNORM && epi == EPI_STORE) GV(PRO_RMSNORM, EPI_STORE, 4, 2, 4, false, 0);
+  if (pro == PRO_RMSNORM && epi == EPI_STORE) {
+    if (variant == 20) GV(PRO_RMSNORM, EPI_STORE, 1, 2, 4, false, 0);   // probe: the streaming core + norm prologue only
+    GV(PRO_RMSNORM, EPI_STORE, 4, 2, 4, false, 0);
+  }
+  if (variant == 20) GV(PRO_COPY, EPI_STORE, 1, 2, 4, false, 0);         // probes (dtk_bench_gemv | 0x200): streaming core,
+  if (variant == 21) GV(PRO_COPY, EPI_STORE, 1, 8, 4, false, 0);         // plain x copy, plain store
   GV(PRO_COPY, EPI_STORE, 4, 2, 4, false, 0);
 }
 #undef GV
