@@ -99,6 +99,20 @@ struct SamplingDev {
   int32_t always_ids[8];
 };
 
+// scratch of the multi-block sampler (kernels_sample_mb.hip), one per sequence / slot
+#define DTK_SAMPLE_MB_MAX_SLICES 32      // 32 x 8192 = vocabularies up to 262 144
+struct SampleMB {
+  float bmax[DTK_SAMPLE_MB_MAX_SLICES];
+  int32_t barg[DTK_SAMPLE_MB_MAX_SLICES];
+  unsigned long long bkept[DTK_SAMPLE_MB_MAX_SLICES];
+  unsigned long long hmass[4][256];      // [radix level][bin]: integer probability mass
+  unsigned int hcnt[4][256];
+  unsigned long long above[4];           // mass strictly above the chosen bin, per level
+  unsigned int bin[4];
+  unsigned long long total;
+  unsigned int thr, pad;
+};
+
 // splitmix64: the counter-based RNG shared with oracle/sampling.py
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;

@@ -143,6 +143,11 @@ struct dtk_ctx {
   hipGraph_t bgraph = nullptr;
   hipGraphExec_t bgraph_exec = nullptr;
   dtk_sampling sampling{};
+  SampleMB* smb = nullptr;           // multi-block sampler scratch (single sequence) / per slot
+  SampleMB* smb_b = nullptr;
+  bool mb_single = false;            // the captured single-sequence graph uses the multi-block sampler
+  bool mb_batch = false;             // ... the batched graph
+  bool slot_topk[DTK_MAX_BATCH + 1] = {};   // slots whose sampling needs top-k (single-block sampler only)
   uint64_t launched = 0, waited = 0;
   hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -351,6 +356,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->attn_ctr = P.take<unsigned>(c->H);
   c->st = P.take<DecState>(1);
   c->sp = P.take<SamplingDev>(1);
+  c->smb = P.take<SampleMB>(1);
   c->tok_ring_dev = P.take<int64_t>(DTK_MAX_INFLIGHT);
   c->probs_dev = P.take<float>(V);
   c->pixels_dev = P.take<float>((size_t)3 * c->cfg.vit_image * c->cfg.vit_image);
@@ -399,6 +405,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pob = P.take<float>((size_t)c->nb * c->H * c->S * 128);
     c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
     c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
+    c->smb_b = P.take<SampleMB>(DTK_MAX_BATCH + 1);
     c->bs_dev = P.take<BatchState>(1);
     if (c->wfmt == 1) {             // fp8: pair-tiled fp8 copies (+6.6 GB for cl-7b), no bf16 tiles
       for (int i = 0; i < L; ++i) {
@@ -503,8 +510,8 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
   SampleArgs sa;
   sa.logits = c->logits; sa.V = c->V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed;
   sa.x = c->x; sa.d = c->d; sa.tok_ring = c->tok_ring_dev; sa.ring = DTK_MAX_INFLIGHT;
-  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = nullptr; sa.logits_stride = 0;
-  launch_sample(sa, s);
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = nullptr; sa.logits_stride = 0; sa.nslots = 1; sa.mb = c->smb;
+  if (c->mb_single) launch_sample_mb(sa, s); else launch_sample(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
@@ -550,8 +557,8 @@ void batch_step_launches(dtk_ctx* c) {
   SampleArgs sa;
   sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
   sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
-  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = 16 * c->nt;
-  launch_sample_b(sa, s);
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = 16 * c->nt; sa.mb = c->smb_b;
+  if (c->mb_batch) launch_sample_mb(sa, s); else launch_sample_b(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
   for (int l = 0; l < c->L; ++l) {
@@ -710,6 +717,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->cfg = *cfg;
   c->device = device;
   c->d = cfg->hidden; c->L = cfg->layers; c->H = cfg->heads; c->ff = cfg->ffn; c->V = cfg->vocab;
+  c->mb_single = c->mb_batch = sample_mb_supported(cfg->vocab);   // default sampling is greedy: the multi-block chain serves it
   c->KVH = cfg->reserved[2] > 0 ? cfg->reserved[2] : cfg->heads;      // GQA (v2: LLaMA-3.1, 32 / 8)
   c->proj_bias = (cfg->reserved[3] & DTK_ARCH_PROJ_NO_BIAS) == 0;     // v2 connector: Linear(3*D -> d, bias=False)
   c->Tmax = cfg->max_positions;
@@ -1070,6 +1078,32 @@ static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp
   const uint32_t zero = 0;
   HIPCHK(c, hipMemcpy(&st_dst->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
   if (is_single) { c->sampling = *sp; c->launched = c->waited = 0; }
+  // which sampler the captured graphs must contain: the multi-block chain serves large vocabularies unless a
+  // configuration needs top-k; a change of kind drops the graph (re-captured by the next launch)
+  const bool needs_topk = sp->do_sample && sp->top_k > 0 && sp->top_k < c->V;
+  if (is_single) {
+    const bool mb = sample_mb_supported(c->V) && !needs_topk;
+    if (mb != c->mb_single) {
+      c->mb_single = mb;
+      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+      if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+      if (c->graph_short_exec) { (void)hipGraphExecDestroy(c->graph_short_exec); c->graph_short_exec = nullptr; }
+      if (c->graph_short) { (void)hipGraphDestroy(c->graph_short); c->graph_short = nullptr; }
+      c->graph_ready = false;
+    }
+  } else {
+    const int slot = (int)(sp_dst - c->sp_b);
+    c->slot_topk[slot] = needs_topk;
+    bool any = false;
+    for (int j = 0; j < c->nb; ++j) any = any || c->slot_topk[j];
+    const bool mb = sample_mb_supported(c->V) && !any;
+    if (mb != c->mb_batch) {
+      c->mb_batch = mb;
+      if (c->bgraph_exec) { (void)hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
+      if (c->bgraph) { (void)hipGraphDestroy(c->bgraph); c->bgraph = nullptr; }
+      c->bgraph_ready = false;
+    }
+  }
   return DTK_OK;
 }
 
@@ -1514,8 +1548,9 @@ int dtk_op_sample(dtk_ctx* c, const float* logits, int V, int step, int64_t* tok
   SampleArgs sa;
   sa.logits = dl; sa.V = V; sa.sp = c->sp; sa.st = c->st; sa.embed = c->embed; sa.x = c->x; sa.d = c->d;
   sa.tok_ring = dtok; sa.ring = 1; sa.probs_out = probs_out ? c->probs_dev : nullptr; sa.advance = 0;
-  sa.step_override = step; sa.bs = nullptr; sa.logits_stride = 0;
-  launch_sample(sa, s);
+  sa.step_override = step; sa.bs = nullptr; sa.logits_stride = 0; sa.nslots = 1; sa.mb = c->smb;
+  const bool needs_topk = c->sampling.do_sample && c->sampling.top_k > 0 && c->sampling.top_k < V;
+  if (sample_mb_supported(V) && !needs_topk && !getenv("DTK_SAMPLER")) launch_sample_mb(sa, s); else launch_sample(sa, s);
   HIPCHK(c, hipMemcpyAsync(token_out, dtok, 8, hipMemcpyDeviceToHost, s));
   if (probs_out) HIPCHK(c, hipMemcpyAsync(probs_out, c->probs_dev, (size_t)V * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

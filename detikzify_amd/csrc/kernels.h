@@ -70,9 +70,13 @@ struct SampleArgs {
   const BatchState* bs;  // batched mode: block = slot, inactive slots return; pointers are slot 0's
   int logits_stride;     // elements between slots' logits (batched mode)
   int nslots;            // batched mode: grid = 16 or 32 slots
+  SampleMB* mb;          // scratch of the multi-block sampler (slot 0's in batched mode), or null
 };
 void launch_sample_b(const SampleArgs& a, hipStream_t s);
 void launch_sample(const SampleArgs& a, hipStream_t s);
+// 7-kernel chain for V > 32768 (greedy / temperature / top-p; not top-k); single sequence or (a.bs) every active slot
+void launch_sample_mb(const SampleArgs& a, hipStream_t s);
+static inline bool sample_mb_supported(int V) { return V > 32768 && V <= DTK_SAMPLE_MB_MAX_SLICES * 8192; }
 
 // ---------------------------------------------------------------- batched decode (16 slots share W)
 struct GemvBArgs {

@@ -1133,3 +1133,99 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
         assert got == ref, max_batch
         print(f"engine max_batch={max_batch}: prefix encodes {engine.prefix_encodes}, in-place {engine.inplace_reuses}")
         assert engine.prefix_encodes < len(jobs)
+
+
+# ------------------------------------------------------------------------------------------ multi-block sampler (V > 32768)
+@pytest.fixture(scope="module")
+def bigvocab():
+    """tiny-v2 with a 40 000-token vocabulary (4 full slices of 8192 + a ragged one): large-vocabulary sampler path"""
+    from detikzify_amd.model.config import preset
+    from detikzify_amd.model.modeling import DetikzifyForCausalLM
+    cfg = preset("detikzify-tiny-v2")
+    cfg.vocab, cfg.name_or_path, cfg.batch_slots = 40000, "detikzify-tiny-v2-bigvocab", 5
+    m = DetikzifyForCausalLM(cfg, 0)
+    m.fill_synthetic(99)
+    return m
+
+
+@pytest.mark.parametrize("T,k,p", [(0.8, 0, 0.95), (1.0, 0, 1.0), (1.3, 0, 0.3), (0.7, 40, 0.9), (0.5, 0, 0.999)])
+def test_multiblock_sampler_matches_oracle_and_single_block_kernel(bigvocab, T, k, p):
+    """the 7-kernel multi-block sampler (V > 32768; top-k falls back to the single-block kernel): kept set, probabilities and
+    every draw equal the oracle's integer-mass sampler and the single-block kernel, bit for bit"""
+    import os
+    model = bigvocab
+    V = model.config.vocab
+    g = torch.Generator().manual_seed(int(T * 10) + k + 5)
+    logits = rb(torch.randn(V, generator=g) * 2.5)
+    logits[V - 3] = float(logits.max()) + 0.5          # the arg-max sits in the ragged last slice
+    lb = logits.numpy().copy()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    bad, begin = [5, 8192 * 2 + 7], [V - 3]
+    tok = C.c_int64()
+    model.set_sampling(do_sample=False, bad_ids=bad, begin_suppress_ids=begin)
+    for step, first in ((0, True), (3, False)):
+        model._check(model.lib.dtk_op_sample(model._ctx, ptr(lb), V, step, C.byref(tok), None), "dtk_op_sample")
+        assert tok.value == sampling.greedy(logits, bad, begin, first)
+    model.set_sampling(do_sample=True, temperature=T, top_p=p, top_k=k, seed=321, bad_ids=bad, begin_suppress_ids=begin)
+    probs, probs1 = np.empty(V, dtype=np.float32), np.empty(V, dtype=np.float32)
+    tok1 = C.c_int64()
+    for step in range(12):
+        model._check(model.lib.dtk_op_sample(model._ctx, ptr(lb), V, step, C.byref(tok), ptr(probs)), "dtk_op_sample")
+        os.environ["DTK_SAMPLER"] = "generic"           # the single-block kernel on the same input
+        try:
+            model._check(model.lib.dtk_op_sample(model._ctx, ptr(lb), V, step, C.byref(tok1), ptr(probs1)), "dtk_op_sample")
+        finally:
+            del os.environ["DTK_SAMPLER"]
+        rt, rp = sampling.draw(logits, T, k, p, 321, step, bad, begin, step == 0)
+        assert int(((probs > 0) ^ (rp.numpy() > 0)).sum()) == 0, f"kept sets differ at step {step}"
+        assert np.allclose(probs, rp.numpy(), rtol=1e-5, atol=1e-9)
+        assert np.array_equal(probs, probs1) and tok.value == tok1.value == rt, (step, tok.value, tok1.value, rt)
+
+
+def test_multiblock_sampler_in_the_decode_graphs(bigvocab):
+    """end to end on a large vocabulary: sampled decode through the captured graph == the oracle's draw from the device's own
+    logits; batched slots == the same sequences alone; switching to top-k re-captures with the single-block sampler"""
+    model = bigvocab
+    cfgd = model.config.oracle_dict()
+    n_img = model.config.num_patches
+    ids = torch.tensor([model.config.image_token_id] * n_img + [77, 30123, 9])
+    px = torch.zeros(1, 3, model.config.vit_image, model.config.vit_image)
+    bad = [model.config.image_token_id]
+    for top_k in (0, 50, 0):
+        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=top_k, seed=4, bad_ids=bad, begin_suppress_ids=[2])
+        model.prefill(ids, px)
+        toks = []
+        for i in range(16):
+            logits = model.get_logits()
+            model.decode_launch()
+            t = model.decode_wait()
+            rt, _ = sampling.draw(logits, 0.8, top_k, 0.95, 4, i, bad, [2], i == 0)
+            assert t == rt, (top_k, i, t, rt)
+            toks.append(t)
+        assert len(set(toks)) > 4
+    # greedy through the same graph
+    model.set_sampling(do_sample=False, bad_ids=bad)
+    model.prefill(ids, px)
+    for i in range(6):
+        logits = model.get_logits()
+        model.decode_launch()
+        assert model.decode_wait() == sampling.greedy(logits, bad, [], i == 0)
+    # batched: three slots together == alone
+    def setup(sl, seed, extra):
+        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=seed, bad_ids=bad, begin_suppress_ids=[2], slot=sl)
+        model.prefill(torch.cat([ids, torch.tensor(extra, dtype=torch.long)]), px, slot=sl)
+    alone = []
+    for sl, seed, extra in ((0, 7, []), (1, 8, [15, 6]), (2, 9, [39999])):
+        setup(sl, seed, extra)
+        out = []
+        for _ in range(12):
+            model.decode_batch_launch([sl]); out.append(model.decode_batch_wait()[sl])
+        alone.append(out)
+    for sl, seed, extra in ((0, 7, []), (1, 8, [15, 6]), (2, 9, [39999])):
+        setup(sl, seed, extra)
+    got = [[], [], []]
+    for _ in range(12):
+        model.decode_batch_launch([0, 1, 2]); t = model.decode_batch_wait()
+        for sl in range(3):
+            got[sl].append(t[sl])
+    assert got == alone
