@@ -113,6 +113,52 @@ struct SampleMB {
   unsigned int thr, pad;
 };
 
+// Top-p radix level: among the 256 (mass, count) bins of one level pick the LOWEST non-empty bin whose strictly-above
+// mass (above_in + mass of all higher bins) is still < pq; if even the highest non-empty bin fails, pick that one.  This
+// is exactly the serial scan `for b = 255..0` of the samplers (whose dependent LDS reads cost ~10 us per level), done by
+// threads 0..255 with a wave suffix scan + ballots.  EVERY thread of the block must call it (it contains barriers);
+// s_w: 8 x u64 of LDS scratch, s_i: 8 ints.  Results (bin, strictly-above mass of that bin) are returned to all threads.
+__device__ __forceinline__ void bin_select_mass(const unsigned long long* s_m, const unsigned int* s_c, unsigned long long pq,
+                                                unsigned long long above_in, unsigned long long* s_w, int* s_i,
+                                                unsigned int& bin_out, unsigned long long& above_out) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long m = 0, incl = 0; unsigned int c = 0;
+  if (tid < 256) {
+    m = s_m[tid]; c = s_c[tid];
+    incl = m;                                   // inclusive suffix sum over the wave's 64 bins (lanes >= lane)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long v = __shfl_down(incl, off, 64);
+      if (lane + off < 64) incl += v;
+    }
+    if (lane == 0) s_w[w] = incl;
+  }
+  __syncthreads();
+  unsigned long long above = 0;
+  bool ok = false;
+  if (tid < 256) {
+    unsigned long long hi = 0;
+    for (int k = w + 1; k < 4; ++k) hi += s_w[k];
+    above = above_in + hi + (incl - m);          // mass strictly above bin tid
+    ok = c > 0 && above < pq;
+    const unsigned long long mk = __ballot(ok), ne = __ballot(c > 0);
+    if (lane == 0) {
+      s_i[w] = mk ? (__ffsll((long long)mk) - 1) + 64 * w : -1;             // lowest qualifying bin of this wave
+      s_i[4 + w] = ne ? (63 - __clzll((long long)ne)) + 64 * w : -1;        // highest non-empty bin of this wave
+    }
+  }
+  __syncthreads();
+  int sel = -1;
+  for (int k = 0; k < 4 && sel < 0; ++k) sel = s_i[k];
+  if (sel < 0) for (int k = 3; k >= 0 && sel < 0; --k) sel = s_i[4 + k];
+  if (sel < 0) sel = 0;
+  __syncthreads();
+  if (tid == sel) s_w[4] = above;
+  __syncthreads();
+  bin_out = (unsigned)sel; above_out = s_w[4];
+  __syncthreads();
+}
+
 // splitmix64: the counter-based RNG shared with oracle/sampling.py
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;

@@ -148,6 +148,7 @@ struct dtk_ctx {
   bool mb_single = false;            // the captured single-sequence graph uses the multi-block sampler
   bool mb_batch = false;             // ... the batched graph
   bool slot_topk[DTK_MAX_BATCH + 1] = {};   // slots whose sampling needs top-k (single-block sampler only)
+  bool slot_samples[DTK_MAX_BATCH + 1] = {}; // slots that sample (not greedy)
   uint64_t launched = 0, waited = 0;
   hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -1082,7 +1083,7 @@ static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp
   // configuration needs top-k; a change of kind drops the graph (re-captured by the next launch)
   const bool needs_topk = sp->do_sample && sp->top_k > 0 && sp->top_k < c->V;
   if (is_single) {
-    const bool mb = sample_mb_supported(c->V) && !needs_topk;
+    const bool mb = sample_mb_preferred(c->V, sp->do_sample != 0) && !needs_topk;
     if (mb != c->mb_single) {
       c->mb_single = mb;
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -1094,9 +1095,10 @@ static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp
   } else {
     const int slot = (int)(sp_dst - c->sp_b);
     c->slot_topk[slot] = needs_topk;
-    bool any = false;
-    for (int j = 0; j < c->nb; ++j) any = any || c->slot_topk[j];
-    const bool mb = sample_mb_supported(c->V) && !any;
+    c->slot_samples[slot] = sp->do_sample != 0;
+    bool any = false, any_sampling = false;
+    for (int j = 0; j < c->nb; ++j) { any = any || c->slot_topk[j]; any_sampling = any_sampling || c->slot_samples[j]; }
+    const bool mb = sample_mb_preferred(c->V, any_sampling) && !any;
     if (mb != c->mb_batch) {
       c->mb_batch = mb;
       if (c->bgraph_exec) { (void)hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
@@ -1550,7 +1552,7 @@ int dtk_op_sample(dtk_ctx* c, const float* logits, int V, int step, int64_t* tok
   sa.tok_ring = dtok; sa.ring = 1; sa.probs_out = probs_out ? c->probs_dev : nullptr; sa.advance = 0;
   sa.step_override = step; sa.bs = nullptr; sa.logits_stride = 0; sa.nslots = 1; sa.mb = c->smb;
   const bool needs_topk = c->sampling.do_sample && c->sampling.top_k > 0 && c->sampling.top_k < V;
-  if (sample_mb_supported(V) && !needs_topk && !getenv("DTK_SAMPLER")) launch_sample_mb(sa, s); else launch_sample(sa, s);
+  if (sample_mb_preferred(V, c->sampling.do_sample != 0) && !needs_topk && !getenv("DTK_SAMPLER")) launch_sample_mb(sa, s); else launch_sample(sa, s);
   HIPCHK(c, hipMemcpyAsync(token_out, dtok, 8, hipMemcpyDeviceToHost, s));
   if (probs_out) HIPCHK(c, hipMemcpyAsync(probs_out, c->probs_dev, (size_t)V * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

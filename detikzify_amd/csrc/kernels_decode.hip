@@ -1066,6 +1066,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
   __shared__ int s_token;
   __shared__ float s_max;
   __shared__ unsigned long long s_total;
+  __shared__ unsigned long long s_bw[8];
+  __shared__ int s_bi[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = a.V;
   if (tid < (int)(sizeof(SamplingDev) / 4)) reinterpret_cast<uint32_t*>(&s_sp)[tid] = reinterpret_cast<const uint32_t*>(a.sp)[tid];
@@ -1207,19 +1209,10 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
         }
         if (cc) { atomicAdd(&h_mass[cur], cm); atomicAdd(&h_cnt[cur], cc); }
         __syncthreads();
-        if (tid == 0) {
-          unsigned long long ab = above; int bsel = -1; unsigned long long ab_sel = above;
-          for (int b = 255; b >= 0; --b) {
-            if (h_cnt[b] == 0) continue;
-            if (ab < pq || bsel < 0) { bsel = b; ab_sel = ab; } else break;
-            ab += h_mass[b];
-          }
-          sc_above_q = ab_sel; sc_bin = (unsigned)bsel;
-        }
-        __syncthreads();
-        above = sc_above_q;
-        prefix |= (sc_bin << shift);
-        __syncthreads();
+        unsigned int bsel; unsigned long long ab_sel;
+        bin_select_mass(h_mass, h_cnt, pq, above, s_bw, s_bi, bsel, ab_sel);   // parallel form of the serial 255..0 scan
+        above = ab_sel;
+        prefix |= (bsel << shift);
       }
       thr = prefix > thr_k ? prefix : thr_k;
     }

@@ -89,13 +89,15 @@ struct MbCommon {
 __device__ __forceinline__ void mb_common(const SampleArgs& a, int nblk, MbCommon* cm) {
   const int tid = threadIdx.x;
   if (tid < (int)(sizeof(SamplingDev) / 4)) reinterpret_cast<uint32_t*>(&cm->sp)[tid] = reinterpret_cast<const uint32_t*>(a.sp)[tid];
-  if (tid == 0) {
-    float b = a.mb->bmax[0]; int bi = a.mb->barg[0];
-    for (int k = 1; k < nblk; ++k) {
-      const float v = a.mb->bmax[k]; const int vi = a.mb->barg[k];
-      if (v > b || (v == b && vi < bi)) { b = v; bi = vi; }
+  if (tid < 64) {   // <= 32 slices: one wave reduces (max, first arg-max)
+    float b = tid < nblk ? a.mb->bmax[tid] : -INFINITY; int bi = tid < nblk ? a.mb->barg[tid] : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(b, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
     }
-    cm->zmax = b; cm->argmax = bi;
+    if (tid == 0) { cm->zmax = b; cm->argmax = bi; }
   }
   __syncthreads();
 }
@@ -140,23 +142,14 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_max(SampleArgs a) {
   }
 }
 
-// bin of radix level `lv` from its global histogram: the lowest non-empty bin whose strictly-above mass is still < pq
-// (identical to the tid == 0 scan of k_sample); called by every block, published by block 0
+// bin of radix level `lv` from its global histogram (bin_select_mass, common.h); called by every block, published by block 0
 __device__ __forceinline__ void mb_select(const SampleArgs& a, int lv, unsigned long long pq, unsigned long long above_in,
-                                          unsigned long long* s_m, unsigned int* s_c, unsigned int* bin_out, unsigned long long* above_out) {
+                                          unsigned long long* s_m, unsigned int* s_c, unsigned long long* s_w, int* s_i,
+                                          unsigned int& bin_out, unsigned long long& above_out) {
   const int tid = threadIdx.x;
   if (tid < 256) { s_m[tid] = a.mb->hmass[lv][tid]; s_c[tid] = a.mb->hcnt[lv][tid]; }
   __syncthreads();
-  if (tid == 0) {
-    unsigned long long ab = above_in; int bsel = -1; unsigned long long ab_sel = above_in;
-    for (int b = 255; b >= 0; --b) {
-      if (s_c[b] == 0) continue;
-      if (ab < pq || bsel < 0) { bsel = b; ab_sel = ab; } else break;
-      ab += s_m[b];
-    }
-    *bin_out = (unsigned)(bsel < 0 ? 0 : bsel); *above_out = ab_sel;
-  }
-  __syncthreads();
+  bin_select_mass(s_m, s_c, pq, above_in, s_w, s_i, bin_out, above_out);
 }
 
 // ---- P1..P4: LV = 3, 2, 1, 0
@@ -168,8 +161,8 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_hist(SampleArgs a, int nblk)
   __shared__ unsigned int w_c[16][256];
   __shared__ unsigned long long s_m[256];
   __shared__ unsigned int s_c[256];
-  __shared__ unsigned int s_bin;
-  __shared__ unsigned long long s_above;
+  __shared__ unsigned long long s_w[8];
+  __shared__ int s_i[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   mb_common(a, nblk, &cm);
   if (!cm.sp.do_sample || !(cm.sp.top_p < 1.0f)) return;   // greedy / no nucleus: nothing to select (block-uniform)
@@ -179,12 +172,16 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_hist(SampleArgs a, int nblk)
   if (LV < 3) {
     // total mass = sum of the level-3 histogram
     unsigned long long total = 0, above = 0;
-    if (LV + 1 == 3) {
-      if (tid < 256) s_m[tid] = a.mb->hmass[3][tid];
+    if (LV + 1 == 3) {     // total mass = sum of the level-3 bins: the same suffix machinery with pq = 0 (nothing qualifies)
+      unsigned long long t = 0;
+      if (tid < 256) {
+        t = a.mb->hmass[3][tid];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) s_w[wave] = t;
+      }
       __syncthreads();
-      if (tid == 0) { unsigned long long t = 0; for (int b = 0; b < 256; ++b) t += s_m[b]; s_above = t; }
-      __syncthreads();
-      total = s_above;
+      total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
       __syncthreads();
       if (blk == 0 && tid == 0) a.mb->total = total;
     } else {
@@ -192,9 +189,10 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_hist(SampleArgs a, int nblk)
       for (int l = 3; l > LV + 1; --l) prefix |= a.mb->bin[l] << (l * 8);
     }
     const unsigned long long pq = (unsigned long long)((double)cm.sp.top_p * (double)total);
-    mb_select(a, LV + 1, pq, above, s_m, s_c, &s_bin, &s_above);
-    prefix |= s_bin << ((LV + 1) * 8);
-    if (blk == 0 && tid == 0) { a.mb->bin[LV + 1] = s_bin; a.mb->above[LV + 1] = s_above; }
+    unsigned int bin; unsigned long long ab;
+    mb_select(a, LV + 1, pq, above, s_m, s_c, s_w, s_i, bin, ab);
+    prefix |= bin << ((LV + 1) * 8);
+    if (blk == 0 && tid == 0) { a.mb->bin[LV + 1] = bin; a.mb->above[LV + 1] = ab; }
   }
   for (int i = tid; i < 16 * 256; i += MB_THREADS) { (&w_m[0][0])[i] = 0ull; (&w_c[0][0])[i] = 0u; }
   __syncthreads();
@@ -235,8 +233,8 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_kept(SampleArgs a, int nblk)
   __shared__ MbCommon cm;
   __shared__ unsigned long long s_m[256];
   __shared__ unsigned int s_c[256];
-  __shared__ unsigned int s_bin;
-  __shared__ unsigned long long s_above;
+  __shared__ unsigned long long s_w[8];
+  __shared__ int s_i[8];
   __shared__ unsigned long long s_q[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   mb_common(a, nblk, &cm);
@@ -248,8 +246,9 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_kept(SampleArgs a, int nblk)
     const unsigned long long pq = (unsigned long long)((double)cm.sp.top_p * (double)total);
     uint32_t prefix = 0;
     for (int l = 3; l > 0; --l) prefix |= a.mb->bin[l] << (l * 8);
-    mb_select(a, 0, pq, a.mb->above[1], s_m, s_c, &s_bin, &s_above);
-    thr = prefix | s_bin;
+    unsigned int bin; unsigned long long ab;
+    mb_select(a, 0, pq, a.mb->above[1], s_m, s_c, s_w, s_i, bin, ab);
+    thr = prefix | bin;
   }
   if (blk == 0 && tid == 0) a.mb->thr = thr;
   const float invT = 1.f / cm.sp.temperature;
