@@ -290,9 +290,13 @@ def main():
             n = after["probe_kernel_launches"] - before["probe_kernel_launches"]
             ms = after["probe_kernel_ms_sum"] - before["probe_kernel_ms_sum"]
             if n > 0 and ms > 0:
+                # `achieved` uses the RAW interval between the two events (conservative: an event pair with nothing in
+                # between already reads empty_event_pair_us on this stream, and rocprofv3's start->end for the same
+                # kernel — profiles/r01_kernel_stats.csv, rocprofv3_avg_us below — is ~8 % shorter than the interval)
+                pair_ms = float(after.get("probe_event_pair_ms", 0.0) or 0.0)
                 avg_ms = ms / n
                 ach = after["probe_kernel_bytes"] / (avg_ms * 1e-3) / 1e9
-                roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_us=avg_ms * 1e3,
+                roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_us=avg_ms * 1e3, empty_event_pair_us=pair_ms * 1e3,
                             bytes_per_launch=after["probe_kernel_bytes"], launches_timed=n)
         except Exception as e:  # the bench line must still be printed
             roof["error"] = repr(e)
@@ -308,6 +312,13 @@ def main():
                         roof["traffic"] = float(row["hbm_read_bytes_per_launch_x2"])
                         roof["traffic_source"] = "profiles/r01_pmc_fetch.csv (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)"
                         break
+                ks = ROOT / "profiles" / "r01_kernel_stats.csv"
+                if ks.exists():
+                    for row in csv.DictReader(ks.open()):
+                        if row["kernel"].startswith("void k_gemv<1, 3,"):
+                            roof["rocprofv3_avg_us"] = float(row["avg_us"])     # committed kernel-trace summary of the same command
+                            roof["frac_at_rocprofv3_duration"] = roof["bytes_per_launch"] / (roof["rocprofv3_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if roof.get("bytes_per_launch") else None
+                            break
         except Exception:
             pass
         result["roofline"] = roof

@@ -45,7 +45,7 @@ class DtkStats(C.Structure):
         ("decode_steps", C.c_uint64), ("prefill_tokens", C.c_uint64), ("vit_images", C.c_uint64),
         ("last_prefill_ms", C.c_double), ("last_vit_ms", C.c_double),
         ("probe_kernel_ms_sum", C.c_double), ("probe_kernel_launches", C.c_uint64),
-        ("probe_kernel_bytes", C.c_uint64),
+        ("probe_kernel_bytes", C.c_uint64), ("probe_event_pair_ms", C.c_double),
     ]
 
 

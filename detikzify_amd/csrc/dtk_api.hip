@@ -723,6 +723,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->proj_bias = (cfg->reserved[3] & DTK_ARCH_PROJ_NO_BIAS) == 0;     // v2 connector: Linear(3*D -> d, bias=False)
   c->Tmax = cfg->max_positions;
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
+  if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
   // up to 32 decoding slots (one or two 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
   c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_BATCH + 1 ? DTK_MAX_BATCH + 1 : cfg->reserved[0]);
@@ -1248,6 +1249,20 @@ int dtk_set_graph_mode(dtk_ctx* c, int enabled) {
   if (!c) return DTK_ERR_ARG;
   c->use_graph = enabled == 1;
   c->probe = enabled == 2;   // 2: plain launches with HIP-event probe around the gate/up GEMV
+  if (c->probe && c->stats.probe_event_pair_ms == 0.0) {
+    // what an event pair costs with NOTHING between the two records (timestamp packets): part of every probe interval
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0; int n = 0;
+    for (int i = 0; i < 40; ++i) {
+      HIPCHK(c, hipEventRecord(c->probe_a, c->stream));
+      HIPCHK(c, hipEventRecord(c->probe_b, c->stream));
+      HIPCHK(c, hipEventSynchronize(c->probe_b));
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->probe_a, c->probe_b) == hipSuccess && i >= 8) { sum += ms; ++n; }
+    }
+    if (n) c->stats.probe_event_pair_ms = sum / n;
+  }
   return DTK_OK;
 }
 

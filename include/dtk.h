@@ -104,6 +104,8 @@ typedef struct dtk_stats {
   double   probe_kernel_ms_sum;     /* in-graph event probe around the gate/up GEMV of the middle layer */
   uint64_t probe_kernel_launches;
   uint64_t probe_kernel_bytes;      /* algorithmic bytes of one such launch           */
+  double   probe_event_pair_ms;     /* elapsed time of an EMPTY hipEventRecord pair on the stream (the fixed cost inside every
+                                     * probe interval; calibrated when probe mode is switched on)            */
 } dtk_stats;
 
 int  dtk_abi_version(void);
