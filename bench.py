@@ -271,7 +271,8 @@ def main():
             result["mcts_stub_reward"] = {
                 "trees_per_gpu": trees, "expansions_per_tree": args.mcts_expansions, "rollouts": world * len(res),
                 "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "max_length": T0 + min(n_new, 256),
-                "vit_passes": model.stats()["vit_images"] - vit_before,
+                "vit_passes": model.stats()["vit_images"] - vit_before, "engine": getattr(model, "last_batch_stats", None),
+                "tokens_generated": getattr(model, "last_batch_stats", {}).get("tokens_out"),
                 "reward": "SelfSim (device ViT) of SyntheticTikzDocument renderings; LaTeX absent offline",
                 "scores_min_max": [float(min(s for s, _ in res)), float(max(s for s, _ in res))] if res else None}
         except Exception as e:

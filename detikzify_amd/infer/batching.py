@@ -56,6 +56,7 @@ class BatchEngine:
         self.prefix_key = None
         self.prefix_ids = None
         self.slot_img: Dict[int, Tuple[int, int]] = {}      # slot -> (image key, prefix length) whose KV prefix it still holds
+        self.joins = 0
         self.inplace_reuses = 0                              # joins that found their image prefix already in their slot
         self.prefix_encodes = 0                              # ViT + prefix prefills run for the prefix cache (diagnostics)
         self.capacity = min(dec - (1 if self.share_prefix and n <= maxdec else 0), max_batch or dec)
@@ -86,6 +87,11 @@ class BatchEngine:
             self.gather_left = min(int(n), self.capacity)
             self.gather_deadline = time.perf_counter() + timeout
             self.t_first_launch = self.t_last_collect = None
+
+    def stats(self) -> Dict[str, Any]:
+        return {"steps": self.steps, "tokens_out": self.tokens_out, "wait_s": round(self.t_wait, 3), "launch_s": round(self.t_launch, 3),
+                "prefill_s": round(self.t_prefill, 3), "host_bound_steps": self.host_bound_steps, "prefix_encodes": self.prefix_encodes,
+                "inplace_reuses": self.inplace_reuses, "joins": self.joins}
 
     def close(self):
         with self.cv:
@@ -126,6 +132,7 @@ class BatchEngine:
                 while not q.empty():       # leftovers of the slot's previous sequence
                     q.get_nowait()
                 self.active.add(slot)
+                self.joins += 1
                 self.gather_left = max(0, self.gather_left - 1)
                 joined = True
             yield _Sequence(self, slot)
@@ -307,3 +314,4 @@ def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, see
             th.join(timeout=60)
         if engine is not None:
             engine.close()
+            pipeline.model.last_batch_stats = engine.stats()

@@ -375,6 +375,32 @@ class DetikzifyForCausalLM:
         buf = torch.empty((1, max(max_length, T)), dtype=torch.int64)
         buf[0, :T] = ids[0]
         cur = T
+        # per-token host work (runs under the GPU's next step): append, stream, stopping criteria.  Kept light: 32 rollouts
+        # share one GIL.  The token tensor the HF protocols expect is only built for callers that need it.
+        put_token = getattr(streamer, "put_token", None) if streamer is not None else None
+        from ..util.generation import ExplicitAbort
+        light = [c for c in criteria if type(c) is ExplicitAbort]        # polled flag: ignores its arguments
+        heavy = [c for c in criteria if type(c) is not ExplicitAbort]
+        new_tokens: List[int] = []
+
+        def emit(tok: int) -> bool:
+            nonlocal cur
+            new_tokens.append(tok)
+            cur += 1
+            if put_token is not None:
+                put_token(tok)
+            elif streamer is not None:
+                streamer.put(torch.tensor([tok], dtype=torch.int64))
+            stop = tok in eos_set or cur >= max_length
+            for c in light:
+                stop = stop or c.should_stop
+            if heavy:
+                buf[0, cur - 1] = tok
+                for crit in heavy:
+                    r = crit(buf[:, :cur], None)
+                    stop = stop or bool(r.all() if isinstance(r, torch.Tensor) else r)
+            return stop
+
         engine = self.batch_engine
         if n_new_max > 0 and engine is not None:
             # batched mode: this sequence decodes in a KV slot, in lock-step with the other threads'
@@ -384,14 +410,7 @@ class DetikzifyForCausalLM:
                     begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ())) as seq:
                 while True:
                     tok = seq.next_token()
-                    buf[0, cur] = tok
-                    cur += 1
-                    if streamer is not None:
-                        streamer.put(torch.tensor([tok], dtype=torch.int64))
-                    stop = tok in eos_set or cur >= max_length
-                    for crit in criteria:
-                        r = crit(buf[:, :cur], None)
-                        stop = stop or bool(r.all() if isinstance(r, torch.Tensor) else r)
+                    stop = emit(tok)
                     if stop:
                         break
         elif n_new_max > 0:
@@ -405,18 +424,13 @@ class DetikzifyForCausalLM:
                 self.decode_launch(); launched += 1
             while received < launched:
                 tok = self.decode_wait(); received += 1
-                buf[0, cur] = tok
-                cur += 1
-                if streamer is not None:
-                    streamer.put(torch.tensor([tok], dtype=torch.int64))
-                stop = tok in eos_set or cur >= max_length
-                for crit in criteria:
-                    r = crit(buf[:, :cur], None)
-                    stop = stop or bool(r.all() if isinstance(r, torch.Tensor) else r)
+                stop = emit(tok)
                 if stop:
                     break
                 if launched < n_new_max:
                     self.decode_launch(); launched += 1
         if streamer is not None:
             streamer.end()
+        if new_tokens:
+            buf[0, T:T + len(new_tokens)] = torch.tensor(new_tokens, dtype=torch.int64)
         return buf[:, :cur].clone()

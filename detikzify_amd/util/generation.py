@@ -75,6 +75,10 @@ class TokenStreamer(_QueueStreamer):
         for token_id in value.tolist():
             self.queue.put(token_id, timeout=self.timeout)
 
+    def put_token(self, token_id: int):
+        """one generated token as a plain int (the generate loop's fast path: no tensor per token)"""
+        self.queue.put(token_id, timeout=self.timeout)
+
     def end(self):
         self.next_tokens_are_prompt = True
         super().end()

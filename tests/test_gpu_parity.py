@@ -616,11 +616,12 @@ def test_batch_engine_threads_match_slot_alone(tiny_batched):
         def run(i):
             ids, px = prompts[i]
             res[i] = model.generate(input_ids=ids[None], pixel_values=px, seed=50 + i, **kw)[0].tolist()
+        engine.expect(len(prompts), timeout=30.0)      # warm start: no step before all three have joined
         ths = [threading.Thread(target=run, args=(i,)) for i in range(len(prompts))]
         [t.start() for t in ths]
         [t.join(timeout=120) for t in ths]
         assert res == alone
-        assert engine.steps - steps_alone < 2 * 24      # the three sequences shared their decode steps
+        assert engine.steps - steps_alone <= 24 + 2     # the three sequences shared their decode steps
     finally:
         engine.close()
     # single-sequence path is unaffected by the engine having existed
