@@ -85,6 +85,8 @@ class ImageSim:
             image = expand(image, max(image.size), do_trim=True)
         with torch.inference_mode():
             enc = self.processor(images=image, return_tensors="pt")
+            if self.mode == "cos" and hasattr(self.model, "pooled_only"):
+                return self.model.pooled_only(enc["pixel_values"]).squeeze()    # same value, no patch-feature copy-back
             out = self.model(**enc)
             if self.mode == "cos":
                 return out.pooler_output.squeeze()

@@ -65,6 +65,10 @@ class DetikzifyVisionModel:
         feats, pooled = self._owner.vit_encode(pixel_values, want_pooled=True)
         return VisionOutput(last_hidden_state=feats, pooler_output=pooled)
 
+    def pooled_only(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """pooler_output without copying the 729 x 1152 patch features back (SelfSim "cos": the reward's hot call)"""
+        return self._owner.vit_encode(pixel_values, want_pooled=True, want_feats=False)[1]
+
     def get_intermediate_layers(self, pixel_values: torch.Tensor, *_, **__):
         feats, _ = self._owner.vit_encode(pixel_values, want_pooled=False)
         return [feats]
@@ -195,23 +199,23 @@ class DetikzifyForCausalLM:
         self.load_tensor("rope.sin", freqs.sin().to(torch.bfloat16))
 
     # ---- vision tower -------------------------------------------------------------------------
-    def vit_encode(self, pixel_values: torch.Tensor, want_pooled: bool = True):
+    def vit_encode(self, pixel_values: torch.Tensor, want_pooled: bool = True, want_feats: bool = True):
         px = pixel_values.detach().to("cpu", torch.float32).contiguous()
         if px.dim() == 3:
             px = px[None]
         B = px.shape[0]
         c = self.config
         n = (c.vit_image // c.vit_patch) ** 2
-        feats = np.empty((B, n, c.vit_dim), dtype=np.uint16)
+        feats = np.empty((B, n, c.vit_dim), dtype=np.uint16) if want_feats else None
         pooled = np.empty((B, c.vit_dim), dtype=np.uint16)
         # a context is driven by one thread at a time: with a batch engine, take its lock (the SelfSim
         # reward of one tree runs while other trees decode)
         guard = self.batch_engine.cv if self.batch_engine is not None else contextlib.nullcontext()
         with guard:
             self._check(self.lib.dtk_vit_encode(
-                self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p),
+                self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p) if want_feats else None,
                 pooled.ctypes.data_as(C.c_void_p) if want_pooled else None), "dtk_vit_encode")
-        f = _bf16_tensor_from_bits(feats.reshape(-1)).view(B, n, c.vit_dim)
+        f = _bf16_tensor_from_bits(feats.reshape(-1)).view(B, n, c.vit_dim) if want_feats else None
         p = _bf16_tensor_from_bits(pooled.reshape(-1)).view(B, c.vit_dim) if want_pooled else None
         return f, p
 
