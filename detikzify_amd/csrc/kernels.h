@@ -171,7 +171,7 @@ struct AttnArgs {
   int causal; int q_offset;   // query i sits at absolute position q_offset + i
   float scale;
   int kv_group;  // query heads per K/V head (GQA): head h reads K/V head h / kv_group; 0 or 1 = one K/V head per query head
-  int impl;   // 0 auto (MFMA flash kernel when hd is 72/128 and Tq >= 16), 1 VALU kernel, 2 MFMA kernel
+  int impl;   // 0 auto (MFMA flash kernel when hd is 72/128), 1 VALU kernel, 2 MFMA kernel
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

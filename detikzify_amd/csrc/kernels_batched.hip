@@ -636,7 +636,10 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnArgs a) {
 void launch_attention(const AttnArgs& a, hipStream_t s) {
   const bool can_mfma = (a.hd == 72 || a.hd == 128) && (a.q_st % 8 == 0) && (a.k_st % 8 == 0) && (a.v_st % 8 == 0) &&
                         (a.o_st % 4 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) && (a.v_sh % 8 == 0) && (a.o_sh % 4 == 0);
-  const bool mfma = can_mfma && (a.impl == 2 || (a.impl == 0 && a.Tq >= 16));
+  // the choice must not depend on Tq: a tail prefill after a KV-prefix reuse (1 query) and the full prefill (all queries) have
+  // to round identically, and they do when the same kernel scans the same 64-key tiles (a query's result does not depend on
+  // which block / lane holds it)
+  const bool mfma = can_mfma && a.impl != 1;
   if (mfma) {
     dim3 grid((a.Tq + 63) / 64, a.H);
     if (a.hd == 72) hipLaunchKernelGGL((k_attention_mfma<72>), grid, dim3(256), 0, s, a);

@@ -1230,3 +1230,54 @@ def test_multiblock_sampler_in_the_decode_graphs(bigvocab):
         for sl in range(3):
             got[sl].append(t[sl])
     assert got == alone
+
+
+def test_long_context_properties_ds13b():
+    """context near max_positions (2048) at BASELINE size: many key tiles in the flash prefill kernel, long split-K chunks in
+    the decode attention, the LCP-reuse prefill from position 1900.  Size-independent properties: prefill(T) == prefill(T-1) +
+    one decode step (within the two-pipelines bound); prefix reuse and kv_fork are bit-identical to the full prefill; the
+    context limit is enforced exactly."""
+    import gc
+    from detikzify_amd._lib import DtkError
+    from detikzify_amd.model import load
+    model, proc = load("detikzify-ds-1.3b", synthetic=1234, batch_slots=2)
+    try:
+        enc = proc(images=sketch_image(0, 224), return_tensors="pt")
+        g = torch.Generator().manual_seed(5)
+        text = torch.randint(100, 30000, (1900 - 243,), generator=g)
+        ids, px = torch.cat([enc.input_ids[0], text]), enc.pixel_values
+        assert ids.numel() == 1900
+        model.set_sampling(do_sample=False, bad_ids=[model.config.image_token_id])
+        full = model.prefill(ids, px, return_logits=True)
+        assert torch.isfinite(full).all()
+        # (1) incremental vs batched at T = 1901
+        model.decode_launch(); t = model.decode_wait()
+        inc = model.get_logits()
+        batched = model.prefill(torch.cat([ids, torch.tensor([t])]), px, return_logits=True)
+        r = rel_l2(inc, batched)
+        bound = 6e-3 * model.config.layers ** 0.5
+        print(f"ds-1.3b T=1901: incremental-vs-batched logits rel_l2 {r:.2e} (bound {bound:.2e})")
+        assert r < bound
+        # (2) LCP reuse from deep inside the context is bit-identical to the full prefill
+        again = model.prefill(ids, px, return_logits=True, reuse=True)      # keeps 1899 tokens, recomputes the last one
+        assert model.stats()["prefill_tokens"] > 0 and torch.equal(again, full)
+        # (3) slots: fork 1900 tokens, decode both slots -> identical tokens
+        model.set_sampling(do_sample=False, bad_ids=[model.config.image_token_id], slot=0)
+        model.set_sampling(do_sample=False, bad_ids=[model.config.image_token_id], slot=1)
+        s0 = model.prefill(ids, px, slot=0, return_logits=True)
+        assert torch.equal(s0, full)
+        model.kv_fork(0, 1, ids.numel())
+        for _ in range(4):
+            model.decode_batch_launch([0, 1]); out = model.decode_batch_wait()
+            assert out[0] == out[1]
+        # (4) the last position: decode up to exactly max_positions, then DTK_ERR_RANGE
+        model.prefill(ids, px)
+        n = 0
+        while model.context_len() < model.config.max_positions:
+            model.decode_launch(); model.decode_wait(); n += 1
+        assert n == model.config.max_positions - 1900
+        with pytest.raises(DtkError):
+            model.decode_launch()
+    finally:
+        del model
+        gc.collect()
