@@ -17,7 +17,7 @@ The features of the *reference* image are identical for every rollout; `cache_re
 """
 from __future__ import annotations
 
-from typing import Dict, List, Literal, Optional, Union
+from typing import Dict, Literal, Union
 
 import math
 

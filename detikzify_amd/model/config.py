@@ -8,7 +8,7 @@ the vision fields written by initialize_vision_modules, v1/modeling_detikzify.py
 from __future__ import annotations
 
 import json
-from dataclasses import asdict, dataclass, field
+from dataclasses import asdict, dataclass
 from pathlib import Path
 from typing import Any, Dict
 

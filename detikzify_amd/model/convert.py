@@ -16,7 +16,7 @@ SiglipVisionModel), so conversion is renaming plus two row-concatenations:
 from __future__ import annotations
 
 import re
-from typing import Dict, Iterator, List, Optional, Tuple
+from typing import Dict, Iterator, List, Tuple
 
 import torch
 

@@ -10,7 +10,7 @@ Pure numpy/PIL (the reference needs py3.11 typing.Unpack and timm, absent here).
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Sequence, Union
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
