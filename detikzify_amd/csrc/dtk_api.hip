@@ -1426,7 +1426,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
   else if (!strcmp(name, "gemm_tile")) {   // MFMA GEMM block tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (process-wide)
-    if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..3");
+    if (value < 0 || value > 5) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..5");
     set_gemm_tile(value);
   }
   else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;

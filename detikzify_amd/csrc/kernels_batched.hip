@@ -38,7 +38,7 @@ __device__ __forceinline__ float gemm_epilogue(float acc, int m, int n, const Ge
 // per output element is the same for every tile shape, so all variants (and the naive twin) round identically.
 template <int TBM, int TBN, int D = 1>   // D = k-tiles of global loads kept in flight in registers
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
-  constexpr int TM = TBM / 32, TN = TBN / 32;      // MFMA tiles per wave
+  constexpr int TM = TBM / 32, TN = TBN / 32;      // MFMA tiles per wave (2 x 2 wave grid; TBM, TBN >= 32)
   constexpr int AI = TBM / 32, WI = TBN / 32;      // 16-byte staging chunks per thread per operand
   __shared__ __attribute__((aligned(16))) bf16_t As[TBM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[TBN * LDS_STRIDE];
@@ -145,33 +145,41 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
 
 static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
 void set_gemm_stages(int v) { g_gemm_stages = v; }
-static int g_gemm_tile = -1;   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (dtk_set_option "gemm_tile" / DTK_GEMM_TILE)
+static int g_gemm_tile = -1;   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32 (dtk_set_option "gemm_tile" / DTK_GEMM_TILE)
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 static int gemm_tile_override() {
   if (g_gemm_tile < 0) {
     const char* e = getenv("DTK_GEMM_TILE");
-    g_gemm_tile = !e ? 0 : (!strcmp(e, "64x64") ? 1 : (!strcmp(e, "128x64") ? 2 : (!strcmp(e, "128x128") ? 3 : 0)));
+    g_gemm_tile = !e ? 0 : (!strcmp(e, "64x64") ? 1 : (!strcmp(e, "128x64") ? 2 : (!strcmp(e, "128x128") ? 3 : (!strcmp(e, "64x32") ? 4 : (!strcmp(e, "32x32") ? 5 : 0)))));
   }
   return g_gemm_tile;
 }
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int tile = gemm_tile_override();
-  if (!tile) tile = 1;   // measured (ds-7b, M = 243 / 729): 64x64 17.1 / 4.6 ms, 128x64 18.7 / 5.5, 128x128 22.6 / 7.1 —
-                         // these GEMMs are latency- and tile-count-bound, not LDS-read-bound; the big tiles stay selectable
-  (void)blocks;
-  auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
-  if (tile == 3) hipLaunchKernelGGL((k_gemm_mfma<128, 128>), grid(128, 128), dim3(256), 0, s, a);
-  else if (tile == 2) hipLaunchKernelGGL((k_gemm_mfma<128, 64>), grid(128, 64), dim3(256), 0, s, a);
-  else {
-    if (g_gemm_stages < 0) { const char* e = getenv("DTK_GEMM_STAGES"); g_gemm_stages = e ? atoi(e) : 3; }
-    switch (g_gemm_stages) {
-      case 1: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 1>), grid(64, 64), dim3(256), 0, s, a); break;
-      case 2: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 2>), grid(64, 64), dim3(256), 0, s, a); break;
-      case 4: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 4>), grid(64, 64), dim3(256), 0, s, a); break;
-      default: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 3>), grid(64, 64), dim3(256), 0, s, a); break;
-    }
+  if (!tile) {
+    // measured (ds-7b, M = 243 / 729): 64x64 17.1 / 4.6 ms, 128x64 18.7 / 5.5, 128x128 22.6 / 7.1 — these GEMMs are latency- and
+    // tile-count-bound, not LDS-read-bound.  Shapes that give fewer than two 64x64 blocks per CU (N = d in the prefill,
+    // N = 1152 in the ViT) take the smaller tiles: more blocks, more waves in flight
+    tile = 1;
+    if (blocks(64, 64) < 512) tile = blocks(64, 32) >= 512 ? 4 : 5;
   }
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
+  if (g_gemm_stages < 0) { const char* e = getenv("DTK_GEMM_STAGES"); g_gemm_stages = e ? atoi(e) : 3; }
+  const int D = g_gemm_stages;
+#define GEMM_LAUNCH(BM_, BN_)                                                                                         \
+  switch (D) {                                                                                                        \
+    case 1: hipLaunchKernelGGL((k_gemm_mfma<BM_, BN_, 1>), grid(BM_, BN_), dim3(256), 0, s, a); break;                \
+    case 2: hipLaunchKernelGGL((k_gemm_mfma<BM_, BN_, 2>), grid(BM_, BN_), dim3(256), 0, s, a); break;                \
+    case 4: hipLaunchKernelGGL((k_gemm_mfma<BM_, BN_, 4>), grid(BM_, BN_), dim3(256), 0, s, a); break;                \
+    default: hipLaunchKernelGGL((k_gemm_mfma<BM_, BN_, 3>), grid(BM_, BN_), dim3(256), 0, s, a); break;               \
+  }
+  if (tile == 3) { GEMM_LAUNCH(128, 128) }
+  else if (tile == 2) { GEMM_LAUNCH(128, 64) }
+  else if (tile == 4) { GEMM_LAUNCH(64, 32) }
+  else if (tile == 5) { GEMM_LAUNCH(32, 32) }
+  else { GEMM_LAUNCH(64, 64) }
+#undef GEMM_LAUNCH
 }
 
 // Plain one-thread-per-output GEMM: the obviously-correct twin of k_gemm_mfma (selected

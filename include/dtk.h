@@ -198,7 +198,7 @@ int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
 int  dtk_bench_gemv(dtk_ctx* ctx, int role, int variant, int reps, float* avg_us);
 int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
 int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);   /* "attn_full_max", "attn_combine", "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
-                                                                     "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128) */
+                                                                     "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32) */
 
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the
  * hot path on host buffers.  All matrices row-major; bf16 as uint16.  They exist so a
