@@ -463,7 +463,15 @@ void set_gemv_default_variant(int epi, int variant) { if (epi >= 0 && epi < 8) g
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s) {
   if (a.W8) return launch_gemv_f8(pro, epi, a, s);
-  launch_gemv_variant(pro, epi, g_variant[epi & 7], a, s);
+  int v = g_variant[epi & 7];
+  // d <= 2048 (ds-1.3b / tl-1.1b): the per-layer kernels stream only 8-45 MB each, so fewer, fatter waves win
+  // (tools/tune_gemv.py on ds-1.3b: gate/up persistent 8-wave 9.35 us vs 10.44; decode 1049 -> 1100 tok/s)
+  if (v == 0 && a.d > 0 && a.d <= 2048) {
+    if (epi == EPI_SWIGLU) v = 5;        // (R 1, U 4, 8 waves, persistent, 2 blocks per CU)
+    else if (epi == EPI_QKV) v = 9;      // (R 1, U 1, 4 waves)
+    else if (epi == EPI_RESID) v = 10;   // (R 1, U 8, 8 waves)
+  }
+  launch_gemv_variant(pro, epi, v, a, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from detikzify_amd.model import load  # noqa: E402
 
-ROLES = {0: ("qkv", 1), 1: ("o_proj", 1), 2: ("gate_up", 1), 3: ("down", 1), 4: ("lm_head", 1)}
+ROLES = {0: ("qkv", 12), 1: ("o_proj", 13), 2: ("gate_up", 12), 3: ("down", 13), 4: ("lm_head", 5)}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")
