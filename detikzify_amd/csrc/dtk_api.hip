@@ -67,7 +67,7 @@ struct dtk_ctx {
   std::string err;
 
   // derived sizes
-  int d, L, H, ff, V, Tmax, S;
+  int d, L, H, ff, V, Tmax, S, Sb = 8;   // S / Sb: split-K factor of the decode attention (one sequence / batched step)
   int vD, vDepth, vH, vHd, vMlp, vN, vPatchK, vPatchLd, nImg;
 
   // weights
@@ -401,9 +401,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->aob = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)d, 32));
     c->actb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)ff, 32));
     c->logits_b = P.take<float>((size_t)c->nb * V);
-    c->pmb = P.take<float>((size_t)c->nb * c->H * c->S);
-    c->plb = P.take<float>((size_t)c->nb * c->H * c->S);
-    c->pob = P.take<float>((size_t)c->nb * c->H * c->S * 128);
+    c->pmb = P.take<float>((size_t)c->nb * c->H * c->Sb);
+    c->plb = P.take<float>((size_t)c->nb * c->H * c->Sb);
+    c->pob = P.take<float>((size_t)c->nb * c->H * c->Sb * 128);
     c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
     c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
     c->smb_b = P.take<SampleMB>(DTK_MAX_BATCH + 1);
@@ -574,7 +574,7 @@ void batch_step_launches(dtk_ctx* c) {
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
@@ -722,8 +722,12 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->KVH = cfg->reserved[2] > 0 ? cfg->reserved[2] : cfg->heads;      // GQA (v2: LLaMA-3.1, 32 / 8)
   c->proj_bias = (cfg->reserved[3] & DTK_ARCH_PROJ_NO_BIAS) == 0;     // v2 connector: Linear(3*D -> d, bias=False)
   c->Tmax = cfg->max_positions;
-  c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
-  if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = v; }   // tuning aid
+  // split-K factor of the decode attention: an explicit config value applies to both paths; auto = 16 for one sequence
+  // (ds-7b 369.6 -> 373.0, ds-1.3b 1092 -> 1111, v2-8b 343.4 -> 345.1 tok/s over 8) and 8 for the batched step
+  // (32 slots already give 8192 blocks: 4.53 ms/step vs 4.69 with 16)
+  c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 16;
+  c->Sb = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
+  if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = c->Sb = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
   // up to 32 decoding slots (one or two 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
   c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_BATCH + 1 ? DTK_MAX_BATCH + 1 : cfg->reserved[0]);
@@ -739,6 +743,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   const char* ac = getenv("DTK_ATTN_COMBINE");
   c->attn_combine = !ac ? 2 : (!strcmp(ac, "consumer") ? 0 : (!strcmp(ac, "inkernel") ? 1 : 2));
   if (c->S > 16) c->S = 16;
+  if (c->Sb > 16) c->Sb = 16;
   if (const char* fm = getenv("DTK_ATTN_FULL_MAX")) c->attn_full_max = atoi(fm);
   if (const char* gv = getenv("DTK_GEMV_VARIANTS")) {  // "epi:variant,epi:variant" (tuning aid)
     int e = 0, v = 0;

@@ -48,7 +48,7 @@ class DetikzifyConfig:
     patch_token_id: int = 32013      # == BOS (v1/__init__.py:49); v2: image_token_id 128005 (configuration_detikzify.py:89)
     proj_bias: bool = True           # v1 mm_projector nn.Linear(3D, d) with bias; v2 connector bias=False (modeling_detikzify.py:67)
     arch: str = "v1"                 # "v1" (timm tower + LlamaModel subclass) | "v2" (HF SigLIP + Idefics3-style merger)
-    attn_splits: int = 8
+    attn_splits: int = 0             # split-K factor of the decode attention; 0 = auto (16 for one sequence, 8 for the batched step)
     batch_slots: int = 0             # KV slots for batched decode of independent rollouts (0 = none)
     weight_format: str = "bf16"      # "bf16" | "fp8" (e4m3 decoder Linear weights, per-row 2^e scales)
     model_type: str = "detikzify"
