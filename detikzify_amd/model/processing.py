@@ -64,6 +64,21 @@ class DetikzifyImageProcessor:
                 "do_normalize": self.do_normalize, "image_mean": self.image_mean,
                 "image_std": self.image_std, "image_processor_type": "TimmImageProcessor"}
 
+    def _lut(self, channel: int) -> np.ndarray:
+        """value of rescale -> normalise for each of the 256 uint8 inputs of one channel (the same numpy expressions)"""
+        key = (channel, self.do_rescale, self.rescale_factor, self.do_normalize, self.image_mean[channel], self.image_std[channel])
+        cache = self.__dict__.setdefault("_lut_cache", {})
+        if key not in cache:
+            x = np.arange(256, dtype=np.uint8)
+            if self.do_rescale:
+                x = (x.astype(np.float64) * self.rescale_factor).astype(np.float32)
+            if self.do_normalize:
+                mean = np.array(self.image_mean[channel], dtype=x.dtype)
+                std = np.array(self.image_std[channel], dtype=x.dtype)
+                x = (x - mean) / std
+            cache[key] = x
+        return cache[key]
+
     @staticmethod
     def _to_numpy(image) -> np.ndarray:
         if isinstance(image, Image.Image):
@@ -90,6 +105,13 @@ class DetikzifyImageProcessor:
             arr = self._to_numpy(im)
             if self.do_resize:
                 arr = self._resize(arr)
+            if arr.dtype == np.uint8 and arr.ndim == 3 and arr.shape[2] == len(self.image_mean):
+                # uint8 input (every path through _resize): the per-pixel arithmetic below has only 256 possible inputs per
+                # channel, so it is evaluated once per value and gathered — bit-identical, ~15 ms less GIL time per image
+                # (the SelfSim reward calls this once per rollout from 32 threads)
+                x = np.stack([self._lut(c)[arr[:, :, c]] for c in range(arr.shape[2])])
+                out.append(np.ascontiguousarray(x))
+                continue
             x = arr
             if self.do_rescale:
                 x = (x.astype(np.float64) * self.rescale_factor).astype(np.float32)
