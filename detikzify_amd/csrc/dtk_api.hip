@@ -1435,6 +1435,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     set_gemm_tile(value);
   }
   else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;
+  else if (!strcmp(name, "gemm_bk")) {
+    if (value != 64 && value != 128) return fail(c, DTK_ERR_ARG, "gemm_bk must be 64 or 128");
+    set_gemm_bk(value);
+  }
   else if (!strcmp(name, "gemm_stages")) {
     if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_stages must be 1..4");
     set_gemm_stages(value);

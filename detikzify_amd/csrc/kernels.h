@@ -142,6 +142,7 @@ struct GemmArgs {
   int flags;
 };
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
+void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4
 void set_gemm_tile(int v);   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32
 void launch_gemm_naive(const GemmArgs& a, hipStream_t s);

@@ -11,8 +11,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BK 64
-#define LDS_STRIDE 72  // bf16 elements per LDS row (64 + 8 pad -> 144 B, 16-byte aligned)
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
@@ -36,10 +34,13 @@ __device__ __forceinline__ float gemm_epilogue(float acc, int m, int n, const Ge
 // wave reads TM + TN fragments from LDS for TM*TN MFMAs.  64x64 (2+2 reads per 4 MFMAs) is LDS-read-bound; 128x64 and
 // 128x128 (4+4 per 16) are not, but need M*N large enough to fill 256 CUs: launch_gemm_mfma picks per shape.  The k order
 // per output element is the same for every tile shape, so all variants (and the naive twin) round identically.
-template <int TBM, int TBN, int D = 1>   // D = k-tiles of global loads kept in flight in registers
+template <int TBM, int TBN, int D = 1, int TBK = 64>   // D = k-tiles of global loads kept in flight in registers; TBK = k-tile
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
   constexpr int TM = TBM / 32, TN = TBN / 32;      // MFMA tiles per wave (2 x 2 wave grid; TBM, TBN >= 32)
-  constexpr int AI = TBM / 32, WI = TBN / 32;      // 16-byte staging chunks per thread per operand
+  constexpr int CH = TBK / 8;                      // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CH;                    // tile rows staged per pass of the 256 threads
+  constexpr int AI = TBM / RPP, WI = TBN / RPP;    // 16-byte staging chunks per thread per operand
+  constexpr int LDS_STRIDE = TBK + 8;              // bf16 elements per LDS row (+8 pad: 16-byte aligned, conflict-free fragment reads)
   __shared__ __attribute__((aligned(16))) bf16_t As[TBM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[TBN * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,21 +55,21 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
   if (nt >= NB) return;
   const int m0 = mb * TBM, n0 = nt * TBN;
 
-  // staging map: thread -> (row, 16-byte chunk); rows srow + 32*i
-  const int srow = tid >> 3;  // 0..31
-  const int schk = tid & 7;   // 0..7 (8 bf16 each)
+  // staging map: thread -> (row, 16-byte chunk); rows srow + RPP*i
+  const int srow = tid / CH;
+  const int schk = tid % CH;  // 8 bf16 each
   const int K = a.K;
 
   const bf16_t* Ag[AI];
   const bf16_t* Wg[WI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int am = m0 + srow + 32 * i; if (am >= a.M) am = a.M - 1;
+    int am = m0 + srow + RPP * i; if (am >= a.M) am = a.M - 1;
     Ag[i] = a.A + (size_t)am * a.lda;
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    int wn = n0 + srow + 32 * i; if (wn >= a.N) wn = a.N - 1;
+    int wn = n0 + srow + RPP * i; if (wn >= a.N) wn = a.N - 1;
     Wg[i] = a.W + (size_t)wn * a.ldw;
   }
 
@@ -93,15 +94,15 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
   };
   auto stage_write = [&](const u32x4 (&pa)[AI], const u32x4 (&pw)[WI]) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&As[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = pa[i];
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&As[(srow + RPP * i) * LDS_STRIDE + schk * 8]) = pa[i];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(&Bs[(srow + 32 * i) * LDS_STRIDE + schk * 8]) = pw[i];
+    for (int i = 0; i < WI; ++i) *reinterpret_cast<u32x4*>(&Bs[(srow + RPP * i) * LDS_STRIDE + schk * 8]) = pw[i];
   };
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + TBK - 1) / TBK;
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < nk) stage_load(ra[d], rw[d], d * BK);
+    if (d < nk) stage_load(ra[d], rw[d], d * TBK);
   for (int t0 = 0; t0 < nk; t0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
       __syncthreads();  // previous tile's fragment reads are done
       stage_write(ra[d], rw[d]);
       __syncthreads();
-      if (t + D < nk) stage_load(ra[d], rw[d], (t + D) * BK);  // in flight under the next D tiles of MFMAs
+      if (t + D < nk) stage_load(ra[d], rw[d], (t + D) * TBK);  // in flight under the next D tiles of MFMAs
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < TBK / 32; ++ks) {
         bf16x8_t af[TM], bfr[TN];
         const int kk = ks * 32 + (lane >> 4) * 8;
 #pragma unroll
@@ -145,6 +146,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
 
 static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
 void set_gemm_stages(int v) { g_gemm_stages = v; }
+static int g_gemm_bk = 64;      // k-tile of the 64x64 kernel: 64 | 128 (dtk_set_option "gemm_bk")
+void set_gemm_bk(int v) { g_gemm_bk = v; }
 static int g_gemm_tile = -1;   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32 (dtk_set_option "gemm_tile" / DTK_GEMM_TILE)
 void set_gemm_tile(int v) { g_gemm_tile = v; }
 static int gemm_tile_override() {
@@ -178,6 +181,13 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   else if (tile == 2) { GEMM_LAUNCH(128, 64) }
   else if (tile == 4) { GEMM_LAUNCH(64, 32) }
   else if (tile == 5) { GEMM_LAUNCH(32, 32) }
+  else if (g_gemm_bk == 128) {
+    switch (D) {
+      case 1: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 1, 128>), grid(64, 64), dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 2, 128>), grid(64, 64), dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm_mfma<64, 64, 3, 128>), grid(64, 64), dim3(256), 0, s, a); break;
+    }
+  }
   else { GEMM_LAUNCH(64, 64) }
 #undef GEMM_LAUNCH
 }

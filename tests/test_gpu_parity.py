@@ -137,7 +137,11 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
         model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K,
                                            flags | (_lib.DTK_GEMM_NAIVE if tile == "naive" else 0), p(out)), "dtk_op_gemm")
         outs[tile] = out
-    model.set_option("gemm_tile", 0)
+    model.set_option("gemm_tile", 1); model.set_option("gemm_bk", 128)      # 128-wide k-tile of the 64x64 kernel
+    out = np.empty((M, N), dtype=np.uint16)
+    model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
+    model.set_option("gemm_bk", 64); model.set_option("gemm_tile", 0)
+    assert np.array_equal(out, outs[1])
     assert all(np.array_equal(outs[1], outs[t]) for t in (2, 3, 4, 5))
     frac = float((outs[1] != outs["naive"]).mean())
     assert frac < 2e-3     # fmaf chain vs MFMA tree inside a 32-wide k-step: rare 1-ulp flips only
