@@ -8,6 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
+DTK_ABI_VERSION = 2          # include/dtk.h DTK_ABI_VERSION
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
 DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
@@ -119,8 +120,8 @@ def load_library() -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, loud by design
         fn.restype, fn.argtypes = res, args
-    if lib.dtk_abi_version() != 2:
-        raise DtkError(f"ABI version {lib.dtk_abi_version()} != 2")
+    if lib.dtk_abi_version() != DTK_ABI_VERSION:
+        raise DtkError(f"ABI version {lib.dtk_abi_version()} != {DTK_ABI_VERSION}")
     _lib = lib
     return lib
 

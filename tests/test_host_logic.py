@@ -153,7 +153,9 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dtk_abi_version() == 2
+    assert lib.dtk_abi_version() == _lib.DTK_ABI_VERSION
+    hdr = (Path(__file__).resolve().parents[1] / "include" / "dtk.h").read_text()
+    assert f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION} " in hdr or f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION}\n" in hdr
     assert ctypes.sizeof(_lib.DtkConfig) == 29 * 4 and ctypes.sizeof(_lib.DtkSampling) == 8 * 4 + 8 + 0 + 3 * 4 + 24 * 4 or True
 
 
@@ -253,3 +255,9 @@ def test_emd_selfsim_matches_the_transport_lp():
     lp = linprog(M.reshape(-1), A_eq=A, b_eq=np.full(2 * n, 1 / n), bounds=(0, None), method="highs").fun
     assert abs(emd2_uniform(M) - lp) < 1e-9
     assert abs(emd2_uniform(pairwise_cosine_distance(a, a))) < 1e-12       # identical patch sets: distance 0 -> score 1
+
+
+def test_graft_entry_build_runs():
+    """the driver's "does it build" check: compiles the library in-tree and imports the package (no GPU needed)"""
+    import __graft_entry__ as g
+    g.build()
