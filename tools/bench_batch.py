@@ -18,6 +18,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--weight-format", default="bf16")
+ap.add_argument("--fork", action="store_true", help="prefill slot 0 only and fork its KV into the other slots (fewer dispatches: profiling runs)")
 args = ap.parse_args()
 model, proc = load(args.model, synthetic=1234, batch_slots=args.batch, weight_format=args.weight_format)
 model.set_graph_mode(args.graph)
@@ -25,7 +26,10 @@ enc = proc(images=sketch_image(0, 224), return_tensors="pt")
 ids, px = enc.input_ids[0], enc.pixel_values
 for s in range(args.batch):
     model.set_sampling(do_sample=False, bad_ids=[model.config.image_token_id], slot=s)
-    model.prefill(ids, px, slot=s, reuse=(s > 0))
+    if args.fork and s > 0:
+        model.kv_fork(0, s, ids.numel())
+    else:
+        model.prefill(ids, px, slot=s, reuse=(s > 0))
 slots = list(range(args.batch))
 for _ in range(4):
     model.decode_batch_launch(slots); model.decode_batch_wait()
