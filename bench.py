@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--probe-tokens", type=int, default=64)
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
-    ap.add_argument("--batch", type=int, default=32, help="independent rollouts decoded as one batch per GPU in the "
+    ap.add_argument("--batch", type=int, default=64, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     ap.add_argument("--mcts-trees", type=int, default=0, help="optional extra phase: root-parallel MCTS (reference search logic per "
                     "tree, SelfSim reward on the device ViT, LaTeX replaced by the synthetic renderer) with this many trees per GPU")
@@ -123,7 +123,7 @@ def main():
         ddist.init_process_group(backend, timeout_s=1800)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=(min(32, args.batch) + 1) if args.batch > 1 else 0,   # + the prefix-cache slot
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=(min(64, args.batch) + 1) if args.batch > 1 else 0,   # + the prefix-cache slot
                        weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config

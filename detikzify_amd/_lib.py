@@ -8,12 +8,12 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
-DTK_ABI_VERSION = 2          # include/dtk.h DTK_ABI_VERSION
+DTK_ABI_VERSION = 3          # include/dtk.h DTK_ABI_VERSION
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
 DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
 DTK_MAX_INFLIGHT = 4
-DTK_MAX_BATCH = 32          # entries of the active / tokens_out arrays of dtk_decode_batch_*
+DTK_MAX_BATCH = 64          # entries of the active / tokens_out arrays of dtk_decode_batch_*
 DTK_EPI_BIAS, DTK_EPI_GELU, DTK_EPI_RESIDUAL, DTK_GEMM_NAIVE = 1, 2, 4, 256
 
 

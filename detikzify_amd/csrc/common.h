@@ -62,9 +62,9 @@ struct DecState {
   int32_t pad[3];
 };
 
-// Batched decode (kernels_batch_decode.hip): which of the (up to 32) slots take part in this step.
+// Batched decode (kernels_batch_decode.hip): which of the (up to 64) slots take part in this step.
 #ifndef DTK_MAX_BATCH
-#define DTK_MAX_BATCH 32   // == include/dtk.h
+#define DTK_MAX_BATCH 64   // == include/dtk.h
 #endif
 struct BatchState {
   int32_t active[DTK_MAX_BATCH];

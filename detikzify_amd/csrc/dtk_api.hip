@@ -729,9 +729,9 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->Sb = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = c->Sb = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
-  // up to 32 decoding slots (one or two 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
+  // up to 64 decoding slots (one, two or four 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
   c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_BATCH + 1 ? DTK_MAX_BATCH + 1 : cfg->reserved[0]);
-  c->nt = c->nb > 17 ? 2 : 1;          // 17 = 16 decoding slots + the prefix slot
+  c->nt = c->nb > 33 ? 4 : (c->nb > 17 ? 2 : 1);   // 17 / 33 / 65 = 16 / 32 / 64 decoding slots + the prefix slot
   c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
   c->vMlp = cfg->vit_mlp; c->vN = np * np;

@@ -42,10 +42,12 @@ __device__ __forceinline__ bf16x8_t f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
 // F8: the weights come from the fp8 pair-tiled copy (half the bytes); they are widened to bf16 in registers and
 // fed to the same bf16 MFMA in the same k order, the per-row power-of-two scale multiplies the reduced fp32
 // sum — bit-identical to the bf16 kernel on the de-quantised weights.
-// NT = 16-slot column tiles (1: up to 16 slots, 2: up to 32): the A (weight) fragment of a k-step is reused by NT MFMAs
+// NT = 16-slot column tiles (1: up to 16 slots, 2: up to 32, 4: up to 64): the A (weight) fragment of a k-step is reused by NT
+// MFMAs.  The cross-wave reduction goes through LDS two column tiles at a time (NP), so NT = 4 needs no more LDS than NT = 2.
 template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES, int NT = 1, int KS = 4>   // KS = k-steps per register stage
 __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
-  __shared__ float red[WAVES][T][NT][256];
+  constexpr int NP = NT > 2 ? 2 : NT;   // column tiles per reduction pass
+  __shared__ float red[WAVES][T][NP][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
   const int K = a.K;
@@ -134,87 +136,100 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
       mma(wA, xA);
     }
   }
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][t][nt][lane * 4 + r] = acc[t][nt][r];
-  __syncthreads();
-  if (tid >= 256 * NT) return;
-  // thread -> (m, n) of a 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
-  const int nt = tid >> 8, ti = tid & 255;
-  const int l2 = ti >> 2, r2 = ti & 3;
-  const int n = nt * 16 + (l2 & 15);  // slot
-  const int m = (l2 >> 4) * 4 + r2;   // row inside the tile
-  float v[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    float sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) sum += red[w][t][nt][ti];
-    if (F8) {
-      int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
-      if (row >= a.N) row = a.N - 1;
-      sum *= a.wscale[row];   // power of two: exact
-    }
-    v[t] = sum;
-  }
-  if (!a.bs->active[n]) return;
-  if (EPI == EPI_RESID) {
-#pragma unroll
+  // cross-wave reduction + epilogue, NP column tiles per pass
+  auto finish = [&](int q, int nt, int ti) {
+    // thread -> (m, n) of a 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
+    const int l2 = ti >> 2, r2 = ti & 3;
+    const int n = nt * 16 + (l2 & 15);  // slot
+    const int m = (l2 >> 4) * 4 + r2;   // row inside the tile
+    float v[T];
+  #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
-      if (row < a.N) {
-        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
-        *y = f2bf(bf2f(*y) + rbf(v[t]));
+      float sum = 0.f;
+  #pragma unroll
+      for (int w = 0; w < WAVES; ++w) sum += red[w][t][q][ti];
+      if (F8) {
+        int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+        if (row >= a.N) row = a.N - 1;
+        sum *= a.wscale[row];   // power of two: exact
+      }
+      v[t] = sum;
+    }
+    if (!a.bs->active[n]) return;
+    if (EPI == EPI_RESID) {
+  #pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+        if (row < a.N) {
+          bf16_t* y = a.Y + (size_t)n * a.ldy + row;
+          *y = f2bf(bf2f(*y) + rbf(v[t]));
+        }
+      }
+    } else if (EPI == EPI_LOGITS) {
+  #pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+        if (row < a.N) a.logits[(size_t)n * a.N + row] = rbf(v[t]);
+      }
+    } else if (EPI == EPI_STORE) {
+  #pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
+        if (row < a.N) a.Y[(size_t)n * a.ldy + row] = f2bf(v[t]);
+      }
+    } else if (EPI == EPI_SWIGLU) {
+      const int i = blk * 16 + m;
+      if (i < a.ff) {
+        const float gte = rbf(v[0]), up = rbf(v[T - 1]);
+        const float sl = rbf(gte / (1.f + expf(-gte)));
+        a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
+      }
+    } else if (EPI == EPI_QKV) {
+      const int hb = blk >> 2, i = (blk & 3) * 16 + m;
+      const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+      const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
+      const int pos = a.st[n].pos;
+      const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
+      const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+      if (sec == 2) {
+        bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
+        dst[i] = f2bf(x1);
+        dst[i + 64] = f2bf(x2);
+      } else {
+        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+        const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+        const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+        bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                                 : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
+        dst[i] = f2bf(o1);
+        dst[i + 64] = f2bf(o2);
       }
     }
-  } else if (EPI == EPI_LOGITS) {
+
+  };
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
-      if (row < a.N) a.logits[(size_t)n * a.N + row] = rbf(v[t]);
-    }
-  } else if (EPI == EPI_STORE) {
+  for (int p0 = 0; p0 < NT; p0 += NP) {
+    if (p0) __syncthreads();   // the previous pass's reads of `red` are done
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int row = gb_tile_row0<EPI, T>(a, blk, t) + m;
-      if (row < a.N) a.Y[(size_t)n * a.ldy + row] = f2bf(v[t]);
-    }
-  } else if (EPI == EPI_SWIGLU) {
-    const int i = blk * 16 + m;
-    if (i < a.ff) {
-      const float gte = rbf(v[0]), up = rbf(v[T - 1]);
-      const float sl = rbf(gte / (1.f + expf(-gte)));
-      a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
-    }
-  } else if (EPI == EPI_QKV) {
-    const int hb = blk >> 2, i = (blk & 3) * 16 + m;
-    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
-    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
-    const int pos = a.st[n].pos;
-    const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
-    const size_t slot_kv = (size_t)n * a.kv_slot_stride;
-    if (sec == 2) {
-      bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
-      dst[i] = f2bf(x1);
-      dst[i + 64] = f2bf(x2);
-    } else {
-      const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-      const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
-      const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
-      const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
-      bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
-                               : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
-      dst[i] = f2bf(o1);
-      dst[i + 64] = f2bf(o2);
-    }
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][q][lane * 4 + r] = acc[t][p0 + q][r];
+    __syncthreads();
+    if (tid < 256 * NP) finish(tid >> 8, p0 + (tid >> 8), tid & 255);
   }
 }
 
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
+  if (a.nt >= 3) {
+    if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1, false, GB_WAVES, 4>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, false, GB_WAVES, 4>), g, b, 0, s, a);
+    return;
+  }
   if (a.nt == 2) {
     if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
     else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1, false, GB_WAVES, 2>), g, b, 0, s, a);
@@ -255,7 +270,8 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
   }
 }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (a.nt == 2) { if (a.W8) launch_gemv_b_impl<true, 2>(epi, a, s); else launch_gemv_b_impl<false, 2>(epi, a, s); }
+  if (a.nt >= 3) { if (a.W8) launch_gemv_b_impl<true, 4>(epi, a, s); else launch_gemv_b_impl<false, 4>(epi, a, s); }
+  else if (a.nt == 2) { if (a.W8) launch_gemv_b_impl<true, 2>(epi, a, s); else launch_gemv_b_impl<false, 2>(epi, a, s); }
   else { if (a.W8) launch_gemv_b_impl<true, 1>(epi, a, s); else launch_gemv_b_impl<false, 1>(epi, a, s); }
 }
 

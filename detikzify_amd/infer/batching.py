@@ -49,7 +49,7 @@ class BatchEngine:
         # one slot is set aside as the prefix cache: it holds the KV of the image prefix ([image_token]*n
         # + pixels) of the current image; sequences fork it (bit-identical KV) and only
         # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
-        maxdec = 32 if n > 17 else 16   # the kernels use one 16-slot MFMA column tile up to 17 slots, two above (include/dtk.h)
+        maxdec = 64 if n > 33 else (32 if n > 17 else 16)   # one / two / four 16-slot MFMA column tiles (include/dtk.h)
         dec = min(n, maxdec)
         self.share_prefix = share_prefix and n >= 2 and (n > maxdec or max_batch is None or max_batch < n)
         self.prefix_slot = n - 1 if self.share_prefix else None

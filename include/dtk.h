@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DTK_ABI_VERSION 2   /* 2: batch arrays are DTK_MAX_BATCH (32) entries (were 16) */
+#define DTK_ABI_VERSION 3   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64 */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -178,10 +178,11 @@ int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
  * of slots (<= DTK_MAX_BATCH + 1), each with its own KV cache, sampling state and logits.  One
  * dtk_decode_batch_* step = one _sample iteration for every active slot with ONE pass over the weights
  * (bytes/step = W + sum_b K*t_b).  Up to 17 slots: slots 0..15 decode (one 16-column MFMA tile); 18..33 slots:
- * slots 0..31 decode (two tiles); a further slot can only be prefilled / forked from (prefix cache).
+ * slots 0..31 decode (two tiles); 34..65 slots: slots 0..63 decode (four tiles); a further slot can only be
+ * prefilled / forked from (prefix cache).
  * The `active` / `tokens_out` arrays always have DTK_MAX_BATCH entries.
  * The image embeddings cache is shared (DTK_PREFILL_REUSE_IMAGE). */
-#define DTK_MAX_BATCH 32
+#define DTK_MAX_BATCH 64
 int  dtk_num_slots(const dtk_ctx* ctx);
 int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const float* pixels,
                       uint64_t image_key, int flags, float* logits_last_out);

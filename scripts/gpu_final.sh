@@ -16,13 +16,13 @@ timeout 600 python bench.py --model detikzify-cl-7b --weight-format fp8 --no-cpu
 import json
 d=json.loads(open("$OUT/bench_cl7b_fp8.log").read().strip().splitlines()[-1]); print("cl-7b fp8: tok/s", round(d["value"],1), "decode", round(d["decode_tokens_per_sec_per_gpu"],1), "frac", round(d["decode_step"]["frac_of_hbm_peak"],3))
 PY
-timeout 600 python bench.py --model detikzify-cl-7b --weight-format fp8 --no-cpu-baseline --steps 1 --batch 32 > "$OUT/bench_cl7b_fp8_b32.log" 2>/dev/null; python - <<PY
+timeout 600 python bench.py --model detikzify-cl-7b --weight-format fp8 --no-cpu-baseline --steps 1 --batch 64 > "$OUT/bench_cl7b_fp8_b64.log" 2>/dev/null; python - <<PY
 import json
-d=json.loads(open("$OUT/bench_cl7b_fp8_b32.log").read().strip().splitlines()[-1]); b=d["batched_rollouts"]; print("cl-7b fp8 B=32: rollouts/s", round(b["rollouts_per_sec"],2), "tok/s", round(b["tokens_per_sec"]))
+d=json.loads(open("$OUT/bench_cl7b_fp8_b64.log").read().strip().splitlines()[-1]); b=d["batched_rollouts"]; print("cl-7b fp8 B=64: rollouts/s", round(b["rollouts_per_sec"],2), "tok/s", round(b["tokens_per_sec"]))
 PY
-timeout 600 python bench.py --model detikzify-v2-8b --no-cpu-baseline --steps 2 --batch 32 > "$OUT/bench_v2_8b.log" 2>/dev/null; python - <<PY
+timeout 600 python bench.py --model detikzify-v2-8b --no-cpu-baseline --steps 2 --batch 64 > "$OUT/bench_v2_8b.log" 2>/dev/null; python - <<PY
 import json
-d=json.loads(open("$OUT/bench_v2_8b.log").read().strip().splitlines()[-1]); b=d["batched_rollouts"]; print("v2-8b: tok/s", round(d["value"],1), "decode", round(d["decode_tokens_per_sec_per_gpu"],1), "frac", round(d["decode_step"]["frac_of_hbm_peak"],3), "| B=32 rollouts/s", round(b["rollouts_per_sec"],2))
+d=json.loads(open("$OUT/bench_v2_8b.log").read().strip().splitlines()[-1]); b=d["batched_rollouts"]; print("v2-8b: tok/s", round(d["value"],1), "decode", round(d["decode_tokens_per_sec_per_gpu"],1), "frac", round(d["decode_step"]["frac_of_hbm_peak"],3), "| B=64 rollouts/s", round(b["rollouts_per_sec"],2))
 PY
 timeout 600 python bench.py --sample --no-cpu-baseline --batch 0 --steps 2 > "$OUT/bench_sample.log" 2>/dev/null; python - <<PY
 import json
@@ -34,6 +34,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python "
 echo "rocprof exit $?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/prof_pmc" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 0 --new-tokens 16 --no-cpu-baseline --probe-tokens 2 --batch 0 > "$OUT/prof_pmc.log" 2>&1
 echo "rocprof pmc exit $?"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_batch" -o trace -- python "$REPO/tools/bench_batch.py" --batch 32 --steps 32 > "$OUT/prof_batch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_batch" -o trace -- python "$REPO/tools/bench_batch.py" --batch 64 --steps 24 --fork > "$OUT/prof_batch.log" 2>&1
 grep "ms/step" "$OUT/prof_batch.log"
 cd "$REPO"

@@ -46,7 +46,7 @@ class _FakeModel:
         self.forks += 1
 
     def decode_batch_launch(self, slots):
-        assert len(self.launched) < 2 and slots == sorted(slots) and all(0 <= s < 32 for s in slots)
+        assert len(self.launched) < 2 and slots == sorted(slots) and all(0 <= s < 64 for s in slots)
         assert all(self.pos[s] < self.config.max_positions for s in slots)
         self.launched.append(list(slots))
         for s in slots:
@@ -56,7 +56,7 @@ class _FakeModel:
         time.sleep(0.0003)
         sl = self.launched.pop(0)
         self.steps += 1
-        out = [-1] * 32
+        out = [-1] * 64
         for s in sl:
             out[s] = s * 1000 + self.cnt[s]
             self.cnt[s] += 1

@@ -953,16 +953,17 @@ def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
 
 
 # ------------------------------------------------------------------------------------------ 32 slots (two MFMA column tiles)
-def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
-    """load(batch_slots=33): slots 0..31 decode in one step (two 16-column MFMA tiles reuse each weight
-    fragment).  Every slot's tokens and logits equal the same sequence decoded on the 16-slot build: the
+@pytest.mark.parametrize("nslots", [32, 64])
+def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots):
+    """load(batch_slots=33 | 65): slots 0..31 | 0..63 decode in one step (two | four 16-column MFMA tiles reuse each
+    weight fragment).  Every slot's tokens and logits equal the same sequence decoded on the 16-slot build: the
     per-column arithmetic (k order, reduction order) does not depend on the tile count."""
     from detikzify_amd.model import load
     m16, proc = tiny_batched
-    m32, _ = load("detikzify-tiny", synthetic=1234, batch_slots=33)
-    assert m32.num_slots() == 33
+    m32, _ = load("detikzify-tiny", synthetic=1234, batch_slots=nslots + 1)
+    assert m32.num_slots() == nslots + 1
     enc = [proc(images=sketch_image(40 + i % 3, 96), return_tensors="pt") for i in range(3)]
-    prompts = [torch.cat([enc[i % 3].input_ids[0], torch.tensor([10 + i, 3 * i + 5][: 1 + i % 2])]) for i in range(32)]
+    prompts = [torch.cat([enc[i % 3].input_ids[0], torch.tensor([10 + i, 3 * i + 5][: 1 + i % 2])]) for i in range(nslots)]
     n = 24
 
     def setup(m, slot, i):
@@ -971,7 +972,7 @@ def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
 
     # reference: sequences 0..3 and 28..31 on the 16-slot model, four at a time
     ref = {}
-    for group in ([0, 1, 2, 3], [28, 29, 30, 31]):
+    for group in ([0, 1, 2, 3], [nslots - 4, nslots - 3, nslots - 2, nslots - 1], [17, 30, 31, nslots // 2 + 3]):
         for sl, i in enumerate(group):
             setup(m16, sl, i)
         toks = {i: [] for i in group}
@@ -982,13 +983,13 @@ def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
                 toks[i].append(out[sl])
         for sl, i in enumerate(group):
             ref[i] = (toks[i], m16.get_logits_slot(sl).clone())
-    for i in range(32):
+    for i in range(nslots):
         setup(m32, i, i)
-    got = {i: [] for i in range(32)}
+    got = {i: [] for i in range(nslots)}
     for step in range(n):
-        m32.decode_batch_launch(range(32))
+        m32.decode_batch_launch(range(nslots))
         out = m32.decode_batch_wait()
-        for i in range(32):
+        for i in range(nslots):
             got[i].append(out[i])
     for i, (toks, logits) in ref.items():
         assert got[i] == toks, i
@@ -996,9 +997,9 @@ def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched):
     assert len({tuple(v) for v in got.values()}) > 20       # the 32 sequences really differ
     # a partially active step leaves the idle slots untouched
     before = m32.get_logits_slot(20).clone()
-    m32.decode_batch_launch([0, 17, 31])
+    m32.decode_batch_launch([0, 17, nslots - 1])
     out = m32.decode_batch_wait()
-    assert out[20] == -1 and out[0] >= 0 and out[17] >= 0 and out[31] >= 0
+    assert out[20] == -1 and out[0] >= 0 and out[17] >= 0 and out[nslots - 1] >= 0
     assert torch.equal(m32.get_logits_slot(20), before) and m32.context_len_slot(20) == prompts[20].numel() + n
 
 
