@@ -152,6 +152,11 @@ struct dtk_ctx {
   uint64_t launched = 0, waited = 0;
   hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  // dtk_vit_encode (the SelfSim reward's ViT passes) runs on its own stream so it overlaps with decode steps of other
+  // sequences; the caller serialises it with prefills (they share the ViT activation buffers), see model/modeling.py
+  hipStream_t stream_vit = nullptr;
+  hipStream_t cur_stream = nullptr;   // stream of the GEMMs being issued (vit_forward sets it)
+  hipEvent_t ev_va = nullptr, ev_vb = nullptr;
   hipEvent_t probe_a = nullptr, probe_b = nullptr;
   bool use_graph = true;
   bool graph_ready = false;
@@ -438,8 +443,9 @@ void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags;
-  if (c->gemm_naive) launch_gemm_naive(g, c->stream);
-  else launch_gemm_mfma(g, c->stream);
+  hipStream_t s = c->cur_stream ? c->cur_stream : c->stream;
+  if (c->gemm_naive) launch_gemm_naive(g, s);
+  else launch_gemm_mfma(g, s);
 }
 
 int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
@@ -448,9 +454,10 @@ bf16_t* kcache(dtk_ctx* c, int layer) { return c->kv + (size_t)layer * 2 * c->KV
 bf16_t* vcache(dtk_ctx* c, int layer) { return kcache(c, layer) + (size_t)c->KVH * c->Tmax * 128; }
 
 // ViT trunk + (optionally) MAP head for the image already in pixels_dev.
-void vit_forward(dtk_ctx* c, bool want_pooled) {
+void vit_forward(dtk_ctx* c, bool want_pooled, hipStream_t s) {
   const int D = c->vD, N = c->vN, mlp = c->vMlp, Hh = c->vH, hd = c->vHd;
-  hipStream_t s = c->stream;
+  struct StreamScope { dtk_ctx* c; hipStream_t prev; ~StreamScope() { c->cur_stream = prev; } } scope{c, c->cur_stream};
+  c->cur_stream = s;
   launch_im2col(c->pixels_dev, c->patches, c->cfg.vit_image, c->cfg.vit_patch, c->vPatchLd, s);
   // conv(patch)+bias -> bf16, then + pos_embed -> bf16 (timm PatchEmbed, _pos_embed)
   gemm(c, c->patches, c->vPatchLd, c->pe_w, c->vPatchLd, c->pe_b, c->pos_embed, D, c->VX, D, N, D,
@@ -767,6 +774,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   } while (0)
   CCHK(hipSetDevice(device));
   CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CCHK(hipStreamCreateWithFlags(&c->stream_vit, hipStreamNonBlocking));
   Planner sz;
   plan(c, sz, false);
   c->arena_bytes = align_up(sz.off, 256) + 256;
@@ -783,6 +791,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
     for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->bstep_done[i], hipEventDisableTiming));
   }
   CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
+  CCHK(hipEventCreate(&c->ev_va)); CCHK(hipEventCreate(&c->ev_vb));
   CCHK(hipEventCreate(&c->probe_a)); CCHK(hipEventCreate(&c->probe_b));
   // default RoPE tables (the Python loader overrides them with torch-computed ones)
   std::vector<uint16_t> cosv, sinv;
@@ -825,6 +834,9 @@ void dtk_destroy(dtk_ctx* c) {
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   if (c->tok_ring_host) (void)hipHostFree(c->tok_ring_host);
   if (c->arena) (void)hipFree(c->arena);
+  if (c->stream_vit) (void)hipStreamDestroy(c->stream_vit);
+  if (c->ev_va) (void)hipEventDestroy(c->ev_va);
+  if (c->ev_vb) (void)hipEventDestroy(c->ev_vb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -917,19 +929,20 @@ int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, 
   if (!c || !pixels || batch < 1) return fail(c, DTK_ERR_ARG, "dtk_vit_encode: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
+  hipStream_t sv = c->stream_vit;
   for (int b = 0; b < batch; ++b) {
-    HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b * img, img * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-    vit_forward(c, pooled_out != nullptr);
-    HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b * img, img * 4, hipMemcpyHostToDevice, sv));
+    HIPCHK(c, hipEventRecord(c->ev_va, sv));
+    vit_forward(c, pooled_out != nullptr, sv);
+    HIPCHK(c, hipEventRecord(c->ev_vb, sv));
     if (feats_out)
-      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, c->feats, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, c->feats, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, sv));
     if (pooled_out)
-      HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b * c->vD, c->pooled, (size_t)c->vD * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b * c->vD, c->pooled, (size_t)c->vD * 2, hipMemcpyDeviceToHost, sv));
+    HIPCHK(c, hipStreamSynchronize(sv));
     HIPCHK(c, hipGetLastError());
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.last_vit_ms = ms;
+    if (hipEventElapsedTime(&ms, c->ev_va, c->ev_vb) == hipSuccess) c->stats.last_vit_ms = ms;
     c->stats.vit_images++;
   }
   return DTK_OK;  // IMG (the projected prefix of the cached prefill image) is left untouched
@@ -980,7 +993,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
       if (!pixels) return fail(c, DTK_ERR_ARG, "pixels required (no cached image for this key)");
       const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
       HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels, img * 4, hipMemcpyHostToDevice, c->stream));
-      vit_forward(c, false);
+      vit_forward(c, false, c->stream);
       project_image(c);
       c->stats.vit_images++;
       c->have_image = true;

@@ -13,8 +13,8 @@ There is no CPU fallback: constructing the model without the HIP library or a GP
 """
 from __future__ import annotations
 
-import contextlib
 import math
+import threading
 import ctypes as C
 import hashlib
 from types import SimpleNamespace
@@ -103,6 +103,10 @@ class DetikzifyForCausalLM:
         self.model = SimpleNamespace(vision_model=DetikzifyVisionModel(self))
         self.reuse_prefix = False     # output-identical KV/image reuse across rollouts
         self.batch_engine = None      # set by infer.batching.BatchEngine: generate() then decodes in a slot
+        # ViT passes (SelfSim reward) run on their own HIP stream and overlap with the decode steps of other sequences; they
+        # share activation buffers with the image branch of a prefill, so those two are serialised by this lock (a reward
+        # never takes the batch engine's lock: the trees that are decoding keep stepping)
+        self._vit_lock = threading.RLock()
         self._weights_ready = False
 
     # ---- HF-shaped attributes ---------------------------------------------------------------
@@ -208,10 +212,7 @@ class DetikzifyForCausalLM:
         n = (c.vit_image // c.vit_patch) ** 2
         feats = np.empty((B, n, c.vit_dim), dtype=np.uint16) if want_feats else None
         pooled = np.empty((B, c.vit_dim), dtype=np.uint16)
-        # a context is driven by one thread at a time: with a batch engine, take its lock (the SelfSim
-        # reward of one tree runs while other trees decode)
-        guard = self.batch_engine.cv if self.batch_engine is not None else contextlib.nullcontext()
-        with guard:
+        with self._vit_lock:
             self._check(self.lib.dtk_vit_encode(
                 self._ctx, px.numpy().ctypes.data_as(C.c_void_p), B, feats.ctypes.data_as(C.c_void_p) if want_feats else None,
                 pooled.ctypes.data_as(C.c_void_p) if want_pooled else None), "dtk_vit_encode")
@@ -238,12 +239,13 @@ class DetikzifyForCausalLM:
         flags = (_lib.DTK_PREFILL_REUSE_PREFIX | _lib.DTK_PREFILL_REUSE_IMAGE) if reuse else 0
         logits = np.empty(self.config.vocab, dtype=np.float32) if return_logits else None
         lp = logits.ctypes.data_as(C.c_void_p) if return_logits else None
-        if slot is None:
-            self._check(self.lib.dtk_prefill(self._ctx, ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
-                                             C.c_uint64(key), flags, lp), "dtk_prefill")
-        else:
-            self._check(self.lib.dtk_prefill_slot(self._ctx, int(slot), ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
-                                                  C.c_uint64(key), flags, lp), "dtk_prefill_slot")
+        with self._vit_lock:    # the image branch shares the ViT buffers with vit_encode (which runs on its own stream)
+            if slot is None:
+                self._check(self.lib.dtk_prefill(self._ctx, ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
+                                                 C.c_uint64(key), flags, lp), "dtk_prefill")
+            else:
+                self._check(self.lib.dtk_prefill_slot(self._ctx, int(slot), ids.numpy().ctypes.data_as(C.c_void_p), T, px_ptr,
+                                                      C.c_uint64(key), flags, lp), "dtk_prefill_slot")
         return torch.from_numpy(logits) if return_logits else None
 
     def set_sampling(self, do_sample=False, temperature=1.0, top_p=1.0, top_k=0, seed=0,
