@@ -117,7 +117,7 @@ struct dtk_ctx {
   float* s_lm_head = nullptr;
   uint64_t cached_image_key = 0;
   bool have_image = false;
-  // ---- batched decode (dtk_*_slot / dtk_decode_batch_*): up to 16 slots with their own KV
+  // ---- batched decode (dtk_*_slot / dtk_decode_batch_*): up to 64 decoding slots (+1) with their own KV
   int KVH = 0;                       // key/value heads (dtk_config.reserved[2]; 0 -> heads)
   bool proj_bias = true;             // mm_projector has a bias (v1) / bias-free connector (v2)
   int nb = 0;                        // number of batch slots (dtk_config.reserved[0])

@@ -71,7 +71,7 @@ struct SampleArgs {
   int step_override;     // >=0: use as draw index (tests)
   const BatchState* bs;  // batched mode: block = slot, inactive slots return; pointers are slot 0's
   int logits_stride;     // elements between slots' logits (batched mode)
-  int nslots;            // batched mode: grid = 16 or 32 slots
+  int nslots;            // batched mode: grid = 16, 32 or 64 slots
   SampleMB* mb;          // scratch of the multi-block sampler (slot 0's in batched mode), or null
 };
 void launch_sample_b(const SampleArgs& a, hipStream_t s);
@@ -87,7 +87,7 @@ static inline bool sample_mb_preferred(int V, bool do_sample) {
   return sample_mb_supported(V) || (force && do_sample && V >= 16384 && V <= 32768);
 }
 
-// ---------------------------------------------------------------- batched decode (16 slots share W)
+// ---------------------------------------------------------------- batched decode (up to 64 slots share W)
 struct GemvBArgs {
   const bf16_t* W; int N; int K;       // weight [N][K] in the fragment-major (tiled) copy
   const bf16_t* X; int ldx;            // inputs [16][ldx] (slot-major)
@@ -103,7 +103,7 @@ struct GemvBArgs {
   int H; int KVH;                      // QKV: head counts (rows = [H | KVH | KVH] x 128)
   const uint8_t* W8;                   // fp8 (e4m3) pair-tiled copy of the weights, or null; then wscale[N] = per-row 2^e scales
   const float* wscale;
-  int nt;                              // 16-slot column tiles: 1 (<= 16 slots) or 2 (<= 32 slots)
+  int nt;                              // 16-slot column tiles: 1 (<= 16 slots), 2 (<= 32) or 4 (<= 64)
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);

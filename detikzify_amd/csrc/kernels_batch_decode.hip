@@ -1,13 +1,14 @@
-// kernels_batch_decode.hip — one decode step for up to 16 independent sequences ("slots") that
+// kernels_batch_decode.hip — one decode step for up to 64 independent sequences ("slots") that
 // share ONE pass over the weights: the MCTS rollouts/sec kernel set (independent
 // rollouts of one GPU are batched so W is read once for b sequences; bytes/step = W + sum_b K*t_b).
 //
 // k_gemv_b: Y[slot][n] = W[n][:] . X[slot][:] as a skinny GEMM on v_mfma_f32_16x16x32_bf16 with the
-// 16 slots as the MFMA N dimension.  The weights are read from a FRAGMENT-MAJOR ("tiled") copy built
+// slots as the MFMA N dimension (NT = 1, 2 or 4 tiles of 16 columns).  The weights are read from a FRAGMENT-MAJOR ("tiled") copy built
 // once by k_retile: tile (n/16, k/32) is 1 KiB stored in MFMA A-operand lane order (lane = (k%32/8)*16
 // + n%16, 8 bf16 per lane), so one wave-load is 1 KiB CONTIGUOUS and lands directly in the operand
 // registers (row-major weights would make every wave-load touch 16 rows x 64 B: measured 3.5 TB/s).
-// The B fragment is X[slot = l&15][k..k+8) from L2.  A block owns 16*T weight
+// The B fragments are the slots' input vectors, kept by their producers in B-operand fragment order (xtile_off,
+// common.h: one 1 KiB contiguous load per tile, L2 resident).  A block owns 16*T weight
 // rows; its 8 waves split K (each wave streams a contiguous K slice of those rows, 4 k-steps in
 // flight) and reduce their 16x16 partials through LDS.  Inactive slots are computed and discarded
 // (columns are independent), so the captured graph is identical for every active set.
@@ -275,7 +276,7 @@ void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
   else { if (a.W8) launch_gemv_b_impl<true, 1>(epi, a, s); else launch_gemv_b_impl<false, 1>(epi, a, s); }
 }
 
-// RMSNorm of the active slots' vectors: grid = 16 slots, one block each (HF LlamaRMSNorm rounding).
+// RMSNorm of the active slots' vectors: one block per slot (HF LlamaRMSNorm rounding); output fragment-major.
 __global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y,
                                                    int ldy, int D, float eps, const BatchState* bs) {
   const int slot = blockIdx.x;
