@@ -139,9 +139,12 @@ struct dtk_ctx {
   int64_t* tokb_host = nullptr;      // pinned mirror
   uint64_t blaunched = 0, bwaited = 0;
   hipEvent_t bstep_done[DTK_MAX_INFLIGHT] = {};
-  bool bgraph_ready = false;
-  hipGraph_t bgraph = nullptr;
-  hipGraphExec_t bgraph_exec = nullptr;
+  // one captured step per column-tile count (1, 2, 4 tiles of 16 slots): a step only pays for the tiles up to its highest
+  // active slot (32 trees on a 65-slot context run the 2-tile kernels)
+  bool bgraph_ready[3] = {false, false, false};
+  hipGraph_t bgraph[3] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t bgraph_exec[3] = {nullptr, nullptr, nullptr};
+  int nt_step = 1;                   // tile count of the step being launched / captured
   dtk_sampling sampling{};
   SampleMB* smb = nullptr;           // multi-block sampler scratch (single sequence) / per slot
   SampleMB* smb_b = nullptr;
@@ -565,7 +568,7 @@ void batch_step_launches(dtk_ctx* c) {
   SampleArgs sa;
   sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
   sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
-  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = 16 * c->nt; sa.mb = c->smb_b;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = 16 * c->nt_step; sa.mb = c->smb_b;
   if (c->mb_batch) launch_sample_mb(sa, s); else launch_sample_b(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
@@ -574,28 +577,28 @@ void batch_step_launches(dtk_ctx* c) {
     bf16_t* kc = c->kvb + (size_t)l * kv_layer;
     bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
     GemvBArgs g{};
-    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt;
+    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt_step;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
-    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
+    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
     g.W = w.t_wqkv; g.W8 = w.t8_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
     ad.scale = scale;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
-    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
+    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
     g.W = w.t_wgu; g.W8 = w.t8_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
     launch_gemv_b(EPI_SWIGLU, g, s);
     g.W = w.t_wdown; g.W8 = w.t8_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
   }
-  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt, s);
+  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
   GemvBArgs g{};
   g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.W8 = c->t8_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
-  g.d = d; g.ff = ff; g.nt = c->nt;
+  g.d = d; g.ff = ff; g.nt = c->nt_step;
   launch_gemv_b(EPI_LOGITS, g, s);
 }
 
@@ -643,15 +646,26 @@ void ensure_tiled_weights(dtk_ctx* c) {
   c->tiled_ready = true;
 }
 
-int ensure_batch_graph(dtk_ctx* c) {
-  if (c->bgraph_ready) return DTK_OK;
+static inline int nt_index(int nt) { return nt >= 3 ? 2 : nt - 1; }
+
+void drop_batch_graphs(dtk_ctx* c) {
+  for (int i = 0; i < 3; ++i) {
+    if (c->bgraph_exec[i]) { (void)hipGraphExecDestroy(c->bgraph_exec[i]); c->bgraph_exec[i] = nullptr; }
+    if (c->bgraph[i]) { (void)hipGraphDestroy(c->bgraph[i]); c->bgraph[i] = nullptr; }
+    c->bgraph_ready[i] = false;
+  }
+}
+
+int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step
+  const int gi = nt_index(c->nt_step);
+  if (c->bgraph_ready[gi]) return DTK_OK;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   batch_step_launches(c);
   HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH,
                            hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph));
-  HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec, c->bgraph, nullptr, nullptr, 0));
-  c->bgraph_ready = true;
+  HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph[gi]));
+  HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec[gi], c->bgraph[gi], nullptr, nullptr, 0));
+  c->bgraph_ready[gi] = true;
   return DTK_OK;
 }
 
@@ -824,8 +838,7 @@ void dtk_destroy(dtk_ctx* c) {
   if (c->graph) (void)hipGraphDestroy(c->graph);
   if (c->graph_short_exec) (void)hipGraphExecDestroy(c->graph_short_exec);
   if (c->graph_short) (void)hipGraphDestroy(c->graph_short);
-  if (c->bgraph_exec) (void)hipGraphExecDestroy(c->bgraph_exec);
-  if (c->bgraph) (void)hipGraphDestroy(c->bgraph);
+  drop_batch_graphs(c);
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->bstep_done[i]) (void)hipEventDestroy(c->bstep_done[i]);
   if (c->bs_host) (void)hipHostFree(c->bs_host);
   if (c->tokb_host) (void)hipHostFree(c->tokb_host);
@@ -1120,9 +1133,7 @@ static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp
     const bool mb = sample_mb_preferred(c->V, any_sampling) && !any;
     if (mb != c->mb_batch) {
       c->mb_batch = mb;
-      if (c->bgraph_exec) { (void)hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
-      if (c->bgraph) { (void)hipGraphDestroy(c->bgraph); c->bgraph = nullptr; }
-      c->bgraph_ready = false;
+      drop_batch_graphs(c);
     }
   }
   return DTK_OK;
@@ -1165,11 +1176,14 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     hb->share_len[j] = sh_ok ? c->bseq[(size_t)j].share_len : 0;
   }
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
+  int hi = 0;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) if (active[j]) hi = j;
+  c->nt_step = hi < 16 ? 1 : (hi < 32 ? 2 : 4);      // column tiles this step needs (per-column results do not depend on it)
   HIPCHK(c, hipMemcpyAsync(c->bs_dev, hb, sizeof(BatchState), hipMemcpyHostToDevice, c->stream));
   if (c->use_graph) {
     int rc = ensure_batch_graph(c);
     if (rc) return rc;
-    HIPCHK(c, hipGraphLaunch(c->bgraph_exec, c->stream));
+    HIPCHK(c, hipGraphLaunch(c->bgraph_exec[nt_index(c->nt_step)], c->stream));
   } else {
     batch_step_launches(c);
     HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipMemcpyDeviceToHost, c->stream));

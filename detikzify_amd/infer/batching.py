@@ -106,11 +106,13 @@ class BatchEngine:
                 self.cv.wait()
             # slot choice: a free slot that holds no prefix worth keeping; else one that already holds THIS image's prefix
             # (re-used in place); else evict the prefix of some other image
-            slot = next((f for f in reversed(self.free) if f not in self.slot_img), None)
+            # (lowest index first: a step only runs the 16-slot column tiles up to its highest active slot)
+            order = sorted(self.free)
+            slot = next((f for f in order if f not in self.slot_img), None)
             if slot is None and want is not None:
-                slot = next((f for f in reversed(self.free) if self.slot_img.get(f) == want), None)
+                slot = next((f for f in order if self.slot_img.get(f) == want), None)
             if slot is None:
-                slot = self.free[-1]
+                slot = order[0]
             self.free.remove(slot)
         joined = False
         try:

@@ -18,9 +18,10 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--weight-format", default="bf16")
+ap.add_argument("--slots", type=int, default=0, help="KV slots to allocate (default: --batch): partial-occupancy timing")
 ap.add_argument("--fork", action="store_true", help="prefill slot 0 only and fork its KV into the other slots (fewer dispatches: profiling runs)")
 args = ap.parse_args()
-model, proc = load(args.model, synthetic=1234, batch_slots=args.batch, weight_format=args.weight_format)
+model, proc = load(args.model, synthetic=1234, batch_slots=max(args.batch, args.slots), weight_format=args.weight_format)
 model.set_graph_mode(args.graph)
 enc = proc(images=sketch_image(0, 224), return_tensors="pt")
 ids, px = enc.input_ids[0], enc.pixel_values
