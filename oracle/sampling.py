@@ -20,7 +20,7 @@ r = splitmix64(seed ^ C*(n+1)) >> 32, first index whose running mass exceeds tar
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional, Tuple
+from typing import Iterable, Tuple
 
 import numpy as np
 import torch

@@ -6,7 +6,6 @@ import socket
 import sys
 from pathlib import Path
 
-import pytest
 import torch.multiprocessing as mp
 
 from detikzify_amd import dist as ddist

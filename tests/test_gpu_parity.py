@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import sampling
 from oracle.model import DetikzifyOracle
-from oracle.ops import bits_to_f32, f32_to_bits, linear, rb
+from oracle.ops import bits_to_f32, f32_to_bits, rb
 from oracle.synth import synth_bits, tensor_specs
 from oracle.vit import layernorm
 from oracle.llama import attention, rmsnorm

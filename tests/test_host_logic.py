@@ -16,7 +16,7 @@ from detikzify_amd.infer import (DetikzifyGenerator, DetikzifyPipeline, DynMinMa
 from detikzify_amd.infer.tikz import TikzDocument
 from detikzify_amd.mcts import MonteCarlo, Node
 from detikzify_amd.model.processing import DetikzifyImageProcessor
-from detikzify_amd.util import ExplicitAbort, StreamerList, TokenStreamer, cache_cast, expand, trim
+from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import _StubMetric, generator_script, mcts_script
 from tests.helpers import FakeModel, fake_processor, sketch_image
 

@@ -7,7 +7,6 @@ import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-import torch  # noqa: E402
 
 from detikzify_amd.model import load  # noqa: E402
 from tests.helpers import sketch_image  # noqa: E402
