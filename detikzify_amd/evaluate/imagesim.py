@@ -9,8 +9,10 @@ cosine distances in float64 -> earth mover's distance with uniform marginals -> 
 calls POT's `ot.emd2(a=[], b=[], M)` (absent here); with uniform marginals over two equally sized patch sets
 the transport polytope's vertices are permutation matrices (Birkhoff), so the exact optimum is the minimum-cost
 assignment divided by n — solved with scipy.optimize.linear_sum_assignment.
-torchmetrics is absent here: update/compute/reset are restated with plain attributes (the
-reference disables metric state sync on this path anyway, infer/generate.py:373).
+torchmetrics is absent here: update/compute/reset are restated with plain accumulators (the
+reference disables metric state sync on this path anyway, infer/generate.py:373).  The accumulators are
+per thread: `simulate_parallel` shares ONE metric between its trees, and each tree runs the reference's
+update -> compute -> reset sequence (infer/generate.py:293-298) on its own thread.
 
 The features of the *reference* image are identical for every rollout; `cache_reference=True`
  memoises them by image bytes — output-identical, one ViT pass per rollout saved.
@@ -20,6 +22,7 @@ from __future__ import annotations
 from typing import Dict, Literal, Union
 
 import math
+import threading
 
 import numpy as np
 import torch
@@ -66,6 +69,7 @@ class ImageSim:
         self.mode, self.preprocess = mode, preprocess
         self.cache_reference = cache_reference
         self._ref_cache: Dict[bytes, torch.Tensor] = {}
+        self._acc = threading.local()
         self.reset()
 
     def __str__(self):
@@ -125,3 +129,20 @@ class ImageSim:
 
     def reset(self):
         self.score, self.n_samples = 0.0, 0
+
+    # metric state of the calling thread (a thread that never called reset() starts from zero)
+    @property
+    def score(self) -> float:
+        return getattr(self._acc, "score", 0.0)
+
+    @score.setter
+    def score(self, v: float):
+        self._acc.score = v
+
+    @property
+    def n_samples(self) -> int:
+        return getattr(self._acc, "n_samples", 0)
+
+    @n_samples.setter
+    def n_samples(self, v: int):
+        self._acc.n_samples = v

@@ -1,0 +1,281 @@
+"""Host side of the generate / rollout / parallel-MCTS path, on the CPU: the REAL `DetikzifyForCausalLM.generate`,
+`BatchEngine`, `DetikzifyGenerator`, `DetikzifyPipeline`, `ImageSim` and `simulate_parallel` run on top of a scripted
+device (the C-ABI calls of modeling.py replaced by a toy language model whose next token is a pure function of
+(image, context, sampling seed)).  What this pins without a GPU:
+
+  * the HF generate protocol the reference relies on (infer/generate.py:218-227, util/generation.py:25-66): the
+    streamer sees the prompt once, then one token at a time, then end(); every stopping criterion is evaluated on every
+    token with the ids so far; EOS / max_length / max_new_tokens stop exactly there; one decode step is kept in flight
+    and never more than the length budget allows
+  * a sequence decoded in a KV slot of the batch engine (threads, prefix-cache fork, in-place reuse, donors, slot
+    recycling) gets exactly the tokens it gets when decoded alone — the scripted device asserts that every
+    prefix-reusing prefill really finds that image's prefix in the slot
+  * root-parallel trees share one metric object: every yielded score is the score of ITS document
+"""
+import threading
+import time
+import zlib
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from detikzify_amd.evaluate.imagesim import ImageSim
+from detikzify_amd.infer import DetikzifyGenerator, DetikzifyPipeline, SyntheticTikzDocument
+from detikzify_amd.infer.batching import BatchEngine, simulate_parallel
+from detikzify_amd.model.modeling import DetikzifyForCausalLM, GenerationConfig
+from detikzify_amd.util import ExplicitAbort, TokenStreamer
+
+from .helpers import fake_processor, sketch_image
+
+IMG, EOS, VOCAB, NIMG = 1, 2, 512, 12
+
+
+class _Lib:
+    def __init__(self, dev):
+        self.dev = dev
+
+    def dtk_context_len_slot(self, ctx, s):
+        return len(self.dev.ctx[s])
+
+
+class _Vision:
+    """pooled 'features' = 4x4 average pool of the pixels; the sleep releases the GIL like the ctypes call does"""
+
+    def pooled_only(self, pixel_values):
+        time.sleep(0.002)
+        return torch.nn.functional.adaptive_avg_pool2d(pixel_values.float(), 4).flatten() + 1.5
+
+    def __call__(self, pixel_values, **_):
+        return SimpleNamespace(pooler_output=self.pooled_only(pixel_values)[None], last_hidden_state=None)
+
+
+class ScriptedDevice(DetikzifyForCausalLM):
+    """DetikzifyForCausalLM without a GPU: everything above the C-ABI wrappers is the shipped code"""
+    SINGLE = -1
+
+    def __init__(self, slots=0, max_positions=160):      # no super().__init__: that one creates the device context
+        cfg = SimpleNamespace(image_token_id=IMG, eos_token_id=EOS, pad_token_id=0, bos_token_id=1, vocab=VOCAB,
+                              max_positions=max_positions, pooling_mode="cos")
+        cfg.text_config = cfg
+        self.config = cfg
+        self.generation_config = GenerationConfig(eos_token_id=EOS, pad_token_id=0, bos_token_id=1)
+        self.name_or_path = "scripted"
+        self.model = SimpleNamespace(vision_model=_Vision())
+        self.reuse_prefix, self.batch_engine, self._weights_ready = False, None, True
+        self._vit_lock = threading.RLock()
+        self.lib, self._ctx, self.slots = _Lib(self), None, slots
+        self.ctx, self.img, self.samp, self.gen0 = {}, {}, {}, {}
+        self.pending, self.bpending = [], []
+        self.max_in_flight = self.launches = self.prefills = self.forks = self.tail_prefills = 0
+        tok = fake_processor(VOCAB, NIMG).tokenizer
+        self.newline = [i for i, t in enumerate(tok._id2tok) if "\n" in t and i > 2]
+        self.plain = [i for i, t in enumerate(tok._id2tok) if "\n" not in t and i > 2]
+
+    # ---- the toy LM ---------------------------------------------------------------------------------------------
+    def _next(self, s):
+        sp, ctx = self.samp[s], self.ctx[s]
+        seed = sp.get("seed", 0) if sp.get("do_sample") else 0
+        h = zlib.crc32(repr((self.img[s], ctx, seed)).encode())
+        r, pick = (h & 0xFFFF) / 65536.0, h >> 16
+        first = len(ctx) == self.gen0[s]
+        if r < 0.05 and not (first and EOS in sp.get("begin_suppress_ids", ())) and EOS not in sp.get("always_suppress_ids", ()):
+            tok = EOS
+        elif r < 0.4:
+            tok = self.newline[pick % len(self.newline)]
+        else:
+            tok = self.plain[pick % len(self.plain)]
+        assert tok not in sp.get("bad_ids", ())
+        ctx.append(tok)
+        return tok
+
+    # ---- C-ABI wrappers of modeling.py, scripted ------------------------------------------------------------------
+    def num_slots(self):
+        return self.slots
+
+    def set_sampling(self, do_sample=False, temperature=1.0, top_p=1.0, top_k=0, seed=0, bad_ids=(), begin_suppress_ids=(),
+                     always_suppress_ids=(), slot=None):
+        self.samp[self.SINGLE if slot is None else slot] = dict(
+            do_sample=do_sample, seed=seed, bad_ids=tuple(bad_ids), begin_suppress_ids=tuple(begin_suppress_ids),
+            always_suppress_ids=tuple(always_suppress_ids))
+
+    def prefill(self, input_ids, pixel_values=None, return_logits=False, reuse=None, slot=None):
+        assert not self.bpending, "prefill while a batched step is un-collected"
+        s = self.SINGLE if slot is None else slot
+        ids = [int(t) for t in input_ids.reshape(-1)]
+        key = self.image_key(pixel_values) if pixel_values is not None else 0
+        if reuse:       # the engine claims this slot already holds the image prefix: check it
+            n = next((i for i, t in enumerate(ids) if t != IMG), len(ids))
+            assert self.img.get(s) == key and self.ctx[s][:n] == ids[:n], "prefix reuse without the prefix in the slot"
+            self.tail_prefills += 1
+        self.pending.clear()
+        self.ctx[s], self.img[s], self.gen0[s] = ids, key, len(ids)
+        self.prefills += 1
+
+    def kv_fork(self, src_slot, dst_slot, n_tokens):
+        assert len(self.ctx[src_slot]) >= n_tokens
+        self.ctx[dst_slot], self.img[dst_slot] = self.ctx[src_slot][:n_tokens], self.img[src_slot]
+        self.gen0[dst_slot] = n_tokens
+        self.forks += 1
+
+    def decode_launch(self):
+        assert len(self.ctx[self.SINGLE]) < self.config.max_positions
+        self.pending.append(self._next(self.SINGLE))
+        self.launches += 1
+        self.max_in_flight = max(self.max_in_flight, len(self.pending))
+
+    def decode_wait(self):
+        return self.pending.pop(0)
+
+    def decode_batch_launch(self, active_slots):
+        slots = list(active_slots)
+        assert len(self.bpending) < 2 and slots == sorted(slots)
+        self.bpending.append({s: self._next(s) for s in slots})
+
+    def decode_batch_wait(self):
+        time.sleep(0.0002)
+        step = self.bpending.pop(0)
+        return [step.get(s, -1) for s in range(64)]
+
+
+def _prompt(proc, image_seed, extra=()):
+    enc = proc(images=sketch_image(image_seed, 96), return_tensors="pt")
+    ids = torch.cat([enc.input_ids[0], torch.tensor(list(extra), dtype=torch.int64)])
+    return ids, enc.pixel_values
+
+
+class _Recorder:
+    def __init__(self):
+        self.events = []
+
+    def put(self, value):
+        self.events.append(("put", value.reshape(-1).tolist()))
+
+    def end(self):
+        self.events.append(("end",))
+
+
+def test_generate_protocol_streamer_criteria_and_length_budget():
+    dev, proc = ScriptedDevice(), fake_processor(VOCAB, NIMG)
+    ids, px = _prompt(proc, 0)
+    T = ids.numel()
+    seen = []
+
+    def criterion(input_ids, scores):
+        seen.append(input_ids.shape[1])
+        assert scores is None and input_ids[0, :T].tolist() == ids.tolist()
+        return False
+
+    rec = _Recorder()
+    out = dev.generate(input_ids=ids[None], pixel_values=px, bad_words_ids=[[IMG]], begin_suppress_tokens=[EOS],
+                       streamer=rec, stopping_criteria=[criterion], max_length=T + 40, do_sample=True, seed=7)
+    new = out[0, T:].tolist()
+    assert out.shape[0] == 1 and out[0, :T].tolist() == ids.tolist() and 1 <= len(new) <= 40
+    assert (new[-1] == EOS or len(new) == 40) and EOS not in new[:-1] and new[0] != EOS and IMG not in new
+    assert rec.events[0] == ("put", ids.tolist()) and rec.events[-1] == ("end",)
+    assert [e[1] for e in rec.events[1:-1]] == [[t] for t in new]          # one token per put, in order
+    assert seen == list(range(T + 1, T + len(new) + 1))                    # every token, with the ids so far
+    assert dev.max_in_flight == 2 and dev.launches <= min(40, len(new) + 1)   # one step ahead, never past the budget
+
+    # same seed -> same tokens; max_new_tokens wins over max_length; EOS-free run stops at the budget exactly
+    again = dev.generate(input_ids=ids[None], pixel_values=px, bad_words_ids=[[IMG]], begin_suppress_tokens=[EOS],
+                         max_length=T + 40, do_sample=True, seed=7)
+    assert torch.equal(again, out)
+    dev.launches = 0
+    fixed = dev.generate(input_ids=ids, pixel_values=px, suppress_tokens=[EOS], max_new_tokens=9, max_length=5, eos_token_id=-1)
+    assert fixed.shape == (1, T + 9) and dev.launches == 9
+    assert dev.generate(input_ids=ids[None], pixel_values=px, max_length=T).shape == (1, T)      # nothing to generate
+    assert dev.generate(input_ids=ids[None], pixel_values=px, max_length=10 ** 6, suppress_tokens=[EOS],
+                        eos_token_id=-1).shape[1] == dev.config.max_positions                    # clipped to the KV capacity
+
+    # a criterion that fires stops after that token; ExplicitAbort is polled; TokenStreamer gets plain ints
+    stop_at = dev.generate(input_ids=ids[None], pixel_values=px, suppress_tokens=[EOS], max_new_tokens=30,
+                           stopping_criteria=[lambda i, s: i.shape[1] >= T + 4])
+    assert stop_at.shape[1] == T + 4
+    ctl = ExplicitAbort()
+    ctl.abort()
+    assert dev.generate(input_ids=ids[None], pixel_values=px, suppress_tokens=[EOS], max_new_tokens=30,
+                        stopping_criteria=[ctl]).shape[1] == T + 1
+    ts = TokenStreamer()
+    th = threading.Thread(target=lambda: dev.generate(input_ids=ids[None], pixel_values=px, suppress_tokens=[EOS],
+                                                      max_new_tokens=6, streamer=ts, do_sample=True, seed=3))
+    th.start()
+    streamed = list(ts)
+    th.join()
+    assert len(streamed) == 6 and all(isinstance(t, int) for t in streamed)
+
+    with pytest.raises(ValueError):
+        dev.generate(input_ids=torch.stack([ids, ids]), pixel_values=px)
+    with pytest.raises(NotImplementedError):
+        dev.generate(input_ids=ids[None], pixel_values=px, bad_words_ids=[[3, 4]])
+    dev._weights_ready = False
+    with pytest.raises(Exception, match="no weights"):
+        dev.generate(input_ids=ids[None], pixel_values=px)
+
+
+def test_sequences_in_engine_slots_decode_exactly_as_alone():
+    proc = fake_processor(VOCAB, NIMG)
+    jobs = []       # (prompt ids, pixels, seed): 3 images, prompts = the bare image prefix or prefix + a few tokens
+    for j in range(18):
+        ids, px = _prompt(proc, j % 3, extra=[40 + j, 50 + j][: j % 3])
+        jobs.append((ids, px, 100 + j))
+    kw = dict(bad_words_ids=[[IMG]], begin_suppress_tokens=[EOS], do_sample=True, max_length=NIMG + 60)
+    alone_dev = ScriptedDevice()
+    alone = [alone_dev.generate(input_ids=i[None], pixel_values=p, seed=s, **kw) for i, p, s in jobs]
+
+    dev = ScriptedDevice(slots=5)
+    eng = BatchEngine(dev, max_batch=4)
+    got, errs = [None] * len(jobs), []
+
+    def worker(k):
+        try:
+            for j in range(k, len(jobs), 6):
+                i, p, s = jobs[j]
+                got[j] = dev.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(6)]     # more threads than slots
+    [t.start() for t in ths]
+    [t.join(timeout=60) for t in ths]
+    assert not any(t.is_alive() for t in ths) and not errs, errs[:1]
+    eng.close()
+    assert dev.batch_engine is None and not dev.bpending
+    for a, g in zip(alone, got):
+        assert torch.equal(a, g)
+    st = eng.stats()
+    # every join got its image prefix without a full prefill: one ViT + prefix prefill per image CHANGE of the prefix
+    # cache at most, everything else forked / reused in place; the scripted device has checked every reuse claim
+    assert st["joins"] == 18 and dev.forks + st["inplace_reuses"] == 18
+    assert dev.prefills == st["prefix_encodes"] + dev.tail_prefills and st["prefix_encodes"] <= 18
+
+
+def test_parallel_trees_share_one_metric_but_never_a_score():
+    """simulate_parallel hands the SAME ImageSim to every tree; each tree runs update -> compute -> reset on its own
+    thread (reference infer/generate.py:293-298).  Every yielded score must be the similarity of its own document."""
+    proc = fake_processor(VOCAB, NIMG)
+    dev = ScriptedDevice(slots=7)
+    pipe = DetikzifyPipeline(dev, proc, metric="model", document_class=SyntheticTikzDocument, max_length=NIMG + 50,
+                             compile_timeout=None)
+    assert isinstance(pipe.metric, ImageSim) and pipe.metric.mode == "cos"
+    image = sketch_image(5, 96)
+    compute = pipe.metric.compute
+    pipe.metric.compute = lambda: (time.sleep(0.003), compute())[1]     # widen the update -> compute -> reset window
+    res = list(simulate_parallel(pipe, image, trees=6, expansions_per_tree=5))
+    assert len(res) == 30 and dev.batch_engine is None
+    check = ImageSim.from_detikzify(dev, proc)
+    ref_img = pipe.load(image)
+    scored = 0
+    for score, doc in res:
+        if doc.is_rasterizable:
+            assert score == pytest.approx(check.get_similarity(doc.rasterize(), ref_img), abs=1e-12), doc.code[:40]
+            scored += 1
+        else:
+            assert score == -1
+    assert scored >= 10 and pipe.metric.n_samples == 0
+    assert 6 <= dev.last_batch_stats["joins"] <= 30 and dev.last_batch_stats["prefix_encodes"] == 1   # a rollout from a finished node never reaches the model
+
+    # one tree = the sequential search of the reference, through the same code path and the same device
+    seq = list(simulate_parallel(pipe, image, trees=1, expansions_per_tree=4))
+    gen = DetikzifyGenerator(dev, proc, image=ref_img, metric=pipe.metric, **pipe.gen_kwargs)
+    assert len(seq) == 4 and len(list(gen.simulate(expansions=2))) == 2
