@@ -279,3 +279,43 @@ def test_parallel_trees_share_one_metric_but_never_a_score():
     seq = list(simulate_parallel(pipe, image, trees=1, expansions_per_tree=4))
     gen = DetikzifyGenerator(dev, proc, image=ref_img, metric=pipe.metric, **pipe.gen_kwargs)
     assert len(seq) == 4 and len(list(gen.simulate(expansions=2))) == 2
+
+
+def test_device_error_surfaces_from_every_layer_without_hanging():
+    """a failing native call inside a batched step reaches the caller of simulate_parallel (engine -> sequence ->
+    generate in the rollout's worker thread -> streamer.propagate_error -> the tree's thread -> the result queue)"""
+    proc = fake_processor(VOCAB, NIMG)
+
+    class Dying(ScriptedDevice):
+        steps = 0
+
+        def decode_batch_wait(self):
+            Dying.steps += 1
+            if Dying.steps > 25:
+                raise RuntimeError("HIP error 719 in k_gemv_b")
+            return super().decode_batch_wait()
+
+    dev = Dying(slots=5)
+    pipe = DetikzifyPipeline(dev, proc, metric="fast", document_class=SyntheticTikzDocument, max_length=NIMG + 50,
+                             compile_timeout=None)
+    done, box = threading.Event(), []
+
+    def run():
+        try:
+            list(simulate_parallel(pipe, sketch_image(6, 96), trees=4, expansions_per_tree=50))
+        except BaseException as e:  # noqa: BLE001
+            box.append(e)
+        done.set()
+
+    threading.Thread(target=run, daemon=True).start()
+    assert done.wait(timeout=60), "simulate_parallel hangs after a device error"
+    assert box and "HIP error 719" in str(box[0])
+    assert dev.batch_engine is None
+
+    # single sequence: the error comes out of generate() itself
+    class DyingSingle(ScriptedDevice):
+        def decode_wait(self):
+            raise RuntimeError("HIP error 700")
+    ids, px = _prompt(proc, 0)
+    with pytest.raises(RuntimeError, match="700"):
+        DyingSingle().generate(input_ids=ids[None], pixel_values=px, max_new_tokens=5)
