@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import re
 from collections import deque
+from contextlib import nullcontext
 from dataclasses import dataclass
 from functools import cached_property
 from math import sqrt
@@ -205,10 +206,12 @@ class DetikzifyGenerator:
     def newlineinfo(self) -> Dict[int, SimpleNamespace]:
         """token id -> (#newlines it contains, whether it ends with one); tokens may hold several."""
         info = {}
-        for token_id in unwrap(self.processor).tokenizer.vocab.values():
-            text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
-            if n := text.count("\n"):
-                info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
+        # the tokenizer is shared by the trees of simulate_parallel and HF fast tokenizers are not re-entrant
+        with getattr(unwrap(self.processor), "_tok_lock", nullcontext()):
+            for token_id in unwrap(self.processor).tokenizer.vocab.values():
+                text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
+                if n := text.count("\n"):
+                    info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
         assert info
         return info
 

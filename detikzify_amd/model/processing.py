@@ -10,6 +10,7 @@ Pure numpy/PIL (the reference needs py3.11 typing.Unpack and timm, absent here).
 """
 from __future__ import annotations
 
+import threading
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -143,6 +144,9 @@ class DetikzifyProcessor:
         self.image_processor, self.tokenizer = image_processor, tokenizer
         self.image_token, self.image_seq_len = image_token, image_seq_len
         self.model_expects_text = model_expects_text
+        # HF fast tokenizers are not re-entrant (`truncation=True` re-configures the Rust object: "Already borrowed" when
+        # another thread encodes or decodes meanwhile); the trees of simulate_parallel share one processor
+        self._tok_lock = threading.RLock()
 
     def __call__(self, text=None, images=None, image_seq_len: Optional[int] = None,
                  add_bos_token: Optional[bool] = None, add_eos_token: Optional[bool] = None,
@@ -174,7 +178,8 @@ class DetikzifyProcessor:
         tk.update(text_kwargs or {})
         tk.pop("padding_side", None)
         image_inputs = self.image_processor(images=images, return_tensors=return_tensors)
-        enc = self.tokenizer(text=prompts, **tk)
+        with self._tok_lock:
+            enc = self.tokenizer(text=prompts, **tk)
         ids, mask = enc["input_ids"], enc["attention_mask"]
         if return_tensors == "pt":
             ids = torch.tensor(ids, dtype=torch.long) if not isinstance(ids, torch.Tensor) else ids
@@ -182,10 +187,12 @@ class DetikzifyProcessor:
         return BatchFeature({**image_inputs, "input_ids": ids, "attention_mask": mask})
 
     def batch_decode(self, *a, **k):
-        return self.tokenizer.batch_decode(*a, **k)
+        with self._tok_lock:
+            return self.tokenizer.batch_decode(*a, **k)
 
     def decode(self, *a, **k):
-        return self.tokenizer.decode(*a, **k)
+        with self._tok_lock:
+            return self.tokenizer.decode(*a, **k)
 
     @property
     def model_input_names(self):

@@ -15,7 +15,7 @@ from detikzify_amd.infer import (DetikzifyGenerator, DetikzifyPipeline, DynMinMa
                                  TikzGenerator)
 from detikzify_amd.infer.tikz import TikzDocument
 from detikzify_amd.mcts import MonteCarlo, Node
-from detikzify_amd.model.processing import DetikzifyImageProcessor
+from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import _StubMetric, generator_script, mcts_script
 from tests.helpers import FakeModel, fake_processor, sketch_image
@@ -261,3 +261,34 @@ def test_graft_entry_build_runs():
     """the driver's "does it build" check: compiles the library in-tree and imports the package (no GPU needed)"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_processor_is_safe_under_threads_with_a_fast_tokenizer():
+    """HF fast tokenizers raise "Already borrowed" when one thread re-configures truncation while another encodes or
+    decodes; the trees of simulate_parallel share one processor and call it exactly like that (truncation=True in
+    DetikzifyGenerator.generate, none for the root prompt, decode for every document)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, **{f"w{i}": i for i in range(4, 300)}}
+    t = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    t.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>",
+                                  model_max_length=64)
+    proc = DetikzifyProcessor(image_processor=DetikzifyImageProcessor(size={"height": 28, "width": 28}), tokenizer=tok,
+                              image_seq_len=12, image_token="<s>")
+    img, errs = sketch_image(0, 64), []
+
+    def worker(k):
+        try:
+            for _ in range(150):
+                enc = proc(images=img, text_kwargs={"truncation": True}, return_tensors="pt") if k % 2 else \
+                    proc(images=img, return_tensors="pt")
+                assert enc.input_ids.tolist() == [[1] * 12]
+                assert proc.decode([5, 6, 7], skip_special_tokens=True) == "w5 w6 w7"
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+    [x.start() for x in ths]
+    [x.join(timeout=120) for x in ths]
+    assert not errs, errs[:1]
