@@ -117,7 +117,11 @@ class BatchEngine:
         joined = False
         try:
             with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
+                if self.error is not None:
+                    raise self.error        # a native call has failed: the context is not to be touched again
                 self._collect()     # a prefill drops un-collected steps on the C side: collect first
+                if self.error is not None:
+                    raise self.error
                 t0 = time.perf_counter()
                 self.model.set_sampling(slot=slot, **sampling)
                 forked = self._fork_prefix(slot, ids, pixel_values, want) if want is not None else 0
