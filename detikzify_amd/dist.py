@@ -98,3 +98,31 @@ def merge_rollouts(per_rank: Sequence[Sequence[Sequence[Any]]]) -> List[List[Any
                 seen.add((score, code))
                 out.append([score, code])
     return sorted(out, key=lambda sc: sc[0])
+
+
+def root_parallel_search(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
+                         **gen_kwargs) -> List[List[Any]]:
+    """BASELINE configs 4/5: one image, every rank grows `trees` independent trees as ONE batched decode on its GPU
+    (infer/batching.simulate_parallel; trees == 1 is the sequential search), then the single exchange of the path:
+    all (score, code) records to every rank, merged like eval.py:106.  Tree t of rank r samples with seed stream
+    seed_base * (r + 1) + t, so the trees of different ranks differ and a run is reproducible for a fixed world size."""
+    from .infer.batching import simulate_parallel
+    mine = [[float(score), doc.code] for score, doc in
+            simulate_parallel(pipeline, image, trees=trees, expansions_per_tree=expansions_per_tree,
+                              seed_base=seed_base * (rank() + 1), **gen_kwargs)]
+    return merge_rollouts(gather_objects(mine))
+
+
+def sharded_sample(pipeline, images: Sequence[Any], **gen_kwargs) -> List[str]:
+    """Shard by image (exact reference semantics, examples/eval.py:80-83,125): rank r samples images[r::world]; every
+    rank gets the TikZ programs of all images in input order."""
+    mine = [pipeline.sample(image=img, **gen_kwargs).code for img in chunk(images, world())[rank()]]
+    return interleave_all(gather_objects(mine), len(images))
+
+
+def interleave_all(chunks: Sequence[Sequence[Any]], total: int) -> List[Any]:
+    """inverse of chunk() for ragged chunks (len(items) not a multiple of the world size)"""
+    out: List[Any] = [None] * total
+    for r, c in enumerate(chunks):
+        out[r::len(chunks)] = c
+    return out

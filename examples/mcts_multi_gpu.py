@@ -17,14 +17,13 @@ import torch  # noqa: E402
 
 from detikzify_amd import dist as ddist  # noqa: E402
 from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument  # noqa: E402
-from detikzify_amd.infer.batching import simulate_parallel  # noqa: E402
 from detikzify_amd.model import load  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", required=True)
 ap.add_argument("--image", required=True)
 ap.add_argument("--synthetic", type=int, default=None)
-ap.add_argument("--trees", type=int, default=32, help="independent trees per GPU (<= 32: one batched decode)")
+ap.add_argument("--trees", type=int, default=32, help="independent trees per GPU (<= 64: one batched decode)")
 ap.add_argument("--expansions", type=int, default=4, help="rollouts per tree")
 ap.add_argument("--no-latex", action="store_true")
 ap.add_argument("--keep", type=int, default=5)
@@ -34,12 +33,10 @@ local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_c
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     torch.cuda.set_device(local_rank)
     ddist.init_process_group(os.environ.get("DTK_DIST_BACKEND"))      # default nccl (= RCCL); "gloo" for a control-flow test
-model, processor = load(args.model, synthetic=args.synthetic, device_map=local_rank, batch_slots=min(32, args.trees) + 1)
+model, processor = load(args.model, synthetic=args.synthetic, device_map=local_rank, batch_slots=min(64, args.trees) + 1)
 kw = dict(document_class=SyntheticTikzDocument) if args.no_latex else {}
 pipe = DetikzifyPipeline(model, processor, **kw)
-mine = [(float(score), doc.code) for score, doc in
-        simulate_parallel(pipe, args.image, trees=args.trees, expansions_per_tree=args.expansions, seed_base=1000 * (ddist.rank() + 1))]
-everyone = ddist.gather_objects(mine) if ddist.world() > 1 else [mine]
+best = ddist.root_parallel_search(pipe, args.image, trees=args.trees, expansions_per_tree=args.expansions)
 if ddist.rank() == 0:
-    for score, code in ddist.merge_rollouts(everyone)[-args.keep:][::-1]:      # merge_rollouts sorts ascending (eval.py:106)
+    for score, code in best[-args.keep:][::-1]:      # merge_rollouts sorts ascending (eval.py:106)
         print(f"% score {score:.4f}\n{code}\n")

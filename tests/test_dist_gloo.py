@@ -39,8 +39,22 @@ def _worker(rank, world, port, outdir):
                              document_class=SyntheticTikzDocument, max_length=80, compile_timeout=None)
     local = [[float(s), d.code] for s, d in gen.simulate(expansions=share)]
     merged = dd.merge_rollouts(dd.gather_objects(local))
+    # (3) the library entry points of BASELINE configs 4/5 on the real generate loop / batch engine (scripted device):
+    #     3 batched trees per rank, one gather; and shard-by-image sampling
+    from detikzify_amd.infer import DetikzifyPipeline
+    from tests.test_generate_loop import NIMG, VOCAB, ScriptedDevice
+    proc = fake_processor(VOCAB, NIMG)
+    pipe = DetikzifyPipeline(ScriptedDevice(slots=4), proc, metric="fast", document_class=SyntheticTikzDocument,
+                             max_length=NIMG + 40, compile_timeout=None)
+    best = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2)
+    images = [sketch_image(10 + i, 64) for i in range(5)]
+    codes = dd.sharded_sample(pipe, images, do_sample=False)
     if rank == 0:
-        Path(outdir, "merged.json").write_text(json.dumps({"n": len(merged), "scores": [m[0] for m in merged]}))
+        alone = [pipe.sample(image=im, do_sample=False).code for im in images]
+        Path(outdir, "merged.json").write_text(json.dumps({
+            "n": len(merged), "scores": [m[0] for m in merged], "best": best, "codes": codes, "alone": alone}))
+    else:
+        Path(outdir, "rank1.json").write_text(json.dumps({"best": best, "codes": codes}))
     import torch.distributed as td
     td.barrier()
     td.destroy_process_group()
@@ -51,6 +65,10 @@ def test_two_rank_gather_and_root_parallel_merge(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     res = json.loads((tmp_path / "merged.json").read_text())
     assert 1 <= res["n"] <= 6 and res["scores"] == sorted(res["scores"])
+    other = json.loads((tmp_path / "rank1.json").read_text())
+    assert res["best"] == other["best"] and 1 <= len(res["best"]) <= 12          # every rank holds the merged records
+    assert [b[0] for b in res["best"]] == sorted(b[0] for b in res["best"])
+    assert res["codes"] == other["codes"] == res["alone"] and len(res["codes"]) == 5   # input order, ragged shards
 
 
 def test_chunk_interleave_roundtrip_and_expansion_split():
