@@ -113,6 +113,22 @@ def root_parallel_search(pipeline, image, trees: int, expansions_per_tree: int, 
     return merge_rollouts(gather_objects(mine))
 
 
+def root_parallel_search_images(pipeline, images: Sequence[Any], trees_per_image: int, expansions_per_tree: int,
+                                seed_base: int = 1000, **gen_kwargs) -> List[List[List[Any]]]:
+    """BASELINE config 5 (a batch of images, N rollouts each, 8 GPUs): images are striped over the ranks (images[r::world]),
+    each rank searches ITS images concurrently — len(mine) * trees_per_image trees in one batched decode, every image
+    encoded once — and one gather returns, for every image in input order, its (score, code) records sorted by score."""
+    from .infer.batching import simulate_parallel_images
+    mine = chunk(list(range(len(images))), world())[rank()]
+    local: List[List[List[Any]]] = [[] for _ in mine]
+    if mine:
+        for k, score, doc in simulate_parallel_images(pipeline, [images[i] for i in mine], trees_per_image, expansions_per_tree,
+                                                      seed_base=seed_base * (rank() + 1), **gen_kwargs):
+            local[k].append([float(score), doc.code])
+    per_image = interleave_all(gather_objects(local), len(images))
+    return [merge_rollouts([records]) for records in per_image]
+
+
 def sharded_sample(pipeline, images: Sequence[Any], **gen_kwargs) -> List[str]:
     """Shard by image (exact reference semantics, examples/eval.py:80-83,125): rank r samples images[r::world]; every
     rank gets the TikZ programs of all images in input order."""

@@ -51,15 +51,17 @@ class BatchEngine:
         # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
         maxdec = 64 if n > 33 else (32 if n > 17 else 16)   # one / two / four 16-slot MFMA column tiles (include/dtk.h)
         dec = min(n, maxdec)
-        self.share_prefix = share_prefix and n >= 2 and (n > maxdec or max_batch is None or max_batch < n)
-        self.prefix_slot = n - 1 if self.share_prefix else None
+        self.share_prefix = share_prefix and n >= 2
+        # the prefix-cache slot exists when a slot is to spare; without it the sequences still share prefixes among
+        # themselves (in place / from a donor slot), only the first rollout of an image prefills in full
+        self.prefix_slot = n - 1 if self.share_prefix and (n > maxdec or max_batch is None or max_batch < n) else None
         self.prefix_key = None
         self.prefix_ids = None
         self.slot_img: Dict[int, Tuple[int, int]] = {}      # slot -> (image key, prefix length) whose KV prefix it still holds
         self.joins = 0
         self.inplace_reuses = 0                              # joins that found their image prefix already in their slot
         self.prefix_encodes = 0                              # ViT + prefix prefills run for the prefix cache (diagnostics)
-        self.capacity = min(dec - (1 if self.share_prefix and n <= maxdec else 0), max_batch or dec)
+        self.capacity = min(dec - (1 if self.prefix_slot is not None and n <= maxdec else 0), max_batch or dec)
         self.pipeline = pipeline
         self.cv = threading.Condition()
         self.free: List[int] = list(range(self.capacity))
@@ -156,6 +158,7 @@ class BatchEngine:
                     else:
                         self._collect()             # nobody left to collect the speculative step
                 else:
+                    self.slot_img.pop(slot, None)   # the prefill did not complete: the slot holds nobody's prefix
                     self.free.append(slot)
                 self.cv.notify_all()   # a slot may have become free
 
@@ -171,7 +174,8 @@ class BatchEngine:
 
     def _fork_prefix(self, slot: int, ids, pixel_values, key) -> int:
         """Give `slot` the KV of its image prefix without running ViT + prefill again.  Returns 1 (prefix KV in place: the
-        caller prefills what follows with reuse) or 2 (prefix == whole prompt and the next-token logits were forked too).
+        caller prefills what follows with reuse), 2 (prefix == whole prompt and the next-token logits were forked too) or
+        0 (nobody holds this image and there is no prefix-cache slot: the caller prefills in full and becomes a donor).
         Sources, in order: the prefix-cache slot if it holds this image (its fork also carries the logits); the slot itself
         if it still holds this image's prefix from its previous sequence; any other slot that still holds this image's prefix (several images in
         flight: a batch of 8 images x 4 rollouts encodes each image once); otherwise the prefix-cache slot is re-encoded."""
@@ -186,6 +190,9 @@ class BatchEngine:
             if donor is not None:
                 self.model.kv_fork(donor, slot, n_img)      # the donor has decoded past the prefix: no logits to inherit
                 return 1
+            if self.prefix_slot is None:
+                self.prefix_encodes += 1
+                return 0
             self.model.set_sampling(slot=self.prefix_slot, do_sample=False)
             self.model.prefill(ids[:n_img], pixel_values, slot=self.prefix_slot)
             self.prefix_key, self.prefix_ids = key, ids[:n_img].clone()
@@ -283,20 +290,31 @@ def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, see
     """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (thread t uses
     torch seed seed_base + t for its sampling seeds) decoded as one batch.  Yields (score, document)
     pairs in completion order.  trees == 1 is the unmodified sequential search."""
+    for _, score, doc in simulate_parallel_images(pipeline, [image], trees, expansions_per_tree, seed_base, **gen_kwargs):
+        yield score, doc
+
+
+def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_per_tree: int, seed_base: int = 1000,
+                             **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
+    """Several images in flight on one GPU (BASELINE config 5: 8 images x 4 rollouts): len(images) * trees_per_image
+    independent searches decoded as one batch; the engine encodes every image once and forks its KV prefix into the
+    slots of that image's trees.  Yields (image index, score, document) in completion order.  Tree k (image k //
+    trees_per_image) samples with the seed stream seed_base + k."""
     import torch
+    imgs = [pipeline.load(im) for im in images]
+    trees = len(imgs) * trees_per_image
     engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees) if trees > 1 else None
     out: "queue.Queue" = queue.Queue()
-    img = pipeline.load(image)
 
     def worker(t: int):
         try:
             gen = torch.Generator().manual_seed(seed_base + t)
             seeds = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
-            g = pipeline._generator(img, None, False, metric=pipeline.metric, **gen_kwargs)
+            g = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric, **gen_kwargs)
             base_generate = g.generate
             g.generate = lambda input_ids, **kw: base_generate(input_ids, seed=next(seeds), **kw)   # per-tree RNG stream
-            for item in g.simulate(expansions=expansions_per_tree):
-                out.put(item)
+            for score, doc in g.simulate(expansions=expansions_per_tree):
+                out.put((t // trees_per_image, score, doc))
         except BaseException as e:
             out.put(e)
         finally:

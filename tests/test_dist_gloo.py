@@ -49,12 +49,13 @@ def _worker(rank, world, port, outdir):
     best = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2)
     images = [sketch_image(10 + i, 64) for i in range(5)]
     codes = dd.sharded_sample(pipe, images, do_sample=False)
+    per_image = dd.root_parallel_search_images(pipe, images[:3], trees_per_image=2, expansions_per_tree=2)
     if rank == 0:
         alone = [pipe.sample(image=im, do_sample=False).code for im in images]
         Path(outdir, "merged.json").write_text(json.dumps({
-            "n": len(merged), "scores": [m[0] for m in merged], "best": best, "codes": codes, "alone": alone}))
+            "n": len(merged), "scores": [m[0] for m in merged], "best": best, "codes": codes, "alone": alone, "per_image": per_image}))
     else:
-        Path(outdir, "rank1.json").write_text(json.dumps({"best": best, "codes": codes}))
+        Path(outdir, "rank1.json").write_text(json.dumps({"best": best, "codes": codes, "per_image": per_image}))
     import torch.distributed as td
     td.barrier()
     td.destroy_process_group()
@@ -68,6 +69,8 @@ def test_two_rank_gather_and_root_parallel_merge(tmp_path):
     other = json.loads((tmp_path / "rank1.json").read_text())
     assert res["best"] == other["best"] and 1 <= len(res["best"]) <= 12          # every rank holds the merged records
     assert [b[0] for b in res["best"]] == sorted(b[0] for b in res["best"])
+    assert res["per_image"] == other["per_image"] and len(res["per_image"]) == 3       # 3 images over 2 ranks: 2 + 1
+    assert all(1 <= len(r) <= 4 and [x[0] for x in r] == sorted(x[0] for x in r) for r in res["per_image"])
     assert res["codes"] == other["codes"] == res["alone"] and len(res["codes"]) == 5   # input order, ragged shards
 
 

@@ -319,3 +319,28 @@ def test_device_error_surfaces_from_every_layer_without_hanging():
     ids, px = _prompt(proc, 0)
     with pytest.raises(RuntimeError, match="700"):
         DyingSingle().generate(input_ids=ids[None], pixel_values=px, max_new_tokens=5)
+
+
+@pytest.mark.parametrize("slots", [13, 6])
+def test_several_images_in_flight_keep_their_own_prefix_and_reward(slots):
+    """BASELINE config 5 on one GPU: 4 images x 3 trees in one batched decode (13 slots: all at once; 6 slots: the trees
+    queue for slots and prefixes are evicted / re-encoded).  The scripted device checks every prefix-reuse claim against
+    the image actually held by the slot; every score must be the similarity to the tree's OWN image."""
+    from detikzify_amd.infer.batching import simulate_parallel_images
+    proc = fake_processor(VOCAB, NIMG)
+    dev = ScriptedDevice(slots=slots)
+    pipe = DetikzifyPipeline(dev, proc, metric="model", document_class=SyntheticTikzDocument, max_length=NIMG + 40,
+                             compile_timeout=None)
+    images = [sketch_image(20 + i, 96) for i in range(4)]
+    res = list(simulate_parallel_images(pipe, images, trees_per_image=3, expansions_per_tree=3))
+    assert len(res) == 36 and sorted({k for k, _, _ in res}) == [0, 1, 2, 3]
+    check = ImageSim.from_detikzify(dev, proc)
+    refs = [pipe.load(im) for im in images]
+    for k, score, doc in res:
+        if doc.is_rasterizable:
+            sims = [check.get_similarity(doc.rasterize(), r) for r in refs]
+            assert score == pytest.approx(sims[k], abs=1e-12)
+    st = dev.last_batch_stats
+    if slots == 13:
+        assert st["prefix_encodes"] == 4        # every image encoded once (prefix cache, then donors / in place)
+    assert st["prefix_encodes"] + dev.forks + st["inplace_reuses"] >= st["joins"]
