@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--probe-tokens", type=int, default=64)
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
+    ap.add_argument("--batch-images", type=int, default=1, help="spread the rollouts of the batched phase over this many "
+                    "different images (BASELINE config 5: 8 images x 4 rollouts = --batch 32 --batch-images 8)")
     ap.add_argument("--batch", type=int, default=64, help="independent rollouts decoded as one batch per GPU in the "
                     "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
     ap.add_argument("--mcts-trees", type=int, default=0, help="optional extra phase: root-parallel MCTS (reference search logic per "
@@ -209,8 +211,12 @@ def main():
             # MCTS rollouts sample with the pipeline's defaults (temperature .8, top-p .95: generate.py:362-364)
             mcts_kw = {**gen_kw, "do_sample": True, "temperature": 0.8, "top_p": 0.95, "top_k": 0}
 
+            n_img = max(1, min(args.batch_images, args.batch))
+            px_of = [px] + [proc(images=expand(sketch_image(100 + k, 224), 224, do_trim=True), return_tensors="pt").pixel_values
+                            for k in range(1, n_img)]
+
             def one(i):
-                model.generate(input_ids=ids, seed=5000 + rank * 100 + i, **mcts_kw)
+                model.generate(input_ids=ids, seed=5000 + rank * 100 + i, **{**mcts_kw, "pixel_values": px_of[i % n_img]})
             for rep_i in range(2):          # first pass warms the batch graph up
                 fence()
                 tb = time.perf_counter()
@@ -230,7 +236,8 @@ def main():
             mean_ctx_b = T0 + (n_new - 1) / 2.0
             bytes_step = W + args.batch * Kb * mean_ctx_b
             result["batched_rollouts"] = {
-                "batch_per_gpu": args.batch, "rollouts_per_sec": world * args.batch / tb,
+                "batch_per_gpu": args.batch, "images_in_flight": n_img, "prefix_encodes_both_passes": engine.prefix_encodes,
+                "rollouts_per_sec": world * args.batch / tb,
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
                 "prefix_sharing": bool(engine.share_prefix),

@@ -693,6 +693,27 @@ def test_simulate_parallel_trees(tiny_batched):
     assert model.batch_engine is None
 
 
+def test_several_images_in_flight_on_device(tiny_batched):
+    """BASELINE config 5 on one GPU: 2 images x 2 trees in one batched decode of a 5-slot model; every score is the SelfSim
+    of the document against the tree's OWN image (device ViT), recomputed here single-threaded"""
+    from detikzify_amd.evaluate.imagesim import ImageSim
+    from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
+    from detikzify_amd.infer.batching import simulate_parallel_images
+    model, proc = tiny_batched
+    pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument, max_length=70)
+    images = [sketch_image(30, 128), sketch_image(31, 128)]
+    res = list(simulate_parallel_images(pipe, images, trees_per_image=2, expansions_per_tree=3))
+    assert len(res) == 12 and {k for k, _, _ in res} == {0, 1} and model.batch_engine is None
+    check, refs, scored = ImageSim.from_detikzify(model, proc), [pipe.load(im) for im in images], 0
+    for k, score, doc in res:
+        if doc.is_rasterizable:
+            assert score == pytest.approx(check.get_similarity(doc.rasterize(), refs[k]), abs=1e-9)
+            scored += 1
+        else:
+            assert score == -1
+    assert scored >= 4 and model.last_batch_stats["prefix_encodes"] <= 4
+
+
 # ------------------------------------------------------------------------------------------ fp8 weights (BASELINE config 5)
 def test_fp8_weights_parity_and_quantisation_error():
     """weight_format="fp8": decoder Linear weights are OCP e4m3 with a per-row power-of-two scale, so the
@@ -1119,8 +1140,11 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
             (ids_c, px_c, 8), (ids_c, px_c, 9), (ids, px, 10)]
     assert model.batch_engine is None
     ref = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
-    for max_batch in (1, 2):          # 1: strictly sequential joins (in-place re-use, eviction); 2: donors among live slots
+    # 1: strictly sequential joins (in-place re-use, eviction); 2: donors among live slots; 5 = every slot decodes, no
+    # prefix-cache slot: the first rollout of an image prefills in full and the others fork from it
+    for max_batch in (1, 2, 5):
         engine = BatchEngine(model, max_batch=max_batch)
+        assert (engine.prefix_slot is None) == (max_batch == 5) and engine.share_prefix
         try:
             got = [None] * len(jobs)
 
@@ -1131,8 +1155,8 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
                 for k in range(len(jobs)):
                     run(k)
             else:
-                for k0 in range(0, len(jobs), 2):
-                    ths = [threading.Thread(target=run, args=(k,)) for k in range(k0, min(k0 + 2, len(jobs)))]
+                for k0 in range(0, len(jobs), max_batch):
+                    ths = [threading.Thread(target=run, args=(k,)) for k in range(k0, min(k0 + max_batch, len(jobs)))]
                     [t.start() for t in ths]; [t.join(timeout=120) for t in ths]
         finally:
             engine.close()
