@@ -125,7 +125,7 @@ def main():
         ddist.init_process_group(backend, timeout_s=1800)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=(min(64, args.batch) + 1) if args.batch > 1 else 0,   # + the prefix-cache slot
+    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=min(65, min(64, args.batch) + max(1, args.batch_images)) if args.batch > 1 else 0,   # + a prefix-cache slot per image
                        weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config

@@ -5,16 +5,17 @@ can be batched without touching its semantics are *independent trees* (root para
 divergence as sharding trees across GPUs): every tree runs the reference's logic unchanged in its own
 thread (DetikzifyGenerator.rollout already generates in a worker thread, infer/generate.py:248-258), and
 whenever those threads ask for their next token the BatchEngine issues ONE dtk_decode_batch step for all
-of them: the weights are streamed once per step for up to 32 sequences (bytes/step = W + sum_b K*t_b).
+of them: the weights are streamed once per step for up to 64 sequences (bytes/step = W + sum_b K*t_b).
 
 BatchEngine      lock-step scheduler over the C ABI's slots (dtk_prefill_slot / dtk_decode_batch_*)
-simulate_parallel  B independent DetikzifyGenerator trees on one image, results as they complete
+simulate_parallel / simulate_parallel_images   independent DetikzifyGenerator trees on one / several images
 """
 from __future__ import annotations
 
 import queue
 import threading
 import time
+from collections import OrderedDict
 from contextlib import contextmanager
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
@@ -41,27 +42,29 @@ class BatchEngine:
     serialises every other use of the context (prefill of a joining sequence, the SelfSim ViT passes)."""
 
     def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True,
-                 gather: int = 0, gather_timeout: float = 0.5):
+                 gather: int = 0, gather_timeout: float = 0.5, prefix_slots: Optional[int] = None):
         n = model.num_slots()
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
         self.model = model
-        # one slot is set aside as the prefix cache: it holds the KV of the image prefix ([image_token]*n
-        # + pixels) of the current image; sequences fork it (bit-identical KV, SURVEY §8 f1) and only
-        # prefill what follows.  Needs a spare slot; otherwise every sequence prefills in full.
         maxdec = 64 if n > 33 else (32 if n > 17 else 16)   # one / two / four 16-slot MFMA column tiles (include/dtk.h)
         dec = min(n, maxdec)
         self.share_prefix = share_prefix and n >= 2
-        # the prefix-cache slot exists when a slot is to spare; without it the sequences still share prefixes among
-        # themselves (in place / from a donor slot), only the first rollout of an image prefills in full
-        self.prefix_slot = n - 1 if self.share_prefix and (n > maxdec or max_batch is None or max_batch < n) else None
-        self.prefix_key = None
-        self.prefix_ids = None
+        self.capacity = min(dec, max_batch) if max_batch else (dec if n > maxdec else dec - 1)
+        # Slots the decode batch does not need are the prefix cache (the highest indices: a step only runs the column
+        # tiles up to its highest ACTIVE slot): each holds the KV of one image prefix ([image_token]*n + pixels), least
+        # recently used first out; sequences fork it (bit-identical KV, SURVEY §8 f1) and only prefill what follows.  With
+        # one image one slot is enough; a batch of images (BASELINE config 5) wants one per image in flight
+        # (load(batch_slots = rollouts + images)).  Without any spare slot the sequences still share prefixes among
+        # themselves (in place / from a donor slot); only the first rollout of an image prefills in full.
+        spare = n - self.capacity
+        n_prefix = min(spare, 8 if prefix_slots is None else int(prefix_slots)) if self.share_prefix else 0
+        self.prefix_slots: List[int] = list(range(n - n_prefix, n))
+        self.prefix_cache: "OrderedDict[Tuple[int, int], int]" = OrderedDict()     # (image key, prefix length) -> prefix slot, LRU order
         self.slot_img: Dict[int, Tuple[int, int]] = {}      # slot -> (image key, prefix length) whose KV prefix it still holds
         self.joins = 0
         self.inplace_reuses = 0                              # joins that found their image prefix already in their slot
         self.prefix_encodes = 0                              # ViT + prefix prefills run for the prefix cache (diagnostics)
-        self.capacity = min(dec - (1 if self.prefix_slot is not None and n <= maxdec else 0), max_batch or dec)
         self.pipeline = pipeline
         self.cv = threading.Condition()
         self.free: List[int] = list(range(self.capacity))
@@ -176,29 +179,41 @@ class BatchEngine:
         """Give `slot` the KV of its image prefix without running ViT + prefill again.  Returns 1 (prefix KV in place: the
         caller prefills what follows with reuse), 2 (prefix == whole prompt and the next-token logits were forked too) or
         0 (nobody holds this image and there is no prefix-cache slot: the caller prefills in full and becomes a donor).
-        Sources, in order: the prefix-cache slot if it holds this image (its fork also carries the logits); the slot itself
-        if it still holds this image's prefix from its previous sequence; any other slot that still holds this image's prefix (several images in
-        flight: a batch of 8 images x 4 rollouts encodes each image once); otherwise the prefix-cache slot is re-encoded."""
+        Sources, in order: a prefix-cache slot that holds this image (its fork also carries the logits); the slot itself
+        if it still holds this image's prefix from its previous sequence; any other slot that still holds this image's
+        prefix; otherwise the image is encoded into a free — else the least recently used — prefix-cache slot.  A batch of
+        8 images x 4 rollouts encodes each image once either way; with a prefix-cache slot per image the joins of later
+        rollouts are pure forks (no 1-token tail prefill to recover the logits)."""
         ids = ids.reshape(-1)
         n_img = key[1]
-        if self.prefix_key != key and self.slot_img.get(slot) == key:
+        src = self.prefix_cache.get(key)
+        if src is None and self.slot_img.get(slot) == key:
             self.inplace_reuses += 1
             return 1                                        # in place: dtk_prefill_slot(REUSE_PREFIX) keeps the prefix rows
         self.slot_img[slot] = key
-        if self.prefix_key != key:
+        if src is None:
             donor = next((s for s, k in self.slot_img.items() if k == key and s != slot), None)
             if donor is not None:
                 self.model.kv_fork(donor, slot, n_img)      # the donor has decoded past the prefix: no logits to inherit
                 return 1
-            if self.prefix_slot is None:
-                self.prefix_encodes += 1
-                return 0
-            self.model.set_sampling(slot=self.prefix_slot, do_sample=False)
-            self.model.prefill(ids[:n_img], pixel_values, slot=self.prefix_slot)
-            self.prefix_key, self.prefix_ids = key, ids[:n_img].clone()
             self.prefix_encodes += 1
-        self.model.kv_fork(self.prefix_slot, slot, n_img)
+            if not self.prefix_slots:
+                return 0
+            used = set(self.prefix_cache.values())
+            src = next((s for s in reversed(self.prefix_slots) if s not in used), None)
+            if src is None:
+                _, src = self.prefix_cache.popitem(last=False)      # evict the least recently used image
+            self.model.set_sampling(slot=src, do_sample=False)
+            self.model.prefill(ids[:n_img], pixel_values, slot=src)
+            self.prefix_cache[key] = src
+        self.prefix_cache.move_to_end(key)
+        self.model.kv_fork(src, slot, n_img)
         return 2 if ids.numel() == n_img else 1
+
+    @property
+    def prefix_slot(self) -> Optional[int]:
+        """the (first-used) prefix-cache slot, None if the engine has none"""
+        return self.prefix_slots[-1] if self.prefix_slots else None
 
     def _launch(self):
         # a slot whose context is full cannot take another (speculative) step; its sequence is at max_length

@@ -321,10 +321,10 @@ def test_device_error_surfaces_from_every_layer_without_hanging():
         DyingSingle().generate(input_ids=ids[None], pixel_values=px, max_new_tokens=5)
 
 
-@pytest.mark.parametrize("slots", [13, 6])
+@pytest.mark.parametrize("slots", [16, 13, 6])
 def test_several_images_in_flight_keep_their_own_prefix_and_reward(slots):
-    """BASELINE config 5 on one GPU: 4 images x 3 trees in one batched decode (13 slots: all at once; 6 slots: the trees
-    queue for slots and prefixes are evicted / re-encoded).  The scripted device checks every prefix-reuse claim against
+    """BASELINE config 5 on one GPU: 4 images x 3 trees in one batched decode (16 slots: a prefix-cache slot per image; 13: one prefix-cache slot,
+    the rest through donors / in place; 6 slots: the trees queue for slots, no prefix cache at all).  The scripted device checks every prefix-reuse claim against
     the image actually held by the slot; every score must be the similarity to the tree's OWN image."""
     from detikzify_amd.infer.batching import simulate_parallel_images
     proc = fake_processor(VOCAB, NIMG)
@@ -341,6 +341,8 @@ def test_several_images_in_flight_keep_their_own_prefix_and_reward(slots):
             sims = [check.get_similarity(doc.rasterize(), r) for r in refs]
             assert score == pytest.approx(sims[k], abs=1e-12)
     st = dev.last_batch_stats
-    if slots == 13:
+    if slots >= 13:
         assert st["prefix_encodes"] == 4        # every image encoded once (prefix cache, then donors / in place)
+    if slots == 16:                             # a prefix-cache slot per image: every join is a fork
+        assert dev.forks == st["joins"] and dev.prefills == 4 + dev.tail_prefills      # tails: rollouts from inner nodes
     assert st["prefix_encodes"] + dev.forks + st["inplace_reuses"] >= st["joins"]

@@ -1142,9 +1142,10 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
     ref = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
     # 1: strictly sequential joins (in-place re-use, eviction); 2: donors among live slots; 5 = every slot decodes, no
     # prefix-cache slot: the first rollout of an image prefills in full and the others fork from it
+    # (1 with a single prefix-cache slot; 2 with three: one per image, every join a pure fork)
     for max_batch in (1, 2, 5):
-        engine = BatchEngine(model, max_batch=max_batch)
-        assert (engine.prefix_slot is None) == (max_batch == 5) and engine.share_prefix
+        engine = BatchEngine(model, max_batch=max_batch, prefix_slots=1 if max_batch == 1 else None)
+        assert len(engine.prefix_slots) == {1: 1, 2: 3, 5: 0}[max_batch] and engine.share_prefix
         try:
             got = [None] * len(jobs)
 
