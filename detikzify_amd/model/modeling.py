@@ -107,6 +107,7 @@ class DetikzifyForCausalLM:
         # share activation buffers with the image branch of a prefill, so those two are serialised by this lock (a reward
         # never takes the batch engine's lock: the trees that are decoding keep stepping)
         self._vit_lock = threading.RLock()
+        self._single_busy = threading.Lock()     # held by a generate() that decodes on the context's single sequence
         self._weights_ready = False
 
     # ---- HF-shaped attributes ---------------------------------------------------------------
@@ -420,21 +421,30 @@ class DetikzifyForCausalLM:
                     if stop:
                         break
         elif n_new_max > 0:
-            self.set_sampling(do_sample, temperature, top_p, top_k, seed, bad,
-                              begin_suppress_tokens or (), suppress_tokens or ())
-            self.prefill(ids[0], pixel_values)
-            launched = received = 0
-            stop = False
-            ahead = 2  # one step always in flight while the host handles the previous token
-            while launched < min(ahead, n_new_max):
-                self.decode_launch(); launched += 1
-            while received < launched:
-                tok = self.decode_wait(); received += 1
-                stop = emit(tok)
-                if stop:
-                    break
-                if launched < n_new_max:
+            # the context has ONE un-slotted sequence: a second generate() on it from another thread would interleave its
+            # prefill / decode steps with ours and both would return garbage — refuse loudly (the reference never does
+            # this either; concurrent rollouts go through a BatchEngine)
+            if not self._single_busy.acquire(blocking=False):
+                raise _lib.DtkError("concurrent generate() calls on one model: decode them as a batch "
+                                    "(detikzify_amd.infer.batching.BatchEngine / simulate_parallel)")
+            try:
+                self.set_sampling(do_sample, temperature, top_p, top_k, seed, bad,
+                                  begin_suppress_tokens or (), suppress_tokens or ())
+                self.prefill(ids[0], pixel_values)
+                launched = received = 0
+                stop = False
+                ahead = 2  # one step always in flight while the host handles the previous token
+                while launched < min(ahead, n_new_max):
                     self.decode_launch(); launched += 1
+                while received < launched:
+                    tok = self.decode_wait(); received += 1
+                    stop = emit(tok)
+                    if stop:
+                        break
+                    if launched < n_new_max:
+                        self.decode_launch(); launched += 1
+            finally:
+                self._single_busy.release()
         if streamer is not None:
             streamer.end()
         if new_tokens:

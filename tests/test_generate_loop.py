@@ -63,7 +63,7 @@ class ScriptedDevice(DetikzifyForCausalLM):
         self.name_or_path = "scripted"
         self.model = SimpleNamespace(vision_model=_Vision())
         self.reuse_prefix, self.batch_engine, self._weights_ready = False, None, True
-        self._vit_lock = threading.RLock()
+        self._vit_lock, self._single_busy = threading.RLock(), threading.Lock()
         self.lib, self._ctx, self.slots = _Lib(self), None, slots
         self.ctx, self.img, self.samp, self.gen0 = {}, {}, {}, {}
         self.pending, self.bpending = [], []
@@ -203,6 +203,19 @@ def test_generate_protocol_streamer_criteria_and_length_budget():
     streamed = list(ts)
     th.join()
     assert len(streamed) == 6 and all(isinstance(t, int) for t in streamed)
+
+    # a second generate() on the same (engine-less) model while one is running is refused, not interleaved
+    gate, inside = threading.Event(), threading.Event()
+    blocker = threading.Thread(target=lambda: dev.generate(
+        input_ids=ids[None], pixel_values=px, suppress_tokens=[EOS], max_new_tokens=3,
+        stopping_criteria=[lambda i, s: (inside.set(), gate.wait(10), False)[2]]))
+    blocker.start()
+    assert inside.wait(10)
+    with pytest.raises(Exception, match="concurrent generate"):
+        dev.generate(input_ids=ids[None], pixel_values=px, max_new_tokens=3)
+    gate.set()
+    blocker.join()
+    assert dev.generate(input_ids=ids[None], pixel_values=px, suppress_tokens=[EOS], max_new_tokens=3).shape[1] == T + 3
 
     with pytest.raises(ValueError):
         dev.generate(input_ids=torch.stack([ids, ids]), pixel_values=px)
