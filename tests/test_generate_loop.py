@@ -359,3 +359,46 @@ def test_several_images_in_flight_keep_their_own_prefix_and_reward(slots):
     if slots == 16:                             # a prefix-cache slot per image: every join is a fork
         assert dev.forks == st["joins"] and dev.prefills == 4 + dev.tail_prefills      # tails: rollouts from inner nodes
     assert st["prefix_encodes"] + dev.forks + st["inplace_reuses"] >= st["joins"]
+
+
+def test_a_failing_streamer_or_criterion_frees_its_slot_and_leaves_the_others_alone():
+    """exceptions raised by caller-supplied objects inside generate() (streamer.put, a stopping criterion) leave through
+    generate(); in the engine the sequence's slot is recycled and the other sequences keep decoding"""
+    proc = fake_processor(VOCAB, NIMG)
+    dev = ScriptedDevice(slots=4)
+    eng = BatchEngine(dev, max_batch=3)
+    ids, px = _prompt(proc, 1)
+    kw = dict(bad_words_ids=[[IMG]], suppress_tokens=[EOS], do_sample=True)
+    good = ScriptedDevice().generate(input_ids=ids[None], pixel_values=px, seed=11, max_new_tokens=40, **kw)
+
+    class BadStreamer(_Recorder):
+        def put(self, value):
+            super().put(value)
+            if len(self.events) == 4:
+                raise KeyError("consumer went away")
+
+    def bad_criterion(input_ids, scores):
+        if input_ids.shape[1] >= NIMG + 5:
+            raise ZeroDivisionError("criterion bug")
+        return False
+
+    out, errs = {}, {}
+
+    def run(name, **extra):
+        try:
+            out[name] = dev.generate(input_ids=ids[None], pixel_values=px, max_new_tokens=40, **kw, **extra)
+        except BaseException as e:  # noqa: BLE001
+            errs[name] = e
+
+    ths = [threading.Thread(target=run, args=("good",), kwargs=dict(seed=11)),
+           threading.Thread(target=run, args=("streamer",), kwargs=dict(seed=12, streamer=BadStreamer())),
+           threading.Thread(target=run, args=("criterion",), kwargs=dict(seed=13, stopping_criteria=[bad_criterion]))]
+    [t.start() for t in ths]
+    [t.join(timeout=60) for t in ths]
+    assert not any(t.is_alive() for t in ths)
+    assert isinstance(errs.get("streamer"), KeyError) and isinstance(errs.get("criterion"), ZeroDivisionError)
+    assert "good" not in errs and torch.equal(out["good"], good)
+    # the engine is still usable and every decode slot is free again
+    again = dev.generate(input_ids=ids[None], pixel_values=px, seed=11, max_new_tokens=40, **kw)
+    eng.close()
+    assert torch.equal(again, good) and sorted(eng.free) == [0, 1, 2] and not eng.zombies and eng.error is None
