@@ -205,13 +205,22 @@ class DetikzifyGenerator:
     @cached_property
     def newlineinfo(self) -> Dict[int, SimpleNamespace]:
         """token id -> (#newlines it contains, whether it ends with one); tokens may hold several."""
-        info = {}
-        # the tokenizer is shared by the trees of simulate_parallel and HF fast tokenizers are not re-entrant
-        with getattr(unwrap(self.processor), "_tok_lock", nullcontext()):
-            for token_id in unwrap(self.processor).tokenizer.vocab.values():
-                text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
-                if n := text.count("\n"):
-                    info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
+        # The table depends on the tokenizer alone: it is kept on the processor, so the trees of simulate_parallel (one
+        # DetikzifyGenerator each) build it once instead of once per tree (a vocabulary-sized loop of decode() calls under
+        # the tokenizer lock — HF fast tokenizers are not re-entrant).
+        owner = unwrap(self.processor)
+        with getattr(owner, "_tok_lock", nullcontext()):
+            info = getattr(owner, "_newlineinfo", None)
+            if info is None:
+                info = {}
+                for token_id in owner.tokenizer.vocab.values():
+                    text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
+                    if n := text.count("\n"):
+                        info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
+                try:
+                    owner._newlineinfo = info
+                except AttributeError:      # a processor type that forbids new attributes: per-generator table
+                    pass
         assert info
         return info
 
