@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--probe-tokens", type=int, default=64)
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
+    ap.add_argument("--skip-batched", action="store_true", help="allocate the --batch slots (for --mcts-trees) but skip the "
+                    "batched_rollouts phase itself")
     ap.add_argument("--batch-images", type=int, default=1, help="spread the rollouts of the batched phase over this many "
                     "different images (BASELINE config 5: 8 images x 4 rollouts = --batch 32 --batch-images 8)")
     ap.add_argument("--batch", type=int, default=64, help="independent rollouts decoded as one batch per GPU in the "
@@ -203,7 +205,7 @@ def main():
 
     # ---- extra phase: B independent rollouts per GPU decoded as ONE batch (root-parallel trees of one
     # GPU): the weights are streamed once per step for all B sequences
-    if args.batch > 1:
+    if args.batch > 1 and not args.skip_batched:
         import threading
         from detikzify_amd.infer.batching import BatchEngine
         engine = BatchEngine(model, max_batch=args.batch)

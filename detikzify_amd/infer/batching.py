@@ -17,7 +17,10 @@ import threading
 import time
 from collections import OrderedDict
 from contextlib import contextmanager
-from typing import Any, Dict, Iterator, List, Optional, Tuple
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
+
+
+_NUDGE = object()      # wakes a thread that waits on its slot's queue without handing it a token
 
 
 class _Sequence:
@@ -25,7 +28,14 @@ class _Sequence:
         self.engine, self.slot = engine, slot
 
     def next_token(self) -> int:
+        """pull: the calling thread gets the slot's next token (one thread hand-off per token)"""
         return self.engine._next_token(self.slot)
+
+    def run(self, emit: Callable[[int], bool]):
+        """push: `emit(token) -> stop` is called for every token of this sequence by whichever thread drives the decode
+        steps; returns when emit returned True (or re-raises what it raised).  No thread hand-off per token: with dozens
+        of sequences in one batch that hand-off — not the GPU step — is what bounds the step rate under the GIL."""
+        self.engine._run(self.slot, emit)
 
 
 class BatchEngine:
@@ -71,6 +81,11 @@ class BatchEngine:
         self.active: set = set()
         self.ready: set = set()
         self.tokq: List["queue.SimpleQueue"] = [queue.SimpleQueue() for _ in range(n)]   # per-slot token hand-off
+        self.sinks: Dict[int, Callable[[int], bool]] = {}   # push sequences: slot -> emit(token) -> stop
+        self.finished: Dict[int, Optional[BaseException]] = {}   # push sequences that are done (what their emit raised)
+        self.driver: Optional[int] = None               # the push sequence whose thread currently drives the steps
+        self.pending = 0                                # threads that want `cv` (joins, leaves): the driver lets them in
+        self._plock = threading.Lock()
         self.inflight: Optional[List[int]] = None      # slots of the launched, not yet collected step
         self.zombies: set = set()                      # left while in flight: freed when that step completes
         self.error: Optional[BaseException] = None
@@ -85,10 +100,23 @@ class BatchEngine:
         self.gather_deadline = time.perf_counter() + gather_timeout
         model.batch_engine = self
 
+    @contextmanager
+    def _locked(self):
+        """`cv` for everybody but the driving thread: Python locks are not fair, and a driver that re-takes `cv` for the
+        next step the moment it has released it would starve joining / leaving sequences — it waits while `pending` > 0"""
+        with self._plock:
+            self.pending += 1
+        try:
+            with self.cv:
+                yield
+        finally:
+            with self._plock:
+                self.pending -= 1
+
     def expect(self, n: int, timeout: float = 0.5):
         """n sequences are about to join (e.g. the trees of simulate_parallel): no decode step before all of
         them have been prefilled / forked, or `timeout` seconds have passed"""
-        with self.cv:
+        with self._locked():
             self.gather_left = min(int(n), self.capacity)
             self.gather_deadline = time.perf_counter() + timeout
             self.t_first_launch = self.t_last_collect = None
@@ -99,16 +127,22 @@ class BatchEngine:
                 "inplace_reuses": self.inplace_reuses, "joins": self.joins}
 
     def close(self):
-        with self.cv:
+        with self._locked():
             self._collect()
         self.model.batch_engine = None
 
     @contextmanager
     def sequence(self, ids, pixel_values, sampling: Dict[str, Any]) -> Iterator[_Sequence]:
         want = self._prefix_key(ids, pixel_values) if (self.share_prefix and pixel_values is not None) else None
-        with self.cv:
+        with self._locked():
             while not self.free:
-                self.cv.wait()
+                with self._plock:       # waiting for a slot is not wanting the lock: the driver must keep stepping
+                    self.pending -= 1
+                try:
+                    self.cv.wait()
+                finally:
+                    with self._plock:
+                        self.pending += 1
             # slot choice: a free slot that holds no prefix worth keeping; else one that already holds THIS image's prefix
             # (re-used in place); else evict the prefix of some other image
             # (lowest index first: a step only runs the 16-slot column tiles up to its highest active slot)
@@ -121,7 +155,7 @@ class BatchEngine:
             self.free.remove(slot)
         joined = False
         try:
-            with self.cv:   # prefill needs the context exclusively (same stream as the decode steps)
+            with self._locked():   # prefill needs the context exclusively (same stream as the decode steps)
                 if self.error is not None:
                     raise self.error        # a native call has failed: the context is not to be touched again
                 self._collect()     # a prefill drops un-collected steps on the C side: collect first
@@ -146,9 +180,11 @@ class BatchEngine:
                 self.joins += 1
                 self.gather_left = max(0, self.gather_left - 1)
                 joined = True
+                if self.driver is not None:
+                    self.tokq[self.driver].put(_NUDGE)      # it may be sleeping through the warm start
             yield _Sequence(self, slot)
         finally:
-            with self.cv:
+            with self._locked():
                 if joined:
                     self.active.discard(slot)
                     self.ready.discard(slot)
@@ -156,10 +192,10 @@ class BatchEngine:
                         self.zombies.add(slot)      # recycled by _collect()
                     else:
                         self.free.append(slot)
-                    if self.active:
-                        self._maybe_step()          # the others may all be waiting on this one
-                    else:
+                    if not self.active:
                         self._collect()             # nobody left to collect the speculative step
+                    elif self.driver is None:
+                        self._maybe_step()          # the others may all be waiting on this one
                 else:
                     self.slot_img.pop(slot, None)   # the prefill did not complete: the slot holds nobody's prefix
                     self.free.append(slot)
@@ -237,10 +273,12 @@ class BatchEngine:
             self.tokq[s].put(e)
         self.cv.notify_all()
 
-    def _collect(self):
-        """wait for the in-flight step, hand its tokens to the sequences that are still active"""
+    def _collect(self, dispatch: bool = True):
+        """wait for the in-flight step, hand its tokens to the sequences that are still active (push sequences: through
+        _dispatch, here or — dispatch=False — by the caller once it has launched the next step)"""
+        pushed: List[Tuple[int, int]] = []
         if self.inflight is None:
-            return
+            return pushed
         try:
             t0 = time.perf_counter()
             toks = self.model.decode_batch_wait()
@@ -251,7 +289,10 @@ class BatchEngine:
                 self.host_bound_steps += 1      # the GPU had already finished: this step waited for the host
             for s in self.inflight:
                 if s in self.active:
-                    self.tokq[s].put(toks[s])
+                    if s in self.sinks:
+                        pushed.append((s, toks[s]))
+                    else:
+                        self.tokq[s].put(toks[s])
                     self.tokens_out += 1
             self.steps += 1
         except BaseException as e:
@@ -262,27 +303,96 @@ class BatchEngine:
                 self.free.append(s)
         self.inflight = None
         self.cv.notify_all()
+        if dispatch:
+            self._dispatch(pushed)
+            return []
+        return pushed
+
+    def _dispatch(self, pushed):
+        """the per-token host work of the push sequences (append, streamer, stopping criteria), in the driving thread"""
+        for s, tok in pushed:
+            emit = self.sinks.get(s)
+            if emit is None or s not in self.active:
+                continue
+            exc = None
+            try:
+                stop = emit(tok)
+            except BaseException as e:  # noqa: BLE001  (re-raised in the sequence's own thread)
+                stop, exc = True, e
+            if stop:
+                self.active.discard(s)
+                self.ready.discard(s)
+                del self.sinks[s]
+                self.finished[s] = exc
+                self.tokq[s].put(_NUDGE)
 
     def _maybe_step(self):
         """every active sequence waits for a token -> collect the step in flight (launch it first if there
         is none) and immediately launch the next one"""
         if not self.active or self.error is not None or not (self.ready >= self.active):
-            return
+            return False
         if self.gather_left > 0:
             if time.perf_counter() < self.gather_deadline:
-                return                  # more sequences are about to join
+                return False            # more sequences are about to join
             self.gather_left = 0
         if self.inflight is None:
             self._launch()
-        self._collect()
+        pushed = self._collect(dispatch=False)
         self.ready.clear()
         if self.pipeline:
-            self._launch()
+            self._launch()              # speculative, like for the pull sequences: the push sequences' host work below
+        self._dispatch(pushed)          # runs under the GPU's next step; one that stops discards its token of that step
+        self.ready.update(s for s in self.sinks if s in self.active)     # push sequences never run dry
+        return True
+
+    def _run(self, slot: int, emit: Callable[[int], bool]):
+        q = self.tokq[slot]
+        with self._locked():
+            if self.error is not None:
+                raise self.error
+            self.sinks[slot] = emit
+            self.ready.add(slot)
+            if self.driver is None:
+                self.driver = slot
+            else:
+                self.tokq[self.driver].put(_NUDGE)      # it may have been waiting for this sequence to get ready
+        try:
+            while True:
+                with (self.cv if self.driver == slot else self._locked()):
+                    if slot in self.finished:
+                        exc = self.finished.pop(slot)
+                        if exc is not None:
+                            raise exc
+                        return
+                    if self.error is not None:
+                        raise self.error
+                    mine = self.driver == slot
+                    stepped = mine and self._maybe_step()
+                if stepped:
+                    while self.pending > 0:         # joins / leaves go first (they queue on `cv`, which is free now)
+                        time.sleep(0.0002)
+                    continue
+                # not the driver, or the driver with nothing to do right now (warm start still gathering, a pull
+                # sequence still busy): sleep until nudged (own completion, driver hand-over, a join, an error)
+                try:
+                    item = q.get(timeout=0.05 if mine else None)
+                except queue.Empty:
+                    continue
+                if isinstance(item, BaseException):
+                    raise item
+        finally:
+            with self._locked():
+                self.sinks.pop(slot, None)
+                self.finished.pop(slot, None)
+                if self.driver == slot:         # hand the wheel to another push sequence that is still decoding
+                    self.driver = next((s for s in self.sinks if s in self.active), None)
+                    if self.driver is not None:
+                        self.tokq[self.driver].put(_NUDGE)
 
     def _next_token(self, slot: int) -> int:
         q = self.tokq[slot]
         if q.empty():
-            with self.cv:
+            with self._locked():
                 if self.error is not None:
                     raise self.error
                 if q.empty():
@@ -291,9 +401,11 @@ class BatchEngine:
         while True:                         # blocks (GIL released) until this slot's token of the next step arrives
             try:
                 item = q.get(timeout=None if self.gather_left <= 0 else 0.05)
+                if item is _NUDGE:
+                    continue
                 break
             except queue.Empty:             # warm start only: re-check the gather deadline
-                with self.cv:
+                with self._locked():
                     self._maybe_step()
         if isinstance(item, BaseException):
             raise item

@@ -21,12 +21,12 @@ directly.  `document_class` selects the reward back-end (TikzDocument = latexmk,
 from __future__ import annotations
 
 import re
+import threading
 from collections import deque
 from contextlib import nullcontext
 from dataclasses import dataclass
 from functools import cached_property
 from math import sqrt
-from multiprocessing.pool import ThreadPool
 from time import time
 from types import SimpleNamespace
 from typing import Any, Dict, Generator, List, Literal, Optional, Set, Tuple, Type, Union
@@ -143,6 +143,29 @@ class DynMinMaxNorm:
         __radd__, __rmul__ = __add__, __mul__
 
 
+class _BackgroundCall:
+    """func(*args, **kwds) in one worker thread; an exception goes to error_callback; wait() joins.  This is what the
+    reference gets from `ThreadPool(processes=1).apply_async(...)` + `pending.wait()` (infer/generate.py:248-258) without
+    the pool's three housekeeping threads, whose start-up and 0.1 s polling cost 50-100 ms per rollout — nothing next to a
+    LaTeX run, but a sixth of a rollout that is decoded in a 64-wide batch."""
+
+    def __init__(self, func, args=(), kwds=None, error_callback=None):
+        self._func, self._args, self._kwds, self._error_callback = func, args, kwds or {}, error_callback
+        self.value = None
+        self._thread = threading.Thread(target=self._run, name="detikzify-rollout", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            self.value = self._func(*self._args, **self._kwds)
+        except BaseException as e:  # noqa: BLE001  (forwarded: the consumer of the streamer must never wait forever)
+            if self._error_callback is not None:
+                self._error_callback(e)
+
+    def wait(self, timeout: Optional[float] = None):
+        self._thread.join(timeout)
+
+
 class DetikzifyGenerator:
     def __init__(self, model, processor, image: Optional[Image.Image], text: Optional[str] = None,
                  metric=None, compile_timeout: Optional[int] = 60, mcts_timeout: Optional[int] = None,
@@ -155,6 +178,7 @@ class DetikzifyGenerator:
         self.document_class = document_class
         self.gen_kwargs = gen_kwargs
 
+        self._processed = None      # processor output for (image, text), built on first use
         self.solution: deque = deque(maxlen=1)
         self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}
         self.norm = DynMinMaxNorm()
@@ -189,8 +213,12 @@ class DetikzifyGenerator:
             streamers.end()
             return input_ids  # never continue past EOS / the length budget
         with torch.inference_mode():
-            enc = self.processor(images=self.image, text=self.text, text_kwargs={"truncation": True},
-                                 return_tensors="pt")
+            # image and text are fixed for the life of the generator: the reference re-runs the processor on every call
+            # (:216), the result is the same tensor every time — keep it (6 ms of resize + normalise per rollout)
+            enc = self._processed
+            if enc is None:
+                enc = self._processed = self.processor(images=self.image, text=self.text, text_kwargs={"truncation": True},
+                                                       return_tensors="pt")
             adapter_kwargs = {k: v for k, v in enc.to(self.model.device).items() if k.startswith("adapter")}
             return self.model.generate(
                 input_ids=input_ids.unsqueeze(0),
@@ -228,32 +256,31 @@ class DetikzifyGenerator:
         """Continue `state` to completion in a worker thread; yield one (prefix, #lines) per
         generated source line as the tokens stream in."""
         input_ids, num_lines, continuation = state.token_ids, state.num_lines, False
-        with ThreadPool(processes=1) as pool:
-            streamer = TokenStreamer()
-            pending = pool.apply_async(
-                func=self.generate, args=[input_ids], error_callback=streamer.propagate_error,
-                kwds=dict(stopping_criteria=[self.control.reset()], streamer=streamer))
-            try:
-                prefix, line = input_ids, []
-                for token in streamer:
-                    line.append(token)
-                    if nl := self.newlineinfo.get(token):
-                        # a token may continue with text after its newline ("continuation")
-                        num_lines += nl.num_lines - continuation
-                        continuation = not nl.trailing
-                        prefix = torch.cat((prefix, torch.tensor(line, device=prefix.device)))
-                        line.clear()
-                        yield prefix, num_lines
-                if line:
-                    yield torch.cat((prefix, torch.tensor(line, device=prefix.device))), num_lines - continuation
-            except (GeneratorExit, KeyboardInterrupt):
-                self.control.abort()
-                raise
-            else:
-                if self.control.should_stop:
-                    raise InterruptedError
-            finally:
-                pending.wait()
+        streamer = TokenStreamer(flush_on=self.newlineinfo)      # same tokens, handed over one source line at a time
+        pending = _BackgroundCall(
+            func=self.generate, args=[input_ids], error_callback=streamer.propagate_error,
+            kwds=dict(stopping_criteria=[self.control.reset()], streamer=streamer))
+        try:
+            prefix, line = input_ids, []
+            for token in streamer:
+                line.append(token)
+                if nl := self.newlineinfo.get(token):
+                    # a token may continue with text after its newline ("continuation")
+                    num_lines += nl.num_lines - continuation
+                    continuation = not nl.trailing
+                    prefix = torch.cat((prefix, torch.tensor(line, device=prefix.device)))
+                    line.clear()
+                    yield prefix, num_lines
+            if line:
+                yield torch.cat((prefix, torch.tensor(line, device=prefix.device))), num_lines - continuation
+        except (GeneratorExit, KeyboardInterrupt):
+            self.control.abort()
+            raise
+        else:
+            if self.control.should_stop:
+                raise InterruptedError
+        finally:
+            pending.wait()
 
     def decode(self, token_ids: torch.Tensor) -> TikzDocument:
         n_prompt = len(self.montecarlo.root_node.token_ids)

@@ -415,11 +415,7 @@ class DetikzifyForCausalLM:
             with engine.sequence(ids[0], pixel_values, dict(
                     do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k, seed=seed, bad_ids=bad,
                     begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ())) as seq:
-                while True:
-                    tok = seq.next_token()
-                    stop = emit(tok)
-                    if stop:
-                        break
+                seq.run(emit)       # emit() is called per token by the thread that drives the batch (no per-token hand-off)
         elif n_new_max > 0:
             # the context has ONE un-slotted sequence: a second generate() on it from another thread would interleave its
             # prefill / decode steps with ours and both would return garbage — refuse loudly (the reference never does

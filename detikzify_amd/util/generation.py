@@ -56,13 +56,22 @@ class _QueueStreamer:
 
 
 class TokenStreamer(_QueueStreamer):
-    """Streams raw token ids; the first put() (the prompt) is dropped when skip_prompt."""
+    """Streams raw token ids; the first put() (the prompt) is dropped when skip_prompt.
 
-    def __init__(self, skip_prompt: bool = True, timeout: Optional[float] = None):
+    `flush_on` (optional, a container of token ids): tokens are handed to the consumer in bursts that end with one of
+    these ids (and at end()).  The consumer iterates over exactly the same ids in the same order; it is merely woken
+    once per burst instead of once per token.  DetikzifyGenerator.rollout acts on newline tokens only and passes its
+    newline table: with dozens of rollouts decoding in one batch, a thread hand-off per token per rollout is what the
+    GIL cannot keep up with (one per source line it can)."""
+
+    def __init__(self, skip_prompt: bool = True, timeout: Optional[float] = None, flush_on=None):
         super().__init__(timeout)
         self.skip_prompt = skip_prompt
         self.next_tokens_are_prompt = True
         self.token_queue = self.queue  # reference attribute name
+        self.flush_on = flush_on
+        self._out: list = []        # producer side: tokens of the burst being built
+        self._in: list = []         # consumer side: the burst being handed out (reversed)
 
     def put(self, value):
         if len(value.shape) > 1:
@@ -73,15 +82,40 @@ class TokenStreamer(_QueueStreamer):
             self.next_tokens_are_prompt = False
             return
         for token_id in value.tolist():
-            self.queue.put(token_id, timeout=self.timeout)
+            self.put_token(token_id)
 
     def put_token(self, token_id: int):
         """one generated token as a plain int (the generate loop's fast path: no tensor per token)"""
-        self.queue.put(token_id, timeout=self.timeout)
+        if self.flush_on is None:
+            self.queue.put(token_id, timeout=self.timeout)
+            return
+        self._out.append(token_id)
+        if token_id in self.flush_on:
+            self._flush()
+
+    def _flush(self):
+        if self._out:
+            burst, self._out = self._out, []
+            self.queue.put(burst, timeout=self.timeout)
+
+    def propagate_error(self, exc: BaseException):
+        self._flush()
+        super().propagate_error(exc)
 
     def end(self):
         self.next_tokens_are_prompt = True
+        self._flush()
         super().end()
+
+    def __next__(self):
+        if self._in:
+            return self._in.pop()
+        item = super().__next__()
+        if isinstance(item, list):
+            item.reverse()
+            self._in = item
+            return self._in.pop()
+        return item
 
 
 class TextIteratorStreamer(_QueueStreamer):

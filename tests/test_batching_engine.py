@@ -63,8 +63,11 @@ class _FakeModel:
         return out
 
 
+@pytest.mark.parametrize("mode", ["pull", "push", "mixed"])
 @pytest.mark.parametrize("pipeline", [True, False])
-def test_engine_random_joins_and_leaves(pipeline):
+def test_engine_random_joins_and_leaves(pipeline, mode):
+    """pull = seq.next_token() per token in the sequence's own thread; push = seq.run(emit): emit is called by whichever
+    thread drives the steps (what model.generate uses); mixed = both kinds in one batch"""
     m = _FakeModel(5)
     eng = BatchEngine(m, max_batch=4, pipeline=pipeline)
     assert eng.share_prefix and eng.prefix_slot == 4 and eng.capacity == 4
@@ -76,7 +79,11 @@ def test_engine_random_joins_and_leaves(pipeline):
             for _ in range(5):
                 n = rng.randint(1, 20)
                 with eng.sequence(torch.tensor([1, 1, 1, 7][: 3 + (i % 2)]), torch.ones(1), {}) as seq:
-                    got = [seq.next_token() for _ in range(n)]
+                    if mode == "pull" or (mode == "mixed" and i % 2):
+                        got = [seq.next_token() for _ in range(n)]
+                    else:
+                        got = []
+                        seq.run(lambda tok: got.append(tok) or len(got) >= n)
                     assert [g % 1000 for g in got] == list(range(n)) and len({g // 1000 for g in got}) == 1
                 total[0] += n
                 time.sleep(rng.random() * 0.001)
