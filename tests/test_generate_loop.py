@@ -402,3 +402,29 @@ def test_a_failing_streamer_or_criterion_frees_its_slot_and_leaves_the_others_al
     again = dev.generate(input_ids=ids[None], pixel_values=px, seed=11, max_new_tokens=40, **kw)
     eng.close()
     assert torch.equal(again, good) and sorted(eng.free) == [0, 1, 2] and not eng.zombies and eng.error is None
+
+
+def test_bench_shaped_batch_of_64_threads_two_passes():
+    """what bench.py's batched phase does: 64 threads call generate() at once (engine.expect holds the first step until
+    all have joined), twice; every sequence gets its full length and the batch stays full"""
+    proc = fake_processor(VOCAB, NIMG)
+    dev = ScriptedDevice(slots=65, max_positions=NIMG + 64)
+    eng = BatchEngine(dev, max_batch=64)
+    ids, px = _prompt(proc, 2)
+    outs = {}
+
+    def one(i):
+        outs[i] = dev.generate(input_ids=ids[None], pixel_values=px, seed=5000 + i, do_sample=True, bad_words_ids=[[IMG]],
+                               suppress_tokens=[EOS], eos_token_id=-1, max_new_tokens=48)
+    for rep in range(2):
+        outs.clear()
+        steps0 = eng.steps
+        eng.expect(64)
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(64)]
+        [t.start() for t in ths]
+        [t.join(timeout=120) for t in ths]
+        assert not any(t.is_alive() for t in ths)
+        assert len(outs) == 64 and all(o.shape == (1, NIMG + 48) for o in outs.values())
+        assert eng.steps - steps0 <= 48 + 3, eng.steps - steps0        # lock-step: one step per token for all 64
+    eng.close()
+    assert len(eng.prefix_cache) == 1 and dev.forks == 128 and sorted(eng.free) == list(range(64))
