@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Is the host fast enough for the GPU?  Runs the shipped Python stack (DetikzifyPipeline -> simulate_parallel -> DetikzifyGenerator
+trees -> model.generate -> BatchEngine) on the scripted device of tests/test_generate_loop.py with the GPU emulated by sleeps:
+a decode step takes --step-ms, a reward ViT pass 4 ms, joins are free.  Prints the wall time per step next to the emulated step
+time; everything above the emulated time is host overhead (GIL hand-offs, reward image work, joins).  No GPU needed.
+
+    python tools/host_emulation.py --trees 32 --step-ms 4.1
+    python tools/host_emulation.py --trees 64 --step-ms 5.8
+"""
+import argparse
+import sys
+import time
+import zlib
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+import tests.test_generate_loop as T  # noqa: E402
+from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument  # noqa: E402
+from detikzify_amd.infer.batching import simulate_parallel  # noqa: E402
+from tests.helpers import fake_processor, sketch_image  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--trees", type=int, default=32)
+ap.add_argument("--expansions", type=int, default=3)
+ap.add_argument("--step-ms", type=float, default=4.1, help="emulated duration of one batched decode step")
+ap.add_argument("--new-tokens", type=int, default=256)
+args = ap.parse_args()
+
+
+def pooled_only(self, pixel_values):
+    time.sleep(0.004)       # the device ViT pass of the reward
+    return torch.nn.functional.adaptive_avg_pool2d(pixel_values.float(), 4).flatten() + 1.5
+
+
+def launch(self, active_slots):
+    slots = list(active_slots)
+    ready = max(time.perf_counter(), getattr(self, "_busy_until", 0.0)) + args.step_ms * 1e-3
+    self.bpending.append(({s: self._next(s) for s in slots}, ready))
+    self._busy_until = ready
+
+
+def wait(self):
+    step, ready = self.bpending.pop(0)
+    delay = ready - time.perf_counter()
+    if delay > 0:
+        time.sleep(delay)
+    return [step.get(s, -1) for s in range(64)]
+
+
+def next_token(self, s):    # no EOS: every rollout runs to the length budget, a newline token every ~16 tokens
+    ctx = self.ctx[s]
+    h = zlib.crc32(repr((self.img[s], len(ctx), ctx[-4:], self.samp[s].get("seed", 0))).encode())
+    tok = self.newline[(h >> 16) % len(self.newline)] if (h & 0xFFFF) < 0.06 * 65536 else self.plain[(h >> 16) % len(self.plain)]
+    ctx.append(tok)
+    return tok
+
+
+T._Vision.pooled_only = pooled_only
+T.ScriptedDevice.decode_batch_launch, T.ScriptedDevice.decode_batch_wait, T.ScriptedDevice._next = launch, wait, next_token
+proc = fake_processor(T.VOCAB, T.NIMG, 384)
+dev = T.ScriptedDevice(slots=args.trees + 1, max_positions=T.NIMG + args.new_tokens + 8)
+pipe = DetikzifyPipeline(dev, proc, metric="model", document_class=SyntheticTikzDocument, max_length=T.NIMG + args.new_tokens,
+                         compile_timeout=None)
+img = sketch_image(3, 224)
+for rep in range(2):        # the first pass warms caches (newline table, reference features)
+    t0 = time.perf_counter()
+    res = list(simulate_parallel(pipe, img, trees=args.trees, expansions_per_tree=args.expansions))
+    dt = time.perf_counter() - t0
+st = dev.last_batch_stats
+print(f"{args.trees} trees x {args.expansions}: {len(res)} rollouts in {dt:.2f} s = {len(res) / dt:.1f} rollouts/s; {st['steps']} steps, "
+      f"{1e3 * dt / st['steps']:.2f} ms wall per step for an emulated {args.step_ms} ms step ({st['steps'] * args.step_ms / 1e3:.2f} s of "
+      f"'GPU' time); steps that found the 'GPU' idle: {st['host_bound_steps']}; tokens {st['tokens_out']}")
