@@ -40,16 +40,22 @@ class _Sequence:
 
 class BatchEngine:
     """All methods are thread-safe; one engine per model.  A sequence is 'active' from the end of its
-    prefill until it leaves.  Steps are pipelined one deep: as soon as the tokens of step k are handed
-    out, step k+1 is launched for the same slots, so the threads' per-token host work (streamer,
-    stopping criteria, Python) runs under the GPU's next step; a sequence that stops after token k just
-    discards its token of step k+1 (its slot is recycled once that step has completed).
+    prefill until it leaves.  Steps are pipelined one deep: as soon as step k has been collected, step k+1 is
+    launched for the same slots, so the per-token host work (streamer, stopping criteria, Python) runs under the
+    GPU's next step; a sequence that stops after token k just discards its token of step k+1 (its slot is
+    recycled once that step has completed).
 
-    Tokens are handed to the threads through one SimpleQueue per slot, not through the shared condition
-    variable: a step wakes every waiting thread exactly once and without a contended lock (with 32 threads
-    a notify_all on one Condition cost ~1.3 ms of lock / GIL hand-offs per step, more than the GPU step hides).
-    The last thread to run out of tokens drives the step (collect + launch) while holding `cv`, which also
-    serialises every other use of the context (prefill of a joining sequence, the SelfSim ViT passes)."""
+    Two ways to consume a sequence (they mix freely in one batch):
+      * push — `seq.run(emit)`, what model.generate uses: emit(token) -> stop is called by the thread that drives
+        the steps (the thread of one of the push sequences; the wheel is handed over when its sequence ends).  No
+        thread is woken per token: under the GIL a hand-off per token per sequence costs more than a 64-slot GPU
+        step hides.
+      * pull — `seq.next_token()`: tokens travel through one SimpleQueue per slot (not through the shared condition
+        variable: a notify_all on one Condition cost ~1.3 ms of lock / GIL hand-offs per step with 32 threads) and
+        the last thread to run out of tokens drives the step.
+    Whoever drives holds `cv`, which also serialises every other use of the context's main stream (prefill of a
+    joining sequence); joins and leaves announce themselves (`pending`) and the driver lets them in between steps.
+    The SelfSim ViT passes do not take `cv`: they run on their own stream under the model's ViT lock."""
 
     def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True,
                  gather: int = 0, gather_timeout: float = 0.5, prefix_slots: Optional[int] = None):
