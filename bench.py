@@ -242,6 +242,11 @@ def main():
                 "rollouts_per_sec": world * args.batch / tb,
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
                 "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
+                # one lock-step decode step per generated token; joins / forks / host time are inside tb, so this is the
+                # end-to-end fraction of the decode-step HBM roofline (W once per step + every sequence's own KV)
+                "achieved_GBps": bytes_step * n_new / tb / 1e9,
+                "frac_of_hbm_peak": bytes_step * n_new / tb / 1e9 / HBM_PEAK_GBS,
+                "roofline_rollouts_per_sec": world * args.batch * HBM_PEAK_GBS * 1e9 / (bytes_step * n_new),
                 "prefix_sharing": bool(engine.share_prefix),
                 "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3),
                                    "host_bound_steps": engine.host_bound_steps, **phases},
