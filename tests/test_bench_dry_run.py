@@ -1,0 +1,80 @@
+"""bench.py end to end on the CPU: the model behind `load` is the scripted device of test_generate_loop (the real generate
+loop, batch engine and MCTS stack run), torch.cuda.synchronize is a no-op.  Checks the one-JSON-line contract the driver
+parses — keys, types, arithmetic consistency — and that every optional phase (batched rollouts over several images, the
+MCTS phase, --skip-batched) runs through.  The numbers themselves mean nothing here."""
+import json
+import sys
+from collections import defaultdict
+
+import pytest
+import torch
+
+from .helpers import fake_processor
+from .test_generate_loop import NIMG, VOCAB, ScriptedDevice
+
+
+class _BenchDevice(ScriptedDevice):
+    def __init__(self, slots):
+        super().__init__(slots=slots, max_positions=NIMG + 80)
+        self.reuse_prefix = False
+        self._stats = defaultdict(float, weight_bytes_per_token=1.0e9, kv_bytes_per_ctx_token=1.0e5, last_prefill_ms=1.0,
+                                  last_vit_ms=0.5, vit_images=0)
+
+    def stats(self):
+        return dict(self._stats)
+
+    def synchronize(self):
+        pass
+
+    def set_graph_mode(self, mode):
+        pass
+
+
+def _run_bench(monkeypatch, capsys, argv):
+    import bench
+    import detikzify_amd.model as dm
+
+    def fake_load(name, synthetic=None, device_map=None, batch_slots=0, weight_format="bf16", **kw):
+        return _BenchDevice(batch_slots), fake_processor(VOCAB, NIMG, 64)
+    monkeypatch.setattr(dm, "load", fake_load)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_and_phases(monkeypatch, capsys):
+    d = _run_bench(monkeypatch, capsys, ["--steps", "2", "--warmup", "1", "--new-tokens", "24", "--no-cpu-baseline",
+                                         "--batch", "8", "--batch-images", "3", "--mcts-trees", "4", "--mcts-expansions", "2",
+                                         "--probe-tokens", "2"])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(2 * 24 / (2 * d["ms_per_step"] / 1e3), rel=0.05)      # tokens / wall time
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"]
+    b = d["batched_rollouts"]
+    assert "error" not in b, b
+    assert b["batch_per_gpu"] == 8 and b["images_in_flight"] == 3 and b["rollouts_per_sec"] > 0
+    assert b["frac_of_hbm_peak"] == pytest.approx(b["achieved_GBps"] / 8000.0)
+    assert b["roofline_rollouts_per_sec"] == pytest.approx(b["rollouts_per_sec"] / b["frac_of_hbm_peak"], rel=1e-6)
+    m = d["mcts_stub_reward"]
+    assert "error" not in m, m
+    assert m["rollouts"] == 8 and m["trees_per_gpu"] == 4
+
+
+def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):
+    d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
+                                         "--batch", "4", "--skip-batched", "--mcts-trees", "2", "--mcts-expansions", "1",
+                                         "--probe-tokens", "2"])
+    assert "batched_rollouts" not in d and d["mcts_stub_reward"]["rollouts"] == 2
+    d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
+                                         "--batch", "0", "--probe-tokens", "2", "--sample"])
+    assert "batched_rollouts" not in d and "mcts_stub_reward" not in d and d["value"] > 0
