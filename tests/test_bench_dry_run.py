@@ -78,3 +78,46 @@ def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):
     d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
                                          "--batch", "0", "--probe-tokens", "2", "--sample"])
     assert "batched_rollouts" not in d and "mcts_stub_reward" not in d and d["value"] > 0
+
+
+def _rank_main(rank, world, port, outdir):
+    import os
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parents[1])
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DTK_DIST_BACKEND="gloo")
+    import io
+    from contextlib import redirect_stdout
+
+    import bench
+    import detikzify_amd.model as dm
+    from tests.test_bench_dry_run import _BenchDevice
+    dm.load = lambda name, batch_slots=0, **kw: (_BenchDevice(batch_slots), fake_processor(VOCAB, NIMG, 64))
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--new-tokens", "16", "--no-cpu-baseline",
+                "--batch", "4", "--probe-tokens", "2"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    Path(outdir, f"rank{rank}.out").write_text(buf.getvalue())
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    """the N > 1 control flow of bench.py (barriers, the string gather, max-over-ranks timing) with two CPU ranks:
+    rank 0 prints the one JSON line with whole-job totals, rank 1 prints nothing"""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out0 = [ln for ln in (tmp_path / "rank0.out").read_text().splitlines() if ln.startswith("{")]
+    assert len(out0) == 1 and not [ln for ln in (tmp_path / "rank1.out").read_text().splitlines() if ln.startswith("{")]
+    d = json.loads(out0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 2 * 16 / (2 * d["ms_per_step"] / 1e3), rel=0.2)   # both ranks' tokens / max time
+    assert d["batched_rollouts"]["rollouts_per_sec"] > 0
