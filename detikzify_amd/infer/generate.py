@@ -1,22 +1,18 @@
 """
-Inference API + MCTS glue (rows a·G, a·R, a·M): DetikzifyGenerator / DetikzifyPipeline with the
-reference's semantics (detikzify/infer/generate.py:35-467), `TikzGenerator` as the alias the
-north-star names.  What each piece preserves:
+DetikzifyGenerator — one image, one search tree (rows a·G, a·R, a·M; the reference's semantics,
+detikzify/infer/generate.py:145-353), `TikzGenerator` being the alias the north-star names:
 
-  NodeState / WideNode      :35-82    a tree node = token prefix + #lines; every real node owns a
-                                      "widen" child whose expansion re-rolls from the same prefix
-  DynMinMaxNorm             :85-142   scores are min-max normalised LAZILY against all scores seen
-  generate()                :209-227  early-out on EOS / max_length, re-run the processor, call
-                                      model.generate with bad_words_ids=[[image_token]] and
-                                      begin_suppress_tokens=[eos]
-  newlineinfo               :229-244  vocabulary scan: which tokens contain newlines
-  rollout()                 :246-282  generate in a ThreadPool(1) worker, split the token stream
-                                      at newline tokens into (prefix, #lines) states on the caller
-  child_finder()/merge()    :305-353  sqrt(n) node insertion, error-line pruning, failed-tail memo,
-                                      (normalised) back-propagation
-  DetikzifyPipeline         :356-467  sample() / simulate() front-end
-The model object is detikzify_amd.model.DetikzifyForCausalLM (HIP); nothing here touches the GPU
-directly.  `document_class` selects the reward back-end (TikzDocument = latexmk, unchanged).
+  generate()                :209-227  early-out on EOS / max_length, the processor output for (image, text), then
+                                      model.generate with bad_words_ids=[[image_token]], begin_suppress_tokens=[eos]
+  newlineinfo               :229-244  vocabulary scan: which tokens contain newlines (kept per processor)
+  rollout()                 :246-282  generate in a worker thread, split the token stream at newline tokens into
+                                      (prefix, #lines) states on the caller's side
+  child_finder() / merge()  :305-353  sqrt(n) node insertion, error-line pruning, failed-tail memo, (normalised)
+                                      back-propagation
+The tree's value types live in infer/tree.py, the sample() / simulate() front-end in infer/pipeline.py, several
+trees in one batched decode in infer/batching.py.  The model object is detikzify_amd.model.DetikzifyForCausalLM
+(HIP); nothing here touches the GPU directly.  `document_class` selects the reward back-end (TikzDocument =
+latexmk, unchanged).
 """
 from __future__ import annotations
 
@@ -24,123 +20,20 @@ import re
 import threading
 from collections import deque
 from contextlib import nullcontext
-from dataclasses import dataclass
 from functools import cached_property
 from math import sqrt
 from time import time
 from types import SimpleNamespace
-from typing import Any, Dict, Generator, List, Literal, Optional, Set, Tuple, Type, Union
+from typing import Dict, Generator, List, Optional, Tuple, Type
 
 import torch
 from PIL import Image
 
-from ..evaluate.imagesim import ImageSim
-from ..mcts import MonteCarlo, Node
-from ..util import ExplicitAbort, StreamerList, TokenStreamer, cache_cast, expand, load
+from ..mcts import MonteCarlo
+from ..util import ExplicitAbort, StreamerList, TokenStreamer, cache_cast
 from ..util import unwrap_processor as unwrap
 from .tikz import TikzDocument
-
-Numeric = Union[int, float]
-
-
-@dataclass(frozen=True)
-class NodeState:
-    token_ids: torch.Tensor
-    num_lines: int = 0
-
-    def __eq__(self, other: Any) -> bool:
-        try:
-            return self.token_ids.equal(other.token_ids)
-        except (AttributeError, TypeError):
-            return False
-
-    def __hash__(self):
-        return hash(tuple(self.token_ids.tolist()))
-
-
-class WideNode(Node):
-    state: NodeState
-
-    def __init__(self, *args, exploration: float = 0.6, is_widen_node: bool = False, **kwargs):
-        super().__init__(NodeState(*args, **kwargs))
-        self.discovery_factor = exploration
-        self.is_widen_node = is_widen_node
-        self.update_policy_value(1.0)
-        if not is_widen_node:  # the sibling that widens the tree at this prefix
-            self.add_child(WideNode(*args, exploration=exploration, is_widen_node=True, **kwargs))
-
-    def add_child(self, child: "WideNode"):
-        # only real children make a node "expanded" (selectable for descent)
-        self.expanded = self.expanded or not child.is_widen_node
-        super().add_child(child)
-
-    @property
-    def depth(self) -> int:
-        d, cur = 0, self
-        while cur.parent is not None:
-            d, cur = d + 1, cur.parent
-        return d
-
-    @property
-    def token_ids(self) -> torch.Tensor:
-        return self.state.token_ids
-
-    @property
-    def num_lines(self) -> int:
-        return self.state.num_lines
-
-
-class DynMinMaxNorm:
-    """normalize(score) returns a lazy value whose `.score` is (s-min)/(max-min) over ALL scores
-    registered so far (re-evaluated at read time), summable with further scores / plain numbers."""
-
-    def __init__(self, default_value: Numeric = 0):
-        self.scores: Set[Numeric] = set()
-        self.default_value = default_value
-
-    def normalize(self, score: Numeric) -> "DynMinMaxNorm.MinMaxScore":
-        self.scores.add(score)
-        return self.MinMaxScore(score, all_scores=self.scores, default_value=self.default_value)
-
-    __call__ = normalize
-
-    class MinMaxScore:
-        def __init__(self, *scores: Numeric, all_scores: Set[Numeric], default_value: Numeric,
-                     no_minmax_scores: Optional[List[Numeric]] = None):
-            self.scores = list(scores)
-            self.all_scores = all_scores
-            self.default_value = default_value
-            self.no_minmax_scores = list(no_minmax_scores or [])
-
-        @property
-        def score(self) -> Numeric:
-            lo, hi = min(self.all_scores), max(self.all_scores)
-            try:
-                value = sum((s - lo) / (hi - lo) for s in self.scores)
-            except ZeroDivisionError:
-                value = self.default_value
-            return value + sum(self.no_minmax_scores)
-
-        def __add__(self, other: Any) -> "DynMinMaxNorm.MinMaxScore":
-            merged = type(self)(*self.scores, all_scores=self.all_scores, default_value=self.default_value,
-                                no_minmax_scores=self.no_minmax_scores)
-            if hasattr(other, "scores") and hasattr(other, "no_minmax_scores"):
-                merged.scores.extend(other.scores)
-                merged.no_minmax_scores.extend(other.no_minmax_scores)
-            else:
-                merged.no_minmax_scores.append(other)
-            return merged
-
-        def __mul__(self, other: Any):
-            return self.score * other
-
-        def __truediv__(self, other: Any):
-            return self.score / other
-
-        def __rtruediv__(self, other: Any):
-            return other / self.score
-
-        __radd__, __rmul__ = __add__, __mul__
+from .tree import DynMinMaxNorm, NodeState, Numeric, WideNode
 
 
 class _BackgroundCall:
@@ -351,53 +244,6 @@ class DetikzifyGenerator:
                 break
             node, nodes_to_merge = match, nodes_to_merge[1:]
         return node, nodes_to_merge
-
-
-class DetikzifyPipeline:
-    def __init__(self, model, processor, temperature: float = 0.8, top_p: float = 0.95, top_k: int = 0,
-                 compile_timeout: Optional[int] = 60,
-                 metric: Union[Literal["model", "fast"], Any] = "model", **gen_kwargs):
-        self.model, self.processor = model, processor
-        if metric == "model":      # SelfSim
-            self.metric = ImageSim.from_detikzify(model, processor, sync_on_compute=False)
-        elif metric == "fast":     # compiler diagnostics
-            self.metric = None
-        else:
-            self.metric = metric
-        self.gen_kwargs: Dict[str, Any] = {**dict(
-            temperature=temperature, top_p=top_p, top_k=top_k,
-            max_length=unwrap(processor).tokenizer.model_max_length,
-            do_sample=True, compile_timeout=compile_timeout), **gen_kwargs}
-
-    def load(self, image: Union[Image.Image, str], preprocess: bool = True) -> Image.Image:
-        image = load(image)
-        return expand(image, max(image.size), do_trim=True) if preprocess else image
-
-    def check_inputs(self, image, text):
-        assert text is None or hasattr(self.model, "adapter"), "You need to load an adapter for textual inputs!"
-        assert image or text, "Either image or text (or both) required!"
-
-    def _generator(self, image, text, preprocess, **kw) -> DetikzifyGenerator:
-        self.check_inputs(image, text)
-        return DetikzifyGenerator(
-            model=self.model, processor=self.processor,
-            image=self.load(image, preprocess=preprocess) if image is not None else None,
-            text=text, **{**self.gen_kwargs, **kw})
-
-    def sample(self, image=None, text: Optional[str] = None, preprocess: bool = True, **gen_kwargs) -> TikzDocument:
-        """One sampled TikZ program for the image."""
-        return self._generator(image, text, preprocess, **gen_kwargs).sample()
-
-    def simulate(self, image=None, text: Optional[str] = None, preprocess: bool = True,
-                 expansions: Optional[Numeric] = None, timeout: Optional[int] = None,
-                 **gen_kwargs) -> Generator[Tuple[Numeric, TikzDocument], None, None]:
-        """MCTS: yields (score, document) for every rollout until `expansions` / `timeout`."""
-        generator = self._generator(image, text, preprocess, metric=self.metric,
-                                    mcts_timeout=timeout or None, **gen_kwargs)
-        yield from generator.simulate(expansions or None)
-
-    def __call__(self, *args, **kwargs) -> TikzDocument:
-        return self.sample(*args, **kwargs)
 
 
 # the name BASELINE.json's north_star uses for the drop-in (SURVEY.md §0 row 1)

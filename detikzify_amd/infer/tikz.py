@@ -1,14 +1,16 @@
 """
-TikzDocument — the unchanged CPU reward back-end (row a·X): compile with latexmk, keep the last
-page, crop, rasterise, parse `file:line:error` diagnostics.  Same behaviour as reference
-detikzify/infer/tikz.py:21-168 (engines fallback :28,111-131; error map :54-73; 420 px raster
-:149-156).  TeX Live / ghostscript / poppler / pymupdf / pdf2image / pdfCropMargins are external
-and absent in this environment: they are imported lazily and a missing toolchain degrades exactly
-like the reference does (:141-142: log an error, status -1, nothing rasterisable).
+TikzDocument — the CPU reward back-end (row a·X, unchanged by design): compile with latexmk, keep the last page,
+crop, rasterise, read `file:line:error` diagnostics.  Behaviour of reference detikzify/infer/tikz.py:21-168: engine
+fallback in order, the engine whose first error comes LATEST decides status and log (:111-131), diagnostics keyed by
+line with 0 for "elsewhere" (:54-73), 420 px raster (:149-156).
 
-SyntheticTikzDocument is a TeX-free stand-in with the same interface (deterministic pseudo
-compile result derived from a hash of the code) used by tests and by bench.py's stub reward —
-never mixed with real-reward numbers.
+The external programs (latexmk of TeX Live, pymupdf, pdfCropMargins, pdf2image / poppler) sit behind `LatexToolchain`,
+so the compile policy above is testable with a fake toolchain (tests/test_host_logic.py) — none of them exists in this
+environment.  A missing toolchain degrades like the reference (:141-142): an error is logged, status -1, nothing to
+rasterise.
+
+SyntheticTikzDocument is a TeX-free stand-in with the same interface (deterministic pseudo compile result derived from
+a hash of the code) used by tests and by bench.py's stub reward — never mixed with real-reward numbers.
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ from os.path import isfile, join
 from re import MULTILINE, escape, findall, search
 from subprocess import DEVNULL, CalledProcessError, TimeoutExpired
 from tempfile import NamedTemporaryFile, TemporaryDirectory
-from typing import Dict, Optional, Union
+from typing import Dict, List, Optional, Union
 
 from PIL import Image, ImageDraw
 
@@ -32,9 +34,62 @@ logger = logging.getLogger("detikzify_amd")
 
 Output = namedtuple("Output", ["pdf", "status", "log"], defaults=[None, -1, ""])
 
+NO_PAGE_NUMBERS = r"{cmd}\AtBeginDocument{{{cmd}}}".format(cmd=r"\thispagestyle{empty}\pagestyle{empty}")
+
+
+class LatexToolchain:
+    """The programs a compile needs.  Constructing it imports the Python-side ones (ImportError = not installed);
+    latexmk itself is found (or not: FileNotFoundError) when it is first run."""
+
+    def __init__(self):
+        import pymupdf
+        from pdfCropMargins import crop
+        self._pymupdf, self._crop = pymupdf, crop
+
+    def latexmk(self, engine: str, texfile: str, cwd: str, timeout: Optional[int]):
+        """one latexmk run; raises CalledProcessError / TimeoutExpired (with .output = the log) when it fails"""
+        check_output(cwd=cwd, timeout=timeout, stderr=DEVNULL,
+                     env=environ | dict(max_print_line="1000"),     # long log lines: file:line:error stays on one line
+                     args=["latexmk", "-f", "-nobibtex", "-norc", "-file-line-error", "-interaction=nonstopmode",
+                           f"-{engine}", texfile])
+
+    def keep_last_page(self, src_pdf: str, dst_pdf: str):
+        doc = self._pymupdf.open(src_pdf)
+        doc.select([len(doc) - 1])
+        doc.save(dst_pdf)
+
+    def crop(self, src_pdf: str, dst_pdf: str):
+        self._crop(["-gsf", "-c", "gb", "-p", "0", "-a", "-1", "-o", dst_pdf, src_pdf], quiet=True)
+
+    def open_pdf(self, path: str):
+        return self._pymupdf.open(path)
+
+    @staticmethod
+    def to_image(pdf, size: int) -> Image.Image:
+        from pdf2image.pdf2image import convert_from_bytes
+        return convert_from_bytes(pdf.tobytes(), size=size, single_file=True)[0]
+
+
+def first_error_line(log: str, texfile: str) -> int:
+    """line of the first `texfile:LINE: message` diagnostic in a latexmk log, 0 if there is none"""
+    hit = search(rf"^{escape(texfile)}:(\d+):.+$", log, MULTILINE)
+    return int(hit.group(1)) if hit else 0
+
+
+def located_errors(log: str) -> Dict[int, str]:
+    """{line: message} of a -file-line-error log; errors outside the root file (the first `(path` the log opens) go
+    under line 0; a log without any located error still reports the fatal one"""
+    opened = search(r"^\((.+)$", log, MULTILINE)
+    root = opened.group(1) if opened else None
+    out: Dict[int, str] = {}
+    for file, line, message in findall(r"^(.+):(\d+):(.+)$", log, MULTILINE):
+        out[int(line) if file == root else 0] = message.strip()
+    return out or {0: "Fatal error occurred, no output PDF file produced!"}
+
 
 class TikzDocument:
-    engines = ["pdflatex", "lualatex", "xelatex"]
+    engines: List[str] = ["pdflatex", "lualatex", "xelatex"]
+    toolchain = LatexToolchain          # a callable returning the toolchain; tests substitute a fake
     Output = Output
 
     def __init__(self, code: str, timeout: Optional[int] = 60):
@@ -42,7 +97,7 @@ class TikzDocument:
         self.timeout = timeout
         self._compiled: Optional[Output] = None
 
-    # ---- compile results (memoised per document, reference :31) --------------------------------
+    # ---- compile results (one compile per document, reference :31) --------------------------------------------
     def compile(self) -> Output:
         if self._compiled is None:
             self._compiled = self._compile()
@@ -66,16 +121,7 @@ class TikzDocument:
 
     @property
     def errors(self) -> Dict[int, str]:
-        """{line: message}; line 0 collects errors that cannot be located in the root file."""
-        if not self.compiled_with_errors:
-            return {}
-        root = None
-        if m := search(r"^\((.+)$", self.log, MULTILINE):
-            root = m.group(1)
-        found: Dict[int, str] = {}
-        for file, line, msg in findall(r"^(.+):(\d+):(.+)$", self.log, MULTILINE):
-            found[int(line) if file == root else 0] = msg.strip()
-        return found or {0: "Fatal error occurred, no output PDF file produced!"}
+        return located_errors(self.log) if self.compiled_with_errors else {}
 
     @cached_property
     def is_rasterizable(self) -> bool:
@@ -90,85 +136,76 @@ class TikzDocument:
     def set_engines(cls, engines: Union[str, list]):
         cls.engines = [engines] if isinstance(engines, str) else engines
 
+    # ---- the compile policy -----------------------------------------------------------------------------------------
+    def _source(self) -> str:
+        """the document with page numbers switched off right after its first line (they would defeat cropping)"""
+        lines = self.code.split("\n")
+        lines.insert(1, NO_PAGE_NUMBERS)
+        return "\n".join(lines)
+
     def _compile(self) -> Output:
-        result: dict = {}
         try:
-            import pymupdf
-            from pdfCropMargins import crop
-        except ImportError as e:  # same degradation as a missing TeX Live
+            tools = self.toolchain()
+        except ImportError as e:        # same degradation as a missing TeX Live
             logger.error("Missing dependencies: %s (TeX Live, ghostscript, poppler needed)", e)
-            return Output(**result)
-        with TemporaryDirectory() as tmpdir:
-            with NamedTemporaryFile(dir=tmpdir, buffering=0) as tmp:
-                lines = self.code.split("\n")
-                # no page numbers in the compiled pdf (they would defeat cropping)
-                lines.insert(1, r"{cmd}\AtBeginDocument{{{cmd}}}".format(cmd=r"\thispagestyle{empty}\pagestyle{empty}"))
-                tmp.write("\n".join(lines).encode())
-                try:
-                    best_line, tmppdf, outpdf = -1, f"{tmp.name}.pdf", join(tmpdir, "tikz.pdf")
-                    open(f"{tmp.name}.bbl", "a").close()
-
-                    def keep_last_page():
-                        try:
-                            doc = pymupdf.open(tmppdf)
-                            doc.select([len(doc) - 1])
-                            doc.save(outpdf)
-                        except Exception:
-                            pass
-
-                    for engine in self.engines:
-                        try:
-                            check_output(
-                                cwd=tmpdir, timeout=self.timeout, stderr=DEVNULL,
-                                env=environ | dict(max_print_line="1000"),
-                                args=["latexmk", "-f", "-nobibtex", "-norc", "-file-line-error",
-                                      "-interaction=nonstopmode", f"-{engine}", tmp.name])
-                        except (CalledProcessError, TimeoutExpired) as proc:
-                            log = (getattr(proc, "output", b"") or b"").decode(errors="ignore")
-                            err = search(rf"^{escape(tmp.name)}:(\d+):.+$", log, MULTILINE)
-                            line = int(err.group(1)) if err else 0
-                            if line > best_line:  # keep the engine that got furthest
-                                best_line = line
-                                result.update(status=getattr(proc, "returncode", -1), log=log)
-                                keep_last_page()
-                        else:
-                            result.update(status=0, log="")
-                            keep_last_page()
-                            break
-                    cropped = f"{tmp.name}.crop"
-                    crop(["-gsf", "-c", "gb", "-p", "0", "-a", "-1", "-o", cropped, outpdf], quiet=True)
-                    if isfile(cropped):
-                        result["pdf"] = pymupdf.open(cropped)
-                except FileNotFoundError:
-                    logger.error("Missing dependencies: Did you install TeX Live?")
-                except RuntimeError:
-                    pass
-        if result.get("status") == 0 and not result.get("pdf"):
+            return Output()
+        status, log, pdf = -1, "", None
+        with TemporaryDirectory() as workdir, NamedTemporaryFile(dir=workdir, buffering=0) as tex:
+            tex.write(self._source().encode())
+            produced, last_page, cropped = f"{tex.name}.pdf", join(workdir, "tikz.pdf"), f"{tex.name}.crop"
+            open(f"{tex.name}.bbl", "a").close()        # some classes insist on a bibliography file
+            try:
+                furthest = -1
+                for engine in self.engines:
+                    try:
+                        tools.latexmk(engine, tex.name, workdir, self.timeout)
+                    except (CalledProcessError, TimeoutExpired) as failed:
+                        engine_log = (getattr(failed, "output", b"") or b"").decode(errors="ignore")
+                        line = first_error_line(engine_log, tex.name)
+                        if line <= furthest:
+                            continue            # an earlier engine got at least as far: its verdict stands
+                        furthest, status, log = line, getattr(failed, "returncode", -1), engine_log
+                    else:
+                        status, log = 0, ""
+                    try:                        # whatever this engine produced: its last page is the figure
+                        tools.keep_last_page(produced, last_page)
+                    except Exception:  # noqa: BLE001
+                        pass
+                    if status == 0:
+                        break
+                tools.crop(last_page, cropped)
+                if isfile(cropped):
+                    pdf = tools.open_pdf(cropped)
+            except FileNotFoundError:
+                logger.error("Missing dependencies: Did you install TeX Live?")
+            except RuntimeError:            # pdf trouble while cropping
+                pass
+        if status == 0 and not pdf:
             logger.warning("Could compile document but something seems to have gone wrong during cropping!")
-        return Output(**result)
+        return Output(pdf=pdf, status=status, log=log)
 
     def rasterize(self, size: int = 420, expand_to_square: bool = True, **_) -> Optional[Image.Image]:
         pdf = self.pdf
         if not pdf:
             return None
-        from pdf2image.pdf2image import convert_from_bytes
-        image = convert_from_bytes(pdf.tobytes(), size=size, single_file=True)[0]
+        image = self.toolchain.to_image(pdf, size)
         return expand(image, size) if expand_to_square else image
 
     def save(self, filename: str, *args, **kwargs):
-        ext = filename.rsplit(".", 1)[-1]
-        if ext == "tex":
-            content = self.code.encode()
-        elif ext == "pdf" and self.pdf:
-            content = self.pdf.tobytes()
-        elif (img := self.rasterize(*args, **kwargs)) is not None:
-            buf = BytesIO()
-            img.save(buf, format=ext)
-            content = buf.getvalue()
+        kind = filename.rsplit(".", 1)[-1]
+        if kind == "tex":
+            data = self.code.encode()
+        elif kind == "pdf" and self.pdf:
+            data = self.pdf.tobytes()
         else:
-            raise ValueError(f"Couldn't save with format '{ext}'!")
+            image = self.rasterize(*args, **kwargs)
+            if image is None:
+                raise ValueError(f"Couldn't save with format '{kind}'!")
+            buffer = BytesIO()
+            image.save(buffer, format=kind)
+            data = buffer.getvalue()
         with open(filename, "wb") as f:
-            f.write(content)
+            f.write(data)
 
 
 class SyntheticTikzDocument(TikzDocument):

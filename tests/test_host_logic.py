@@ -292,3 +292,100 @@ def test_processor_is_safe_under_threads_with_a_fast_tokenizer():
     [x.start() for x in ths]
     [x.join(timeout=120) for x in ths]
     assert not errs, errs[:1]
+
+
+class _FakePdf:
+    def __init__(self, data: bytes):
+        self.data = data
+
+    def tobytes(self):
+        return self.data
+
+    def __bool__(self):
+        return True
+
+
+def _fake_toolchain(script, calls):
+    """script: engine -> None (compiles) | error line (fails there; 0 = an error without a location) | exception"""
+    from subprocess import CalledProcessError
+
+    class Fake:
+        def latexmk(self, engine, texfile, cwd, timeout):
+            calls.append(("latexmk", engine, Path(texfile).read_text().split("\n")[1]))
+            outcome = script[engine]
+            if isinstance(outcome, BaseException):
+                raise outcome
+            Path(texfile + ".pdf").write_bytes(engine.encode())
+            if outcome is not None:
+                log = f"({texfile}\n" + (f"{texfile}:{outcome}: Undefined control sequence.\n" if outcome else "! Emergency stop.\n")
+                raise CalledProcessError(12, "latexmk", output=log.encode())
+
+        def keep_last_page(self, src, dst):
+            calls.append(("last_page", Path(src).read_bytes().decode()))
+            Path(dst).write_bytes(Path(src).read_bytes())
+
+        def crop(self, src, dst):
+            Path(dst).write_bytes(b"cropped:" + Path(src).read_bytes())
+
+        def open_pdf(self, path):
+            return _FakePdf(Path(path).read_bytes())
+
+        @staticmethod
+        def to_image(pdf, size):
+            from PIL import Image
+            return Image.new("RGB", (size, size // 2), "white")
+    return Fake
+
+
+def test_tikz_document_compile_policy_with_a_fake_toolchain():
+    """reference detikzify/infer/tikz.py:89-147: engines in order, stop at the first that compiles; among failing engines
+    the one whose first error comes latest decides status / log / pdf; page numbers are switched off on line 2"""
+    from subprocess import TimeoutExpired
+
+    def doc(script, calls):
+        class Doc(TikzDocument):
+            toolchain = _fake_toolchain(script, calls)
+        return Doc("\\documentclass{standalone}\n\\begin{document}\nx\n\\end{document}", timeout=5)
+
+    calls = []
+    d = doc({"pdflatex": 3, "lualatex": None, "xelatex": None}, calls)
+    assert d.status == 0 and d.log == "" and not d.compiled_with_errors and d.errors == {}
+    assert d.pdf.tobytes() == b"cropped:lualatex"                                      # xelatex never ran
+    assert [c[1] for c in calls if c[0] == "latexmk"] == ["pdflatex", "lualatex"]
+    assert all("\\pagestyle{empty}" in c[2] and "\\AtBeginDocument" in c[2] for c in calls if c[0] == "latexmk")
+    assert d.is_rasterizable and d.rasterize(size=64).size == (64, 64) and d.rasterize(size=64, expand_to_square=False).size == (64, 32)
+
+    calls = []
+    d = doc({"pdflatex": 5, "lualatex": 9, "xelatex": 7}, calls)
+    assert d.status == 12 and list(d.errors) == [9] and d.pdf.tobytes() == b"cropped:lualatex"
+    assert [c[1] for c in calls if c[0] == "last_page"] == ["pdflatex", "lualatex"]    # xelatex (line 7 < 9) is ignored
+
+    calls = []
+    d = doc({"pdflatex": 0, "lualatex": TimeoutExpired("latexmk", 5), "xelatex": 0}, calls)
+    assert d.status == 12 and d.errors == {0: "Fatal error occurred, no output PDF file produced!"}
+    assert [c[1] for c in calls if c[0] == "last_page"] == ["pdflatex"]                # later engines got no further
+
+    d = doc({"pdflatex": FileNotFoundError("latexmk")}, [])                            # TeX Live is not installed
+    assert d.status == -1 and d.pdf is None and not d.is_rasterizable and d.errors == {0: "Fatal error occurred, no output PDF file produced!"}
+
+    class NoTools(TikzDocument):
+        @staticmethod
+        def toolchain():
+            raise ImportError("No module named 'pymupdf'")
+    d = NoTools("x")
+    assert d.status == -1 and d.pdf is None and d.rasterize() is None
+    assert TikzDocument("x").status == -1            # this environment: the real toolchain is absent, same degradation
+
+
+def test_tikz_document_save(tmp_path):
+    class Doc(TikzDocument):
+        toolchain = _fake_toolchain({"pdflatex": None}, [])
+    d = Doc("\\documentclass{standalone}\n\\begin{document}x\\end{document}")
+    d.save(str(tmp_path / "a.tex")); d.save(str(tmp_path / "a.pdf")); d.save(str(tmp_path / "a.png"), size=32)
+    assert (tmp_path / "a.tex").read_text() == d.code and (tmp_path / "a.pdf").read_bytes() == b"cropped:pdflatex"
+    assert (tmp_path / "a.png").read_bytes()[:4] == b"\x89PNG"
+    bad = SyntheticTikzDocument("never compiles 0")
+    while bad.pdf:      # find a synthetic document without output
+        bad = SyntheticTikzDocument(bad.code + "0")
+    with pytest.raises(ValueError):
+        bad.save(str(tmp_path / "b.png"))
