@@ -1,4 +1,3 @@
-from .montecarlo import MonteCarlo
-from .node import Node
+from .search import MonteCarlo, Node
 
 __all__ = ["MonteCarlo", "Node"]
