@@ -53,9 +53,19 @@ class DetikzifyPipeline:
         return self._generator(image, text, preprocess, **gen_kwargs).sample()
 
     def simulate(self, image=None, text: Optional[str] = None, preprocess: bool = True,
-                 expansions: Optional[Numeric] = None, timeout: Optional[int] = None,
+                 expansions: Optional[Numeric] = None, timeout: Optional[int] = None, trees: int = 1,
                  **gen_kwargs) -> Generator[Tuple[Numeric, TikzDocument], None, None]:
-        """MCTS: yields (score, document) for every rollout until `expansions` / `timeout`."""
+        """MCTS: yields (score, document) for every rollout until `expansions` / `timeout`.
+
+        `trees` > 1 (not in the reference): that many independent searches of the same image decoded as ONE batch on
+        this GPU (infer/batching.py; the model must have been loaded with batch_slots > trees), each with its own
+        `expansions` / `timeout` budget — root parallelisation; results arrive in completion order."""
+        if trees > 1:
+            from .batching import simulate_parallel
+            assert preprocess and text is None, "parallel trees take an image and the default preprocessing"
+            yield from simulate_parallel(self, image, trees=trees, expansions_per_tree=expansions or None,
+                                         mcts_timeout=timeout or None, **gen_kwargs)
+            return
         generator = self._generator(image, text, preprocess, metric=self.metric,
                                     mcts_timeout=timeout or None, **gen_kwargs)
         yield from generator.simulate(expansions or None)

@@ -428,3 +428,15 @@ def test_bench_shaped_batch_of_64_threads_two_passes():
         assert eng.steps - steps0 <= 48 + 3, eng.steps - steps0        # lock-step: one step per token for all 64
     eng.close()
     assert len(eng.prefix_cache) == 1 and dev.forks == 128 and sorted(eng.free) == list(range(64))
+
+
+def test_pipeline_simulate_with_parallel_trees_by_expansions_and_by_timeout():
+    proc = fake_processor(VOCAB, NIMG)
+    pipe = DetikzifyPipeline(ScriptedDevice(slots=4), proc, metric="fast", document_class=SyntheticTikzDocument,
+                             max_length=NIMG + 30, compile_timeout=None)
+    image = sketch_image(9, 96)
+    assert len(list(pipe.simulate(image, expansions=2, trees=3))) == 6
+    assert len(list(pipe.simulate(image, expansions=2))) == 2                 # the sequential search of the reference
+    t0 = time.perf_counter()
+    got = list(pipe.simulate(image, timeout=0.4, trees=3))                    # every tree stops after its own time budget
+    assert got and time.perf_counter() - t0 < 20
