@@ -346,6 +346,88 @@ def golden_generator():
     print("generator_trace.json", {k: (len(v["results"]) if isinstance(v, dict) else v) for k, v in res.items()})
 
 
+# ------------------------------------------------------------------------------------- G: reference TikzDocument.compile
+TIKZ_SCENARIOS = {          # engine -> None (compiles) | first error line (0 = error without location) | "timeout" | "missing"
+    "second_engine_compiles": {"pdflatex": 3, "lualatex": None, "xelatex": None},
+    "latest_error_wins": {"pdflatex": 5, "lualatex": 9, "xelatex": 7},
+    "ties_keep_the_first": {"pdflatex": 4, "lualatex": 4, "xelatex": 2},
+    "no_location_then_timeout": {"pdflatex": 0, "lualatex": "timeout", "xelatex": 0},
+    "first_engine_compiles": {"pdflatex": None, "lualatex": 1, "xelatex": 1},
+    "no_tex_live": {"pdflatex": "missing"},
+    "foreign_file_error": {"pdflatex": -6, "lualatex": -6, "xelatex": -6},     # negative: the error sits in another file
+}
+TIKZ_CODE = "\\documentclass{standalone}\n\\begin{document}\nx\n\\end{document}"
+
+
+def tikz_fake_run(script, engine, texfile, trace):
+    """what a latexmk run does in the scenarios above (shared by the reference-side stubs here and by the fake toolchain
+    of tests/test_host_logic.py): record the call, write <texfile>.pdf, fail as scripted"""
+    from subprocess import CalledProcessError, TimeoutExpired
+    trace.append(["latexmk", engine, Path(texfile).read_text().split("\n")[1]])
+    outcome = script[engine]
+    if outcome == "missing":
+        raise FileNotFoundError("latexmk")
+    Path(texfile + ".pdf").write_bytes(engine.encode())
+    if outcome == "timeout":
+        raise TimeoutExpired("latexmk", 5)
+    if outcome is not None:
+        where = f"{texfile}:{outcome}" if outcome > 0 else (f"/usr/share/texmf/x.sty:{-outcome}" if outcome < 0 else None)
+        log = f"({texfile}\n" + (f"{where}: Undefined control sequence.\n" if where else "! Emergency stop.\n")
+        raise CalledProcessError(12, "latexmk", output=log.encode())
+
+
+def golden_tikz():
+    """execute the reference's detikzify/infer/tikz.py with stubs for latexmk / pymupdf / pdfCropMargins / pdf2image and
+    record what TikzDocument.compile decides in every scenario"""
+    trace = []
+
+    class FakeDoc:
+        def __init__(self, path):
+            self.data = Path(path).read_bytes()
+
+        def __len__(self):
+            return 1
+
+        def select(self, pages):
+            pass
+
+        def save(self, dst):
+            trace.append(["last_page", self.data.decode()])
+            Path(dst).write_bytes(self.data)
+
+        def tobytes(self):
+            return self.data
+
+    def fake_crop(argv, quiet=True):
+        Path(argv[argv.index("-o") + 1]).write_bytes(b"cropped:" + Path(argv[-1]).read_bytes())
+    for name, attrs in (("pdf2image", {}), ("pdf2image.pdf2image", {"convert_from_bytes": None}),
+                        ("pdfCropMargins", {"crop": fake_crop}), ("pymupdf", {"open": FakeDoc, "Document": FakeDoc})):
+        m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m
+    sys.modules["pdf2image"].__path__ = []
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    util = types.ModuleType("detikzify.util"); util.__path__ = []
+    util.check_output = util.expand = util.redact = None
+    sys.modules["detikzify.util"] = util
+    inf = types.ModuleType("detikzify.infer"); inf.__path__ = []; sys.modules["detikzify.infer"] = inf
+    ref = _load_ref_module("detikzify.infer.tikz", "detikzify/infer/tikz.py")
+    res = {}
+    for scen, script in TIKZ_SCENARIOS.items():
+        del trace[:]
+
+        def fake_check_output(cwd, timeout, stderr, env, args, _script=script):
+            assert args[:6] == ["latexmk", "-f", "-nobibtex", "-norc", "-file-line-error", "-interaction=nonstopmode"]
+            assert env.get("max_print_line") == "1000" and Path(args[-1]).parent == Path(cwd)
+            tikz_fake_run(_script, args[-2].lstrip("-"), args[-1], trace)
+        ref.check_output = fake_check_output
+        doc = ref.TikzDocument(TIKZ_CODE, timeout=5)
+        out = doc.compile()
+        res[scen] = {"status": out.status, "pdf": out.pdf.tobytes().decode() if out.pdf else None,
+                     "errors": {str(k): v for k, v in doc.errors.items()}, "log_is_empty": out.log == "",
+                     "trace": [list(t) for t in trace]}
+    (OUT / "tikz_compile.json").write_text(json.dumps(res, indent=1))
+    print("tikz_compile.json", {k: (v["status"], v["pdf"]) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -353,3 +435,4 @@ if __name__ == "__main__":
     golden_processors()
     golden_mcts()
     golden_generator()
+    golden_tikz()
