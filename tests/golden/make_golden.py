@@ -23,7 +23,10 @@ Nothing here is read at test time except the written fixtures.
 """
 from __future__ import annotations
 
+import base64
+import hashlib
 import importlib.util
+import io
 import json
 import random
 import sys
@@ -32,6 +35,7 @@ from pathlib import Path
 
 import numpy as np
 import torch
+from PIL import Image
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
@@ -428,6 +432,55 @@ def golden_tikz():
     print("tikz_compile.json", {k: (v["status"], v["pdf"]) for k, v in res.items()})
 
 
+# ------------------------------------------------------------------------------------- H: reference image preparation
+def image_cases():
+    """seeded inputs of row a·P1: RGB sketch with a wide white margin, RGBA with a transparent background, a uniform
+    image (nothing to trim), a tall grayscale one; and what is done to each"""
+    from PIL import ImageDraw
+    rng = np.random.default_rng(7)
+    out = {}
+    img = Image.new("RGB", (200, 140), "white")
+    ImageDraw.Draw(img).line([(60, 30), (150, 100), (90, 110)], fill="black", width=3)
+    out["rgb_margin"] = img
+    rgba = Image.new("RGBA", (120, 160), (0, 0, 0, 0))
+    d = ImageDraw.Draw(rgba)
+    d.ellipse([30, 40, 90, 120], outline=(200, 30, 30, 255), width=4)
+    d.rectangle([10, 10, 40, 30], fill=(0, 0, 255, 128))
+    out["rgba_transparent"] = rgba
+    out["uniform"] = Image.new("RGB", (50, 70), "white")
+    gray = Image.fromarray((rng.integers(0, 2, (90, 30)) * 255).astype(np.uint8), "L")
+    out["gray_tall"] = gray
+    return out
+
+
+def image_digest(img) -> dict:
+    return {"mode": img.mode, "size": list(img.size), "sha256": hashlib.sha256(img.tobytes()).hexdigest()}
+
+
+def golden_image():
+    """run the reference's detikzify/util/image.py (pymupdf / requests stubbed: only `redact` and URL loading use
+    them) on the seeded cases; store digests of load(), trim(), expand(size, do_trim) and expand(max side, do_trim)"""
+    for name in ("pymupdf", "requests"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    import transformers.utils.hub as hub
+    if not hasattr(hub, "is_remote_url"):           # removed in transformers 5 (the reference pins 4.52)
+        hub.is_remote_url = lambda s: s.startswith(("http://", "https://"))
+    ref = _load_ref_module("detikzify.util.image_ref", "detikzify/util/image.py")
+    res = {}
+    for name, img in image_cases().items():
+        rgb = ref.load(img)
+        res[name] = {"load": image_digest(rgb), "trim": image_digest(ref.trim(rgb)),
+                     "expand_384_trim": image_digest(ref.expand(rgb, 384, do_trim=True)),
+                     "expand_max_trim": image_digest(ref.expand(rgb, max(rgb.size), do_trim=True)),
+                     "expand_96": image_digest(ref.expand(rgb, 96))}
+    buf = io.BytesIO(); image_cases()["rgba_transparent"].save(buf, format="PNG")
+    res["from_bytes"] = image_digest(ref.load(buf.getvalue()))
+    res["from_base64"] = image_digest(ref.load(base64.b64encode(buf.getvalue()).decode()))
+    (OUT / "image_prep.json").write_text(json.dumps(res, indent=1))
+    print("image_prep.json", sorted(res))
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -436,3 +489,4 @@ if __name__ == "__main__":
     golden_mcts()
     golden_generator()
     golden_tikz()
+    golden_image()

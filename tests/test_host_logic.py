@@ -17,8 +17,8 @@ from detikzify_amd.infer.tikz import TikzDocument
 from detikzify_amd.mcts import MonteCarlo, Node
 from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
-from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, _StubMetric, generator_script, mcts_script,
-                                      tikz_fake_run)
+from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, _StubMetric, generator_script, image_cases,
+                                      image_digest, mcts_script, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -425,3 +425,25 @@ def test_tikz_document_compile_matches_the_reference_in_every_scenario(golden_di
         assert {str(k): v for k, v in doc.errors.items()} == want["errors"], name
         assert (doc.log == "") == want["log_is_empty"], name
         assert trace == want["trace"], name
+
+
+def test_image_preparation_matches_the_reference_bit_for_bit(golden_dir):
+    """row a·P1: tests/golden/image_prep.json holds digests computed by the reference's own detikzify/util/image.py
+    (load / trim / expand) on seeded RGB, RGBA, uniform and grayscale inputs; ours must produce the same pixels"""
+    import base64
+    import io
+
+    from detikzify_amd.util import load
+    golden = json.loads((golden_dir / "image_prep.json").read_text())
+    cases = image_cases()
+    for name, img in cases.items():
+        rgb = load(img)
+        got = {"load": image_digest(rgb), "trim": image_digest(trim(rgb)),
+               "expand_384_trim": image_digest(expand(rgb, 384, do_trim=True)),
+               "expand_max_trim": image_digest(expand(rgb, max(rgb.size), do_trim=True)),
+               "expand_96": image_digest(expand(rgb, 96))}
+        assert got == golden[name], name
+    buf = io.BytesIO()
+    cases["rgba_transparent"].save(buf, format="PNG")
+    assert image_digest(load(buf.getvalue())) == golden["from_bytes"]
+    assert image_digest(load(base64.b64encode(buf.getvalue()).decode())) == golden["from_base64"]
