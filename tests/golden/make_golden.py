@@ -481,6 +481,58 @@ def golden_image():
     print("image_prep.json", sorted(res))
 
 
+# ------------------------------------------------------------------------------------- I: reference v2 processor
+def processor_tokenizer():
+    """a small HF *fast* tokenizer (what real checkpoints ship) with a dedicated image token"""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "<img>": 4, **{f"w{i}": i for i in range(5, 60)}}
+    t = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    t.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    return PreTrainedTokenizerFast(tokenizer_object=t, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>",
+                                   model_max_length=12, additional_special_tokens=["<img>"])
+
+
+def processor_calls():
+    """(name, kwargs) of the processor calls the inference path makes (infer/generate.py:179-183,216-217) and some more"""
+    a, b = sketch_image(40, 50), sketch_image(41, 70)
+    return [("image_only", dict(images=a)), ("text", dict(images=a, text="w5 w6 w7")),
+            ("bos_eos", dict(images=a, text="w5", add_bos_token=True, add_eos_token=True)),
+            ("two_images", dict(images=[a, b], text=["w8", "w9 w10"])), ("trl_nesting", dict(images=[[a], [b]], text=["w8", "w9"])),
+            ("seq_len_override", dict(images=a, image_seq_len=3)),
+            ("truncation", dict(images=a, text="w5 w6 w7 w8 w9 w10 w11 w12 w13", text_kwargs={"truncation": True})),
+            ("no_images", dict(text="w5")), ("count_mismatch", dict(images=[a, b], text=["w5"])),
+            ("image_token_in_text", dict(images=a, text="w5 <img>"))]
+
+
+def golden_processor():
+    """run the reference's v2 DetikzifyProcessor (detikzify/model/processing_detikzify.py; typing.Unpack back-ported for
+    Python 3.10) with HF's SigLIP image processor and a fast tokenizer; store ids, masks and a digest of the pixels"""
+    import typing
+
+    import typing_extensions
+    typing.Unpack = typing_extensions.Unpack
+    from transformers import SiglipImageProcessor
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    sys.modules.setdefault("detikzify.model", types.ModuleType("detikzify.model")).__path__ = []
+    ref = _load_ref_module("detikzify.model.processing_detikzify", "detikzify/model/processing_detikzify.py")
+    proc = ref.DetikzifyProcessor(image_processor=SiglipImageProcessor(size={"height": 28, "width": 28}),
+                                  tokenizer=processor_tokenizer(), image_seq_len=6, image_token="<img>")
+    res = {}
+    for name, kw in processor_calls():
+        try:
+            out = proc(return_tensors="pt", **kw)
+            res[name] = {"input_ids": out["input_ids"].tolist(), "attention_mask": out["attention_mask"].tolist(),
+                         "pixel_shape": list(out["pixel_values"].shape),
+                         "pixel_sha256": hashlib.sha256(out["pixel_values"].float().numpy().tobytes()).hexdigest()}
+        except (ValueError, AssertionError) as e:
+            res[name] = {"raises": type(e).__name__}
+    res["decode"] = proc.decode([1, 5, 6, 2], skip_special_tokens=True)
+    res["model_input_names"] = sorted(proc.model_input_names)
+    (OUT / "processor_v2.json").write_text(json.dumps(res, indent=1))
+    print("processor_v2.json", {k: (v.get("raises") or v.get("input_ids")) if isinstance(v, dict) else v for k, v in res.items()})
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -490,3 +542,4 @@ if __name__ == "__main__":
     golden_generator()
     golden_tikz()
     golden_image()
+    golden_processor()

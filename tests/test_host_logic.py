@@ -18,7 +18,7 @@ from detikzify_amd.mcts import MonteCarlo, Node
 from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, _StubMetric, generator_script, image_cases,
-                                      image_digest, mcts_script, tikz_fake_run)
+                                      image_digest, mcts_script, processor_calls, processor_tokenizer, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -447,3 +447,25 @@ def test_image_preparation_matches_the_reference_bit_for_bit(golden_dir):
     cases["rgba_transparent"].save(buf, format="PNG")
     assert image_digest(load(buf.getvalue())) == golden["from_bytes"]
     assert image_digest(load(base64.b64encode(buf.getvalue()).decode())) == golden["from_base64"]
+
+
+def test_processor_matches_the_reference_v2_processor(golden_dir):
+    """rows a·P2/P3: tests/golden/processor_v2.json was produced by the reference's own DetikzifyProcessor
+    (detikzify/model/processing_detikzify.py) around HF's SigLIP image processor and a fast tokenizer: same prompt
+    (image tokens, bos / eos, per-call image_seq_len), same ids and masks, same pixels, same errors"""
+    import hashlib
+    golden = json.loads((golden_dir / "processor_v2.json").read_text())
+    proc = DetikzifyProcessor(image_processor=DetikzifyImageProcessor(size={"height": 28, "width": 28}),
+                              tokenizer=processor_tokenizer(), image_seq_len=6, image_token="<img>")
+    for name, kw in processor_calls():
+        want = golden[name]
+        if "raises" in want:
+            with pytest.raises({"ValueError": ValueError, "AssertionError": AssertionError}[want["raises"]]):
+                proc(return_tensors="pt", **kw)
+            continue
+        out = proc(return_tensors="pt", **kw)
+        assert out["input_ids"].tolist() == want["input_ids"] and out["attention_mask"].tolist() == want["attention_mask"], name
+        assert list(out["pixel_values"].shape) == want["pixel_shape"], name
+        assert hashlib.sha256(out["pixel_values"].float().numpy().tobytes()).hexdigest() == want["pixel_sha256"], name
+    assert proc.decode([1, 5, 6, 2], skip_special_tokens=True) == golden["decode"]
+    assert sorted(proc.model_input_names) == golden["model_input_names"]
