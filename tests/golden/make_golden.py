@@ -533,6 +533,84 @@ def golden_processor():
     print("processor_v2.json", {k: (v.get("raises") or v.get("input_ids")) if isinstance(v, dict) else v for k, v in res.items()})
 
 
+# ------------------------------------------------------------------------------------- J: the reference's own v2 model
+REFERENCE_V2_SEED = 4321
+REFERENCE_V2_STEPS = 16
+
+
+def reference_v2_inputs():
+    """prompt = 12 image tokens + three text tokens, pixels of a seeded sketch at the tiny-v2 resolution"""
+    from detikzify_amd.model.processing import DetikzifyImageProcessor
+    from tests.helpers import TINY_V2
+    px = DetikzifyImageProcessor(size={"height": TINY_V2.vit_image, "width": TINY_V2.vit_image})(
+        images=sketch_image(4, 96), return_tensors="pt")["pixel_values"]
+    n_img = (TINY_V2.vit_image // TINY_V2.vit_patch) ** 2 // 3
+    ids = torch.tensor([TINY_V2.image_token_id] * n_img + [7, 9, 300])
+    return ids, px
+
+
+def golden_reference_v2():
+    """The reference's OWN model code on the CPU: detikzify/model/modeling_detikzify.py (DetikzifyForConditionalGeneration =
+    HF SiglipVisionModel + DetikzifyConnector + HF LlamaModel + lm_head) instantiated at the tiny-v2 shapes, filled with
+    the seeded synthetic weights of oracle/synth.py (renamed to checkpoint keys by detikzify_amd/model/convert.py — the
+    loader's own mapping, in reverse), run in fp32: prefill logits, then REFERENCE_V2_STEPS greedy steps through the
+    reference's forward with its KV cache (bad words = image token, EOS suppressed at the first step, as
+    infer/generate.py:218-227 asks HF for).  Only `.adapter` (TikZero, out of scope) is stubbed; transformers 5 needs
+    tie_weights to accept keyword arguments and has flattened SiglipVisionModel's state-dict prefix."""
+    from detikzify_amd.model.convert import registry_to_v2
+    from tests.helpers import TINY_V2 as c
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    sys.modules.setdefault("detikzify.model", types.ModuleType("detikzify.model")).__path__ = []
+    ad = types.ModuleType("detikzify.model.adapter")
+    ad.CrossAttentionAdapterMixin = type("CrossAttentionAdapterMixin", (), {"has_adapter": lambda self: False})
+    sys.modules["detikzify.model.adapter"] = ad
+    cfgm = _load_ref_module("detikzify.model.configuration_detikzify", "detikzify/model/configuration_detikzify.py")
+    mod = _load_ref_module("detikzify.model.modeling_detikzify", "detikzify/model/modeling_detikzify.py")
+    tie = mod.DetikzifyForConditionalGeneration.tie_weights
+    mod.DetikzifyForConditionalGeneration.tie_weights = lambda self, *a, **k: tie(self)
+    cfg = cfgm.DetikzifyConfig(
+        image_token_id=c.image_token_id, concat_factor=3, pad_token_id=0, tie_word_embeddings=False,
+        vision_config=dict(hidden_size=c.vit_dim, intermediate_size=c.vit_mlp, num_hidden_layers=c.vit_depth,
+                           num_attention_heads=c.vit_heads, image_size=c.vit_image, patch_size=c.vit_patch,
+                           hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6),
+        text_config=dict(model_type="llama", hidden_size=c.hidden, intermediate_size=c.ffn, num_hidden_layers=c.layers,
+                         num_attention_heads=c.heads, num_key_value_heads=c.kv_heads, vocab_size=c.vocab,
+                         max_position_embeddings=c.max_positions, rms_norm_eps=c.rms_eps, rope_theta=c.rope_theta,
+                         bos_token_id=1, eos_token_id=2, attention_bias=False, mlp_bias=False, tie_word_embeddings=False,
+                         rope_scaling={"rope_type": "llama3", "factor": c.rope_factor, "low_freq_factor": 1.0,
+                                       "high_freq_factor": 4.0,
+                                       "original_max_position_embeddings": c.rope_original_max_position}))
+    model = mod.DetikzifyForConditionalGeneration(cfg).eval().float()
+    sd, inproj = {}, {}
+    for name, t in make_weights(TINY_V2_CFG, REFERENCE_V2_SEED).items():
+        if name.startswith("rope."):
+            continue
+        for k, piece in registry_to_v2(name, t.float(), c.vit_dim):
+            (inproj if k.startswith("__inproj__") else sd)[k] = piece.contiguous()
+    for kind in ("weight", "bias"):
+        sd[f"model.vision_model.vision_model.head.attention.in_proj_{kind}"] = torch.cat(
+            [inproj[f"__inproj__.q.{kind}"], inproj[f"__inproj__.kv.{kind}"]], 0)
+    sd = {k.replace("model.vision_model.vision_model.", "model.vision_model."): v for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ids, px = reference_v2_inputs()
+    toks, step_logits = [], []
+    with torch.no_grad():
+        out = model(input_ids=ids[None], pixel_values=px, use_cache=True)
+        prefill_logits = out.logits[0].float().clone()
+        for n in range(REFERENCE_V2_STEPS):
+            lg = out.logits[0, -1].float().clone()
+            step_logits.append(lg.clone())
+            lg[c.image_token_id] = float("-inf")
+            if n == 0:
+                lg[2] = float("-inf")
+            toks.append(int(torch.argmax(lg)))
+            out = model(input_ids=torch.tensor([[toks[-1]]]), past_key_values=out.past_key_values, use_cache=True)
+    np.savez_compressed(OUT / "reference_v2_tiny.npz", ids=ids.numpy(), pixels=px.numpy(), prefill_logits=prefill_logits.numpy(),
+                        step_logits=torch.stack(step_logits).numpy(), tokens=np.array(toks, dtype=np.int64))
+    print("reference_v2_tiny.npz", toks)
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -543,3 +621,4 @@ if __name__ == "__main__":
     golden_tikz()
     golden_image()
     golden_processor()
+    golden_reference_v2()

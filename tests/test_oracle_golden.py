@@ -1,5 +1,5 @@
 """Pins the CPU oracle against the golden vectors produced by tests/golden/make_golden.py (installed
-HuggingFace Llama / SigLIP / logits processors).  CPU only."""
+HuggingFace Llama / SigLIP / logits processors, and the reference's own v2 model code).  CPU only."""
 import numpy as np
 import torch
 
@@ -119,3 +119,26 @@ def test_synth_weights_are_bf16_representable():
     for k, v in w.items():
         assert torch.equal(v, v.to(torch.bfloat16).float()), k
     assert abs(float(w["lm_head.weight"].std()) - 0.02) < 2e-3
+
+
+def test_oracle_matches_the_reference_v2_model(golden_dir):
+    """tests/golden/reference_v2_tiny.npz comes from the reference's OWN detikzify/model/modeling_detikzify.py
+    (DetikzifyForConditionalGeneration: SigLIP tower -> 3-patch concat -> bias-free connector -> splice -> LLaMA with
+    GQA + llama3 rope -> lm_head) run on the seeded synthetic weights in fp32: prefill logits at every position of the
+    prompt's tail and 16 greedy steps through its KV cache.  The oracle on the same weights: logits within fp32
+    round-off, tokens identical — the whole image-conditioned path, not just its HF building blocks."""
+    from tests.golden.make_golden import REFERENCE_V2_SEED, REFERENCE_V2_STEPS
+    g = np.load(golden_dir / "reference_v2_tiny.npz")
+    ids, px = torch.from_numpy(g["ids"]), torch.from_numpy(g["pixels"])
+    w = make_weights(TINY_V2_CFG, REFERENCE_V2_SEED)
+    o = DetikzifyOracle(TINY_V2_CFG, w, precision="fp32")
+    assert rel_l2(o.prefill(ids, px[0]), g["prefill_logits"][-1]) < 2e-5
+    for cut in (13, 14):       # shorter prompts = earlier positions of the reference's prefill
+        assert rel_l2(DetikzifyOracle(TINY_V2_CFG, w, precision="fp32").prefill(ids[:cut], px[0]), g["prefill_logits"][cut - 1]) < 2e-5
+    toks, logits = DetikzifyOracle(TINY_V2_CFG, w, precision="fp32").generate(
+        ids, px[0], REFERENCE_V2_STEPS, bad=[TINY_V2_CFG["image_token_id"]], begin=[2], return_logits=True)
+    assert toks == g["tokens"].tolist()
+    assert max(rel_l2(a, b) for a, b in zip(logits, g["step_logits"])) < 2e-5
+    # the bf16 policy (what the device computes) stays within bf16 round-off of the reference
+    o16 = DetikzifyOracle(TINY_V2_CFG, w, precision="bf16")
+    assert rel_l2(o16.prefill(ids, px[0]), g["prefill_logits"][-1]) < 2e-2
