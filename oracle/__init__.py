@@ -16,14 +16,19 @@ What is restated, and from where (reference = potamides/DeTikZify @ 2025-08-24):
       `vit_so400m_patch14_siglip_384` incl. AttentionPoolLatent ('map' pooling).
   Their published algorithms are restated in llama.py / vit.py / sampling.py.
 
-Pinning: the reference ships no tests, golden vectors or fixtures and cannot be
-imported in this container (needs py3.11, transformers 4.52, timm, torchmetrics, ...), so the
-restatement is pinned against what CAN run here: the installed HuggingFace LlamaForCausalLM,
-SiglipVisionModel (architecture stand-in for the timm ViT), HF logits processors and the
-reference's own detikzify.mcts package (imports cleanly).  tests/golden/make_golden.py generates
-those fixtures; tests/test_oracle_golden.py checks the oracle against them.  Status for real
-checkpoints / timm weights: PARITY UNPINNED (no weights offline; GELU flavour of the timm tower
-is a config switch, see vit.py).
+Pinning: the reference ships no tests, golden vectors or fixtures and its package cannot be
+imported as a whole in this container (needs py3.11, transformers 4.52, timm, torchmetrics, ...), so the
+restatement is pinned against what CAN run here (tests/golden/make_golden.py generates the fixtures,
+tests/test_oracle_golden.py and tests/test_host_logic.py check against them):
+  * the reference's OWN v2 model code — detikzify/model/modeling_detikzify.py loaded file by file (only the
+    TikZero adapter mixin stubbed) and run on the CPU at toy size with the seeded synthetic weights: the oracle
+    reproduces its prefill and 16 cached greedy steps (logits to 4e-7, tokens identical);
+  * the installed HuggingFace LlamaForCausalLM (MHA + linear rope, GQA + llama3 rope), SiglipVisionModel
+    (architecture stand-in for the timm ViT of v1) and HF logits processors;
+  * the reference's own host code: detikzify.mcts (imports cleanly), infer/generate.py, infer/tikz.py,
+    util/image.py and the v2 processor, each executed with stubs for the packages that are absent.
+Status for the v1 tower against timm itself and for every real checkpoint: PARITY UNPINNED (timm and weights
+are absent offline; the GELU flavour of the timm tower is a config switch, see vit.py).
 
 Precision policy ("bf16" mode, the product's): every tensor HF/timm materialise in bf16 is
 rounded to bf16 at the same point; contractions accumulate in fp32; attention follows the fused
