@@ -20,9 +20,10 @@ Pinning: the reference ships no tests, golden vectors or fixtures (SURVEY.md §4
 imported as a whole in this container (needs py3.11, transformers 4.52, timm, torchmetrics, ...), so the
 restatement is pinned against what CAN run here (tests/golden/make_golden.py generates the fixtures,
 tests/test_oracle_golden.py and tests/test_host_logic.py check against them):
-  * the reference's OWN v2 model code — detikzify/model/modeling_detikzify.py loaded file by file (only the
-    TikZero adapter mixin stubbed) and run on the CPU at toy size with the seeded synthetic weights: the oracle
-    reproduces its prefill and 16 cached greedy steps (logits to 4e-7, tokens identical);
+  * the reference's OWN model code, both families — detikzify/model/modeling_detikzify.py (v2) and
+    detikzify/model/v1/modeling_detikzify.py (v1; timm.create_model replaced by a timm-shaped shim over HF's
+    SiglipVisionModel) loaded file by file and run on the CPU at toy size with the seeded synthetic weights: the
+    oracle reproduces prefill and 16 cached greedy steps (logits to 6e-7, tokens and error messages identical);
   * the installed HuggingFace LlamaForCausalLM (MHA + linear rope, GQA + llama3 rope), SiglipVisionModel
     (architecture stand-in for the timm ViT of v1) and HF logits processors;
   * the reference's own host code: detikzify.mcts (imports cleanly), infer/generate.py, infer/tikz.py,

@@ -611,6 +611,110 @@ def golden_reference_v2():
     print("reference_v2_tiny.npz", toks)
 
 
+# ------------------------------------------------------------------------------------- K: the reference's own v1 model
+REFERENCE_V1_SEED = 1234
+
+
+def reference_v1_inputs():
+    from detikzify_amd.model.processing import DetikzifyImageProcessor
+    from tests.helpers import TINY
+    px = DetikzifyImageProcessor(size={"height": TINY.vit_image, "width": TINY.vit_image})(
+        images=sketch_image(4, 96), return_tensors="pt")["pixel_values"]
+    n_img = (TINY.vit_image // TINY.vit_patch) ** 2 // 3
+    return torch.tensor([TINY.patch_token_id] * n_img + [7, 9, 300]), px
+
+
+def golden_reference_v1():
+    """The reference's OWN v1 model code on the CPU: detikzify/model/v1/modeling_detikzify.py (DetikzifyForCausalLM: a
+    LlamaModel subclass that runs the tower, concatenates 3 consecutive patch features, applies mm_projector WITH bias,
+    splices the result over the image-token run after validating its length and contiguity, then LLaMA with linear rope
+    scaling and lm_head) at the tiny shapes on the seeded synthetic weights, fp32: prefill and 16 greedy steps through
+    its KV cache.  timm is absent: `timm.create_model` is replaced by a shim that offers the four things the reference
+    uses of timm's VisionTransformer (get_intermediate_layers(n=[layer], norm=True), forward_features, forward_head,
+    patch_embed / embed_dim / blocks / pretrained_cfg) on top of HF's SiglipVisionModel with the same weights through
+    timm_to_hf_siglip — so the tower itself is pinned to HF (golden B), everything around it to the reference."""
+    import torch.nn as nn
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from tests.helpers import TINY as c
+    cfg = TINY_CFG
+    w = make_weights(cfg, REFERENCE_V1_SEED)
+
+    class TimmLikeTower(nn.Module):
+        def __init__(self):
+            super().__init__()
+            hc = SiglipVisionConfig(hidden_size=cfg["vit_dim"], intermediate_size=cfg["vit_mlp"], num_hidden_layers=cfg["vit_depth"],
+                                    num_attention_heads=cfg["vit_heads"], image_size=cfg["vit_image"], patch_size=cfg["vit_patch"],
+                                    layer_norm_eps=cfg["vit_ln_eps"], hidden_act="gelu")
+            self.hf = SiglipVisionModel(hc).eval()
+            sd = timm_to_hf_siglip(w, cfg)
+            if not any(k.startswith("vision_model.") for k in self.hf.state_dict()):   # transformers >= 5 drops the prefix
+                sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+            self.hf.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+            self.inner = getattr(self.hf, "vision_model", self.hf)
+            self.pretrained_cfg = {"architecture": "siglip_shim"}
+            self.embed_dim, self.blocks = cfg["vit_dim"], list(range(cfg["vit_depth"]))
+            self.patch_embed = types.SimpleNamespace(num_patches=(cfg["vit_image"] // cfg["vit_patch"]) ** 2,
+                                                     proj=self.inner.embeddings.patch_embedding)
+
+        def get_intermediate_layers(self, x, n, norm=True):
+            hidden = self.hf(pixel_values=x, output_hidden_states=True).hidden_states
+            return [self.inner.post_layernorm(hidden[i + 1]) if norm else hidden[i + 1] for i in n]
+
+        def forward_features(self, x):
+            return self.hf(pixel_values=x).last_hidden_state
+
+        def forward_head(self, feats):
+            return self.inner.head(feats)
+
+    timm = types.ModuleType("timm")
+    timm.create_model = lambda name, **kw: TimmLikeTower()
+    sys.modules["timm"] = timm
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    sys.modules.setdefault("detikzify.model", types.ModuleType("detikzify.model")).__path__ = []
+    sys.modules.setdefault("detikzify.model.v1", types.ModuleType("detikzify.model.v1")).__path__ = []
+    pp = types.ModuleType("detikzify.model.v1.processing_detikzify")      # needs timm.data; only used by initialize_vision_modules
+    pp.DetikzifyImageProcessor = object
+    sys.modules["detikzify.model.v1.processing_detikzify"] = pp
+    cm = _load_ref_module("detikzify.model.v1.configuration_detikzify", "detikzify/model/v1/configuration_detikzify.py")
+    mod = _load_ref_module("detikzify.model.v1.modeling_detikzify", "detikzify/model/v1/modeling_detikzify.py")
+    rcfg = cm.DetikzifyConfig(
+        hidden_size=c.hidden, intermediate_size=c.ffn, num_hidden_layers=c.layers, num_attention_heads=c.heads,
+        num_key_value_heads=c.heads, vocab_size=c.vocab, max_position_embeddings=c.max_positions, rms_norm_eps=c.rms_eps,
+        rope_theta=c.rope_theta, rope_scaling={"rope_type": "linear", "factor": c.rope_factor}, bos_token_id=1, eos_token_id=2,
+        pad_token_id=0, attention_bias=False, mlp_bias=False, tie_word_embeddings=False, use_mm_proj=True,
+        mm_hidden_size=3 * c.vit_dim, vision_tower="siglip_shim", patch_token_id=c.patch_token_id, concat_patches=3,
+        feature_layer=c.vit_feature_layer, num_patches=(c.vit_image // c.vit_patch) ** 2 // 3)
+    model = mod.DetikzifyForCausalLM(rcfg).eval().float()
+    missing, unexpected = model.load_state_dict(
+        {k: v.float() for k, v in w.items() if not k.startswith(("vision_model.", "rope."))}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ids, px = reference_v1_inputs()
+    toks, step_logits = [], []
+    with torch.no_grad():
+        out = model(input_ids=ids[None], pixel_values=px, use_cache=True)
+        prefill_logits = out.logits[0].float().clone()
+        for n in range(REFERENCE_V2_STEPS):
+            lg = out.logits[0, -1].float().clone()
+            step_logits.append(lg.clone())
+            lg[c.patch_token_id] = float("-inf")
+            if n == 0:
+                lg[2] = float("-inf")
+            toks.append(int(torch.argmax(lg)))
+            out = model(input_ids=torch.tensor([[toks[-1]]]), past_key_values=out.past_key_values, use_cache=True)
+        errors = {}
+        for name, bad_ids in (("count", torch.tensor([c.patch_token_id] * 11 + [7, 9])),
+                              ("gap", torch.tensor([c.patch_token_id] * 6 + [7] + [c.patch_token_id] * 6))):
+            try:
+                model(input_ids=bad_ids[None], pixel_values=px)
+                errors[name] = ""
+            except ValueError as e:
+                errors[name] = str(e)
+    np.savez_compressed(OUT / "reference_v1_tiny.npz", ids=ids.numpy(), pixels=px.numpy(), prefill_logits=prefill_logits.numpy(),
+                        step_logits=torch.stack(step_logits).numpy(), tokens=np.array(toks, dtype=np.int64),
+                        error_count=errors["count"], error_gap=errors["gap"])
+    print("reference_v1_tiny.npz", toks, errors)
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -622,3 +726,4 @@ if __name__ == "__main__":
     golden_image()
     golden_processor()
     golden_reference_v2()
+    golden_reference_v1()

@@ -142,3 +142,31 @@ def test_oracle_matches_the_reference_v2_model(golden_dir):
     # the bf16 policy (what the device computes) stays within bf16 round-off of the reference
     o16 = DetikzifyOracle(TINY_V2_CFG, w, precision="bf16")
     assert rel_l2(o16.prefill(ids, px[0]), g["prefill_logits"][-1]) < 2e-2
+
+
+def test_oracle_matches_the_reference_v1_model(golden_dir):
+    """tests/golden/reference_v1_tiny.npz comes from the reference's OWN detikzify/model/v1/modeling_detikzify.py
+    (DetikzifyForCausalLM: 3 consecutive patch features concatenated, mm_projector with bias, validated splice over the
+    image-token run, LLaMA with linear rope scaling, lm_head; tower = HF SigLIP behind a timm-shaped shim): prefill
+    logits, 16 greedy steps through its KV cache, and the two ValueErrors it raises for a bad image-token layout."""
+    import pytest
+
+    from tests.golden.make_golden import REFERENCE_V1_SEED
+    g = np.load(golden_dir / "reference_v1_tiny.npz")
+    ids, px = torch.from_numpy(g["ids"]), torch.from_numpy(g["pixels"])
+    w = make_weights(TINY_CFG, REFERENCE_V1_SEED)
+    tok = TINY_CFG["image_token_id"]
+    for cut in (13, 14, 15):
+        assert rel_l2(DetikzifyOracle(TINY_CFG, w, precision="fp32").prefill(ids[:cut], px[0]), g["prefill_logits"][cut - 1]) < 2e-5
+    toks, logits = DetikzifyOracle(TINY_CFG, w, precision="fp32").generate(ids, px[0], len(g["tokens"]), bad=[tok], begin=[2],
+                                                                           return_logits=True)
+    assert toks == g["tokens"].tolist()
+    assert max(rel_l2(a, b) for a, b in zip(logits, g["step_logits"])) < 2e-5
+    assert rel_l2(DetikzifyOracle(TINY_CFG, w, precision="bf16").prefill(ids, px[0]), g["prefill_logits"][-1]) < 2e-2
+    o = DetikzifyOracle(TINY_CFG, w, precision="fp32")
+    with pytest.raises(ValueError) as e:
+        o.prefill(torch.tensor([tok] * 11 + [7, 9]), px[0])
+    assert str(e.value) == str(g["error_count"])
+    with pytest.raises(ValueError) as e:
+        o.prefill(torch.tensor([tok] * 6 + [7] + [tok] * 6), px[0])
+    assert str(e.value) == str(g["error_gap"])
