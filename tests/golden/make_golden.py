@@ -715,6 +715,28 @@ def golden_reference_v1():
     print("reference_v1_tiny.npz", toks, errors)
 
 
+# ------------------------------------------------------------------------------------- L: reference multi-GPU sharding
+def golden_sharding():
+    """examples/eval.py:79-93 — `chunk` (striped shards) and `interleave` (the inverse, applied to the gathered lists) are
+    cut out of the reference's script by name (the script itself imports the whole package) and run on every
+    (#items, world size) up to (9, 4)"""
+    import ast
+    from itertools import count
+    src = (REF / "examples/eval.py").read_text()
+    ns = {"count": count}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("chunk", "interleave"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "eval.py", "exec"), ns)
+    res = {}
+    for n in range(10):
+        for world in range(1, 5):
+            items = list(range(100, 100 + n))
+            chunks = [list(c) for c in ns["chunk"](items, world)]
+            res[f"{n}/{world}"] = {"chunks": chunks, "interleaved": ns["interleave"](chunks)}
+    (OUT / "sharding.json").write_text(json.dumps(res))
+    print("sharding.json", len(res), "cases; 7/2 ->", res["7/2"])
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -727,3 +749,4 @@ if __name__ == "__main__":
     golden_processor()
     golden_reference_v2()
     golden_reference_v1()
+    golden_sharding()

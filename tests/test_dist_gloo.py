@@ -83,3 +83,16 @@ def test_chunk_interleave_roundtrip_and_expansion_split():
         assert sum(ddist.shard_expansions(16, n)) == 16
     assert ddist.shard_expansions(16, 8) == [2] * 8 and ddist.shard_expansions(5, 2) == [3, 2]
     assert ddist.gather_objects({"a": 1}) == [{"a": 1}]       # world 1: no process group needed
+
+
+def test_sharding_matches_the_reference_script():
+    """tests/golden/sharding.json: `chunk` / `interleave` cut out of the reference's examples/eval.py:79-93 and run on
+    every (#items, world size) up to (9, 4) — ours give the same shards and the same merged order"""
+    golden = json.loads((ROOT / "tests" / "golden" / "sharding.json").read_text())
+    for key, want in golden.items():
+        n, world = (int(v) for v in key.split("/"))
+        items = list(range(100, 100 + n))
+        chunks = ddist.chunk(items, world)
+        assert chunks == want["chunks"], key
+        assert ddist.interleave(chunks) == want["interleaved"] == items, key
+        assert ddist.interleave_all(chunks, n) == items, key
