@@ -737,6 +737,108 @@ def golden_sharding():
     print("sharding.json", len(res), "cases; 7/2 ->", res["7/2"])
 
 
+# ------------------------------------------------------------------------------------- M: reference ImageSim (SelfSim)
+class ImagesimFakeTower:
+    """deterministic stand-in for model.model.vision_model: 9 patch features of 16 dims + a pooled vector, all fixed
+    random projections of the pixels (shared by the reference-side run below and by tests/test_host_logic.py)"""
+
+    def __init__(self):
+        gen = torch.Generator().manual_seed(99)
+        self.p_patch = torch.randn(3 * 28 * 28, 9 * 16, generator=gen, dtype=torch.float64) / 50
+        self.p_pool = torch.randn(3 * 28 * 28, 16, generator=gen, dtype=torch.float64) / 50
+
+    def __call__(self, pixel_values=None, **_):
+        flat = pixel_values.double().reshape(1, -1)
+        return types.SimpleNamespace(last_hidden_state=(flat @ self.p_patch).reshape(1, 9, 16).float() + 0.1,
+                                     pooler_output=(flat @ self.p_pool).float() + 0.1)
+
+
+def imagesim_cases():
+    a, b = sketch_image(50, 120), sketch_image(51, 90)
+    wide = Image.new("RGB", (160, 60), "white")
+    wide.paste(sketch_image(52, 40), (100, 10))
+    return {"same": (a, a), "different": (a, b), "needs_trim_and_pad": (wide, a)}
+
+
+def golden_imagesim():
+    """run the reference's detikzify/evaluate/imagesim.py (ImageSim.from_detikzify / get_similarity / update / compute)
+    with a fake tower and our 28 px image processor.  Stubs: torchmetrics.Metric (add_state only),
+    torchmetrics.functional.pairwise_cosine_similarity (its documented formula: row-normalise, matmul), ot.lp.emd2
+    (the transport LP solved by scipy's HiGHS: the optimum value is unique), the TikZero adapter names."""
+    import torch.nn as nn
+    from scipy.optimize import linprog
+
+    from detikzify_amd.model.processing import DetikzifyImageProcessor
+
+    class Metric(nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            self._device, self._dtype = "cpu", torch.float32
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone())
+
+        def set_dtype(self, dtype):
+            self._dtype = dtype
+
+        device = property(lambda self: self._device)
+        dtype = property(lambda self: self._dtype)
+
+    def pairwise_cosine_similarity(x, y):
+        return (x / x.norm(dim=1, keepdim=True)) @ (y / y.norm(dim=1, keepdim=True)).T
+
+    def emd2(a, b, M):
+        n, m = M.shape
+        A = np.zeros((n + m, n * m))
+        for i in range(n):
+            A[i, i * m:(i + 1) * m] = 1
+        for j in range(m):
+            A[n + j, j::m] = 1
+        return float(linprog(M.reshape(-1), A_eq=A, b_eq=np.r_[np.full(n, 1 / n), np.full(m, 1 / m)], bounds=(0, None),
+                             method="highs").fun)
+    tm = types.ModuleType("torchmetrics"); tm.Metric = Metric; tm.__path__ = []
+    tmf = types.ModuleType("torchmetrics.functional"); tmf.pairwise_cosine_similarity = pairwise_cosine_similarity
+    ot = types.ModuleType("ot"); ot.__path__ = []
+    otlp = types.ModuleType("ot.lp"); otlp.emd2 = emd2
+    sys.modules.update({"torchmetrics": tm, "torchmetrics.functional": tmf, "ot": ot, "ot.lp": otlp})
+    for name in ("pymupdf", "requests"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import transformers.utils.hub as hub
+    if not hasattr(hub, "is_remote_url"):
+        hub.is_remote_url = lambda s: s.startswith(("http://", "https://"))
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    sys.modules.setdefault("detikzify.model", types.ModuleType("detikzify.model")).__path__ = []
+    ad = types.ModuleType("detikzify.model.adapter")
+    ad.AdapterProcessor = ad.CrossAttentionAdapterMixin = object
+    ad.has_adapter = lambda model: hasattr(model, "adapter")
+    sys.modules["detikzify.model.adapter"] = ad
+    ref_img = _load_ref_module("detikzify.util.image_ref2", "detikzify/util/image.py")
+    ref_gen = _load_ref_module("detikzify.util.generation_ref2", "detikzify/util/generation.py")
+    util = types.ModuleType("detikzify.util"); util.__path__ = []
+    util.cast, util.infer_device = (lambda cls, obj: obj), (lambda: "cpu")
+    util.expand, util.load, util.unwrap_processor = ref_img.expand, ref_img.load, ref_gen.unwrap_processor
+    sys.modules["detikzify.util"] = util
+    sys.modules.setdefault("detikzify.evaluate", types.ModuleType("detikzify.evaluate")).__path__ = []
+    ref = _load_ref_module("detikzify.evaluate.imagesim_ref", "detikzify/evaluate/imagesim.py")
+    image_processor = DetikzifyImageProcessor(size={"height": 28, "width": 28})
+    res = {}
+    for mode in ("cos", "cos_avg", "emd"):
+        model = types.SimpleNamespace(name_or_path="fake", device="cpu", dtype=torch.float32,
+                                      config=types.SimpleNamespace(pooling_mode=mode),
+                                      model=types.SimpleNamespace(vision_model=ImagesimFakeTower()))
+        processor = types.SimpleNamespace(image_processor=image_processor, tokenizer=None)
+        sim = ref.ImageSim.from_detikzify(model, processor, sync_on_compute=False)
+        assert sim.mode == mode
+        out = {name: sim.get_similarity(img1=x, img2=y) for name, (x, y) in imagesim_cases().items()}
+        cases = list(imagesim_cases().values())
+        sim.update(img1=[x for x, _ in cases], img2=[y for _, y in cases])
+        out["mean_over_update"] = sim.compute()
+        out["str"] = str(sim)
+        res[mode] = out
+    (OUT / "imagesim.json").write_text(json.dumps(res, indent=1))
+    print("imagesim.json", res)
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -750,3 +852,4 @@ if __name__ == "__main__":
     golden_reference_v2()
     golden_reference_v1()
     golden_sharding()
+    golden_imagesim()

@@ -17,8 +17,9 @@ from detikzify_amd.infer.tikz import TikzDocument
 from detikzify_amd.mcts import MonteCarlo, Node
 from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
-from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, _StubMetric, generator_script, image_cases,
-                                      image_digest, mcts_script, processor_calls, processor_tokenizer, tikz_fake_run)
+from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, ImagesimFakeTower, _StubMetric, generator_script,
+                                      image_cases, image_digest, imagesim_cases, mcts_script, processor_calls,
+                                      processor_tokenizer, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -469,3 +470,27 @@ def test_processor_matches_the_reference_v2_processor(golden_dir):
         assert hashlib.sha256(out["pixel_values"].float().numpy().tobytes()).hexdigest() == want["pixel_sha256"], name
     assert proc.decode([1, 5, 6, 2], skip_special_tokens=True) == golden["decode"]
     assert sorted(proc.model_input_names) == golden["model_input_names"]
+
+
+@pytest.mark.parametrize("mode", ["cos", "cos_avg", "emd"])
+def test_selfsim_matches_the_reference_imagesim(golden_dir, mode):
+    """row a·W: tests/golden/imagesim.json was produced by the reference's own detikzify/evaluate/imagesim.py
+    (from_detikzify -> get_similarity / update / compute) around a fake tower: same image preparation (load, trim, pad to
+    the longer side), same feature per pooling mode, float64 cosine, 2*tanh(-EMD)+1 over pairwise cosine distances"""
+    from types import SimpleNamespace
+
+    from detikzify_amd.evaluate.imagesim import ImageSim
+    want = json.loads((golden_dir / "imagesim.json").read_text())[mode]
+    model = SimpleNamespace(name_or_path="fake", device="cpu", dtype=torch.float32, config=SimpleNamespace(pooling_mode=mode),
+                            model=SimpleNamespace(vision_model=ImagesimFakeTower()))
+    proc = SimpleNamespace(image_processor=DetikzifyImageProcessor(size={"height": 28, "width": 28}), tokenizer=None)
+    for cached in (False, True):
+        sim = ImageSim.from_detikzify(model, proc, sync_on_compute=False, cache_reference=cached)
+        assert sim.mode == mode and str(sim) == want["str"]
+        cases = imagesim_cases()
+        for name, (x, y) in cases.items():
+            assert sim.get_similarity(img1=x, img2=y) == pytest.approx(want[name], abs=1e-9), (name, cached)
+        sim.update(img1=[x for x, _ in cases.values()], img2=[y for _, y in cases.values()])
+        assert sim.compute() == pytest.approx(want["mean_over_update"], abs=1e-9)
+        sim.reset()
+        assert sim.n_samples == 0
