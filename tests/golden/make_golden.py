@@ -1,25 +1,37 @@
 #!/usr/bin/env python
 """
 Generates the golden fixtures under tests/golden/ (run in the BUILD container only:
-`python tests/golden/make_golden.py`).  The reference package cannot be imported here (needs
-py3.11, transformers 4.52, timm, torchmetrics, ...) and ships no fixtures of its
-own, so the vectors come from what the reference delegates to and what of it can run:
+`python tests/golden/make_golden.py`; the run is deterministic — regenerating changes no byte).  The reference
+package cannot be imported as a whole here (needs py3.11, transformers 4.52, timm, torchmetrics, POT, pymupdf, ...;
+SURVEY.md §8c) and ships no fixtures of its own, so the vectors come from (a) the reference's own source files loaded
+ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classes the reference delegates to:
 
-  llama_tiny.npz      installed HuggingFace LlamaForCausalLM (the class the reference subclasses,
-                      v1/modeling_detikzify.py:75,203) on seeded synthetic weights: prefill logits
-                      (fp32 + bf16) and HF generate() greedy tokens with the reference's
-                      bad_words_ids / begin_suppress_tokens.
-  siglip_tiny.npz     HuggingFace SiglipVisionModel as the architecture stand-in of the timm tower
-                      (timm absent): last_hidden_state + pooler_output on timm-layout weights.
-  processors.npz      HF Temperature / TopK / TopP / NoBadWords / SuppressTokensAtBegin processors
-                      on seeded logits, and HF image transforms (resize bicubic / rescale /
-                      normalise) on a seeded image.
-  mcts_trace.json     the reference's OWN detikzify.mcts package (imports cleanly) driven by a
-                      scripted child_finder: tree statistics after every expansion.
-  generator_trace.json the reference's OWN detikzify/infer/generate.py (DetikzifyGenerator) executed
-                      with stub modules for its unavailable imports, a scripted fake model and a
-                      pseudo TikZ compiler: the (score, code) sequence and tree statistics.
-Nothing here is read at test time except the written fixtures.
+  reference_v2_tiny.npz  the reference's OWN v2 model (detikzify/model/modeling_detikzify.py) at toy size on the seeded
+                         synthetic weights, fp32: prefill logits + 16 greedy steps through its KV cache.
+  reference_v1_tiny.npz  the reference's OWN v1 model (detikzify/model/v1/modeling_detikzify.py; timm.create_model
+                         replaced by a timm-shaped shim over HF's SiglipVisionModel): the same, plus the messages of
+                         its two ValueErrors for a bad image-token layout.
+  generator_trace.json   the reference's OWN detikzify/infer/generate.py (DetikzifyGenerator) with a scripted fake
+                         model and a pseudo TikZ compiler: the (score, code) sequence and tree statistics, 3 modes.
+  mcts_trace.json        the reference's OWN detikzify.mcts package (imports cleanly) driven by a scripted
+                         child_finder: tree statistics after every expansion.
+  tikz_compile.json      the reference's OWN detikzify/infer/tikz.py with stubbed latexmk / pymupdf / pdfCropMargins:
+                         what TikzDocument.compile decides in 7 scenarios (engine order, winner, errors, pages kept).
+  image_prep.json        the reference's OWN detikzify/util/image.py: digests of load / trim / expand results.
+  processor_v2.json      the reference's OWN v2 DetikzifyProcessor around HF's SigLIP image processor and a fast
+                         tokenizer: ids, masks, pixel digests, errors.
+  imagesim.json          the reference's OWN detikzify/evaluate/imagesim.py around a fake tower (stubbed torchmetrics
+                         base class and POT solver): similarities in the cos / cos_avg / emd modes, update / compute.
+  sharding.json          `chunk` / `interleave` cut out of the reference's examples/eval.py.
+  llama_tiny.npz, llama_tiny_gqa.npz   installed HuggingFace LlamaForCausalLM (the class the reference subclasses,
+                         v1/modeling_detikzify.py:75,203; MHA + linear rope, GQA + llama3 rope) on seeded synthetic
+                         weights: prefill logits (fp32 + bf16) and HF generate() greedy tokens with the reference's
+                         bad_words_ids / begin_suppress_tokens.
+  siglip_tiny.npz        HuggingFace SiglipVisionModel as the architecture stand-in of the timm tower (timm absent):
+                         last_hidden_state + pooler_output on timm-layout weights, erf and tanh GELU.
+  processors.npz         HF Temperature / TopK / TopP / NoBadWords / SuppressTokensAtBegin processors on seeded
+                         logits, and HF image transforms (resize bicubic / rescale / normalise) on a seeded image.
+Nothing here is read at test time except the written fixtures (and the small seeded-input helpers tests import).
 """
 from __future__ import annotations
 
