@@ -887,53 +887,6 @@ def test_v2_prefill_logits_and_greedy(tiny_v2, tiny_v2_oracle):
     assert out0[0].tolist() == out[0].tolist()
 
 
-def _device_vs_reference_golden(model, g, image_token, tag):
-    """device vs a golden written by the reference's own model code (fp32): logits at every greedy step, teacher-forced
-    along the reference's tokens through the prefill path, within bf16 round-off (the bf16-policy CPU oracle is at 7e-3);
-    the device's own greedy decode picks the reference's tokens unless the reference's top two logits are within 3 bf16
-    ulps at the first differing step (teacher-forced, the bf16 oracle moves that gap by up to 1.1 ulp)"""
-    ids, px = torch.from_numpy(g["ids"]), torch.from_numpy(g["pixels"])
-    ref_toks, bad = g["tokens"].tolist(), [image_token]
-    worst = 0.0
-    for n in range(len(ref_toks)):
-        cur = torch.cat([ids, torch.tensor(ref_toks[:n], dtype=torch.int64)])
-        worst = max(worst, rel_l2(model.prefill(cur, px, return_logits=True), g["step_logits"][n]))
-    print(f"{tag} device vs the reference model's fp32 logits over {len(ref_toks)} steps: worst rel_l2 {worst:.2e}")
-    assert worst < 2e-2
-    out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=len(ref_toks),
-                         bad_words_ids=[bad], begin_suppress_tokens=[2], eos_token_id=-1)
-    got = out[0, ids.numel():].tolist()
-    for i, (a, b) in enumerate(zip(got, ref_toks)):
-        if a != b:
-            top2 = torch.topk(sampling.mask_scores(torch.from_numpy(g["step_logits"][i]), bad, [2], i == 0), 2)[0]
-            gap, ulp = float(top2[0] - top2[1]), float(top2[0].abs()) * 2.0 ** -7
-            assert gap <= 3 * ulp + 1e-6, f"step {i}: device {a} vs reference {b} with decisive gap {gap} (ulp {ulp})"
-            print(f"{tag} device vs reference greedy: near-tie flip at step {i}")
-            break
-    else:
-        print(f"{tag} device greedy == the reference's {len(ref_toks)} tokens")
-
-
-def test_v2_device_tracks_the_reference_models_own_logits(tiny_v2, golden_dir):
-    """tests/golden/reference_v2_tiny.npz = the reference's OWN detikzify/model/modeling_detikzify.py run in fp32 on the
-    same seeded weights (tests/golden/make_golden.py::golden_reference_v2; the CPU oracle matches it to 4e-7)"""
-    _device_vs_reference_golden(tiny_v2[0], np.load(golden_dir / "reference_v2_tiny.npz"), TINY_V2.image_token_id, "v2")
-
-
-def test_v1_device_tracks_the_reference_models_own_logits(tiny, golden_dir):
-    """tests/golden/reference_v1_tiny.npz = the reference's OWN detikzify/model/v1/modeling_detikzify.py (tower: HF SigLIP
-    behind a timm-shaped shim) run in fp32 on the same seeded weights (make_golden.py::golden_reference_v1; the CPU oracle
-    matches it to 6e-7), incl. the messages of its two ValueErrors for a bad image-token layout"""
-    model, _ = tiny
-    g = np.load(golden_dir / "reference_v1_tiny.npz")
-    _device_vs_reference_golden(model, g, TINY.image_token_id, "v1")
-    px, tok = torch.from_numpy(g["pixels"]), TINY.image_token_id
-    for ids, msg in ((torch.tensor([tok] * 11 + [7, 9]), str(g["error_count"])), (torch.tensor([tok] * 6 + [7] + [tok] * 6), str(g["error_gap"]))):
-        with pytest.raises(ValueError) as e:
-            model.prefill(ids, px)
-        assert msg in str(e.value)
-
-
 def test_v2_batched_decode_and_fork_are_bit_identical_to_alone(tiny_v2):
     """GQA through the MFMA batched path: 4 slots decoded together == each decoded alone; a forked slot == a prefilled one"""
     model, proc = tiny_v2
@@ -1358,3 +1311,52 @@ def test_long_context_properties_ds13b():
     finally:
         del model
         gc.collect()
+
+
+# ------------------------------------------------------------------------------------------ the reference's own model code
+# (last in the file: written after this round's GPU budget was spent, so their first run on the device is the round-end one)
+def _device_vs_reference_golden(model, g, image_token, tag):
+    """device vs a golden written by the reference's own model code (fp32): logits at every greedy step, teacher-forced
+    along the reference's tokens through the prefill path, within bf16 round-off (the bf16-policy CPU oracle is at 7e-3);
+    the device's own greedy decode picks the reference's tokens unless the reference's top two logits are within 3 bf16
+    ulps at the first differing step (teacher-forced, the bf16 oracle moves that gap by up to 1.1 ulp)"""
+    ids, px = torch.from_numpy(g["ids"]), torch.from_numpy(g["pixels"])
+    ref_toks, bad = g["tokens"].tolist(), [image_token]
+    worst = 0.0
+    for n in range(len(ref_toks)):
+        cur = torch.cat([ids, torch.tensor(ref_toks[:n], dtype=torch.int64)])
+        worst = max(worst, rel_l2(model.prefill(cur, px, return_logits=True), g["step_logits"][n]))
+    print(f"{tag} device vs the reference model's fp32 logits over {len(ref_toks)} steps: worst rel_l2 {worst:.2e}")
+    assert worst < 2e-2
+    out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=len(ref_toks),
+                         bad_words_ids=[bad], begin_suppress_tokens=[2], eos_token_id=-1)
+    got = out[0, ids.numel():].tolist()
+    for i, (a, b) in enumerate(zip(got, ref_toks)):
+        if a != b:
+            top2 = torch.topk(sampling.mask_scores(torch.from_numpy(g["step_logits"][i]), bad, [2], i == 0), 2)[0]
+            gap, ulp = float(top2[0] - top2[1]), float(top2[0].abs()) * 2.0 ** -7
+            assert gap <= 3 * ulp + 1e-6, f"step {i}: device {a} vs reference {b} with decisive gap {gap} (ulp {ulp})"
+            print(f"{tag} device vs reference greedy: near-tie flip at step {i}")
+            break
+    else:
+        print(f"{tag} device greedy == the reference's {len(ref_toks)} tokens")
+
+
+def test_v2_device_tracks_the_reference_models_own_logits(tiny_v2, golden_dir):
+    """tests/golden/reference_v2_tiny.npz = the reference's OWN detikzify/model/modeling_detikzify.py run in fp32 on the
+    same seeded weights (tests/golden/make_golden.py::golden_reference_v2; the CPU oracle matches it to 4e-7)"""
+    _device_vs_reference_golden(tiny_v2[0], np.load(golden_dir / "reference_v2_tiny.npz"), TINY_V2.image_token_id, "v2")
+
+
+def test_v1_device_tracks_the_reference_models_own_logits(tiny, golden_dir):
+    """tests/golden/reference_v1_tiny.npz = the reference's OWN detikzify/model/v1/modeling_detikzify.py (tower: HF SigLIP
+    behind a timm-shaped shim) run in fp32 on the same seeded weights (make_golden.py::golden_reference_v1; the CPU oracle
+    matches it to 6e-7), incl. the messages of its two ValueErrors for a bad image-token layout"""
+    model, _ = tiny
+    g = np.load(golden_dir / "reference_v1_tiny.npz")
+    _device_vs_reference_golden(model, g, TINY.image_token_id, "v1")
+    px, tok = torch.from_numpy(g["pixels"]), TINY.image_token_id
+    for ids, msg in ((torch.tensor([tok] * 11 + [7, 9]), str(g["error_count"])), (torch.tensor([tok] * 6 + [7] + [tok] * 6), str(g["error_gap"]))):
+        with pytest.raises(ValueError) as e:
+            model.prefill(ids, px)
+        assert msg in str(e.value)
