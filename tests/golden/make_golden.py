@@ -20,6 +20,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
   image_prep.json        the reference's OWN detikzify/util/image.py: digests of load / trim / expand results.
   processor_v2.json      the reference's OWN v2 DetikzifyProcessor around HF's SigLIP image processor and a fast
                          tokenizer: ids, masks, pixel digests, errors.
+  image_processor_v1.json  the reference's OWN v1 DetikzifyImageProcessor (the two timm config look-ups stubbed with the
+                         published data config of the tower): digests of preprocess() outputs.
   imagesim.json          the reference's OWN detikzify/evaluate/imagesim.py around a fake tower (stubbed torchmetrics
                          base class and POT solver): similarities in the cos / cos_avg / emd modes, update / compute.
   sharding.json          `chunk` / `interleave` cut out of the reference's examples/eval.py.
@@ -851,6 +853,46 @@ def golden_imagesim():
     print("imagesim.json", res)
 
 
+# ------------------------------------------------------------------------------------- N: reference v1 image processor
+def image_processor_cases():
+    return {"sketch_224": sketch_image(60, 224), "sketch_500x300": sketch_image(61, 500).crop((0, 0, 500, 300)),
+            "tiny_40": sketch_image(62, 40), "gray": sketch_image(63, 128).convert("L").convert("RGB")}
+
+
+def golden_image_processor_v1():
+    """the reference's OWN v1 DetikzifyImageProcessor (detikzify/model/v1/processing_detikzify.py): `from_pretrained`
+    builds its configuration from timm's data config of the tower — timm is absent, so the two timm look-ups are stubbed
+    to return the published data config of vit_so400m_patch14_siglip_384 (384 x 384, bicubic, mean = std = 0.5, no
+    centre crop) — and `preprocess` (resize, rescale, normalise, channels first) runs unchanged"""
+    timm = sys.modules.get("timm") or types.ModuleType("timm")
+    timm.__path__ = []
+    data, models = types.ModuleType("timm.data"), types.ModuleType("timm.models")
+    data.resolve_data_config = lambda cfg: {"input_size": (3, 384, 384), "interpolation": "bicubic", "mean": (0.5, 0.5, 0.5),
+                                            "std": (0.5, 0.5, 0.5), "crop_pct": 1.0, "crop_mode": "squash"}
+    models.resolve_pretrained_cfg = lambda variant: types.SimpleNamespace(to_dict=lambda: {"architecture": variant})
+    import transformers.image_processing_utils  # noqa: F401  (imported before the stub exists: transformers probes for timm)
+    import transformers.image_transforms  # noqa: F401
+    saved = {k: sys.modules.get(k) for k in ("timm", "timm.data", "timm.models")}
+    sys.modules.update({"timm": timm, "timm.data": data, "timm.models": models})
+    try:
+        ref = _load_ref_module("detikzify.model.v1.processing_detikzify_ref", "detikzify/model/v1/processing_detikzify.py")
+    finally:            # the stub must not outlive the import: transformers would take it for an installed timm
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    proc = ref.DetikzifyImageProcessor.from_pretrained("vit_so400m_patch14_siglip_384.webli")
+    res = {"config": {k: proc.to_dict()[k] for k in ("size", "resample", "rescale_factor", "image_mean", "image_std", "do_resize",
+                                                     "do_rescale", "do_normalize")}}
+    for name, img in image_processor_cases().items():
+        px = proc.preprocess(img, return_tensors="pt")["pixel_values"]
+        res[name] = {"shape": list(px.shape), "dtype": str(px.dtype),
+                     "sha256": hashlib.sha256(px.float().numpy().tobytes()).hexdigest()}
+    (OUT / "image_processor_v1.json").write_text(json.dumps(res, indent=1))
+    print("image_processor_v1.json", res["config"], {k: v["shape"] for k, v in res.items() if k != "config"})
+
+
 if __name__ == "__main__":
     golden_llama()
     golden_llama_gqa()
@@ -865,3 +907,4 @@ if __name__ == "__main__":
     golden_reference_v1()
     golden_sharding()
     golden_imagesim()
+    golden_image_processor_v1()

@@ -18,8 +18,8 @@ from detikzify_amd.mcts import MonteCarlo, Node
 from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, ImagesimFakeTower, _StubMetric, generator_script,
-                                      image_cases, image_digest, imagesim_cases, mcts_script, processor_calls,
-                                      processor_tokenizer, tikz_fake_run)
+                                      image_cases, image_digest, image_processor_cases, imagesim_cases, mcts_script,
+                                      processor_calls, processor_tokenizer, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -494,3 +494,18 @@ def test_selfsim_matches_the_reference_imagesim(golden_dir, mode):
         assert sim.compute() == pytest.approx(want["mean_over_update"], abs=1e-9)
         sim.reset()
         assert sim.n_samples == 0
+
+
+def test_image_processor_matches_the_reference_v1_processor(golden_dir):
+    """row a·P2: tests/golden/image_processor_v1.json was produced by the reference's own v1 DetikzifyImageProcessor
+    (v1/processing_detikzify.py: from_pretrained with the tower's timm data config, then preprocess = resize 384 bicubic,
+    rescale 1/255, normalise with mean = std = 0.5, channels first): ours at its defaults gives the same floats"""
+    import hashlib
+    golden = json.loads((golden_dir / "image_processor_v1.json").read_text())
+    ours = DetikzifyImageProcessor()
+    cfg = golden["config"]
+    assert ours.size == cfg["size"] and list(ours.image_mean) == list(cfg["image_mean"]) and list(ours.image_std) == list(cfg["image_std"])
+    for name, img in image_processor_cases().items():
+        px = ours(images=img, return_tensors="pt")["pixel_values"]
+        assert list(px.shape) == golden[name]["shape"] and str(px.dtype) == golden[name]["dtype"], name
+        assert hashlib.sha256(px.float().numpy().tobytes()).hexdigest() == golden[name]["sha256"], name
