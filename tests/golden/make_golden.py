@@ -308,6 +308,28 @@ def generator_script(DetikzifyGenerator, TikzDocumentClass, metric, expansions=1
     return {"results": results, "tree": stats, "failed": len(gen.failed_rollouts), "calls": model.calls}
 
 
+def pipeline_script(DetikzifyPipeline, **extra):
+    """drives a DetikzifyPipeline (reference's or ours): defaults, image loading, sample / __call__ / simulate, input checks"""
+    random.seed(99)
+    torch.manual_seed(0)
+    pipe = DetikzifyPipeline(FakeModel(seed=9), fake_processor(), metric="fast", compile_timeout=None, **extra)
+    img = sketch_image(2, 80)
+    wide = Image.new("RGB", (120, 50), "white")
+    wide.paste(sketch_image(3, 40), (70, 5))
+    out = {"gen_kwargs": {k: v for k, v in sorted(pipe.gen_kwargs.items()) if k != "document_class"},
+           "loaded_size": list(pipe.load(wide).size), "loaded_raw_size": list(pipe.load(wide, preprocess=False).size),
+           "sample": pipe.sample(image=img).code, "call": pipe(image=wide).code,
+           "simulate": [[round(float(s), 12), d.code] for s, d in pipe.simulate(image=img, expansions=5)],
+           "simulate_raw": [[round(float(s), 12), d.code] for s, d in pipe.simulate(image=wide, preprocess=False, expansions=2)]}
+    for name, kw in (("no_input", {}), ("text_without_adapter", dict(image=img, text="a caption"))):
+        try:
+            pipe.sample(**kw)
+            out[name] = "ok"
+        except AssertionError as e:
+            out[name] = str(e)
+    return out
+
+
 class _StubMetric:
     """stand-in for ImageSim with the update/compute/reset protocol: similarity from image bytes"""
 
@@ -356,12 +378,14 @@ def golden_generator():
         "fast": generator_script(ref.DetikzifyGenerator, SyntheticTikzDocument, None),
         "strict": generator_script(ref.DetikzifyGenerator, SyntheticTikzDocument, None, strict=True),
     }
+    res["pipeline"] = pipeline_script(ref.DetikzifyPipeline)
     # DynMinMaxNorm known answers from the reference class
     n = ref.DynMinMaxNorm()
     a, b, c = n(0.2), n(0.8), n(0.5)
     res["norm"] = [a.score, b.score, c.score, (a + b).score, (a + 1).score, a * 2, 3 / b, (a + b + c) / 2]
     (OUT / "generator_trace.json").write_text(json.dumps(res))
-    print("generator_trace.json", {k: (len(v["results"]) if isinstance(v, dict) else v) for k, v in res.items()})
+    print("generator_trace.json", {k: (len(v["results"]) if isinstance(v, dict) and "results" in v else v) for k, v in res.items() if k != "pipeline"},
+          res["pipeline"]["gen_kwargs"], len(res["pipeline"]["simulate"]))
 
 
 # ------------------------------------------------------------------------------------- G: reference TikzDocument.compile

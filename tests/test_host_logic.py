@@ -19,7 +19,7 @@ from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyPro
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, ImagesimFakeTower, _StubMetric, generator_script,
                                       image_cases, image_digest, image_processor_cases, imagesim_cases, mcts_script,
-                                      processor_calls, processor_tokenizer, tikz_fake_run)
+                                      pipeline_script, processor_calls, processor_tokenizer, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -509,3 +509,12 @@ def test_image_processor_matches_the_reference_v1_processor(golden_dir):
         px = ours(images=img, return_tensors="pt")["pixel_values"]
         assert list(px.shape) == golden[name]["shape"] and str(px.dtype) == golden[name]["dtype"], name
         assert hashlib.sha256(px.float().numpy().tobytes()).hexdigest() == golden[name]["sha256"], name
+
+
+def test_pipeline_matches_the_reference_pipeline(golden_dir):
+    """the `pipeline` entry of tests/golden/generator_trace.json was produced by the reference's own DetikzifyPipeline
+    (infer/generate.py:356-467) over the scripted fake model: sampling defaults, image loading with / without
+    preprocessing, sample(), __call__(), simulate(), and the two input assertions"""
+    want = json.loads((golden_dir / "generator_trace.json").read_text())["pipeline"]
+    got = pipeline_script(DetikzifyPipeline, document_class=SyntheticTikzDocument)
+    assert got == want
