@@ -15,6 +15,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
                          model and a pseudo TikZ compiler: the (score, code) sequence and tree statistics, 3 modes.
   mcts_trace.json        the reference's OWN detikzify.mcts package (imports cleanly) driven by a scripted
                          child_finder: tree statistics after every expansion.
+  streamers.json         the reference's OWN detikzify/util/generation.py + util/functools.py: what a consumer of TokenStreamer /
+                         StreamerList / ExplicitAbort / unwrap_processor / cache_cast observes in one script.
   tikz_compile.json      the reference's OWN detikzify/infer/tikz.py with stubbed latexmk / pymupdf / pdfCropMargins:
                          what TikzDocument.compile decides in 7 scenarios (engine order, winner, errors, pages kept).
   image_prep.json        the reference's OWN detikzify/util/image.py: digests of load / trim / expand results.
@@ -386,6 +388,59 @@ def golden_generator():
     (OUT / "generator_trace.json").write_text(json.dumps(res))
     print("generator_trace.json", {k: (len(v["results"]) if isinstance(v, dict) and "results" in v else v) for k, v in res.items() if k != "pipeline"},
           res["pipeline"]["gen_kwargs"], len(res["pipeline"]["simulate"]))
+
+
+# ------------------------------------------------------------------------------------- F2: reference streamers / helpers
+def streamer_script(TokenStreamer, StreamerList, ExplicitAbort, unwrap_processor, cache_cast):
+    """one script for the reference's util classes and ours: what a consumer observes"""
+    out = {}
+    ts = TokenStreamer()
+    ts.put(torch.tensor([[1, 2, 3]])); ts.put(torch.tensor([7])); ts.put(torch.tensor([[8, 9]])); ts.end()
+    out["skip_prompt"] = list(ts)
+    ts.put(torch.tensor([[1, 2, 3]])); ts.put(torch.tensor([0])); ts.put(torch.tensor([4])); ts.end()
+    out["reused_after_end"] = list(ts)                      # the prompt of the next generation is skipped again; token 0 is a token
+    keep = TokenStreamer(skip_prompt=False)
+    keep.put(torch.tensor([[1, 2]])); keep.put(torch.tensor([5])); keep.end()
+    out["keep_prompt"] = list(keep)
+    try:
+        TokenStreamer().put(torch.tensor([[1], [2]]))
+        out["batch_2"] = "ok"
+    except ValueError as e:
+        out["batch_2"] = str(e)
+    err = TokenStreamer()
+    err.put(torch.tensor([[1]])); err.put(torch.tensor([6])); err.propagate_error(KeyError("worker died")); err.end()
+    seen = []
+    try:
+        for t in err:
+            seen.append(t)
+    except KeyError as e:
+        seen.append(repr(e))
+    out["error_after_tokens"] = seen
+    a, b = TokenStreamer(), TokenStreamer(skip_prompt=False)
+    both = StreamerList([a, b])
+    both.put(torch.tensor([[1, 2]])); both.put(torch.tensor([3])); both.end()
+    out["fan_out"] = [list(a), list(b), len(both)]
+    ctl = ExplicitAbort()
+    states = [bool(ctl(None, None))]
+    ctl.abort(); states.append(bool(ctl(torch.zeros(1, 3), None)))
+    states.append(ctl.reset() is ctl); states.append(bool(ctl(None, None)))
+    out["explicit_abort"] = states
+    inner = types.SimpleNamespace(name="inner")
+    out["unwrap"] = [unwrap_processor(types.SimpleNamespace(processor=types.SimpleNamespace(processor=inner))).name,
+                     unwrap_processor(inner).name]
+    calls = []
+    f = cache_cast(lambda ids, flag=False: (tuple(ids), flag))(lambda ids, flag=False: calls.append(list(ids)) or len(calls))
+    out["cache_cast"] = [f([1, 2]), f([1, 2]), f([1, 3]), f([1, 2], flag=True), f([1, 2]), len(calls)]
+    return out
+
+
+def golden_streamers():
+    """the reference's own detikzify/util/generation.py and util/functools.py (both import cleanly)"""
+    gen = _load_ref_module("detikzify.util.generation_ref3", "detikzify/util/generation.py")
+    fun = _load_ref_module("detikzify.util.functools_ref3", "detikzify/util/functools.py")
+    res = streamer_script(gen.TokenStreamer, gen.StreamerList, gen.ExplicitAbort, gen.unwrap_processor, fun.cache_cast)
+    (OUT / "streamers.json").write_text(json.dumps(res, indent=1))
+    print("streamers.json", res)
 
 
 # ------------------------------------------------------------------------------------- G: reference TikzDocument.compile
@@ -924,6 +979,7 @@ if __name__ == "__main__":
     golden_processors()
     golden_mcts()
     golden_generator()
+    golden_streamers()
     golden_tikz()
     golden_image()
     golden_processor()

@@ -19,7 +19,7 @@ from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyPro
 from detikzify_amd.util import StreamerList, TokenStreamer, cache_cast, expand, trim
 from tests.golden.make_golden import (TIKZ_CODE, TIKZ_SCENARIOS, ImagesimFakeTower, _StubMetric, generator_script,
                                       image_cases, image_digest, image_processor_cases, imagesim_cases, mcts_script,
-                                      pipeline_script, processor_calls, processor_tokenizer, tikz_fake_run)
+                                      pipeline_script, processor_calls, processor_tokenizer, streamer_script, tikz_fake_run)
 from tests.helpers import FakeModel, fake_processor, sketch_image
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -518,3 +518,14 @@ def test_pipeline_matches_the_reference_pipeline(golden_dir):
     want = json.loads((golden_dir / "generator_trace.json").read_text())["pipeline"]
     got = pipeline_script(DetikzifyPipeline, document_class=SyntheticTikzDocument)
     assert got == want
+
+
+def test_streamers_and_helpers_match_the_reference(golden_dir):
+    """tests/golden/streamers.json: one script run on the reference's own util/generation.py + util/functools.py —
+    prompt skipping (also after end()), token 0, batch-size check, an error forwarded after tokens, StreamerList fan-out,
+    ExplicitAbort, unwrap_processor, cache_cast.  Ours observes the same; so does the line-burst mode of TokenStreamer."""
+    from detikzify_amd.util import ExplicitAbort, unwrap_processor
+    want = json.loads((golden_dir / "streamers.json").read_text())
+    assert streamer_script(TokenStreamer, StreamerList, ExplicitAbort, unwrap_processor, cache_cast) == want
+    burst = lambda *a, **k: TokenStreamer(*a, flush_on={3, 8, 0}, **k)      # tokens arrive in bursts ending at these ids
+    assert streamer_script(burst, StreamerList, ExplicitAbort, unwrap_processor, cache_cast) == want
