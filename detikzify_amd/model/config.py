@@ -132,7 +132,8 @@ class DetikzifyConfig:
             rope_factor=float(rs.get("factor", 1.0)) if rtype in ("linear", "llama3") else 1.0,
             rope_type="llama3" if rtype == "llama3" else "linear",
             bos_token_id=t.get("bos_token_id", 1), eos_token_id=t.get("eos_token_id", 2),
-            pad_token_id=j.get("pad_token_id") or t.get("pad_token_id") or 0,
+            pad_token_id=next((v for v in (j.get("pad_token_id"), t.get("pad_token_id")) if v is not None),
+                              128004 if v2 else 0),        # v2 default: configuration_detikzify.py:89
             patch_token_id=j.get("image_token_id", 128005) if v2 else j.get("patch_token_id", j.get("bos_token_id", 1)),
             concat_patches=j.get("concat_factor", 3) if v2 else j.get("concat_patches", 3),
             vit_feature_layer=j.get("feature_layer", 26),

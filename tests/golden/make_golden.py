@@ -8,6 +8,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
 
   reference_v2_tiny.npz  the reference's OWN v2 model (detikzify/model/modeling_detikzify.py) at toy size on the seeded
                          synthetic weights, fp32: prefill logits + 16 greedy steps through its KV cache.
+  config_v2_8b.json      config.json as the reference's OWN v2 DetikzifyConfig serialises it (default vision config + a
+                         LLaMA-3.1-8B text config).
   reference_v1_tiny.npz  the reference's OWN v1 model (detikzify/model/v1/modeling_detikzify.py; timm.create_model
                          replaced by a timm-shaped shim over HF's SiglipVisionModel): the same, plus the messages of
                          its two ValueErrors for a bad image-token layout.
@@ -704,6 +706,26 @@ def golden_reference_v2():
     print("reference_v2_tiny.npz", toks)
 
 
+# ------------------------------------------------------------------------------------- J2: the reference's own v2 config
+def golden_config_v2():
+    """config.json as the reference's own DetikzifyConfig (detikzify/model/configuration_detikzify.py) serialises it for
+    the v2-8b shapes: its default vision config (SigLIP so400m/14 at 420 px, tanh GELU), image_token_id / pad_token_id /
+    concat_factor defaults, and a LLaMA-3.1-8B text config (upstream model card values)"""
+    sys.modules.setdefault("detikzify", types.ModuleType("detikzify")).__path__ = []
+    sys.modules.setdefault("detikzify.model", types.ModuleType("detikzify.model")).__path__ = []
+    cfgm = _load_ref_module("detikzify.model.configuration_detikzify", "detikzify/model/configuration_detikzify.py")
+    cfg = cfgm.DetikzifyConfig(text_config=dict(
+        model_type="llama", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+        num_key_value_heads=8, vocab_size=128256, max_position_embeddings=131072, rms_norm_eps=1e-5, rope_theta=500000.0,
+        rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                      "original_max_position_embeddings": 8192},
+        bos_token_id=128000, eos_token_id=128001, tie_word_embeddings=False))
+    (OUT / "config_v2_8b.json").write_text(cfg.to_json_string(use_diff=False))
+    d = json.loads((OUT / "config_v2_8b.json").read_text())
+    print("config_v2_8b.json", {k: d[k] for k in ("model_type", "image_token_id", "concat_factor")},
+          sorted(d["vision_config"])[:6], [k for k in d["text_config"] if k.startswith("rope")])
+
+
 # ------------------------------------------------------------------------------------- K: the reference's own v1 model
 REFERENCE_V1_SEED = 1234
 
@@ -984,6 +1006,7 @@ if __name__ == "__main__":
     golden_image()
     golden_processor()
     golden_reference_v2()
+    golden_config_v2()
     golden_reference_v1()
     golden_sharding()
     golden_imagesim()

@@ -241,6 +241,14 @@ def test_v2_config_json_and_presets(tmp_path):
               "vit_gelu_tanh", "vit_feature_layer", "proj_bias", "arch", "patch_token_id", "pad_token_id", "eos_token_id"):
         assert getattr(r, f) == getattr(c, f), f
     assert preset("detikzify-ds-7b").num_kv_heads == 32 and preset("detikzify-ds-7b").pooling_mode == "cos"
+    # config.json as the reference's OWN DetikzifyConfig serialises it (tests/golden/make_golden.py::golden_config_v2; written by
+    # transformers 5: `rope_parameters` instead of `rope_scaling`, no top-level pad_token_id) parses to the preset
+    g = DetikzifyConfig.from_hf_json(str(Path(__file__).parent / "golden" / "config_v2_8b.json"))
+    for f in ("hidden", "layers", "heads", "kv_heads", "ffn", "vocab", "rms_eps", "rope_type", "rope_factor", "rope_theta",
+              "rope_original_max_position", "rope_low_freq_factor", "rope_high_freq_factor", "vit_image", "vit_dim", "vit_depth",
+              "vit_heads", "vit_mlp", "vit_patch", "vit_gelu_tanh", "vit_feature_layer", "proj_bias", "arch", "patch_token_id",
+              "pad_token_id", "bos_token_id", "eos_token_id", "num_patches", "concat_patches"):
+        assert getattr(g, f) == getattr(c, f), f
 
 
 def test_emd_selfsim_matches_the_transport_lp():
