@@ -170,3 +170,36 @@ def test_oracle_matches_the_reference_v1_model(golden_dir):
     with pytest.raises(ValueError) as e:
         o.prefill(torch.tensor([tok] * 6 + [7] + [tok] * 6), px[0])
     assert str(e.value) == str(g["error_gap"])
+
+
+def test_real_size_tower_matches_hf_siglip():
+    """the oracle's ViT at the BASELINE size (so400m/14 @ 384: 27 blocks, 729 tokens, D 1152, the 'map' pooling head) on
+    seeded synthetic weights against the installed HF SiglipVisionModel through the timm -> HF name mapping, fp32: the
+    toy-size golden (siglip_tiny.npz) says nothing about depth-27 accumulation or the 729-token attention.  ~30 s."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+
+    from detikzify_amd.model.config import preset
+    from tests.golden.make_golden import timm_to_hf_siglip
+    cfg = preset("detikzify-ds-1.3b").oracle_dict()
+    assert (cfg["vit_depth"], cfg["vit_dim"], cfg["vit_image"]) == (27, 1152, 384)
+    w = make_weights(cfg, 1234, only_prefix="vision_model.")
+    with torch.device("meta"):          # no random initialisation of 428 M parameters: the weights are assigned below
+        hf = SiglipVisionModel(SiglipVisionConfig(
+            hidden_size=cfg["vit_dim"], intermediate_size=cfg["vit_mlp"], num_hidden_layers=cfg["vit_depth"],
+            num_attention_heads=cfg["vit_heads"], image_size=cfg["vit_image"], patch_size=cfg["vit_patch"],
+            layer_norm_eps=cfg["vit_ln_eps"], hidden_act="gelu")).eval()
+    sd = timm_to_hf_siglip(w, cfg)
+    if not any(k.startswith("vision_model.") for k in hf.state_dict()):       # transformers >= 5 drops the prefix
+        sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+    hf.load_state_dict({k: v.float().contiguous() for k, v in sd.items()}, strict=True, assign=True)
+    for name, buf in list(hf.named_buffers()):                                 # position ids: the one non-persistent buffer
+        if buf.is_meta:
+            mod = hf.get_submodule(name.rsplit(".", 1)[0]) if "." in name else hf
+            setattr(mod, name.rsplit(".", 1)[-1], torch.arange(buf.numel()).reshape(buf.shape))
+    px = torch.randn(1, 3, cfg["vit_image"], cfg["vit_image"], generator=torch.Generator().manual_seed(3)).clamp(-1, 1)
+    with torch.no_grad():
+        want = hf(pixel_values=px)
+    v = VitOracle(cfg, w, precision="fp32")
+    feats = v.forward_features(px[0])
+    assert feats.shape == (729, 1152)
+    assert rel_l2(feats, want.last_hidden_state[0]) < 2e-5 and rel_l2(v.forward_head(feats), want.pooler_output[0]) < 2e-5
