@@ -203,3 +203,34 @@ def test_real_size_tower_matches_hf_siglip():
     feats = v.forward_features(px[0])
     assert feats.shape == (729, 1152)
     assert rel_l2(feats, want.last_hidden_state[0]) < 2e-5 and rel_l2(v.forward_head(feats), want.pooler_output[0]) < 2e-5
+
+
+def test_real_width_decoder_matches_hf_llama():
+    """the oracle's LLaMA at the ds-1.3b WIDTH (hidden 2048, 16 heads of 128, ffn 5504, vocab 32256, rope theta 1e5 with
+    linear factor 4, rms eps 1e-6) but 2 layers, on seeded synthetic weights against the installed HF LlamaForCausalLM in
+    fp32: 40 prompt positions and 3 cached decode steps.  The toy goldens (hidden 256) say nothing about K = 2048 / 5504
+    accumulations or the real rope parameters.  ~25 s."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from detikzify_amd.model.config import preset
+    cfg = dict(preset("detikzify-ds-1.3b").oracle_dict(), layers=2)
+    w = make_weights(cfg, 77, only_prefix="model.")
+    w.update(make_weights(cfg, 77, only_prefix="lm_head"))
+    hf = LlamaForCausalLM(LlamaConfig(
+        hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"], num_hidden_layers=2, num_attention_heads=cfg["heads"],
+        num_key_value_heads=cfg["heads"], head_dim=cfg["head_dim"], vocab_size=cfg["vocab"], rms_norm_eps=cfg["rms_eps"],
+        max_position_embeddings=cfg["max_positions"], rope_theta=cfg["rope_theta"],
+        rope_scaling={"rope_type": "linear", "factor": cfg["rope_factor"]}, attention_bias=False,
+        tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, pad_token_id=0)).eval()
+    sd = {k: v.float().contiguous() for k, v in w.items() if k in hf.state_dict()}
+    assert set(sd) == set(hf.state_dict())
+    hf.load_state_dict(sd, strict=True, assign=True)
+    ids = torch.randint(3, cfg["vocab"], (1, 40), generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        out = hf(input_ids=ids, use_cache=True)
+        llm = LlamaOracle(cfg, w, precision="fp32")
+        mine = llm.logits(llm.forward(llm.embed(ids[0])))
+        assert rel_l2(mine, out.logits[0]) < 2e-5
+        for tok in (17, 4096, 31999):
+            out = hf(input_ids=torch.tensor([[tok]]), past_key_values=out.past_key_values, use_cache=True)
+            assert rel_l2(llm.logits(llm.forward(llm.embed(torch.tensor([tok])))[-1]), out.logits[0, -1]) < 2e-5
