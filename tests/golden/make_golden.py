@@ -19,6 +19,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
                          child_finder: tree statistics after every expansion.
   streamers.json         the reference's OWN detikzify/util/generation.py + util/functools.py: what a consumer of TokenStreamer /
                          StreamerList / ExplicitAbort / unwrap_processor / cache_cast observes in one script.
+  subprocess.json        the reference's OWN detikzify/util/subprocess.py on real child processes: output, exit status,
+                         timeout, grandchildren killed.
   tikz_compile.json      the reference's OWN detikzify/infer/tikz.py with stubbed latexmk / pymupdf / pdfCropMargins:
                          what TikzDocument.compile decides in 7 scenarios (engine order, winner, errors, pages kept).
   image_prep.json        the reference's OWN detikzify/util/image.py: digests of load / trim / expand results.
@@ -443,6 +445,51 @@ def golden_streamers():
     res = streamer_script(gen.TokenStreamer, gen.StreamerList, gen.ExplicitAbort, gen.unwrap_processor, fun.cache_cast)
     (OUT / "streamers.json").write_text(json.dumps(res, indent=1))
     print("streamers.json", res)
+
+
+# ------------------------------------------------------------------------------------- F3: reference subprocess helper
+def subprocess_script(check_output, workdir):
+    """real child processes through a check_output (the reference's or ours): output, exit status, timeout, and whether
+    the grandchild a timed-out command had spawned is gone afterwards (latexmk spawns pdflatex, bibtex, ...)"""
+    import os
+    import time
+    from subprocess import CalledProcessError, TimeoutExpired
+    out = {"ok": check_output(["sh", "-c", "printf hello; printf ignored >&2"], stderr=-3).decode()}       # -3 = DEVNULL
+    out["cwd_env"] = check_output(["sh", "-c", "printf %s/%s $(basename $PWD) $MARK"], cwd=str(workdir),
+                                  env=dict(os.environ, MARK="m1")).decode()
+    try:
+        check_output(["sh", "-c", "printf oops; exit 3"])
+        out["fails"] = "no error"
+    except CalledProcessError as e:
+        out["fails"] = [e.returncode, e.output.decode()]
+    pidfile = Path(workdir) / "grandchild.pid"
+    try:
+        check_output(["sh", "-c", f"sleep 30 & echo $! > {pidfile}; printf started; wait"], timeout=0.6)
+        out["timeout"] = "no error"
+    except TimeoutExpired as e:
+        out["timeout"] = [(e.output or b"").decode(), e.timeout]
+    pid, gone = int(pidfile.read_text()), False
+    for _ in range(50):
+        try:
+            os.kill(pid, 0)
+            time.sleep(0.05)
+        except ProcessLookupError:
+            gone = True
+            break
+    out["grandchild_killed"] = gone
+    return out
+
+
+def golden_subprocess():
+    """the reference's own detikzify/util/subprocess.py (pure stdlib)"""
+    import tempfile
+    ref = _load_ref_module("detikzify.util.subprocess_ref", "detikzify/util/subprocess.py")
+    with tempfile.TemporaryDirectory(prefix="dtkwd") as d:
+        work = Path(d) / "work"
+        work.mkdir()
+        res = subprocess_script(ref.check_output, work)
+    (OUT / "subprocess.json").write_text(json.dumps(res, indent=1))
+    print("subprocess.json", res)
 
 
 # ------------------------------------------------------------------------------------- G: reference TikzDocument.compile
@@ -1002,6 +1049,7 @@ if __name__ == "__main__":
     golden_mcts()
     golden_generator()
     golden_streamers()
+    golden_subprocess()
     golden_tikz()
     golden_image()
     golden_processor()
