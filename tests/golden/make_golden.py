@@ -464,7 +464,7 @@ def subprocess_script(check_output, workdir):
         out["fails"] = [e.returncode, e.output.decode()]
     pidfile = Path(workdir) / "grandchild.pid"
     try:
-        check_output(["sh", "-c", f"sleep 30 & echo $! > {pidfile}; printf started; wait"], timeout=0.6)
+        check_output(["sh", "-c", f"sleep 30 & echo $! > {pidfile}; printf started; wait"], timeout=1.5)
         out["timeout"] = "no error"
     except TimeoutExpired as e:
         out["timeout"] = [(e.output or b"").decode(), e.timeout]
