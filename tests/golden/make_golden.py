@@ -37,6 +37,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
                          bad_words_ids / begin_suppress_tokens.
   siglip_tiny.npz        HuggingFace SiglipVisionModel as the architecture stand-in of the timm tower (timm absent):
                          last_hidden_state + pooler_output on timm-layout weights, erf and tanh GELU.
+  generate_protocol.json what installed HF GenerationMixin.generate hands to a streamer and to a stopping criterion
+                         (shapes, dtypes, order, call counts) on a tiny LlamaForCausalLM.
   processors.npz         HF Temperature / TopK / TopP / NoBadWords / SuppressTokensAtBegin processors on seeded
                          logits, and HF image transforms (resize bicubic / rescale / normalise) on a seeded image.
 Nothing here is read at test time except the written fixtures (and the small seeded-input helpers tests import).
@@ -445,6 +447,45 @@ def golden_streamers():
     res = streamer_script(gen.TokenStreamer, gen.StreamerList, gen.ExplicitAbort, gen.unwrap_processor, fun.cache_cast)
     (OUT / "streamers.json").write_text(json.dumps(res, indent=1))
     print("streamers.json", res)
+
+
+# ------------------------------------------------------------------------------------- F2b: HF generate protocol
+class ProtocolRecorder:
+    """a streamer and a stopping criterion that record what generate() hands them (shapes, lengths, order)"""
+
+    def __init__(self, stop_at_len=None):
+        self.events, self.stop_at_len = [], stop_at_len
+
+    def put(self, value):
+        self.events.append(["put", list(value.shape), str(value.dtype), str(value.device)])
+
+    def end(self):
+        self.events.append(["end"])
+
+    def __call__(self, input_ids, scores, **kw):
+        self.events.append(["criterion", list(input_ids.shape), scores is None or isinstance(scores, (tuple, list, torch.Tensor))])
+        return bool(self.stop_at_len and input_ids.shape[1] >= self.stop_at_len)
+
+
+def golden_generate_protocol():
+    """what HF GenerationMixin.generate (the call the reference makes, infer/generate.py:218-227) hands to a streamer and
+    to a stopping criterion: installed transformers on a tiny LlamaForCausalLM, greedy, 6 new tokens / stop at length"""
+    from transformers import LlamaConfig, LlamaForCausalLM, StoppingCriteria, StoppingCriteriaList
+    from transformers.generation.streamers import BaseStreamer
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                         vocab_size=50, bos_token_id=1, eos_token_id=2, pad_token_id=0)).eval()
+    Streamer = type("Streamer", (ProtocolRecorder, BaseStreamer), {})
+    Criterion = type("Criterion", (ProtocolRecorder, StoppingCriteria), {})
+    ids = torch.tensor([[1, 5, 6, 7]])
+    res = {}
+    for name, kw, stop in (("max_new_tokens", dict(max_new_tokens=6), None), ("criterion_stops", dict(max_new_tokens=20), 7)):
+        st, cr = Streamer(), Criterion(stop)
+        out = model.generate(input_ids=ids, do_sample=False, streamer=st, stopping_criteria=StoppingCriteriaList([cr]),
+                             suppress_tokens=[2], pad_token_id=0, **kw)
+        res[name] = {"out_shape": list(out.shape), "streamer": st.events, "criterion": cr.events}
+    (OUT / "generate_protocol.json").write_text(json.dumps(res, indent=1))
+    print("generate_protocol.json", {k: (v["out_shape"], len(v["streamer"]), len(v["criterion"])) for k, v in res.items()})
 
 
 # ------------------------------------------------------------------------------------- F3: reference subprocess helper
@@ -1049,6 +1090,7 @@ if __name__ == "__main__":
     golden_mcts()
     golden_generator()
     golden_streamers()
+    golden_generate_protocol()
     golden_subprocess()
     golden_tikz()
     golden_image()

@@ -440,3 +440,20 @@ def test_pipeline_simulate_with_parallel_trees_by_expansions_and_by_timeout():
     t0 = time.perf_counter()
     got = list(pipe.simulate(image, timeout=0.4, trees=3))                    # every tree stops after its own time budget
     assert got and time.perf_counter() - t0 < 20
+
+
+def test_generate_protocol_matches_hf_generate(golden_dir):
+    """tests/golden/generate_protocol.json: what the installed HF GenerationMixin.generate (the call the reference makes)
+    hands to a streamer and to a stopping criterion — (1, T) prompt once, then a (1,) int64 CPU tensor per token, end();
+    the criterion after every token with the (1, length) ids so far.  Our generate() does exactly the same."""
+    import json
+
+    from tests.golden.make_golden import ProtocolRecorder
+    golden = json.loads((golden_dir / "generate_protocol.json").read_text())
+    dev, proc = ScriptedDevice(), fake_processor(VOCAB, NIMG)
+    ids = torch.tensor([[IMG, 5, 6, 7]])        # 4 prompt tokens like the golden (no image: the scripted LM needs none)
+    for name, kw, stop in (("max_new_tokens", dict(max_new_tokens=6), None), ("criterion_stops", dict(max_new_tokens=20), 7)):
+        st, cr = ProtocolRecorder(), ProtocolRecorder(stop)
+        out = dev.generate(input_ids=ids, do_sample=False, streamer=st, stopping_criteria=[cr], suppress_tokens=[EOS], **kw)
+        assert list(out.shape) == golden[name]["out_shape"]
+        assert st.events == golden[name]["streamer"] and cr.events == golden[name]["criterion"], name
