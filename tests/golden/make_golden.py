@@ -8,6 +8,8 @@ ONE BY ONE with stubs for exactly what is absent, and (b) the HuggingFace classe
 
   reference_v2_tiny.npz  the reference's OWN v2 model (detikzify/model/modeling_detikzify.py) at toy size on the seeded
                          synthetic weights, fp32: prefill logits + 16 greedy steps through its KV cache.
+  reference_v1_layout.json, reference_v2_layout.json   config.json content and state-dict keys / shapes of those two
+                         reference models (what a checkpoint written by the reference looks like to a loader).
   config_v2_8b.json      config.json as the reference's OWN v2 DetikzifyConfig serialises it (default vision config + a
                          LLaMA-3.1-8B text config).
   reference_v1_tiny.npz  the reference's OWN v1 model (detikzify/model/v1/modeling_detikzify.py; timm.create_model
@@ -716,6 +718,14 @@ def golden_processor():
     print("processor_v2.json", {k: (v.get("raises") or v.get("input_ids")) if isinstance(v, dict) else v for k, v in res.items()})
 
 
+def _write_layout(filename, model):
+    """what a checkpoint of this reference model looks like to a loader: config.json content and state-dict keys / shapes"""
+    layout = {"config": json.loads(model.config.to_json_string(use_diff=False)),
+              "state_dict": {k: list(v.shape) for k, v in model.state_dict().items()}}
+    (OUT / filename).write_text(json.dumps(layout))
+    print(filename, len(layout["state_dict"]), "tensors")
+
+
 # ------------------------------------------------------------------------------------- J: the reference's own v2 model
 REFERENCE_V2_SEED = 4321
 REFERENCE_V2_STEPS = 16
@@ -776,6 +786,7 @@ def golden_reference_v2():
     sd = {k.replace("model.vision_model.vision_model.", "model.vision_model."): v for k, v in sd.items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
+    _write_layout("reference_v2_layout.json", model)
     ids, px = reference_v2_inputs()
     toks, step_logits = [], []
     with torch.no_grad():
@@ -891,6 +902,7 @@ def golden_reference_v1():
     missing, unexpected = model.load_state_dict(
         {k: v.float() for k, v in w.items() if not k.startswith(("vision_model.", "rope."))}, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
+    _write_layout("reference_v1_layout.json", model)
     ids, px = reference_v1_inputs()
     toks, step_logits = [], []
     with torch.no_grad():

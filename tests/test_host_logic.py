@@ -548,3 +548,77 @@ def test_check_output_matches_the_reference_on_real_processes(golden_dir, tmp_pa
     work = tmp_path / "work"
     work.mkdir()
     assert subprocess_script(check_output, work) == json.loads((golden_dir / "subprocess.json").read_text())
+
+
+@pytest.mark.parametrize("family", ["v1", "v2"])
+def test_loader_consumes_checkpoints_laid_out_like_the_references(golden_dir, tmp_path, family):
+    """tests/golden/reference_v{1,2}_layout.json = config.json content and state-dict keys / shapes of the reference's
+    OWN models (written while they ran, make_golden.py).  A checkpoint directory with exactly that config.json and those
+    tensor names (values: the seeded synthetic weights, sharded over two files; v1 gets its tower as
+    vision_tower.safetensors since the reference keeps it out of the state dict) goes through the real loader
+    (`_load_safetensors_dir`, on a device stand-in that records load_tensor calls): the config parses to the preset, every
+    checkpoint tensor is consumed, every registry tensor arrives, bit for bit."""
+    from safetensors.torch import save_file
+
+    import detikzify_amd.model as dm
+    from detikzify_amd.model.config import DetikzifyConfig
+    from detikzify_amd.model.convert import registry_to_v2
+    from oracle.synth import make_weights, tensor_specs
+    from tests.helpers import TINY, TINY_CFG, TINY_V2, TINY_V2_CFG
+    layout = json.loads((golden_dir / f"reference_{family}_layout.json").read_text())
+    preset_cfg, cfg, seed = (TINY, TINY_CFG, 1234) if family == "v1" else (TINY_V2, TINY_V2_CFG, 4321)
+    w = {k: v.to(torch.bfloat16) for k, v in make_weights(cfg, seed).items() if not k.startswith("rope.")}
+    if family == "v2":
+        sd, inproj = {}, {}
+        for name, t in w.items():
+            for k, piece in registry_to_v2(name, t, preset_cfg.vit_dim):
+                (inproj if k.startswith("__inproj__") else sd)[k] = piece.contiguous()
+        for kind in ("weight", "bias"):
+            sd[f"model.vision_model.vision_model.head.attention.in_proj_{kind}"] = torch.cat(
+                [inproj[f"__inproj__.q.{kind}"], inproj[f"__inproj__.kv.{kind}"]], 0).contiguous()
+        # the golden was written under transformers 5 (tower keys not nested); 4.52 checkpoints nest once more: try both
+        flat = {k.replace("model.vision_model.vision_model.", "model.vision_model."): v for k, v in sd.items()}
+        assert {k: list(v.shape) for k, v in flat.items()} == layout["state_dict"]
+        variants = [flat, sd]
+    else:
+        body = {k: v.contiguous() for k, v in w.items() if not k.startswith("vision_model.")}
+        assert {k: list(v.shape) for k, v in body.items()} == layout["state_dict"]
+        variants = [body]
+    want = {name for name, *_ in tensor_specs(cfg) if not name.startswith("rope.")}
+    for n, sd in enumerate(variants):
+        d = tmp_path / f"ckpt{n}"
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(layout["config"]))
+        keys = sorted(sd)
+        save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
+        save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+        if family == "v1":
+            save_file({k[len("vision_model."):]: v.contiguous() for k, v in w.items() if k.startswith("vision_model.")},
+                      str(d / "vision_tower.safetensors"))
+        c = DetikzifyConfig.from_hf_json(str(d / "config.json"))
+        fields = ["hidden", "layers", "heads", "ffn", "vocab", "rms_eps", "rope_theta", "rope_factor", "rope_type", "arch", "proj_bias",
+                  "concat_patches", "num_kv_heads", "patch_token_id"]
+        fields += ["vit_feature_layer"] if family == "v1" else ["vit_dim", "vit_depth", "vit_heads", "vit_mlp", "vit_image", "vit_patch",
+                                                                "vit_gelu_tanh", "vit_feature_layer", "rope_original_max_position"]
+        for f in fields:
+            assert getattr(c, f) == getattr(preset_cfg, f), (family, f, getattr(c, f), getattr(preset_cfg, f))
+        got = {}
+
+        class Device:
+            config = preset_cfg
+            _weights_ready = False
+
+            def tensor_names(self):
+                return sorted(want) + ["rope.cos", "rope.sin"]
+
+            def load_tensor(self, name, t):
+                assert name not in got, name
+                got[name] = t
+
+            def _install_rope_tables(self):
+                pass
+        dev = Device()
+        dm._load_safetensors_dir(dev, d)
+        assert dev._weights_ready and set(got) == want
+        for name in want:
+            assert torch.equal(got[name].reshape(w[name].shape), w[name]), name
