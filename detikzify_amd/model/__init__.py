@@ -45,7 +45,7 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
             cfg.max_positions = max_positions
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         try:
-            tokenizer = load_tokenizer(str(path), cfg.max_positions)
+            tokenizer = load_tokenizer(str(path), cfg.max_positions, cfg.arch)
             if cfg.arch == "v1":
                 cfg.patch_token_id = tokenizer.bos_token_id      # v1/__init__.py:49
         except Exception as e:   # checkpoint directory without tokenizer files (synthetic fixtures)

@@ -111,9 +111,14 @@ class SyntheticTokenizer:
         return {"input_ids": enc, "attention_mask": mask}
 
 
-def load_tokenizer(path: str, model_max_length: int = 2048):
-    """HF tokenizer of a real checkpoint, configured as the reference does (v1/__init__.py:26-34)."""
+def load_tokenizer(path: str, model_max_length: int = 2048, arch: str = "v1"):
+    """HF tokenizer of a real checkpoint.  v1: configured as the reference does (v1/__init__.py:26-34: the base model's
+    tokenizer gets a `<pad>` token, no BOS, EOS appended, length 2048).  v2: the checkpoint ships its own processor
+    (`AutoProcessor.from_pretrained`, model/__init__.py:44): the tokenizer is taken as it was saved — overriding its pad
+    token would append a new id behind the embedding table."""
     from transformers import AutoTokenizer
+    if arch == "v2":
+        return AutoTokenizer.from_pretrained(path)
     return AutoTokenizer.from_pretrained(path, model_max_length=model_max_length, add_bos_token=False,
                                          add_eos_token=True, pad_token="<pad>", padding_side="right",
                                          legacy=False)

@@ -622,3 +622,16 @@ def test_loader_consumes_checkpoints_laid_out_like_the_references(golden_dir, tm
         assert dev._weights_ready and set(got) == want
         for name in want:
             assert torch.equal(got[name].reshape(w[name].shape), w[name]), name
+
+
+def test_checkpoint_tokenizers_are_loaded_like_the_reference_loads_them(tmp_path):
+    """v1 (reference v1/__init__.py:26-34): pad token `<pad>`, length 2048, no BOS; v2 (model/__init__.py:44,
+    AutoProcessor): the tokenizer exactly as the checkpoint saved it — same size, its own pad token"""
+    from detikzify_amd.model.tokenizer import load_tokenizer
+    tok = processor_tokenizer()
+    tok.save_pretrained(str(tmp_path))
+    v2 = load_tokenizer(str(tmp_path), 2048, "v2")
+    assert len(v2) == len(tok) and v2.pad_token_id == tok.pad_token_id == 0 and v2.model_max_length == tok.model_max_length
+    v1 = load_tokenizer(str(tmp_path), 2048, "v1")
+    assert v1.pad_token == "<pad>" and v1.model_max_length == 2048 and v1.padding_side == "right"
+    assert v1("w5 w6", add_special_tokens=False)["input_ids"] == v2("w5 w6", add_special_tokens=False)["input_ids"] == [5, 6]
