@@ -73,11 +73,34 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         model = DetikzifyForCausalLM(cfg, dev)
         model.fill_synthetic(int(synthetic))
     model.generation_config.pad_token_id = tokenizer.pad_token_id     # v1/__init__.py:41
-    image_processor = DetikzifyImageProcessor(size={"height": cfg.vit_image, "width": cfg.vit_image})
+    image_processor = _checkpoint_image_processor(path, cfg)
     processor = DetikzifyProcessor(
         image_processor=image_processor, tokenizer=tokenizer, image_seq_len=cfg.num_patches,
         image_token=tokenizer.convert_ids_to_tokens(cfg.patch_token_id))
     return model, processor
+
+
+def _checkpoint_image_processor(path: Path, cfg: DetikzifyConfig) -> DetikzifyImageProcessor:
+    """The image processor a checkpoint was trained with: v2 directories carry preprocessor_config.json (saved by the
+    processor, reference model/__init__.py:44 loads it through AutoProcessor), v1 checkpoints keep the processor's dict in
+    config.json under `vision_config` (v1/modeling_detikzify.py:112).  Without either: the tower's published data config
+    (bicubic, 1/255, mean = std = 0.5) at the tower's resolution."""
+    import json
+    keys = ("size", "resample", "do_resize", "do_rescale", "rescale_factor", "do_normalize", "image_mean", "image_std")
+    saved = {}
+    if path.is_dir():
+        if (path / "preprocessor_config.json").exists():
+            saved = json.loads((path / "preprocessor_config.json").read_text())
+        elif cfg.arch == "v1" and (path / "config.json").exists():
+            saved = json.loads((path / "config.json").read_text()).get("vision_config") or {}
+    kw = {k: saved[k] for k in keys if saved.get(k) is not None}
+    size = kw.get("size")
+    if not (isinstance(size, dict) and size.get("height") == cfg.vit_image and size.get("width") == cfg.vit_image):
+        if size is not None:
+            import warnings
+            warnings.warn(f"image processor size {size} of {path} does not match the tower's {cfg.vit_image} px; using the tower's")
+        kw["size"] = {"height": cfg.vit_image, "width": cfg.vit_image}
+    return DetikzifyImageProcessor(**kw)
 
 
 def _load_safetensors_dir(model: DetikzifyForCausalLM, path: Path):

@@ -635,3 +635,24 @@ def test_checkpoint_tokenizers_are_loaded_like_the_reference_loads_them(tmp_path
     v1 = load_tokenizer(str(tmp_path), 2048, "v1")
     assert v1.pad_token == "<pad>" and v1.model_max_length == 2048 and v1.padding_side == "right"
     assert v1("w5 w6", add_special_tokens=False)["input_ids"] == v2("w5 w6", add_special_tokens=False)["input_ids"] == [5, 6]
+
+
+def test_checkpoint_image_processor_settings_are_honoured(tmp_path):
+    """v2: preprocessor_config.json next to the weights; v1: `vision_config` inside config.json (what the reference
+    writes, v1/modeling_detikzify.py:112); neither: the tower's published data config"""
+    import detikzify_amd.model as dm
+    from tests.helpers import TINY, TINY_V2
+    default = dm._checkpoint_image_processor(tmp_path, TINY_V2)
+    assert default.size == {"height": 84, "width": 84} and default.resample == 3 and default.image_mean == [0.5, 0.5, 0.5]
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps(
+        {"image_processor_type": "SiglipImageProcessor", "size": {"height": 84, "width": 84}, "resample": 2,
+         "image_mean": [0.4, 0.5, 0.6], "image_std": [0.2, 0.2, 0.2], "do_rescale": True, "rescale_factor": 1 / 255,
+         "do_convert_rgb": None}))
+    v2 = dm._checkpoint_image_processor(tmp_path, TINY_V2)
+    assert (v2.resample, v2.image_mean, v2.image_std) == (2, [0.4, 0.5, 0.6], [0.2, 0.2, 0.2])
+    (tmp_path / "preprocessor_config.json").unlink()
+    (tmp_path / "config.json").write_text(json.dumps({"vision_config": {"size": {"height": 64, "width": 64}, "resample": 3,
+                                                                          "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5]}}))
+    with pytest.warns(UserWarning, match="does not match"):
+        v1 = dm._checkpoint_image_processor(tmp_path, TINY)
+    assert v1.size == {"height": TINY.vit_image, "width": TINY.vit_image}
