@@ -124,8 +124,8 @@ def _load_safetensors_dir(model: DetikzifyForCausalLM, path: Path):
                     pairs = conv.feed(k, sf.get_tensor(k))         # v2 checkpoint names (model/convert.py)
                 else:
                     name = k
-                    if bare_timm:
-                        name = "vision_model." + k
+                    if bare_timm:       # timm names; the open_clip file timm downloads for the SigLIP towers says visual.trunk.*
+                        name = "vision_model." + (k[len("visual.trunk."):] if k.startswith("visual.trunk.") else k)
                     for pre in ("model.vision_model.model.0.", "model.vision_model."):
                         if k.startswith(pre):
                             name = "vision_model." + k[len(pre):]

@@ -592,9 +592,10 @@ def test_loader_consumes_checkpoints_laid_out_like_the_references(golden_dir, tm
         keys = sorted(sd)
         save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
         save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
-        if family == "v1":
-            save_file({k[len("vision_model."):]: v.contiguous() for k, v in w.items() if k.startswith("vision_model.")},
-                      str(d / "vision_tower.safetensors"))
+        if family == "v1":      # the tower as timm has it — here in the open_clip naming of the file timm downloads, text tower and all
+            tower = {"visual.trunk." + k[len("vision_model."):]: v.contiguous() for k, v in w.items() if k.startswith("vision_model.")}
+            tower.update({"logit_scale": torch.zeros(()), "text.transformer.resblocks.0.ln_1.weight": torch.ones(4)})
+            save_file(tower, str(d / "vision_tower.safetensors"))
         c = DetikzifyConfig.from_hf_json(str(d / "config.json"))
         fields = ["hidden", "layers", "heads", "ffn", "vocab", "rms_eps", "rope_theta", "rope_factor", "rope_type", "arch", "proj_bias",
                   "concat_patches", "num_kv_heads", "patch_token_id"]
