@@ -676,3 +676,26 @@ def test_text_iterator_streamer_streams_the_same_text_as_hf():
         return [piece for piece in st if piece]
     for ids in ([5, 6, 7, 8, 9, 10, 11], [12], [2, 13, 2, 14]):
         assert run(TextIteratorStreamer, ids) == run(HFStreamer, ids), ids
+
+
+def test_load_builds_the_processor_of_every_preset(monkeypatch):
+    """load() end to end on the CPU with the device class replaced: preset -> tokenizer -> image processor at the tower's
+    resolution -> processor whose prompt is the preset's number of image tokens (243 / 300 at the real sizes)"""
+    import detikzify_amd.model as dm
+
+    class Device:
+        def __init__(self, cfg, dev):
+            self.config, self.generation_config, self.filled = cfg, type("G", (), {})(), None
+
+        def fill_synthetic(self, seed):
+            self.filled = seed
+    monkeypatch.setattr(dm, "DetikzifyForCausalLM", Device)
+    for name, side, n_img, pad in (("detikzify-ds-7b", 384, 243, 32018), ("nllg/detikzify-cl-7b", 384, 243, 32016),
+                                   ("detikzify-v2-8b", 420, 300, 128004), ("detikzify-tiny", 90, 12, 0), ("detikzify-tiny-v2", 84, 12, 0)):
+        model, proc = dm.load(name, synthetic=7, device_map=0, batch_slots=65)
+        enc = proc(images=sketch_image(1, 50), return_tensors="pt")
+        assert model.filled == 7 and model.config.batch_slots == 65 and model.generation_config.pad_token_id == pad, name
+        assert tuple(enc.input_ids.shape) == (1, n_img) and tuple(enc.pixel_values.shape) == (1, 3, side, side), name
+        assert set(enc.input_ids[0].tolist()) == {model.config.image_token_id}, name
+    with pytest.raises(FileNotFoundError):
+        dm.load("nllg/detikzify-ds-7b")            # no local checkpoint, no network: say so
