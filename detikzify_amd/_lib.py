@@ -54,6 +54,7 @@ class DtkStats(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "dtk_abi_version": (C.c_int, []),
+    "dtk_abi_struct_size": (C.c_int, [C.c_int]),
     "dtk_last_error": (C.c_char_p, [_P]),
     "dtk_create": (C.c_int, [C.POINTER(DtkConfig), C.c_int, C.POINTER(_P)]),
     "dtk_destroy": (None, [_P]),
@@ -122,6 +123,12 @@ def load_library() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.dtk_abi_version() != DTK_ABI_VERSION:
         raise DtkError(f"ABI version {lib.dtk_abi_version()} != {DTK_ABI_VERSION}")
+    for which, (struct, field) in enumerate(((DtkConfig, None), (DtkSampling, None), (DtkStats, None), (DtkSampling, "seed"),
+                                             (DtkConfig, "reserved"), (DtkStats, "probe_event_pair_ms"))):
+        ours = C.sizeof(struct) if field is None else getattr(struct, field).offset
+        if lib.dtk_abi_struct_size(which) != ours:     # a drifted struct would corrupt every call: refuse to run
+            raise DtkError(f"struct layout mismatch with include/dtk.h: {struct.__name__}{'.' + field if field else ''} "
+                           f"is {ours} here, {lib.dtk_abi_struct_size(which)} in the library")
     _lib = lib
     return lib
 

@@ -33,6 +33,7 @@ struct TensorEntry {
   int64_t stride = 0;      // destination row stride (elements), >= cols
   float synth_scale = 0.02f;
   float synth_offset = 0.f;
+  bool loaded = false;     // written by dtk_load_tensor / dtk_fill_synthetic
   int64_t numel() const { return rows * cols; }
 };
 
@@ -277,7 +278,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   R("model.norm.weight", c->final_norm, 1, d, d, 0.1f, 1.f);
   c->lm_head = P.take<bf16_t>((size_t)V * d);
   R("lm_head.weight", c->lm_head, V, d, d, ws, 0.f);
-  c->mm_w = P.take<bf16_t>((size_t)d * 3 * D);
+  c->mm_w = P.take<bf16_t>((size_t)d * c->cfg.concat_patches * D);
   c->mm_b = P.take<bf16_t>(d);
   R("model.mm_projector.weight", c->mm_w, d, (int64_t)c->cfg.concat_patches * D,
     (int64_t)c->cfg.concat_patches * D, ws, 0.f);
@@ -708,6 +709,18 @@ extern "C" {
 
 int dtk_abi_version(void) { return DTK_ABI_VERSION; }
 
+int dtk_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(dtk_config);
+    case 1: return (int)sizeof(dtk_sampling);
+    case 2: return (int)sizeof(dtk_stats);
+    case 3: return (int)offsetof(dtk_sampling, seed);
+    case 4: return (int)offsetof(dtk_config, reserved);
+    case 5: return (int)offsetof(dtk_stats, probe_event_pair_ms);
+    default: return -1;
+  }
+}
+
 const char* dtk_last_error(const dtk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
@@ -869,7 +882,7 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   if (!c || !name || !host || !shape || ndim < 1) return fail(c, DTK_ERR_ARG, "dtk_load_tensor: null argument");
   auto it = c->tindex.find(name);
   if (it == c->tindex.end()) return fail(c, DTK_ERR_ARG, "unknown tensor '%s'", name);
-  const TensorEntry& t = c->tensors[it->second];
+  TensorEntry& t = c->tensors[it->second];
   int64_t n = 1;
   for (int i = 0; i < ndim; ++i) n *= shape[i];
   if (n != t.numel()) return fail(c, DTK_ERR_ARG, "tensor '%s': %lld elements given, %lld expected", name, (long long)n, (long long)t.numel());
@@ -893,6 +906,7 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy2D(t.ptr, (size_t)t.stride * 2, src16, (size_t)t.cols * 2, (size_t)t.cols * 2, (size_t)t.rows, hipMemcpyHostToDevice));
+  t.loaded = true;
   c->have_image = false;
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
@@ -918,8 +932,9 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
   if (!c) return DTK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   for (size_t i = 0; i < c->tensors.size(); ++i) {
-    const TensorEntry& t = c->tensors[i];
+    TensorEntry& t = c->tensors[i];
     if (t.name == "rope.cos" || t.name == "rope.sin") continue;
+    t.loaded = true;
     if (t.stride == t.cols) {
       launch_fill_synth(t.ptr, t.numel(), seed, (uint32_t)i, t.synth_scale, t.synth_offset, c->stream);
     } else {  // padded rows: fill contiguously in scratch, then pitch-copy
@@ -940,16 +955,24 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
 
 int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, void* pooled_out) {
   if (!c || !pixels || batch < 1) return fail(c, DTK_ERR_ARG, "dtk_vit_encode: bad argument");
+  if (pooled_out) {   // forward_head needs the attention-pool weights: a checkpoint without them must not pool with zeros
+    for (const TensorEntry& t : c->tensors)
+      if (!t.loaded && t.name.compare(0, 23, "vision_model.attn_pool.") == 0)
+        return fail(c, DTK_ERR_STATE, "pooler_output requested but '%s' was never loaded (checkpoint without the pooling head)", t.name.c_str());
+  }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
   hipStream_t sv = c->stream_vit;
+  // forward() semantics (pooled requested): last_hidden_state = forward_features = ALL blocks + final norm; without the
+  // head: get_intermediate_layers(n=[feature_layer], norm=True).  The two differ when feature_layer != depth - 1.
+  const bf16_t* hidden = (pooled_out && c->cfg.vit_feature_layer != c->vDepth - 1) ? c->last_hidden : c->feats;
   for (int b = 0; b < batch; ++b) {
     HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b * img, img * 4, hipMemcpyHostToDevice, sv));
     HIPCHK(c, hipEventRecord(c->ev_va, sv));
     vit_forward(c, pooled_out != nullptr, sv);
     HIPCHK(c, hipEventRecord(c->ev_vb, sv));
     if (feats_out)
-      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, c->feats, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, sv));
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, hidden, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, sv));
     if (pooled_out)
       HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b * c->vD, c->pooled, (size_t)c->vD * 2, hipMemcpyDeviceToHost, sv));
     HIPCHK(c, hipStreamSynchronize(sv));

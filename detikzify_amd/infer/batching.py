@@ -438,18 +438,29 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
     trees = len(imgs) * trees_per_image
     engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees) if trees > 1 else None
     out: "queue.Queue" = queue.Queue()
+    cancelled = threading.Event()
+    generators: List[Any] = [None] * trees
 
     def worker(t: int):
         try:
             gen = torch.Generator().manual_seed(seed_base + t)
             seeds = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
-            g = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric, **gen_kwargs)
+            g = generators[t] = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric, **gen_kwargs)
             base_generate = g.generate
-            g.generate = lambda input_ids, **kw: base_generate(input_ids, seed=next(seeds), **kw)   # per-tree RNG stream
+
+            def generate(input_ids, **kw):      # per-tree RNG stream; a cancelled search starts no further rollout
+                if cancelled.is_set():
+                    raise InterruptedError("search cancelled")
+                return base_generate(input_ids, seed=next(seeds), **kw)
+
+            g.generate = generate
             for score, doc in g.simulate(expansions=expansions_per_tree):
+                if cancelled.is_set():
+                    break
                 out.put((t // trees_per_image, score, doc))
         except BaseException as e:
-            out.put(e)
+            if not cancelled.is_set():          # errors provoked by the cancellation itself are not results
+                out.put(e)
         finally:
             out.put(None)
 
@@ -467,8 +478,27 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
             else:
                 yield item
     finally:
+        # The consumer may leave early (break / close / an exception of one tree): tell every tree to stop — the running
+        # rollouts through their ExplicitAbort (what the reference's rollout() does on GeneratorExit, generate.py:275-277),
+        # the searches through the flag — and only then take the engine away: a tree that outlived it would fall back to
+        # the single-sequence path of a model other trees are still using.
+        if done < trees:
+            cancelled.set()
+            for g in generators:
+                if g is not None:
+                    g.control.abort()
+        deadline = time.perf_counter() + 120.0
         for th in threads:
-            th.join(timeout=60)
-        if engine is not None:
+            th.join(timeout=max(0.0, deadline - time.perf_counter()))
+            while th.is_alive() and time.perf_counter() < deadline:      # a rollout that reset its abort flag after our abort()
+                for g in generators:
+                    if g is not None:
+                        g.control.abort()
+                th.join(timeout=0.05)
+        alive = [th for th in threads if th.is_alive()]
+        if engine is not None and not alive:
             engine.close()
             pipeline.model.last_batch_stats = engine.stats()
+        if alive:
+            raise RuntimeError(f"{len(alive)} search threads did not stop within 120 s of the cancellation; "
+                               "the batch engine is left attached so they cannot interleave with other sequences")

@@ -31,35 +31,65 @@ def _default_device() -> int:
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+# from_pretrained arguments the reference's callers pass (examples/infer.py:33-37, examples/eval.py:110-115,
+# webui/webui.py:76-81) that have no meaning on this path: placement is one GPU per context, attention is always the fused
+# kernel, there is no remote code and no lazy loading
+_IGNORED_FROM_PRETRAINED = {"attn_implementation", "low_cpu_mem_usage", "trust_remote_code", "use_safetensors", "revision",
+                            "cache_dir", "token", "local_files_only", "use_cache", "offload_folder", "offload_state_dict"}
+
+
+def _check_dtype(torch_dtype) -> None:
+    if torch_dtype is None:
+        return
+    name = str(torch_dtype).replace("torch.", "")
+    if name not in ("bfloat16", "auto"):
+        raise NotImplementedError(f"torch_dtype={torch_dtype}: this build stores weights and activations in bfloat16 "
+                                  "(the dtype the reference's examples load with); other dtypes are not implemented")
+
+
 def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v1: bool = False,
          synthetic: Optional[int] = None, device_map=None, torch_dtype=None, max_positions: Optional[int] = None,
-         batch_slots: int = 0, weight_format: str = "bf16", **unused) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
+         batch_slots: int = 0, weight_format: str = "bf16", synthetic_tokenizer: bool = False,
+         **from_pretrained_kwargs) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
     """(model, processor).  `device_map` may be an int GPU index (the reference passes
-    device_map=RANK, examples/eval.py:112); torch_dtype is accepted and must be bf16/None."""
+    device_map=RANK, examples/eval.py:112); torch_dtype must be bf16 / "auto" / None.
+
+    A checkpoint directory must carry its tokenizer files, as the reference's loader requires
+    (v1/__init__.py:26-34 fails hard otherwise); `synthetic_tokenizer=True` (or `"synthetic_tokenizer": true` in the
+    directory's config.json, written by our weight-only test fixtures) opts into the byte-level stand-in."""
+    unknown = set(from_pretrained_kwargs) - _IGNORED_FROM_PRETRAINED
+    if unknown:
+        raise TypeError(f"load() got arguments it does not implement: {sorted(unknown)}")
+    _check_dtype(torch_dtype)
+    if isinstance(device_map, str) and device_map not in ("auto", "cuda", "cuda:0"):
+        raise NotImplementedError(f"device_map={device_map!r}: pass a GPU index (one full replica per GPU, as examples/eval.py:112)")
     dev = device_map if isinstance(device_map, int) else _default_device()
     path = Path(model_name_or_path)
     if path.is_dir() and (path / "config.json").exists() and synthetic is None:
+        import json
         cfg = DetikzifyConfig.from_hf_json(str(path / "config.json"))
         cfg.name_or_path = str(path)
+        _require_supported(cfg)
         if max_positions:
             cfg.max_positions = max_positions
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
-        try:
-            tokenizer = load_tokenizer(str(path), cfg.max_positions, cfg.arch)
+        if synthetic_tokenizer or json.loads((path / "config.json").read_text()).get("synthetic_tokenizer"):
+            tokenizer = _synthetic_tokenizer(cfg)
+        else:
+            tokenizer = load_tokenizer(str(path), cfg.max_positions, cfg.arch)       # raises when the files are missing / broken
             if cfg.arch == "v1":
                 cfg.patch_token_id = tokenizer.bos_token_id      # v1/__init__.py:49
-        except Exception as e:   # checkpoint directory without tokenizer files (synthetic fixtures)
-            import warnings
-            warnings.warn(f"no usable tokenizer under {path} ({e!r}); using SyntheticTokenizer")
-            tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
-                                           pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions,
-                                           image_token_id=cfg.patch_token_id)
         model = DetikzifyForCausalLM(cfg, dev)
         _load_safetensors_dir(model, path)
         if modality_projector:
             _load_projector(model, modality_projector)
+        gc_file = path / "generation_config.json"
+        if gc_file.exists():                                     # what from_pretrained reads into model.generation_config
+            model.generation_config.update_from_dict(json.loads(gc_file.read_text()))
+        _announce_gelu(cfg, path)
     else:
         cfg = preset(model_name_or_path)
+        _require_supported(cfg)
         if max_positions:
             cfg.max_positions = max_positions
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
@@ -67,9 +97,7 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
             raise FileNotFoundError(
                 f"{model_name_or_path!r} is not a local checkpoint directory and there is no network; "
                 "pass synthetic=<seed> for seeded synthetic weights at this preset's shapes")
-        tokenizer = SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id,
-                                       pad_token_id=cfg.pad_token_id, model_max_length=cfg.max_positions,
-                                           image_token_id=cfg.patch_token_id)
+        tokenizer = _synthetic_tokenizer(cfg)
         model = DetikzifyForCausalLM(cfg, dev)
         model.fill_synthetic(int(synthetic))
     model.generation_config.pad_token_id = tokenizer.pad_token_id     # v1/__init__.py:41
@@ -78,6 +106,36 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         image_processor=image_processor, tokenizer=tokenizer, image_seq_len=cfg.num_patches,
         image_token=tokenizer.convert_ids_to_tokens(cfg.patch_token_id))
     return model, processor
+
+
+def _synthetic_tokenizer(cfg: DetikzifyConfig) -> SyntheticTokenizer:
+    eos = cfg.eos_token_id[0] if isinstance(cfg.eos_token_id, (list, tuple)) else cfg.eos_token_id
+    return SyntheticTokenizer(cfg.vocab, bos_token_id=cfg.bos_token_id, eos_token_id=eos, pad_token_id=cfg.pad_token_id,
+                              model_max_length=cfg.max_positions, image_token_id=cfg.patch_token_id)
+
+
+def _require_supported(cfg: DetikzifyConfig) -> None:
+    """Shapes the kernels are written for; everything else fails here with the reason, not deep inside dtk_create."""
+    if cfg.head_dim != 128:
+        raise NotImplementedError(
+            f"{cfg.name_or_path or 'this checkpoint'}: decoder head_dim {cfg.head_dim} — the decode / prefill kernels are built "
+            "for head_dim 128 (ds-1.3b, ds-7b, cl-7b, v2-8b); nllg/detikzify-tl-1.1b (TinyLlama, head_dim 64) is not supported yet")
+    if cfg.concat_patches < 1 or ((cfg.vit_image // cfg.vit_patch) ** 2) % cfg.concat_patches:
+        raise ValueError(f"concat_patches={cfg.concat_patches} does not divide the tower's {(cfg.vit_image // cfg.vit_patch) ** 2} patches")
+
+
+def _announce_gelu(cfg: DetikzifyConfig, path: Path) -> None:
+    """The v1 tower is timm's vit_so400m_patch14_siglip_384; a v1 config.json does not record the tower's activation, and
+    timm is not available offline to settle it (open item).  Say which one is used, every time."""
+    if cfg.arch != "v1":
+        return
+    import json
+    import warnings
+    if "vit_gelu_tanh" in json.loads((path / "config.json").read_text()):
+        return
+    warnings.warn(f"{path}: config.json does not state the vision tower's GELU flavour; using "
+                  f"{'tanh-approximated' if cfg.vit_gelu_tanh else 'exact (erf)'} GELU, timm's default for "
+                  f"{cfg.vision_tower}.  Set \"vit_gelu_tanh\": 0|1 in config.json to silence or override this.", stacklevel=3)
 
 
 def _checkpoint_image_processor(path: Path, cfg: DetikzifyConfig) -> DetikzifyImageProcessor:

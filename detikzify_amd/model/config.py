@@ -32,7 +32,7 @@ class DetikzifyConfig:
     rope_high_freq_factor: float = 4.0
     rope_original_max_position: int = 8192
     bos_token_id: int = 32013
-    eos_token_id: int = 32014
+    eos_token_id: Any = 32014        # int, or a list of ids (HF allows several)
     pad_token_id: int = 32018
     # vision tower: timm vit_so400m_patch14_siglip_384.webli (v1/__init__.py:24)
     vit_dim: int = 1152
@@ -142,8 +142,8 @@ class DetikzifyConfig:
         )
         kvh = t.get("num_key_value_heads", c.heads)
         c.kv_heads = 0 if kvh == c.heads else int(kvh)
-        if isinstance(c.eos_token_id, list):
-            c.eos_token_id = c.eos_token_id[0]
+        if isinstance(c.eos_token_id, list) and len(c.eos_token_id) == 1:
+            c.eos_token_id = c.eos_token_id[0]      # several ids stay a list: generate() stops on any of them
         if rtype == "llama3":
             c.rope_low_freq_factor = float(rs.get("low_freq_factor", 1.0))
             c.rope_high_freq_factor = float(rs.get("high_freq_factor", 4.0))

@@ -46,6 +46,11 @@ class GenerationConfig:
     def to_dict(self) -> Dict[str, Any]:
         return dict(self.__dict__)
 
+    def update_from_dict(self, values: Dict[str, Any]) -> None:
+        """generation_config.json of a checkpoint (what from_pretrained loads into model.generation_config); bookkeeping
+        keys ("_from_model_config", "transformers_version") are dropped"""
+        self.__dict__.update({k: v for k, v in values.items() if not k.startswith("_") and k != "transformers_version"})
+
 
 class VisionOutput(SimpleNamespace):
     """BaseModelOutputWithPoolingAndNoAttention stand-in (last_hidden_state, pooler_output)."""
@@ -72,6 +77,57 @@ class DetikzifyVisionModel:
     def get_intermediate_layers(self, pixel_values: torch.Tensor, *_, **__):
         feats, _ = self._owner.vit_encode(pixel_values, want_pooled=False)
         return [feats]
+
+
+# HF generate() arguments this path does not implement, each with the value(s) at which HF's _sample does exactly what
+# this loop does.  Passing one of them at such a value is harmless (the reference's callers and HF's own defaults do);
+# any other value, and any name that is neither here nor a parameter of generate(), raises.
+_NEUTRAL_GENERATE_KWARGS: Dict[str, tuple] = {
+    "attention_mask": "any", "use_cache": "any", "pad_token_id": "any", "bos_token_id": "any", "synced_gpus": "any",
+    "return_dict_in_generate": (None, False), "output_scores": (None, False), "output_logits": (None, False),
+    "output_attentions": (None, False), "output_hidden_states": (None, False),
+    "num_beams": (None, 1), "num_beam_groups": (None, 1), "num_return_sequences": (None, 1),
+    "repetition_penalty": (None, 1.0), "encoder_repetition_penalty": (None, 1.0), "length_penalty": (None, 1.0),
+    "diversity_penalty": (None, 0.0), "no_repeat_ngram_size": (None, 0), "encoder_no_repeat_ngram_size": (None, 0),
+    "min_length": (None, 0), "min_new_tokens": (None, 0), "typical_p": (None, 1.0), "min_p": (None, 0.0),
+    "epsilon_cutoff": (None, 0.0), "eta_cutoff": (None, 0.0), "penalty_alpha": (None, 0.0), "early_stopping": (None, False),
+    "renormalize_logits": (None, False), "remove_invalid_values": (None, False), "guidance_scale": (None, 1.0),
+    "forced_bos_token_id": (None,), "forced_eos_token_id": (None,), "exponential_decay_length_penalty": (None,),
+    "sequence_bias": (None,), "logits_processor": (None, [], ()), "prefix_allowed_tokens_fn": (None,),
+    "assistant_model": (None,), "negative_prompt_ids": (None,), "negative_prompt_attention_mask": (None,),
+    "generation_config": (None,), "stop_strings": (None,), "max_time": (None,), "cache_implementation": (None,),
+    "past_key_values": (None,), "inputs_embeds": (None,), "tokenizer": "any",
+}
+
+
+def _is_neutral(value: Any, neutral: Any) -> bool:
+    if neutral is None:
+        return value is None
+    if isinstance(neutral, (list, tuple)):          # "no extra processors"
+        return isinstance(value, (list, tuple)) and len(value) == 0
+    return isinstance(value, (bool, int, float)) and value == neutral
+
+
+def _reject_unsupported_generate_kwargs(kw: Dict[str, Any]) -> None:
+    for name, value in kw.items():
+        allowed = _NEUTRAL_GENERATE_KWARGS.get(name)
+        if allowed is None:
+            raise TypeError(f"generate() got an argument this decoder does not implement: {name!r}")
+        if allowed != "any" and not any(_is_neutral(value, a) for a in allowed):
+            raise NotImplementedError(
+                f"generate({name}={value!r}) is not supported: this path implements greedy / temperature / top-k / top-p "
+                f"sampling of one sequence (the calls DetikzifyGenerator.generate makes); only {name} in {allowed} is accepted")
+
+
+def _flat_ids(values) -> List[int]:
+    """[id, [id, id], ...] -> flat list of ints (an eos_token_id may be a list in HF configs)"""
+    out: List[int] = []
+    for v in values or ():
+        if isinstance(v, (list, tuple)):
+            out.extend(int(x) for x in v)
+        elif v is not None:
+            out.append(int(v))
+    return out
 
 
 def _bf16_tensor_from_bits(bits: np.ndarray) -> torch.Tensor:
@@ -340,13 +396,18 @@ class DetikzifyForCausalLM:
                  temperature: Optional[float] = None, top_p: Optional[float] = None,
                  top_k: Optional[int] = None, max_length: Optional[int] = None,
                  max_new_tokens: Optional[int] = None, eos_token_id=None, seed: Optional[int] = None,
-                 inputs: Optional[torch.Tensor] = None, **unused) -> torch.Tensor:
+                 inputs: Optional[torch.Tensor] = None, **hf_kwargs) -> torch.Tensor:
         """One sequence of HF GenerationMixin.generate/_sample semantics (generation/utils.py
         :2783-2950): streamer.put(prompt) once, then per token: processors -> argmax|draw ->
         append -> streamer.put(token) -> stopping criteria (max length, EOS, user criteria);
-        streamer.end().  Returns (1, T') int64 on the host."""
+        streamer.end().  Returns (1, T') int64 on the host.
+
+        Any other HF generation argument is accepted only at the value that leaves `_sample` unchanged
+        (`_NEUTRAL_GENERATE_KWARGS`); everything else — beams, penalties, several return sequences, constraints,
+        unknown names — raises instead of being dropped: a drop-in must not silently decode something else."""
         if not self._weights_ready:
             raise _lib.DtkError("no weights loaded (load_state_dict / fill_synthetic first)")
+        _reject_unsupported_generate_kwargs(hf_kwargs)
         if input_ids is None:
             input_ids = inputs
         ids = input_ids.detach().to("cpu", torch.int64)
@@ -366,7 +427,9 @@ class DetikzifyForCausalLM:
             max_length = gc.max_length
         max_length = min(int(max_length), self.config.max_positions)
         eos = eos_token_id if eos_token_id is not None else gc.eos_token_id
-        eos_set = set(eos if isinstance(eos, (list, tuple)) else ([] if eos is None else [eos]))
+        eos_set = set(_flat_ids([eos]))
+        begin_suppress_tokens = _flat_ids(begin_suppress_tokens)
+        suppress_tokens = _flat_ids(suppress_tokens)
         bad = []
         for w in (bad_words_ids or []):
             if len(w) != 1:

@@ -109,6 +109,9 @@ typedef struct dtk_stats {
 } dtk_stats;
 
 int  dtk_abi_version(void);
+/* layout check for bindings: sizeof of 0 dtk_config, 1 dtk_sampling, 2 dtk_stats; offsetof of 3 dtk_sampling.seed,
+ * 4 dtk_config.reserved, 5 dtk_stats.probe_event_pair_ms; -1 for anything else */
+int  dtk_abi_struct_size(int which);
 /* last error of a context; ctx may be NULL for the error of a failed dtk_create */
 const char* dtk_last_error(const dtk_ctx* ctx);
 
@@ -138,7 +141,10 @@ int64_t dtk_tensor_numel(const dtk_ctx* ctx, const char* name);
 /* Vision tower: replaces DetikzifyVisionModel.forward / get_intermediate_layers
  * (reference v1/modeling_detikzify.py:63-72).  pixels: B x 3 x S x S fp32 NCHW
  * (host).  feats_out: B x N x D bf16 (post final-LayerNorm features of the
- * configured feature layer), pooled_out: B x D bf16 (MAP head), either may be NULL. */
+ * configured feature layer = get_intermediate_layers(n=[layer], norm=True)), pooled_out: B x D bf16 (MAP head), either
+ * may be NULL.  With pooled_out the call is DetikzifyVisionModel.forward and feats_out receives its last_hidden_state
+ * (forward_features: all blocks + final norm; the same tensor unless feature_layer != depth - 1).  Requesting
+ * pooled_out from a context whose attn_pool tensors were never loaded is DTK_ERR_STATE. */
 int  dtk_vit_encode(dtk_ctx* ctx, const float* pixels, int batch,
                     void* feats_out_bf16, void* pooled_out_bf16);
 

@@ -442,6 +442,45 @@ def test_pipeline_simulate_with_parallel_trees_by_expansions_and_by_timeout():
     assert got and time.perf_counter() - t0 < 20
 
 
+def test_leaving_a_parallel_search_early_stops_every_tree_before_the_engine_goes():
+    """`for s, d in pipe.simulate(trees=N): break` with no expansion limit: the trees must not keep searching in the
+    background, and none may outlive the batch engine (it would fall onto the single-sequence path of a model in use)"""
+    dev = ScriptedDevice(slots=4)
+    pipe = DetikzifyPipeline(dev, fake_processor(VOCAB, NIMG), metric="fast", document_class=SyntheticTikzDocument,
+                             max_length=NIMG + 30, compile_timeout=None)
+    before = {t.ident for t in threading.enumerate()}
+    stream = pipe.simulate(sketch_image(9, 96), trees=3)          # expansions=None, timeout=None: endless
+    first = [next(stream) for _ in range(2)]
+    assert len(first) == 2
+    t0 = time.perf_counter()
+    stream.close()
+    assert time.perf_counter() - t0 < 30
+    time.sleep(0.1)
+    leftover = [t for t in threading.enumerate() if t.ident not in before and t.is_alive()]
+    assert not leftover, leftover
+    assert dev.batch_engine is None                               # closed, after the trees had stopped
+    launches = dev.launches
+    time.sleep(0.2)
+    assert dev.launches == launches and not dev.bpending          # nothing decodes in the background
+    assert len(list(pipe.simulate(sketch_image(9, 96), expansions=1, trees=2))) == 2      # and the model is usable again
+
+
+def test_generate_refuses_hf_arguments_it_does_not_implement():
+    dev = ScriptedDevice()
+    ids, px = _prompt(fake_processor(VOCAB, NIMG), 3)
+    kw = dict(input_ids=ids, pixel_values=px, max_new_tokens=4, do_sample=False)
+    dev.generate(**kw, num_beams=1, repetition_penalty=1.0, use_cache=True, attention_mask=None, logits_processor=[])
+    for bad in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(num_return_sequences=2), dict(min_length=5),
+                dict(no_repeat_ngram_size=3), dict(penalty_alpha=0.6), dict(logits_processor=[object()])):
+        with pytest.raises(NotImplementedError):
+            dev.generate(**kw, **bad)
+    with pytest.raises(TypeError):
+        dev.generate(**kw, adapter_input_ids=None)
+    # several EOS ids (HF allows a list): generation stops on any of them
+    out = dev.generate(**{**kw, "max_new_tokens": 40}, eos_token_id=[EOS, *dev.newline])
+    assert int(out[0, -1]) in {EOS, *dev.newline} and out.shape[1] < NIMG + 40
+
+
 def test_generate_protocol_matches_hf_generate(golden_dir):
     """tests/golden/generate_protocol.json: what the installed HF GenerationMixin.generate (the call the reference makes)
     hands to a streamer and to a stopping criterion — (1, T) prompt once, then a (1,) int64 CPU tensor per token, end();

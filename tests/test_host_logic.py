@@ -159,7 +159,14 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.dtk_abi_version() == _lib.DTK_ABI_VERSION
     hdr = (Path(__file__).resolve().parents[1] / "include" / "dtk.h").read_text()
     assert f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION} " in hdr or f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION}\n" in hdr
-    assert ctypes.sizeof(_lib.DtkConfig) == 29 * 4 and ctypes.sizeof(_lib.DtkSampling) == 8 * 4 + 8 + 0 + 3 * 4 + 24 * 4 or True
+    # struct layouts: the ctypes mirrors against the C compiler's own sizeof / offsetof (exported by the library)
+    assert lib.dtk_abi_struct_size(0) == ctypes.sizeof(_lib.DtkConfig) == 29 * 4
+    assert lib.dtk_abi_struct_size(1) == ctypes.sizeof(_lib.DtkSampling) == 4 * 4 + 8 + 3 * 4 + 24 * 4 + 4
+    assert lib.dtk_abi_struct_size(2) == ctypes.sizeof(_lib.DtkStats) == 11 * 8
+    assert lib.dtk_abi_struct_size(3) == _lib.DtkSampling.seed.offset == 16
+    assert lib.dtk_abi_struct_size(4) == _lib.DtkConfig.reserved.offset == 22 * 4
+    assert lib.dtk_abi_struct_size(5) == _lib.DtkStats.probe_event_pair_ms.offset == 80
+    assert lib.dtk_abi_struct_size(99) == -1
 
 
 def test_model_requires_gpu_and_fails_loudly():
@@ -239,8 +246,9 @@ def test_v2_config_json_and_presets(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps(j))
     r = DetikzifyConfig.from_hf_json(str(tmp_path / "config.json"))
     for f in ("hidden", "layers", "heads", "kv_heads", "ffn", "vocab", "rope_type", "rope_factor", "rope_theta", "vit_image",
-              "vit_gelu_tanh", "vit_feature_layer", "proj_bias", "arch", "patch_token_id", "pad_token_id", "eos_token_id"):
+              "vit_gelu_tanh", "vit_feature_layer", "proj_bias", "arch", "patch_token_id", "pad_token_id"):
         assert getattr(r, f) == getattr(c, f), f
+    assert r.eos_token_id == [128001, 128008]       # several EOS ids stay a list: generate() stops on any of them
     assert preset("detikzify-ds-7b").num_kv_heads == 32 and preset("detikzify-ds-7b").pooling_mode == "cos"
     # config.json as the reference's OWN DetikzifyConfig serialises it (tests/golden/make_golden.py::golden_config_v2; written by
     # transformers 5: `rope_parameters` instead of `rope_scaling`, no top-level pad_token_id) parses to the preset
