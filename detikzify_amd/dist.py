@@ -9,16 +9,18 @@ examples/eval.py:80-83,108-137 (`chunk` striping, `dist.all_gather_object`, `int
     expansions with seed base+rank; all (score, code) pairs are gathered and merged like
     eval.py:106 (sorted by score).  world_size 1 is the unmodified sequential search.
 
-The gather is an RCCL all_gather of a padded uint8 slab on the GPU when the process group's
-backend is nccl (xGMI), a gloo all_gather of CPU tensors otherwise (CPU tests): a few KB per
-rank, latency bound — there is no all-reduce anywhere on this path.
+The exchange sends every rank's records to rank 0 (`dist.gather` of a padded uint8 slab after an 8-byte
+all_gather of the lengths): over RCCL / xGMI with GPU tensors when the process group's backend is nccl, over gloo
+with CPU tensors otherwise (CPU tests).  A few KB per rank, latency bound — there is no all-reduce anywhere on this
+path.  The reference's `all_gather_object` (eval.py:132) hands the list to every rank although only rank 0 uses it
+(:134-136); `all_ranks=True` gives that behaviour (one all_gather instead of the gather).
 """
 from __future__ import annotations
 
 import json
 import os
 from itertools import count
-from typing import Any, List, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -71,9 +73,10 @@ def _device_for_collectives() -> torch.device:
     return torch.device("cpu")
 
 
-def gather_objects(obj: Any) -> List[Any]:
-    """All ranks contribute a JSON-serialisable object; every rank gets the list (rank order).
-    Two fixed-shape collectives: lengths (int64) then a padded uint8 slab."""
+def gather_objects(obj: Any, dst: int = 0, all_ranks: bool = False) -> Optional[List[Any]]:
+    """Every rank contributes one JSON-serialisable object; rank `dst` gets the list in rank order, the others None
+    (`all_ranks=True`: every rank gets it).  Two fixed-shape collectives: the lengths (all_gather of one int64 — every
+    rank needs the maximum to pad its slab), then the padded uint8 slabs (gather to `dst`, or all_gather)."""
     if world() == 1:
         return [obj]
     dev = _device_for_collectives()
@@ -81,12 +84,38 @@ def gather_objects(obj: Any) -> List[Any]:
     n = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n) for _ in range(world())]
     dist.all_gather(sizes, n)
-    cap = int(max(int(s.item()) for s in sizes))
-    slab = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    lengths = [int(s.item()) for s in sizes]
+    slab = torch.zeros(max(lengths), dtype=torch.uint8, device=dev)
     slab[: payload.numel()] = payload
-    slabs = [torch.zeros_like(slab) for _ in range(world())]
-    dist.all_gather(slabs, slab)
-    return [json.loads(bytes(s[: int(k.item())].cpu().tolist()).decode()) for s, k in zip(slabs, sizes)]
+    if all_ranks:
+        slabs = [torch.zeros_like(slab) for _ in range(world())]
+        dist.all_gather(slabs, slab)
+    else:
+        slabs = [torch.zeros_like(slab) for _ in range(world())] if rank() == dst else None
+        dist.gather(slab, gather_list=slabs, dst=dst)
+        if slabs is None:
+            return None
+    return [json.loads(bytes(s[:k].cpu().tolist()).decode()) for s, k in zip(slabs, lengths)]
+
+
+def tree_seed(seed_base: int, tree: int) -> int:
+    """Seed stream of tree `tree` of this rank: seed_base + rank + world * tree.  With one tree per rank that is the
+    protocol of SURVEY.md §8d/e to the letter — rank r searches with seed 1000 + r, world size 1 with seed 1000 — and
+    further trees of a rank interleave behind it without ever colliding with another rank's."""
+    return seed_base + rank() + world() * tree
+
+
+def placement() -> Dict[str, Any]:
+    """Which process group this rank is in and which GPU it drives — bench.py reports it for every rank so that a
+    multi-GPU number can be checked for one-rank-per-GPU placement."""
+    info: Dict[str, Any] = {"rank": rank(), "world": world(), "backend": dist.get_backend() if world() > 1 else None,
+                            "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(i)
+        info.update(cuda_device=i, device_name=props.name, device_uuid=str(getattr(props, "uuid", "")),
+                    pci_bus_id=getattr(props, "pci_bus_id", None))
+    return info
 
 
 def merge_rollouts(per_rank: Sequence[Sequence[Sequence[Any]]]) -> List[List[Any]]:
@@ -101,39 +130,45 @@ def merge_rollouts(per_rank: Sequence[Sequence[Sequence[Any]]]) -> List[List[Any
 
 
 def root_parallel_search(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
-                         **gen_kwargs) -> List[List[Any]]:
+                         all_ranks: bool = False, **gen_kwargs) -> Optional[List[List[Any]]]:
     """BASELINE configs 4/5: one image, every rank grows `trees` independent trees as ONE batched decode on its GPU
     (infer/batching.simulate_parallel; trees == 1 is the sequential search), then the single exchange of the path:
-    all (score, code) records to every rank, merged like eval.py:106.  Tree t of rank r samples with seed stream
-    seed_base * (r + 1) + t, so the trees of different ranks differ and a run is reproducible for a fixed world size."""
+    all (score, code) records to rank 0, merged there like eval.py:106 (other ranks return None unless `all_ranks`).
+    Tree t of rank r samples with the seed stream `tree_seed(seed_base, t)` = seed_base + r + world * t."""
     from .infer.batching import simulate_parallel
     mine = [[float(score), doc.code] for score, doc in
             simulate_parallel(pipeline, image, trees=trees, expansions_per_tree=expansions_per_tree,
-                              seed_base=seed_base * (rank() + 1), **gen_kwargs)]
-    return merge_rollouts(gather_objects(mine))
+                              seeds=[tree_seed(seed_base, t) for t in range(trees)], **gen_kwargs)]
+    gathered = gather_objects(mine, all_ranks=all_ranks)
+    return None if gathered is None else merge_rollouts(gathered)
 
 
 def root_parallel_search_images(pipeline, images: Sequence[Any], trees_per_image: int, expansions_per_tree: int,
-                                seed_base: int = 1000, **gen_kwargs) -> List[List[List[Any]]]:
+                                seed_base: int = 1000, all_ranks: bool = False, **gen_kwargs) -> Optional[List[List[List[Any]]]]:
     """BASELINE config 5 (a batch of images, N rollouts each, 8 GPUs): images are striped over the ranks (images[r::world]),
     each rank searches ITS images concurrently — len(mine) * trees_per_image trees in one batched decode, every image
-    encoded once — and one gather returns, for every image in input order, its (score, code) records sorted by score."""
+    encoded once — and one gather returns to rank 0, for every image in input order, its (score, code) records sorted by
+    score."""
     from .infer.batching import simulate_parallel_images
     mine = chunk(list(range(len(images))), world())[rank()]
     local: List[List[List[Any]]] = [[] for _ in mine]
     if mine:
+        n_trees = len(mine) * trees_per_image
         for k, score, doc in simulate_parallel_images(pipeline, [images[i] for i in mine], trees_per_image, expansions_per_tree,
-                                                      seed_base=seed_base * (rank() + 1), **gen_kwargs):
+                                                      seeds=[tree_seed(seed_base, t) for t in range(n_trees)], **gen_kwargs):
             local[k].append([float(score), doc.code])
-    per_image = interleave_all(gather_objects(local), len(images))
-    return [merge_rollouts([records]) for records in per_image]
+    gathered = gather_objects(local, all_ranks=all_ranks)
+    if gathered is None:
+        return None
+    return [merge_rollouts([records]) for records in interleave_all(gathered, len(images))]
 
 
-def sharded_sample(pipeline, images: Sequence[Any], **gen_kwargs) -> List[str]:
-    """Shard by image (exact reference semantics, examples/eval.py:80-83,125): rank r samples images[r::world]; every
-    rank gets the TikZ programs of all images in input order."""
+def sharded_sample(pipeline, images: Sequence[Any], all_ranks: bool = False, **gen_kwargs) -> Optional[List[str]]:
+    """Shard by image (exact reference semantics, examples/eval.py:80-83,125): rank r samples images[r::world]; rank 0
+    gets the TikZ programs of all images in input order (the others None unless `all_ranks`)."""
     mine = [pipeline.sample(image=img, **gen_kwargs).code for img in chunk(images, world())[rank()]]
-    return interleave_all(gather_objects(mine), len(images))
+    gathered = gather_objects(mine, all_ranks=all_ranks)
+    return None if gathered is None else interleave_all(gathered, len(images))
 
 
 def interleave_all(chunks: Sequence[Sequence[Any]], total: int) -> List[Any]:

@@ -419,23 +419,27 @@ class BatchEngine:
 
 
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
-                      **gen_kwargs) -> Iterator[Tuple[float, Any]]:
-    """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (thread t uses
-    torch seed seed_base + t for its sampling seeds) decoded as one batch.  Yields (score, document)
+                      seeds: Optional[List[int]] = None, **gen_kwargs) -> Iterator[Tuple[float, Any]]:
+    """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (tree t draws its sampling seeds
+    from a torch generator seeded seeds[t], default seed_base + t) decoded as one batch.  Yields (score, document)
     pairs in completion order.  trees == 1 is the unmodified sequential search."""
-    for _, score, doc in simulate_parallel_images(pipeline, [image], trees, expansions_per_tree, seed_base, **gen_kwargs):
+    for _, score, doc in simulate_parallel_images(pipeline, [image], trees, expansions_per_tree, seed_base, seeds=seeds,
+                                                  **gen_kwargs):
         yield score, doc
 
 
 def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_per_tree: int, seed_base: int = 1000,
-                             **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
+                             seeds: Optional[List[int]] = None, **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
     """Several images in flight on one GPU (BASELINE config 5: 8 images x 4 rollouts): len(images) * trees_per_image
     independent searches decoded as one batch; the engine encodes every image once and forks its KV prefix into the
     slots of that image's trees.  Yields (image index, score, document) in completion order.  Tree k (image k //
-    trees_per_image) samples with the seed stream seed_base + k."""
+    trees_per_image) samples with the seed stream seeds[k] (default seed_base + k)."""
     import torch
     imgs = [pipeline.load(im) for im in images]
     trees = len(imgs) * trees_per_image
+    if seeds is None:
+        seeds = [seed_base + t for t in range(trees)]
+    assert len(seeds) == trees, "one seed per tree"
     engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees) if trees > 1 else None
     out: "queue.Queue" = queue.Queue()
     cancelled = threading.Event()
@@ -443,15 +447,15 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
 
     def worker(t: int):
         try:
-            gen = torch.Generator().manual_seed(seed_base + t)
-            seeds = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
+            gen = torch.Generator().manual_seed(int(seeds[t]))
+            draws = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
             g = generators[t] = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric, **gen_kwargs)
             base_generate = g.generate
 
             def generate(input_ids, **kw):      # per-tree RNG stream; a cancelled search starts no further rollout
                 if cancelled.is_set():
                     raise InterruptedError("search cancelled")
-                return base_generate(input_ids, seed=next(seeds), **kw)
+                return base_generate(input_ids, seed=next(draws), **kw)
 
             g.generate = generate
             for score, doc in g.simulate(expansions=expansions_per_tree):

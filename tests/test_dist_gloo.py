@@ -31,14 +31,21 @@ def _worker(rank, world, port, outdir):
     # (1) shard by image: rank r handles items[r::world]
     items = list(range(7))
     mine = dd.chunk(items, world)[rank]
-    gathered = dd.gather_objects([f"tikz-{i}" * (i + 1) for i in mine])
-    assert dd.interleave(gathered)[:6] == [f"tikz-{i}" * (i + 1) for i in range(6)]
+    gathered = dd.gather_objects([f"tikz-{i}" * (i + 1) for i in mine])        # to rank 0 (north_star; eval.py:134-136 uses it there only)
+    assert (gathered is None) == (rank != 0)
+    if rank == 0:
+        assert dd.interleave(gathered)[:6] == [f"tikz-{i}" * (i + 1) for i in range(6)]
+    everywhere = dd.gather_objects([f"tikz-{i}" * (i + 1) for i in mine], all_ranks=True)   # the reference's all_gather_object
+    assert dd.interleave(everywhere)[:6] == [f"tikz-{i}" * (i + 1) for i in range(6)]
+    assert dd.gather_objects({"r": rank}, dst=1) == ([{"r": 0}, {"r": 1}] if rank == 1 else None)
+    assert dd.tree_seed(1000, 0) == 1000 + rank and dd.tree_seed(1000, 2) == 1000 + rank + 2 * world   # 1000 + rank
+    assert dd.placement()["world"] == world and dd.placement()["backend"] == "gloo"
     # (2) one image, 6 expansions root-parallel: each rank grows its own tree with seed base+rank
     share = dd.shard_expansions(6, world)[rank]
     gen = DetikzifyGenerator(FakeModel(seed=1000 + rank), fake_processor(), sketch_image(1, 64), metric=None,
                              document_class=SyntheticTikzDocument, max_length=80, compile_timeout=None)
     local = [[float(s), d.code] for s, d in gen.simulate(expansions=share)]
-    merged = dd.merge_rollouts(dd.gather_objects(local))
+    merged = dd.merge_rollouts(dd.gather_objects(local, all_ranks=True))
     # (3) the library entry points of BASELINE configs 4/5 on the real generate loop / batch engine (scripted device):
     #     3 batched trees per rank, one gather; and shard-by-image sampling
     from detikzify_amd.infer import DetikzifyPipeline
@@ -46,10 +53,15 @@ def _worker(rank, world, port, outdir):
     proc = fake_processor(VOCAB, NIMG)
     pipe = DetikzifyPipeline(ScriptedDevice(slots=4), proc, metric="fast", document_class=SyntheticTikzDocument,
                              max_length=NIMG + 40, compile_timeout=None)
-    best = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2)
+    best = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2, all_ranks=True)
     images = [sketch_image(10 + i, 64) for i in range(5)]
-    codes = dd.sharded_sample(pipe, images, do_sample=False)
-    per_image = dd.root_parallel_search_images(pipe, images[:3], trees_per_image=2, expansions_per_tree=2)
+    codes = dd.sharded_sample(pipe, images, all_ranks=True, do_sample=False)
+    per_image = dd.root_parallel_search_images(pipe, images[:3], trees_per_image=2, expansions_per_tree=2, all_ranks=True)
+    # default: the records travel to rank 0 only
+    only0 = dd.sharded_sample(pipe, images, do_sample=False)
+    assert (only0 == codes) if rank == 0 else (only0 is None)
+    only0 = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=2, expansions_per_tree=1)
+    assert (only0 is None) == (rank != 0)
     if rank == 0:
         alone = [pipe.sample(image=im, do_sample=False).code for im in images]
         Path(outdir, "merged.json").write_text(json.dumps({
