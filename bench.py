@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-bench.py — TikZ tokens/sec (+ MCTS rollouts/sec) of the MI355X-native DeTikZify hot path.
+bench.py — TikZ tokens/sec + MCTS rollouts/sec of the MI355X-native DeTikZify hot path.
 
 Metric (BASELINE.json): TikZ tokens/sec + MCTS rollouts/sec, detikzify-ds-7b, 1 image, N MI355X.
 One "step" = one rollout of the hot path through the product API (model.generate, the call
@@ -9,16 +9,28 @@ on the host -> ViT (666 GF) -> projector -> 243-token prefill -> 512 decoded tok
 fixed work) with bad_words/begin-suppress processors, one D2H per token.  `value` is
 generated tokens / wall time of the whole step loop (ViT + prefill INCLUDED); the decode-only rate and
 the prefill time are reported beside it.  N > 1 (torchrun, one rank per GPU): every rank runs its own
-independent rollouts on a full replica (root-parallel rollouts), the generated token
-strings are gathered to all ranks over RCCL inside the timed region; scaling is weak.
+independent rollouts on a full replica (root-parallel rollouts), the generated TikZ strings
+are gathered to rank 0 over RCCL inside the timed region; scaling is weak.
 
-Extra objects: `roofline` (dominant kernel = the fused RMSNorm + gate/up GEMV + SiLU·mul kernel,
-44 % of the weight bytes; duration measured live with HIP events on the library's stream in a probe
-pass of plain launches; HBM peak 8 TB/s) and `cpu_baseline` (the CPU oracle timed on the host cores).
+Phases after the headline loop (each can be switched off):
+  batched_rollouts  B independent sampled rollouts per GPU as ONE batched decode (the weights stream once per step)
+  mcts              the search itself (DetikzifyGenerator / MonteCarlo, reference semantics): `sequential` = ONE tree per
+                    GPU, expansion k+1 selects on what expansion k back-propagated (reference infer/generate.py:195-207,
+                    305-353; with N ranks this is root parallelisation over the ranks, seeds 1000 + rank); `parallel` =
+                    `--mcts-trees` independent trees per GPU decoded as one batch.  Reward: SelfSim on the device ViT of
+                    the SYNTHETIC renderer's image (no TeX on the box: a stub-reward number, never to be mixed with
+                    real-LaTeX numbers).  Each with its fraction of the decode-step HBM roofline.
+  roofline          dominant kernel (RMSNorm + gate/up GEMV + SiLU*mul, 44 % of the weight bytes): duration measured
+                    live with HIP events on the library's stream in a probe pass of plain launches; HBM peak 8 TB/s
+  cpu_baseline      the reference's arithmetic engine — the installed HuggingFace LlamaForCausalLM with its KV cache, bf16,
+                    on the SAME weights (copied back from the device), image prefix from the oracle's glue — timed on the host
+                    cores; its greedy tokens are compared with the device's (`parity_tokens_identical`); the oracle port and
+                    BASELINE config 1 (ds-1.3b shape on the CPU) ride along as further entries
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,6 +42,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+DOMINANT_KERNEL_SOURCE = ROOT / "detikzify_amd" / "csrc" / "kernels_decode.hip"
 
 
 def parse():
@@ -42,69 +55,177 @@ def parse():
     ap.add_argument("--sample", action="store_true", help="sampling decode (T=.8, p=.95) instead of greedy")
     ap.add_argument("--reuse", action="store_true", help="SURVEY §8 f1: reuse image embeds / prefix KV across rollouts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=8)
+    ap.add_argument("--cpu-tokens", type=int, default=16, help="greedy tokens of the CPU baseline (BASELINE.md §3: 16 for the 7B models)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU decode per baseline entry before it stops early")
+    ap.add_argument("--no-cpu-config1", action="store_true", help="skip the BASELINE config 1 entry (ds-1.3b shape on the host CPU)")
     ap.add_argument("--probe-tokens", type=int, default=64)
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
-    ap.add_argument("--skip-batched", action="store_true", help="allocate the --batch slots (for --mcts-trees) but skip the "
+    ap.add_argument("--skip-batched", action="store_true", help="allocate the --batch slots (for the MCTS phase) but skip the "
                     "batched_rollouts phase itself")
     ap.add_argument("--batch-images", type=int, default=1, help="spread the rollouts of the batched phase over this many "
                     "different images (BASELINE config 5: 8 images x 4 rollouts = --batch 32 --batch-images 8)")
     ap.add_argument("--batch", type=int, default=64, help="independent rollouts decoded as one batch per GPU in the "
-                    "extra 'batched_rollouts' phase (0 = skip); the headline value stays batch 1")
-    ap.add_argument("--mcts-trees", type=int, default=0, help="optional extra phase: root-parallel MCTS (reference search logic per "
-                    "tree, SelfSim reward on the device ViT, LaTeX replaced by the synthetic renderer) with this many trees per GPU")
-    ap.add_argument("--mcts-expansions", type=int, default=3, help="rollouts per tree in the --mcts-trees phase")
+                    "'batched_rollouts' phase and slots available to the MCTS trees (0 = neither); the headline value stays batch 1")
+    ap.add_argument("--mcts-trees", type=int, default=-1, help="trees per GPU of the parallel MCTS phase (-1 = as many as --batch, 0 = skip)")
+    ap.add_argument("--mcts-expansions", type=int, default=2, help="rollouts per tree in the parallel MCTS phase")
+    ap.add_argument("--mcts-seq-expansions", type=int, default=3, help="rollouts of the sequential (one tree per GPU) search, 0 = skip")
     return ap.parse_args()
 
 
-def cpu_baseline(model, cfg, ids, n_tokens):
-    """The oracle (a port: HF LlamaModel restated, oracle/llama.py) timed on the host cores:
-    greedy decode steps at context 243+ on the SAME weights (copied back from the device)."""
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _hf_llama(cfg, weights):
+    """installed transformers LlamaForCausalLM (the class the reference's DetikzifyForCausalLM subclasses,
+    v1/modeling_detikzify.py:203) over the given bf16 tensors — no random init, no copies"""
     import torch
-    from oracle import sampling
-    from oracle.llama import LlamaOracle
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    if cfg.get("rope_type") == "llama3":
+        rope = {"rope_type": "llama3", "factor": cfg["rope_factor"], "low_freq_factor": cfg["rope_low_freq_factor"],
+                "high_freq_factor": cfg["rope_high_freq_factor"],
+                "original_max_position_embeddings": cfg["rope_original_max_position"]}
+    else:
+        rope = {"rope_type": "linear", "factor": cfg["rope_factor"] or 1.0}
+    hc = LlamaConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"], num_hidden_layers=cfg["layers"],
+                     num_attention_heads=cfg["heads"], num_key_value_heads=cfg.get("kv_heads") or cfg["heads"],
+                     head_dim=cfg["head_dim"], vocab_size=cfg["vocab"], rms_norm_eps=cfg["rms_eps"],
+                     max_position_embeddings=cfg["max_positions"], rope_theta=cfg["rope_theta"], rope_scaling=rope,
+                     attention_bias=False, tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    with torch.device("meta"):
+        hf = LlamaForCausalLM(hc)
+    sd = {k: weights[k].to(torch.bfloat16) for k in hf.state_dict()}
+    hf.load_state_dict(sd, strict=True, assign=True)
+    hf.model.rotary_emb = LlamaRotaryEmbedding(hc)          # its buffers are not in the state dict: rebuild them off meta
+    return hf.eval()
+
+
+def _masked_argmax(logits, banned):
+    s = logits.float().clone()
+    for i in banned:
+        s[i] = float("-inf")
+    return int(s.argmax()), s
+
+
+def _teacher_forced_parity(step_fn, first_logits, device_tokens, banned, budget_s):
+    """Greedy decode on the CPU, teacher-forced with the DEVICE's tokens: at every step the CPU's argmax is compared with
+    the token the device produced.  A mismatch counts as a near-tie when the CPU's top-2 logits are within 2 bf16 ulps
+    (two correct bf16 pipelines may order them either way).  Returns (tokens/s, identical, near_ties, compared)."""
+    import torch
+    logits, same, near, done = first_logits, 0, 0, 0
     t0 = time.perf_counter()
-    import psutil
-    names = [n for n in model.tensor_names() if n.startswith(("model.layers.", "model.norm", "lm_head", "model.embed"))]
-    total = sum(model.lib.dtk_tensor_numel(model._ctx, n.encode()) for n in names)
-    fp32 = psutil.virtual_memory().available > 6 * total + (8 << 30)   # fp32 copies when the host has the RAM
-    shapes = {"down_proj": (cfg["hidden"], cfg["ffn"]), "gate_proj": (cfg["ffn"], cfg["hidden"]),
-              "up_proj": (cfg["ffn"], cfg["hidden"])}
+    for tok in device_tokens:
+        mine, scores = _masked_argmax(logits, banned)
+        if mine == tok:
+            same += 1
+        else:
+            top2 = torch.topk(scores, 2)[0]
+            near += int(float(top2[0] - top2[1]) <= 2 * float(top2[0].abs()) * 2.0 ** -7 + 1e-6)
+        done += 1
+        if done == len(device_tokens) or (time.perf_counter() - t0 > budget_s and done >= 2):
+            break
+        logits = step_fn(tok)
+    steps = max(1, done - 1)        # forwards executed inside the timed region
+    return steps / (time.perf_counter() - t0), same, near, done
+
+
+def cpu_baseline(model, ids, px, device_tokens, banned, args):
+    """cpu_baseline of the run's own configuration: weights copied back from the device (fp8: the de-quantised effective
+    weights), prefix embeddings (ViT + projector + splice) from the oracle's glue, then
+      * "reference": HF LlamaForCausalLM, bf16, KV cache — the reference's decode path (generate.py:218-227 ->
+        v1/modeling_detikzify.py:218-283 -> HF LlamaModel) on the host cores;
+      * "port": the oracle's LLaMA restatement (oracle/llama.py) on the same tensors.
+    Both teacher-forced with the device's greedy tokens, which makes the baseline leg a token-parity check as well."""
+    import torch
+    from oracle.model import DetikzifyOracle
+    from oracle.synth import tensor_specs
+    t0 = time.perf_counter()
+    cfg = model.config.oracle_dict()
     w = {}
-    for n in names:
-        t = model.read_tensor(n)
-        if n.endswith("layernorm.weight") or n == "model.norm.weight":
-            w[n] = t.float()
-            continue
-        key = n.split(".")[-2]
-        shape = shapes.get(key, (cfg["vocab"], cfg["hidden"]) if n in ("model.embed_tokens.weight", "lm_head.weight")
-                           else (cfg["hidden"], cfg["hidden"]))
-        w[n] = t.view(*shape).float() if fp32 else t.view(*shape)
-    w["model.embed_tokens.weight"] = w["model.embed_tokens.weight"].float()
-    llm = LlamaOracle(cfg, w, precision="bf16")
-    t_load = time.perf_counter() - t0
+    for name, shape, _, _ in tensor_specs(cfg):
+        t = model.read_tensor(name).reshape(shape)
+        keep_bf16 = t.dim() == 2 and name.startswith(("model.layers.", "lm_head"))     # decoder Linear weights: native bf16 GEMMs
+        w[name] = t if keep_bf16 else t.float()
+    t_copy = time.perf_counter() - t0
+    threads = torch.get_num_threads()
+    out = {"unit": "tokens/s", "cores": threads, "host_cpus": len(os.sched_getaffinity(0))}
+    toks = [int(t) for t in device_tokens[:args.cpu_tokens]]
     with torch.no_grad():
-        h = llm.forward(llm.embed(ids))            # 243-token prefix, not timed (text-only: no CPU ViT)
-        logits = llm.logits(h[-1])
+        oracle = DetikzifyOracle(cfg, w, precision="bf16")
         t1 = time.perf_counter()
-        done = 0
-        for i in range(n_tokens):
-            tok = sampling.greedy(logits, [cfg["image_token_id"]], [], False)
-            logits = llm.logits(llm.forward(llm.embed(torch.tensor([tok])))[-1])
-            done += 1
-            if time.perf_counter() - t1 > 30.0 and done >= 2:
-                break
+        emb = oracle.input_embeds(ids, px[0])                     # ViT + projector + splice on the CPU (oracle glue)
+        t_glue = time.perf_counter() - t1
+        # ---- the reference's engine
+        hf = _hf_llama(cfg, w)
+        t1 = time.perf_counter()
+        res = hf(inputs_embeds=emb.to(torch.bfloat16)[None], use_cache=True)
+        t_prefill = time.perf_counter() - t1
+        state = {"kv": res.past_key_values}
+
+        def hf_step(tok):
+            r = hf(input_ids=torch.tensor([[tok]]), past_key_values=state["kv"], use_cache=True)
+            state["kv"] = r.past_key_values
+            return r.logits[0, -1]
+        rate, same, near, n = _teacher_forced_parity(hf_step, res.logits[0, -1], toks, banned, args.cpu_budget)
+        out.update(value=rate, kind="reference", parity_tokens_identical=f"{same}/{n}", parity_near_ties=near,
+                   prefill_s=round(t_prefill, 2),
+                   sample=f"{n - 1} greedy decode steps at context {ids.numel()}+ of the {cfg['layers']}-layer d={cfg['hidden']} decoder through "
+                          f"the installed HuggingFace LlamaForCausalLM (transformers {__import__('transformers').__version__}, the class the "
+                          f"reference subclasses) in bf16 with its KV cache on {threads} threads, same weights as the device (copied back, "
+                          f"{t_copy:.0f} s, not timed), image prefix by the oracle's CPU glue (ViT + projector, {t_glue:.1f} s, not timed), "
+                          f"prefill {t_prefill:.1f} s (not timed); teacher-forced with the device's greedy tokens")
+        del hf, state, res
+        # ---- the oracle port on the same tensors
+        try:
+            first = oracle.llm.logits(oracle.llm.forward(emb)[-1])
+            rate, same, near, n = _teacher_forced_parity(lambda t: oracle.step(t), first, toks[:max(2, args.cpu_tokens // 2)],
+                                                         banned, args.cpu_budget / 2)
+            out["port"] = {"value": rate, "unit": "tokens/s", "cores": threads, "kind": "port", "parity_tokens_identical": f"{same}/{n}",
+                           "parity_near_ties": near, "sample": f"{n - 1} steps of oracle/llama.py (bf16 rounding policy) on the same tensors"}
+        except Exception as e:  # noqa: BLE001
+            out["port"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline_config1(budget_s):
+    """BASELINE.json configs[0]: detikzify-ds-1.3b, one image, greedy decode on the CPU through the HuggingFace plumbing —
+    LlamaForCausalLM at the ds-1.3b shape in fp32 with KV cache on seeded synthetic weights (no checkpoint offline), a
+    243-position prefix, 64 greedy tokens."""
+    import torch
+    from detikzify_amd.model.config import preset
+    cfg = preset("detikzify-ds-1.3b").oracle_dict()
+    g = torch.Generator().manual_seed(1234)
+    t0 = time.perf_counter()
+    d, ff, V, L = cfg["hidden"], cfg["ffn"], cfg["vocab"], cfg["layers"]
+
+    def rnd(*shape):
+        return (torch.randn(*shape, generator=g) * 0.02).to(torch.bfloat16)
+    w = {"model.embed_tokens.weight": rnd(V, d), "lm_head.weight": rnd(V, d), "model.norm.weight": torch.ones(d, dtype=torch.bfloat16)}
+    for i in range(L):
+        p = f"model.layers.{i}."
+        for n, s in (("self_attn.q_proj", (d, d)), ("self_attn.k_proj", (d, d)), ("self_attn.v_proj", (d, d)), ("self_attn.o_proj", (d, d)),
+                     ("mlp.gate_proj", (ff, d)), ("mlp.up_proj", (ff, d)), ("mlp.down_proj", (d, ff))):
+            w[p + n + ".weight"] = rnd(*s)
+        w[p + "input_layernorm.weight"] = torch.ones(d, dtype=torch.bfloat16)
+        w[p + "post_attention_layernorm.weight"] = torch.ones(d, dtype=torch.bfloat16)
+    hf = _hf_llama(cfg, w).float()          # fp32 on the host, as BASELINE.md §3 specifies for config 1
+    t_build = time.perf_counter() - t0
+    prefix = (torch.randn(1, 243, d, generator=g) * 0.02)
+    with torch.no_grad():
+        t1 = time.perf_counter()
+        res = hf(inputs_embeds=prefix, use_cache=True)
+        t_prefill = time.perf_counter() - t1
+        kv, logits, n = res.past_key_values, res.logits[0, -1], 0
+        t1 = time.perf_counter()
+        while n < 64 and (time.perf_counter() - t1 < budget_s or n < 2):
+            r = hf(input_ids=logits.argmax().reshape(1, 1), past_key_values=kv, use_cache=True)
+            kv, logits, n = r.past_key_values, r.logits[0, -1], n + 1
         dt = time.perf_counter() - t1
-    return {
-        "value": done / dt, "unit": "tokens/s", "cores": torch.get_num_threads(),
-        "host_cpus": len(os.sched_getaffinity(0)), "kind": "port",
-        "sample": f"{done} greedy decode steps at context {ids.numel()}+ of the {cfg['layers']}-layer d={cfg['hidden']} decoder "
-                  f"({'bf16 weights upcast to fp32, fp32 GEMV' if fp32 else 'bf16 weights, native bf16 GEMV'}; prefix prefill and weight copy-back "
-                  f"({t_load:.0f} s) not timed; no CPU ViT)",
-    }
+    return {"value": n / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference", "prefill_s": round(t_prefill, 2),
+            "sample": f"BASELINE config 1: HuggingFace LlamaForCausalLM at the ds-1.3b shape, fp32, KV cache, seeded synthetic weights "
+                      f"(built in {t_build:.0f} s), 243-position prefix (prefill {t_prefill:.1f} s, not timed), {n} greedy tokens"}
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -112,12 +233,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    import detikzify_amd.model as dmodel
     from detikzify_amd import dist as ddist
-    from detikzify_amd.model import load
     from detikzify_amd.util import expand
     from tests.helpers import sketch_image
 
-    backend = os.environ.get("DTK_DIST_BACKEND", "nccl")     # "gloo": control-flow test of N ranks on one GPU
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} (one rank per GPU)")
+    backend = os.environ.get("DTK_DIST_BACKEND", "nccl")     # "gloo": control-flow test of N ranks without N GPUs
     n_dev = max(1, torch.cuda.device_count())
     if world > 1:
         if local_rank >= n_dev and backend == "nccl":
@@ -125,10 +248,15 @@ def main():
         local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
         ddist.init_process_group(backend, timeout_s=1800)
+        assert dist.get_backend() == backend and dist.get_world_size() == world
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    placement = ddist.gather_objects(ddist.placement())         # rank 0: who drives which GPU
+    if rank == 0 and world > 1 and backend == "nccl":
+        gpus = {(p.get("cuda_device"), p.get("pci_bus_id"), p.get("device_uuid")) for p in placement}
+        assert len(gpus) == world, f"{world} ranks on {len(gpus)} distinct GPUs: {placement}"
 
-    model, proc = load(args.model, synthetic=1234, device_map=local_rank, batch_slots=min(65, min(64, args.batch) + max(1, args.batch_images)) if args.batch > 1 else 0,   # + a prefix-cache slot per image
-                       weight_format=args.weight_format)
+    n_slots = min(65, min(64, args.batch) + max(1, args.batch_images)) if args.batch > 1 else 0   # + a prefix-cache slot per image
+    model, proc = dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=n_slots, weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config
     img = sketch_image(0, 224)
@@ -137,8 +265,9 @@ def main():
     ids, px = enc.input_ids, enc.pixel_values
     T0 = ids.shape[1]
     n_new = args.new_tokens
-    gen_kw = dict(pixel_values=px, bad_words_ids=[[cfg.image_token_id]], begin_suppress_tokens=[cfg.eos_token_id],
-                  suppress_tokens=[cfg.eos_token_id], max_new_tokens=n_new, eos_token_id=-1)
+    eos_ids = cfg.eos_token_id if isinstance(cfg.eos_token_id, (list, tuple)) else [cfg.eos_token_id]
+    gen_kw = dict(pixel_values=px, bad_words_ids=[[cfg.image_token_id]], begin_suppress_tokens=list(eos_ids),
+                  suppress_tokens=list(eos_ids), max_new_tokens=n_new, eos_token_id=-1)
     if args.sample:
         gen_kw.update(do_sample=True, temperature=0.8, top_p=0.95, top_k=0)
     else:
@@ -155,12 +284,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for i in range(args.warmup):
         rollout(-1 - i)
     fence()
     per_step, prefill_ms, vit_ms = [], [], []
     t0 = time.perf_counter()
-    codes = []
+    codes, first_tokens = [], None
     for i in range(args.steps):
         ts = time.perf_counter()
         toks = rollout(i)
@@ -168,15 +304,13 @@ def main():
         st = model.stats()
         prefill_ms.append(st["last_prefill_ms"]); vit_ms.append(st["last_vit_ms"])
         codes.append(proc.decode(toks, skip_special_tokens=True))
-    if world > 1:   # the path's one exchange: finished TikZ strings to every rank (rank 0 scores them)
+        if first_tokens is None:
+            first_tokens = toks.tolist()
+    if world > 1:   # the path's one exchange: finished TikZ strings to rank 0 (which scores them, eval.py:134-136)
         gathered = ddist.gather_objects(codes)
-        assert len(gathered) == world
+        assert (gathered is None) == (rank != 0) and (rank != 0 or len(gathered) == world)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     total_tokens = world * args.steps * n_new
     value = total_tokens / elapsed
@@ -191,7 +325,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.weight_format == "bf16" else "fp8-e4m3 weights / bf16 activations", "data": "synthetic",
-        "config": {"workload": f"{args.model} (synthetic weights, seed 1234), 1 image 224x224->384x384, 243-token prefix, "
+        "config": {"workload": f"{args.model} (synthetic weights, seed 1234), 1 image 224x224->384x384, {T0}-token prefix, "
                                f"{'sampling T=.8 p=.95' if args.sample else 'greedy'} decode of {n_new} tokens per rollout, "
                                f"batch 1 per GPU, hipGraph per token" + (", image/prefix reuse" if args.reuse else ""),
                    "tokens_per_rollout": n_new, "prefix_tokens": T0, "rollouts_per_gpu": args.steps},
@@ -201,10 +335,11 @@ def main():
         "decode_step": {"algorithmic_bytes_per_token": bytes_per_token, "achieved_GBps": bytes_per_token * decode_tok_s / 1e9,
                         "frac_of_hbm_peak": bytes_per_token * decode_tok_s / 1e9 / HBM_PEAK_GBS,
                         "roofline_tokens_per_sec": HBM_PEAK_GBS * 1e9 / bytes_per_token},
+        "ranks": placement,
     }
 
-    # ---- extra phase: B independent rollouts per GPU decoded as ONE batch (root-parallel trees of one
-    # GPU): the weights are streamed once per step for all B sequences
+    # ---- B independent rollouts per GPU decoded as ONE batch (root-parallel trees of one GPU): the
+    # weights are streamed once per step for all B sequences
     if args.batch > 1 and not args.skip_batched:
         import threading
         from detikzify_amd.infer.batching import BatchEngine
@@ -212,7 +347,6 @@ def main():
         try:
             # MCTS rollouts sample with the pipeline's defaults (temperature .8, top-p .95: generate.py:362-364)
             mcts_kw = {**gen_kw, "do_sample": True, "temperature": 0.8, "top_p": 0.95, "top_k": 0}
-
             n_img = max(1, min(args.batch_images, args.batch))
             px_of = [px] + [proc(images=expand(sketch_image(100 + k, 224), 224, do_trim=True), return_tensors="pt").pixel_values
                             for k in range(1, n_img)]
@@ -231,12 +365,8 @@ def main():
                 phases = {"start_to_first_step_ms": round(1e3 * (engine.t_first_launch - tb), 1),
                           "last_collect_to_end_ms": round(1e3 * (t_end - engine.t_last_collect), 1)}
                 tb = t_end - tb
-            if world > 1:
-                t = torch.tensor([tb], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tb = float(t.item())
-            mean_ctx_b = T0 + (n_new - 1) / 2.0
-            bytes_step = W + args.batch * Kb * mean_ctx_b
+            tb = max_over_ranks(tb)
+            bytes_step = W + args.batch * Kb * mean_ctx
             result["batched_rollouts"] = {
                 "batch_per_gpu": args.batch, "images_in_flight": n_img, "prefix_encodes_both_passes": engine.prefix_encodes,
                 "rollouts_per_sec": world * args.batch / tb,
@@ -250,47 +380,73 @@ def main():
                 "prefix_sharing": bool(engine.share_prefix),
                 "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3),
                                    "host_bound_steps": engine.host_bound_steps, **phases},
-                "decode": "sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), 512 tokens, EOS suppressed",
+                "decode": f"sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), {n_new} tokens, EOS suppressed",
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
                         f"dtk_decode_batch step serves all of them; the {T0}-token image prefix is encoded once, its KV "
                         "forked into each slot (bit-identical to a full prefill, SURVEY f1) and read from one copy"}
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001
             result["batched_rollouts"] = {"error": repr(e)}
         finally:
             engine.close()
 
-    # ---- optional phase: the MCTS loop itself (detikzify_amd.infer: DetikzifyGenerator per tree, unchanged reference
-    # semantics), `trees` independent trees per GPU decoded as one batch, reward = SelfSim on the device ViT of the
-    # SYNTHETIC renderer's image (no TeX offline: stub-reward number, never to be mixed with real-LaTeX numbers)
-    if args.mcts_trees > 1 and args.batch > 1:
+    # ---- the MCTS metric: the search itself (detikzify_amd.infer: DetikzifyGenerator per tree, reference semantics)
+    trees = min(args.batch, 64) if args.mcts_trees < 0 else min(args.mcts_trees, max(args.batch, 0))
+    if args.mcts_seq_expansions > 0 or trees > 1:
+        mcts = {"reward": "SelfSim (device ViT, reference-image features cached) of SyntheticTikzDocument renderings — LaTeX is absent "
+                          "offline: stub-reward numbers, not comparable with real-LaTeX runs",
+                "max_length": T0 + n_new, "sampling": "temperature .8, top-p .95 (DetikzifyPipeline defaults)",
+                "roofline_note": "bytes moved >= decode steps x W + generated tokens x K x prefix (every rollout's context is at least "
+                                 "the image prefix): the fractions are lower bounds of the decode-step HBM roofline share"}
         try:
             from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
             from detikzify_amd.infer.batching import simulate_parallel
-            from tests.helpers import sketch_image as _sk
-            trees = min(args.mcts_trees, args.batch)
-            pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument,
-                                     max_length=T0 + min(n_new, 256))
+            pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument, max_length=T0 + n_new)
             pipe.metric.cache_reference = True           # f1: the reference image's features are computed once
-            img = _sk(0, 224)
-            vit_before = model.stats()["vit_images"]
-            fence()
-            tm = time.perf_counter()
-            res = list(simulate_parallel(pipe, img, trees=trees, expansions_per_tree=args.mcts_expansions))
-            fence()
-            tm = time.perf_counter() - tm
-            if world > 1:
-                t = torch.tensor([tm], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tm = float(t.item())
-            result["mcts_stub_reward"] = {
-                "trees_per_gpu": trees, "expansions_per_tree": args.mcts_expansions, "rollouts": world * len(res),
-                "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "max_length": T0 + min(n_new, 256),
-                "vit_passes": model.stats()["vit_images"] - vit_before, "engine": getattr(model, "last_batch_stats", None),
-                "tokens_generated": getattr(model, "last_batch_stats", {}).get("tokens_out"),
-                "reward": "SelfSim (device ViT) of SyntheticTikzDocument renderings; LaTeX absent offline",
-                "scores_min_max": [float(min(s for s, _ in res)), float(max(s for s, _ in res))] if res else None}
-        except Exception as e:
-            result["mcts_stub_reward"] = {"error": repr(e)}
+            img0 = sketch_image(0, 224)
+            if args.mcts_seq_expansions > 0:
+                # ONE tree per GPU: the unmodified sequential search (selection k+1 depends on back-propagation k); over N ranks
+                # this is root parallelisation with seeds 1000 + rank (BASELINE config 4)
+                s0 = model.stats()
+                fence()
+                tm = time.perf_counter()
+                res = list(simulate_parallel(pipe, img0, trees=1, expansions_per_tree=args.mcts_seq_expansions,
+                                             seeds=[ddist.tree_seed(1000, 0)]))
+                records = ddist.gather_objects([[float(s), d.code] for s, d in res])
+                fence()
+                tm = max_over_ranks(time.perf_counter() - tm)
+                s1 = model.stats()
+                steps = s1["decode_steps"] - s0["decode_steps"]
+                moved = steps * (W + Kb * T0)
+                mcts["sequential"] = {
+                    "trees_per_gpu": 1, "expansions": args.mcts_seq_expansions, "rollouts": world * len(res),
+                    "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "decode_steps_per_gpu": steps,
+                    "vit_passes_per_gpu": s1["vit_images"] - s0["vit_images"],
+                    "frac_of_hbm_peak": moved / tm / 1e9 / HBM_PEAK_GBS,
+                    "roofline_rollouts_per_sec_at_512_tokens": world * HBM_PEAK_GBS * 1e9 / (bytes_per_token * n_new),
+                    "merged_on_rank0": len(ddist.merge_rollouts(records)) if records is not None else None}
+            if trees > 1:
+                fence()
+                v0 = model.stats()["vit_images"]
+                tm = time.perf_counter()
+                res = list(simulate_parallel(pipe, img0, trees=trees, expansions_per_tree=args.mcts_expansions,
+                                             seeds=[ddist.tree_seed(1000, t) for t in range(trees)]))
+                records = ddist.gather_objects([[float(s), d.code] for s, d in res])
+                fence()
+                tm = max_over_ranks(time.perf_counter() - tm)
+                eng = getattr(model, "last_batch_stats", None) or {}
+                moved = eng.get("steps", 0) * W + eng.get("tokens_out", 0) * Kb * T0
+                mcts["parallel"] = {
+                    "trees_per_gpu": trees, "expansions_per_tree": args.mcts_expansions, "rollouts": world * len(res),
+                    "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "engine": eng,
+                    "tokens_generated_per_gpu": eng.get("tokens_out"), "vit_passes_per_gpu": model.stats()["vit_images"] - v0,
+                    "frac_of_hbm_peak": moved / tm / 1e9 / HBM_PEAK_GBS if moved else None,
+                    "scores_min_max": [float(min(s for s, _ in res)), float(max(s for s, _ in res))] if res else None,
+                    "merged_on_rank0": len(ddist.merge_rollouts(records)) if records is not None else None}
+        except Exception as e:  # noqa: BLE001
+            mcts["error"] = repr(e)
+        result["mcts"] = mcts
+        result["mcts_rollouts_per_sec"] = (mcts.get("parallel") or {}).get("rollouts_per_sec")
+        result["mcts_rollouts_per_sec_sequential"] = (mcts.get("sequential") or {}).get("rollouts_per_sec")
 
     if rank == 0:
         # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)
@@ -306,42 +462,45 @@ def main():
             ms = after["probe_kernel_ms_sum"] - before["probe_kernel_ms_sum"]
             if n > 0 and ms > 0:
                 # `achieved` uses the RAW interval between the two events (conservative: an event pair with nothing in
-                # between already reads empty_event_pair_us on this stream, and rocprofv3's start->end for the same
-                # kernel — profiles/r01_kernel_stats.csv, rocprofv3_avg_us below — is ~8 % shorter than the interval)
+                # between already reads empty_event_pair_us on this stream; rocprofv3's start->end for the same kernel —
+                # rocprofv3_avg_us below, from the committed kernel-trace summary — is shorter than the interval)
                 pair_ms = float(after.get("probe_event_pair_ms", 0.0) or 0.0)
                 avg_ms = ms / n
                 ach = after["probe_kernel_bytes"] / (avg_ms * 1e-3) / 1e9
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_us=avg_ms * 1e3, empty_event_pair_us=pair_ms * 1e3,
                             bytes_per_launch=after["probe_kernel_bytes"], launches_timed=n)
-        except Exception as e:  # the bench line must still be printed
+        except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
             roof["error"] = repr(e)
             model.set_graph_mode(1)
-        # HBM traffic of that kernel from the separate rocprofv3 --pmc FETCH_SIZE pass committed under
-        # profiles/ (x2 gfx950 correction, guides/MI355X_MICROARCH.md §HBM); null if no profile matches
+        # HBM traffic of that kernel: a counter pass cannot run inside this process, so the figure comes from the committed
+        # rocprofv3 --pmc FETCH_SIZE summary (x2 gfx950 correction, guides/MI355X_MICROARCH.md §HBM) — but only while it
+        # describes THIS kernel: profiles/dominant_kernel.json records the model and the sha256 of kernels_decode.hip it was
+        # measured on; any other source or model reports null instead of a stale number
         try:
-            import csv
-            prof = ROOT / "profiles" / "r01_pmc_fetch.csv"
-            if prof.exists() and args.model == "detikzify-ds-7b":
-                for row in csv.DictReader(prof.open()):
-                    if row["counter"] == "FETCH_SIZE" and row["kernel"].startswith("void k_gemv<1, 3,"):
-                        roof["traffic"] = float(row["hbm_read_bytes_per_launch_x2"])
-                        roof["traffic_source"] = "profiles/r01_pmc_fetch.csv (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)"
-                        break
-                ks = ROOT / "profiles" / "r01_kernel_stats.csv"
-                if ks.exists():
-                    for row in csv.DictReader(ks.open()):
-                        if row["kernel"].startswith("void k_gemv<1, 3,"):
-                            roof["rocprofv3_avg_us"] = float(row["avg_us"])     # committed kernel-trace summary of the same command
-                            roof["frac_at_rocprofv3_duration"] = roof["bytes_per_launch"] / (roof["rocprofv3_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if roof.get("bytes_per_launch") else None
-                            break
-        except Exception:
+            meta = json.loads((ROOT / "profiles" / "dominant_kernel.json").read_text())
+            sha = hashlib.sha256(DOMINANT_KERNEL_SOURCE.read_bytes()).hexdigest()
+            if meta.get("model") == args.model and meta.get("weight_format", "bf16") == args.weight_format and meta.get("source_sha256") == sha:
+                roof["traffic"] = meta["hbm_read_bytes_per_launch"]
+                roof["traffic_source"] = meta["traffic_source"]
+                roof["rocprofv3_avg_us"] = meta["rocprofv3_avg_us"]
+                if roof.get("bytes_per_launch"):
+                    roof["frac_at_rocprofv3_duration"] = roof["bytes_per_launch"] / (meta["rocprofv3_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            else:
+                roof["traffic_source"] = "none: profiles/dominant_kernel.json was measured on another model / kernel source"
+        except Exception:  # noqa: BLE001
             pass
         result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
+            banned = [cfg.image_token_id, *eos_ids]
             try:
-                result["cpu_baseline"] = cpu_baseline(model, cfg.kernel_dict(), ids[0], args.cpu_tokens)
-            except Exception as e:
-                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": f"failed: {e!r}"}
+                result["cpu_baseline"] = cpu_baseline(model, ids[0], px, first_tokens, banned, args)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "reference", "sample": f"failed: {e!r}"}
+            if not args.no_cpu_config1:
+                try:
+                    result["cpu_baseline"]["config1_ds1.3b_cpu"] = cpu_baseline_config1(args.cpu_budget)
+                except Exception as e:  # noqa: BLE001
+                    result["cpu_baseline"]["config1_ds1.3b_cpu"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -167,6 +167,7 @@ struct dtk_ctx {
   hipGraph_t graph = nullptr, graph_short = nullptr;
   hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
   int attn_full_max = 0;             // contexts below this use the one-block-per-head attention (measured slower: off)
+  int attn_threads = 0;              // decode attention: 0 = k_attn_decode (contiguous key range per split), 256 | 512 | 1024 = k_attn_decode_t
   int attn_impl = 0;                 // prefill / ViT attention kernel: 0 auto, 1 VALU, 2 MFMA flash (dtk_set_option "attn_impl")
   bool gemm_naive = false;
   int probe = 0;
@@ -359,9 +360,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->q = P.take<bf16_t>(d);
   c->act = P.take<bf16_t>(ff);
   c->logits = P.take<float>(V);
-  c->pm = P.take<float>((size_t)c->H * c->S);
-  c->pl = P.take<float>((size_t)c->H * c->S);
-  c->po = P.take<float>((size_t)c->H * c->S * 130);
+  c->pm = P.take<float>((size_t)c->H * 16);          // sized for the largest split factor (dtk_set_option "attn_splits")
+  c->pl = P.take<float>((size_t)c->H * 16);
+  c->po = P.take<float>((size_t)c->H * 16 * 130);
   c->attn_out = P.take<bf16_t>(d);
   c->attn_ctr = P.take<unsigned>(c->H);
   c->st = P.take<DecState>(1);
@@ -540,11 +541,14 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.q = c->q; ad.kcache = kcache(c, l); ad.vcache = vcache(c, l); ad.st = c->st;
     ad.pm = c->pm; ad.pl = c->pl; ad.po = c->po; ad.H = c->H; ad.S = c->S; ad.T_max = c->Tmax; ad.G = c->H / c->KVH;
     ad.scale = scale;
-    ad.combine = (short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
+    ad.threads = c->attn_threads;
+    ad.combine = (!ad.threads && short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
+    if (ad.threads && ad.combine == 1) ad.combine = 2;      // the tile kernel has no in-kernel combine
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
-    if (c->attn_combine) { g.x = c->attn_out; launch_gemv(PRO_COPY, EPI_RESID, g, s); }
+    const bool partials = ad.combine == 0 && !(ad.threads && ad.S == 1);   // o_proj's prologue reduces the split partials
+    if (!partials) { g.x = c->attn_out; launch_gemv(PRO_COPY, EPI_RESID, g, s); }
     else launch_gemv(PRO_ATTN, EPI_RESID, g, s);
     // 4. post_attention_layernorm + gate/up + SiLU*mul
     g.W = w.wgu; g.W8 = w.q_wgu; g.wscale = w.s_wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act;
@@ -1497,9 +1501,17 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_impl must be 0..2");
     c->attn_impl = value;
   }
-  else if (!strcmp(name, "attn_combine")) {
-    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_combine must be 0..2");
-    c->attn_combine = value;
+  else if (!strcmp(name, "attn_threads") || !strcmp(name, "attn_splits") || !strcmp(name, "attn_combine")) {
+    if (!strcmp(name, "attn_threads")) {
+      if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, DTK_ERR_ARG, "attn_threads must be 0, 256, 512 or 1024");
+      c->attn_threads = value;
+    } else if (!strcmp(name, "attn_splits")) {
+      if (value < 1 || value > 16) return fail(c, DTK_ERR_ARG, "attn_splits must be 1..16");
+      c->S = value;
+    } else {
+      if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_combine must be 0..2");
+      c->attn_combine = value;
+    }
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->graph_short_exec) { (void)hipGraphExecDestroy(c->graph_short_exec); c->graph_short_exec = nullptr; }

@@ -54,6 +54,7 @@ struct AttnDecArgs {
   bf16_t* out;           // [H*128] attention output (combine)
   unsigned* counters;    // [H] arrival tickets, zero between launches
   int G;                 // query heads per kv head (1 = MHA)
+  int threads;           // 0: contiguous key ranges per split (k_attn_decode); 256 | 512 | 1024: k_attn_decode_t, tiles dealt round-robin to the splits
 };
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s);
 

@@ -92,8 +92,11 @@ __device__ __forceinline__ void gemv_fma_f8(float (&acc)[NR], const u32x4 (&w)[N
 
 // Epilogue of one output unit (one lane per wave): `a0` is the fp32 dot product of the unit's row (paired epilogues:
 // a0 / a1 = the two rows of the pair: RoPE partners i, i+64 or gate, up).  Same HF rounding points as the reference.
+// `pre0` / `pre1`: operands the epilogue needs from memory, loaded at kernel start by the lane that runs it (EPI_RESID: the
+// residual value y[u]; EPI_QKV: cos / sin of (pos, i)) — a dependent load in the epilogue was ~1 us of exposed latency at
+// the very end of every wave; `pos` likewise (read once at kernel start).
 template <int EPI, bool F8>
-__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0, float a1) {
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0, float a1, float pre0, float pre1, int pos) {
     if (F8) {  // per-output-channel power-of-two scale (exact)
       if (EPI == EPI_QKV) {
         const int r0 = (u >> 6) * 128 + (u & 63);
@@ -110,7 +113,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0
       a.y[u] = f2bf(a0);
     } else if (EPI == EPI_RESID) {
       // HF: hidden = residual + proj(x); proj output is a bf16 tensor
-      a.y[u] = f2bf(bf2f(a.y[u]) + rbf(a0));
+      a.y[u] = f2bf(pre0 + rbf(a0));
     } else if (EPI == EPI_LOGITS) {
       a.logits[u] = rbf(a0);  // lm_head output is bf16, then .float()
     } else if (EPI == EPI_SWIGLU) {
@@ -122,7 +125,6 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0
       const int hb = u >> 6, i = u & 63;
       const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
       const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
-      const int pos = a.st->pos;
       const float x1 = rbf(a0);      // dim i
       const float x2 = rbf(a1);  // dim i + 64
       if (sec == 2) {
@@ -131,8 +133,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0
         dst[i + 64] = f2bf(x2);
       } else {
         // HF apply_rotary_pos_emb: q*cos + rotate_half(q)*sin, every product a bf16 tensor
-        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+        const float c = pre0, s = pre1;
         const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
         const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
         bf16_t* dst = (sec == 0) ? (a.q_out + head * 128)
@@ -147,11 +148,16 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int u, float a0
 // WAVES = waves per block.  PERSIST: grid-stride over chunks (chunk c -> block c % grid,
 // wave (c / grid) % WAVES) so a grid sized to the machine covers any N with <= 1 chunk of
 // imbalance per wave; otherwise one chunk per wave and the grid covers N.
-template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST, bool F8 = false>
+// KS > 1: split-K over KS waves of the block — the k-groups of a row (pair) are dealt round-robin to KS waves, whose partial
+// sums meet in LDS in a fixed order (deterministic).  For the N = d roles (o_proj, down: only d rows) this puts KS times the
+// waves, hence loads, in flight per row; the block then owns WAVES / KS row-chunks.
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST, bool F8 = false, int KS = 1>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   constexpr bool PAIRED = (EPI == EPI_QKV) || (EPI == EPI_SWIGLU);
   constexpr int NR = PAIRED ? 2 * R : R;
   constexpr int THREADS = WAVES * 64;
+  constexpr int RW = WAVES / KS;               // row-chunks (of R units) per block
+  static_assert(WAVES % KS == 0 && (KS == 1 || !PERSIST), "split-K variants are not persistent");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   const int K8 = a.K >> 3;                     // 16-byte chunks of x (bf16)
@@ -163,13 +169,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int rw = KS > 1 ? wave / KS : wave;    // which row-chunk of the block
+  const int ks = KS > 1 ? wave % KS : 0;       // which share of K
 
   int n_units;
   if (EPI == EPI_QKV) n_units = (a.N >> 1);
   else if (EPI == EPI_SWIGLU) n_units = a.ff;
   else n_units = a.N;
   const int chunk_stride = PERSIST ? (int)gridDim.x * WAVES : 0;
-  int chunk = PERSIST ? (int)blockIdx.x + (int)gridDim.x * wave : (int)blockIdx.x * WAVES + wave;
+  int chunk = PERSIST ? (int)blockIdx.x + (int)gridDim.x * wave : (int)blockIdx.x * RW + rw;
   int unit0 = chunk * R;
 
   const u32x4* rows[NR];
@@ -199,12 +207,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   set_rows(unit0);
 
   const int iters = (KC + 63) >> 6;
-  const int G = (iters + U - 1) / U;
+  const int Gall = (iters + U - 1) / U;
+  const int G = KS > 1 ? (Gall - ks + KS - 1) / KS : Gall;    // k-groups of this wave: ks, ks + KS, ...
+#define GIDX(g) (KS > 1 ? ks + KS * (g) : (g))
   u32x4 wa[NR][U], wb[NR][U];
   float acc[NR];
 
   // first stage of weights goes in flight before the prologue touches x
-  gemv_load<NR, U>(wa, rows, 0, lane, KC);
+  if (G > 0) gemv_load<NR, U>(wa, rows, GIDX(0), lane, KC);
+
+  // operands of the epilogue (see gemv_epilogue): issued now, consumed after the last weight chunk
+  float pre0[R], pre1[R];
+  int pos = 0;
+  if (EPI == EPI_QKV) pos = a.st->pos;
+  auto prefetch_epilogue = [&](int u0) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      pre0[j] = 0.f; pre1[j] = 0.f;
+      if (lane == 0 && ks == 0) {
+        int u = u0 + j;
+        if (u >= n_units) u = n_units - 1;
+        if (EPI == EPI_RESID) pre0[j] = bf2f(a.y[u]);
+        if (EPI == EPI_QKV) {
+          pre0[j] = bf2f(a.rope_cos[(size_t)pos * 64 + (u & 63)]);
+          pre1[j] = bf2f(a.rope_sin[(size_t)pos * 64 + (u & 63)]);
+        }
+      }
+    }
+  };
+  if (EPI == EPI_RESID || EPI == EPI_QKV) prefetch_epilogue(unit0);
 
   // ---- prologue: build the bf16 input vector in LDS
   if (PRO == PRO_COPY) {
@@ -213,56 +244,119 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
   } else if (PRO == PRO_RMSNORM) {
     const u32x4* x4 = reinterpret_cast<const u32x4*>(a.x);
     const u32x4* w4 = reinterpret_cast<const u32x4*>(a.norm_w);
-    float ss = 0.f;
-    for (int c = tid; c < K8; c += THREADS) {
-      const u32x4 v = x4[c];
+    if (K8 <= 2 * THREADS) {
+      // x and the norm weight in ONE memory round trip, kept in registers across the block reduction (the two-pass form
+      // re-read x after the barrier: a second dependent L1 / L2 trip in front of every RMSNorm GEMV)
+      const int c0 = tid, c1 = tid + THREADS;
+      const bool h0 = c0 < K8, h1 = c1 < K8;
+      const u32x4 zz = {0u, 0u, 0u, 0u};
+      const u32x4 v0 = h0 ? x4[c0] : zz, v1 = h1 ? x4[c1] : zz;
+      const u32x4 g0 = h0 ? w4[c0] : zz, g1 = h1 ? w4[c1] : zz;
+      float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = pk_lo(v[e]), hi = pk_hi(v[e]);
+        const float lo = pk_lo(v0[e]), hi = pk_hi(v0[e]);
         ss += lo * lo;
         ss += hi * hi;
       }
-    }
-    ss = wave_sum(ss);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) tot += red[w];
-    const float inv = rsqrtf(tot / (float)a.K + a.eps);
-    for (int c = tid; c < K8; c += THREADS) {
-      const u32x4 v = x4[c];
-      const u32x4 g = w4[c];
-      u32x4 o;
+      for (int e = 0; e < 4; ++e) {
+        const float lo = pk_lo(v1[e]), hi = pk_hi(v1[e]);
+        ss += lo * lo;
+        ss += hi * hi;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot += red[w];
+      const float inv = rsqrtf(tot / (float)a.K + a.eps);
+      u32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // HF LlamaRMSNorm: weight * (x * rsqrt(var+eps)).to(bf16)
-        const float nlo = rbf(pk_lo(v[e]) * inv), nhi = rbf(pk_hi(v[e]) * inv);
-        o[e] = pack2(pk_lo(g[e]) * nlo, pk_hi(g[e]) * nhi);
+        o0[e] = pack2(pk_lo(g0[e]) * rbf(pk_lo(v0[e]) * inv), pk_hi(g0[e]) * rbf(pk_hi(v0[e]) * inv));
+        o1[e] = pack2(pk_lo(g1[e]) * rbf(pk_lo(v1[e]) * inv), pk_hi(g1[e]) * rbf(pk_hi(v1[e]) * inv));
       }
-      xs[c] = o;
+      if (h0) xs[c0] = o0;
+      if (h1) xs[c1] = o1;
+    } else {
+      float ss = 0.f;
+      for (int c = tid; c < K8; c += THREADS) {
+        const u32x4 v = x4[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = pk_lo(v[e]), hi = pk_hi(v[e]);
+          ss += lo * lo;
+          ss += hi * hi;
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot += red[w];
+      const float inv = rsqrtf(tot / (float)a.K + a.eps);
+      for (int c = tid; c < K8; c += THREADS) {
+        const u32x4 v = x4[c];
+        const u32x4 g = w4[c];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float nlo = rbf(pk_lo(v[e]) * inv), nhi = rbf(pk_hi(v[e]) * inv);
+          o[e] = pack2(pk_lo(g[e]) * nlo, pk_hi(g[e]) * nhi);
+        }
+        xs[c] = o;
+      }
     }
   } else {  // PRO_ATTN: reduce the S split-K partials of every head (flash-decode combine)
+    // Every load of a group of 4 splits is issued before the first use: one L2 round trip per group instead of one per
+    // split (a runtime-bounded loop of load -> exp -> fma made the prologue S dependent trips long).  The sums run over
+    // s = 0, 1, 2, ... in that order, as in k_attn_combine.
     const int S = a.S;
     for (int c = tid; c < K8; c += THREADS) {
       const int head = c >> 4;       // 16 chunks of 8 dims per 128-dim head
       const int d0 = (c & 15) * 8;
+      const float* pmh = a.pm + head * S;
+      const float* plh = a.pl + head * S;
       float M = -1e30f;
-      for (int s = 0; s < S; ++s) M = fmaxf(M, a.pm[head * S + s]);
+      for (int s0 = 0; s0 < S; s0 += 4) {
+        float m4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m4[j] = (s0 + j < S) ? pmh[s0 + j] : -1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) M = fmaxf(M, m4[j]);
+      }
       float L = 0.f;
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float w = __expf(a.pm[head * S + s] - M);
-        L += w * a.pl[head * S + s];
-        const f32x4* po4 =
-            reinterpret_cast<const f32x4*>(a.po + ((size_t)(head * S + s)) * 128 + d0);
-        const f32x4 p0 = po4[0], p1 = po4[1];
+      for (int s0 = 0; s0 < S; s0 += 4) {
+        float m4[4], l4[4];
+        f32x4 p0[4], p1[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] += w * p0[e];
-          o[4 + e] += w * p1[e];
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = s0 + j < S;
+          const int sj = ok ? s0 + j : s0;
+          m4[j] = ok ? pmh[sj] : -1e30f;
+          l4[j] = ok ? plh[sj] : 0.f;
+          const f32x4* po4 = reinterpret_cast<const f32x4*>(a.po + ((size_t)(head * S + sj)) * 128 + d0);
+          p0[j] = po4[0];
+          p1[j] = po4[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (s0 + j < S) {
+            const float w = __expf(m4[j] - M);
+            L += w * l4[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] += w * p0[j][e];
+              o[4 + e] += w * p1[j][e];
+            }
+          }
         }
       }
       const float invL = 1.f / L;
@@ -280,36 +374,58 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs a) {
     for (int r = 0; r < NR; ++r) acc[r] = 0.f;
     // ---- main loop: two register stages (wa holds stage 0 on entry)
     for (int g = 0; g < G; g += 2) {
-      if (g + 1 < G) gemv_load<NR, U>(wb, rows, g + 1, lane, KC);
-      if (F8) gemv_fma_f8<NR, U>(acc, wa, xs, g, lane, KC); else gemv_fma<NR, U>(acc, wa, xs, g, lane, KC);
+      if (g + 1 < G) gemv_load<NR, U>(wb, rows, GIDX(g + 1), lane, KC);
+      if (F8) gemv_fma_f8<NR, U>(acc, wa, xs, GIDX(g), lane, KC); else gemv_fma<NR, U>(acc, wa, xs, GIDX(g), lane, KC);
       if (g + 1 < G) {
-        if (g + 2 < G) gemv_load<NR, U>(wa, rows, g + 2, lane, KC);
-        if (F8) gemv_fma_f8<NR, U>(acc, wb, xs, g + 1, lane, KC); else gemv_fma<NR, U>(acc, wb, xs, g + 1, lane, KC);
+        if (g + 2 < G) gemv_load<NR, U>(wa, rows, GIDX(g + 2), lane, KC);
+        if (F8) gemv_fma_f8<NR, U>(acc, wb, xs, GIDX(g + 1), lane, KC); else gemv_fma<NR, U>(acc, wb, xs, GIDX(g + 1), lane, KC);
       }
     }
     const int cur = unit0;
+    float q0[R], q1[R];          // this chunk's epilogue operands (the next chunk's are fetched below)
+#pragma unroll
+    for (int j = 0; j < R; ++j) { q0[j] = pre0[j]; q1[j] = pre1[j]; }
     if (PERSIST) {  // next chunk's first stage goes in flight before this chunk's reduction
       chunk += chunk_stride;
       unit0 = chunk * R;
       if (unit0 < n_units) {
         set_rows(unit0);
         gemv_load<NR, U>(wa, rows, 0, lane, KC);
+        if (EPI == EPI_RESID || EPI == EPI_QKV) prefetch_epilogue(unit0);
       }
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+    if (KS > 1) {   // partial sums of the KS waves of a row-chunk meet in LDS; wave ks == 0 adds them in a fixed order
+      float* part = red + WAVES;                       // [RW][NR][KS]
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) part[(rw * NR + r) * KS + ks] = acc[r];
+      }
+      __syncthreads();
+      if (ks == 0 && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float t = part[(rw * NR + r) * KS];
+#pragma unroll
+          for (int k = 1; k < KS; ++k) t += part[(rw * NR + r) * KS + k];
+          acc[r] = t;
+        }
+      }
+    }
 
-    // ---- epilogue (one lane per wave; a handful of scalars)
-    if (active && lane == 0) {
+    // ---- epilogue (one lane per row-chunk; a handful of scalars)
+    if (active && lane == 0 && ks == 0) {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const int u = cur + j;
         if (u >= n_units) break;
-        gemv_epilogue<EPI, F8>(a, u, PAIRED ? acc[2 * j] : acc[j], PAIRED ? acc[2 * j + 1] : 0.f);
+        gemv_epilogue<EPI, F8>(a, u, PAIRED ? acc[2 * j] : acc[j], PAIRED ? acc[2 * j + 1] : 0.f, q0[j], q1[j], pos);
       }
     }
     if (!PERSIST || unit0 >= n_units) break;
   }
+#undef GIDX
 }
 
 // number of CUs of the current device (cached) — persistent grids are sized from it
@@ -324,22 +440,23 @@ static int num_cus() {
   return n;
 }
 
-template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST>
+template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST, int KS = 1>
 static void launch_gemv_t(const GemvArgs& a, hipStream_t s, int blocks_per_cu) {
   int n_units = (EPI == EPI_QKV) ? (a.N >> 1) : (EPI == EPI_SWIGLU ? a.ff : a.N);
-  const int per_block = WAVES * R;
+  const int per_block = (WAVES / KS) * R;
   int grid = (n_units + per_block - 1) / per_block;
   if (PERSIST) {
     const int cap = num_cus() * (blocks_per_cu > 0 ? blocks_per_cu : 2);
     if (grid > cap) grid = cap;
   }
-  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
-  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, PERSIST>), dim3(grid), dim3(WAVES * 64), lds, s, a);
+  const size_t lds = (size_t)(a.K >> 3) * 16 + 64 + 1024;   // x (bf16) + per-wave RMSNorm partials + split-K partials
+  hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, PERSIST, false, KS>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
 
 // Tuning table: variant -> instantiation.  Variant 0 is the product default for each role; the
 // others exist for the in-situ microbenchmark (dtk_bench_gemv) that picked the default.
 #define GV(PRO, EPI, R, U, W, P, BPC) return launch_gemv_t<PRO, EPI, R, U, W, P>(a, s, BPC)
+#define GVK(PRO, EPI, R, U, W, KS) return launch_gemv_t<PRO, EPI, R, U, W, false, KS>(a, s, 0)
 void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipStream_t s) {
   if (pro == PRO_RMSNORM && epi == EPI_QKV) {
     switch (variant) {
@@ -388,9 +505,32 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
       case 5: GV(PRO_COPY, EPI_RESID, 2, 4, 8, true, 2);
       case 6: GV(PRO_COPY, EPI_RESID, 1, 8, 4, false, 0);
       case 7: GV(PRO_COPY, EPI_RESID, 2, 2, 4, false, 0);
+      // split-K over the waves of a block (KS waves share a row): twice / four times the loads in flight per row
+      case 13: GVK(PRO_COPY, EPI_RESID, 1, 4, 8, 2);    // o_proj (K 4096): one k-group per wave, 4 rows per block
+      case 14: GVK(PRO_COPY, EPI_RESID, 2, 4, 8, 2);    //                  8 rows per block
+      case 15: GVK(PRO_COPY, EPI_RESID, 1, 6, 8, 2);    // down (K 11008): 22 k-iterations = 4 groups of 6, two per wave
+      case 16: GVK(PRO_COPY, EPI_RESID, 2, 6, 8, 2);
+      case 17: GVK(PRO_COPY, EPI_RESID, 1, 6, 16, 4);   // one group of 6 iterations per wave, 4 rows per 16-wave block
+      case 18: GVK(PRO_COPY, EPI_RESID, 1, 2, 16, 4);   // o_proj: 2 iterations per wave
+      case 19: GVK(PRO_COPY, EPI_RESID, 1, 3, 8, 2);    // down, 8 groups of 3 iterations
+      case 20: GVK(PRO_COPY, EPI_RESID, 1, 4, 4, 2);    // 2 rows per 4-wave block
+      case 21: GVK(PRO_COPY, EPI_RESID, 1, 6, 4, 2);
+      case 22: GVK(PRO_COPY, EPI_RESID, 4, 2, 8, 2);
     }
   }
-  if (pro == PRO_ATTN && epi == EPI_RESID) GV(PRO_ATTN, EPI_RESID, 2, 4, 4, false, 0);
+  if (pro == PRO_ATTN && epi == EPI_RESID) {   // o_proj that reduces the attention partials in its prologue: fewer, fatter blocks
+    switch (variant) {                          // (every block reads ALL partials: H * S * 130 floats)
+      default: GV(PRO_ATTN, EPI_RESID, 2, 4, 8, false, 0);   // 16 rows per block
+      case 1: GV(PRO_ATTN, EPI_RESID, 2, 4, 4, false, 0);    // 8 rows (the round-1 shape)
+      case 2: GV(PRO_ATTN, EPI_RESID, 1, 8, 8, false, 0);    // 8 rows, one per wave
+      case 3: GV(PRO_ATTN, EPI_RESID, 4, 2, 8, false, 0);    // 32 rows
+      case 4: GV(PRO_ATTN, EPI_RESID, 4, 2, 4, false, 0);    // 16 rows, 4 waves
+      case 5: GVK(PRO_ATTN, EPI_RESID, 2, 4, 8, 2);          // 8 rows, split-K 2
+      case 6: GVK(PRO_ATTN, EPI_RESID, 4, 4, 8, 2);          // 16 rows, split-K 2
+      case 7: GV(PRO_ATTN, EPI_RESID, 2, 4, 16, false, 0);   // 32 rows, 16 waves
+      case 8: GVK(PRO_ATTN, EPI_RESID, 2, 4, 16, 2);         // 16 rows, 16 waves, split-K 2
+    }
+  }
   if (pro == PRO_RMSNORM && epi == EPI_LOGITS) {
     switch (variant) {
       default: GV(PRO_RMSNORM, EPI_LOGITS, 2, 4, 4, false, 0);
@@ -409,6 +549,7 @@ void launch_gemv_variant(int pro, int epi, int variant, const GemvArgs& a, hipSt
   GV(PRO_COPY, EPI_STORE, 4, 2, 4, false, 0);
 }
 #undef GV
+#undef GVK
 
 template <int PRO, int EPI, int R, int U, int WAVES, bool PERSIST = false, int BPC = 4>
 static void launch_gemv_f8_t(const GemvArgs& a, hipStream_t s) {
@@ -416,7 +557,7 @@ static void launch_gemv_f8_t(const GemvArgs& a, hipStream_t s) {
   const int per_block = WAVES * R;
   int grid = (n_units + per_block - 1) / per_block;
   if (PERSIST && grid > num_cus() * BPC) grid = num_cus() * BPC;
-  const size_t lds = (size_t)(a.K >> 3) * 16 + 64;
+  const size_t lds = (size_t)(a.K >> 3) * 16 + 64 + 1024;
   hipLaunchKernelGGL((k_gemv<PRO, EPI, R, U, WAVES, PERSIST, true>), dim3(grid), dim3(WAVES * 64), lds, s, a);
 }
 // fp8-weight decode GEMVs (requires K % 16 == 0); same roles as the bf16 defaults.  An fp8 row is half
@@ -458,18 +599,26 @@ void launch_gemv_f8(int pro, int epi, const GemvArgs& a, hipStream_t s) {
 #undef F8
 #undef F8P
 
-static int g_variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-epilogue default variant (tuned)
+// per-role default variant (tuned): indexed by epilogue; slot 5 = o_proj (EPI_RESID with K == d) when it has its own choice
+// (-1: same as EPI_RESID), slot 6 = o_proj with the PRO_ATTN prologue
+static int g_variant[8] = {0, 0, 0, 0, 0, -1, 0, 0};
 void set_gemv_default_variant(int epi, int variant) { if (epi >= 0 && epi < 8) g_variant[epi] = variant; }
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, hipStream_t s) {
   if (a.W8) return launch_gemv_f8(pro, epi, a, s);
+  if (pro == PRO_ATTN) return launch_gemv_variant(pro, epi, g_variant[6], a, s);
   int v = g_variant[epi & 7];
-  // d <= 2048 (ds-1.3b / tl-1.1b): the per-layer kernels stream only 8-45 MB each, so fewer, fatter waves win
-  // (tools/tune_gemv.py on ds-1.3b: gate/up persistent 8-wave 9.35 us vs 10.44; decode 1049 -> 1100 tok/s)
+  const bool o_proj = epi == EPI_RESID && a.K == a.d;
+  if (o_proj && g_variant[5] >= 0) v = g_variant[5];
+  // Measured defaults (tools/tune_decode.py, profiles/r02_tune_decode_*.log); variant 0 of a role = "not chosen by the caller".
   if (v == 0 && a.d > 0 && a.d <= 2048) {
-    if (epi == EPI_SWIGLU) v = 5;        // (R 1, U 4, 8 waves, persistent, 2 blocks per CU)
-    else if (epi == EPI_QKV) v = 9;      // (R 1, U 1, 4 waves)
-    else if (epi == EPI_RESID) v = 10;   // (R 1, U 8, 8 waves)
+    // d <= 2048 (ds-1.3b): every kernel streams 8-45 MB and sits on its ~4 us launch + latency floor
+    if (epi == EPI_SWIGLU) v = 5;                    // (R 1, U 4, 8 waves, persistent, 2 blocks per CU): 9.8 us vs 10.3
+    else if (epi == EPI_RESID) v = o_proj ? 1 : 15;  // o_proj (R 1, U 4, 4 waves) 4.08 us; down split-K 2 (R 1, U 6, 8 waves) 6.88 vs 7.41
+    else if (epi == EPI_LOGITS) v = 3;               // (R 1, U 4, 4 waves) 20.0 us vs 21.9
+  } else if (v == 0 && a.d > 2048) {
+    if (epi == EPI_RESID) v = 10;                    // (R 1, U 8, 8 waves): o_proj 7.76 us, down 17.67; whole step 380 -> 383 tok/s
+    else if (epi == EPI_LOGITS) v = 3;               // 37.9 us vs 38.9
   }
   launch_gemv_variant(pro, epi, v, a, s);
 }
@@ -764,7 +913,135 @@ __global__ __launch_bounds__(1024) void k_attn_decode_head(AttnDecArgs a) {
   }
 }
 
+// Position-independent split scheme (variant 1): the keys are cut into tiles of ROWS = 16 * WAVES rows and tile t belongs to
+// split t % S, so a block knows its first tile WITHOUT the position: its K/V loads (and q) go in flight before `pos` has
+// been read — one dependent memory trip less on the critical path of a latency-bound kernel — and are masked once it has.
+// THREADS = 256 / 512 / 1024 trades blocks for rows per memory round trip (64 / 128 / 256); with S splits one round trip
+// covers S * ROWS keys.  S == 1 writes the normalised bf16 head output itself (no partials, no combine).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_attn_decode_t(AttnDecArgs a) {
+  constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
+  const int h = blockIdx.x, sp = blockIdx.y, S = a.S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int kvh = h / a.G;
+  const bf16_t* kbase = a.kcache + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)kvh * a.T_max * 128;
+  u32x4 kv[4], vv[4];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int j = t * ROWS + i * (ROWS / 4) + wave * 4 + grp;
+      j = min(j, a.T_max - 1);        // always a row of the cache; rows at or beyond the context are masked below
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)j * 128)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)j * 128)[sub];
+    }
+  };
+  int t = sp;
+  load_tile(t);
+  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + h * 128)[sub];
+  const int n = a.st->pos + 1;        // keys 0..pos (this step's k/v were appended by the QKV kernel)
+
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  while (t * ROWS < n) {
+    u32x4 kc[4], vc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { kc[i] = kv[i]; vc[i] = vv[i]; }
+    const int tcur = t;
+    t += S;
+    if (t * ROWS < n) load_tile(t);   // contexts beyond S * ROWS keys: next tile in flight under this one's arithmetic
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = tcur * ROWS + i * (ROWS / 4) + wave * 4 + grp;
+      float s = dot8(qv, kc[i], 0.f);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s *= a.scale;
+      if (j < n) {
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn);
+        const float p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = o[2 * e] * corr + p * pk_lo(vc[i][e]);
+          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vc[i][e]);
+        }
+        m = mn;
+      }
+    }
+  }
+  // merge the 4 row-groups of the wave (lanes with equal sub)
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64);
+    const float l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * c1 + o2 * c2;
+    }
+    m = mn;
+  }
+  __shared__ float sm_m[WAVES][16], sm_l[WAVES][16], sm_o[WAVES][16][8];
+  if (grp == 0) {
+    sm_m[wave][sub] = m;
+    sm_l[wave][sub] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float M = sm_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[w][tid]);
+    float L = 0.f;
+    float oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const float c = __expf(sm_m[w][tid] - M);
+      L += c * sm_l[w][tid];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+    }
+    if (S == 1) {     // the whole head in this block: normalise and round once, no partials
+      const float invL = 1.f / L;
+      u32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = pack2(oo[2 * e] * invL, oo[2 * e + 1] * invL);
+      reinterpret_cast<u32x4*>(a.out + h * 128)[tid] = ov;
+      return;
+    }
+    const size_t slot = (size_t)h * S + sp;   // partials for k_attn_combine / the consumer-side combine (k_gemv<PRO_ATTN>)
+    f32x4* dst = reinterpret_cast<f32x4*>(a.po + slot * 128 + tid * 8);
+    dst[0] = (f32x4){oo[0], oo[1], oo[2], oo[3]};
+    dst[1] = (f32x4){oo[4], oo[5], oo[6], oo[7]};
+    if (tid == 0) {
+      a.pm[slot] = M;         // a split without a key below the context keeps M = -1e30, L = 0: weight exp(-1e30 - max) = 0
+      a.pl[slot] = L;
+    }
+  }
+}
+
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s) {
+  if (a.threads) {   // tile-interleaved splits (k_attn_decode_t); a.combine: 0 consumer reduces the partials, 2 own kernel; S == 1: direct
+    const dim3 grid(a.H, a.S);
+    if (a.threads >= 1024) hipLaunchKernelGGL(k_attn_decode_t<1024>, grid, dim3(1024), 0, s, a);
+    else if (a.threads >= 512) hipLaunchKernelGGL(k_attn_decode_t<512>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_attn_decode_t<256>, grid, dim3(256), 0, s, a);
+    if (a.S > 1 && a.combine == 2) hipLaunchKernelGGL(k_attn_combine, dim3(a.H), dim3(128), 0, s, a);
+    return;
+  }
   if (a.combine == 3) {  // one block per head, output written directly
     hipLaunchKernelGGL(k_attn_decode_head, dim3(a.H), dim3(1024), 0, s, a);
     return;

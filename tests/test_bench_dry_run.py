@@ -21,7 +21,7 @@ class _BenchDevice(ScriptedDevice):
                                   last_vit_ms=0.5, vit_images=0)
 
     def stats(self):
-        return dict(self._stats)
+        return defaultdict(float, self._stats, decode_steps=self.launches)
 
     def synchronize(self):
         pass
@@ -65,19 +65,23 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert b["batch_per_gpu"] == 8 and b["images_in_flight"] == 3 and b["rollouts_per_sec"] > 0
     assert b["frac_of_hbm_peak"] == pytest.approx(b["achieved_GBps"] / 8000.0)
     assert b["roofline_rollouts_per_sec"] == pytest.approx(b["rollouts_per_sec"] / b["frac_of_hbm_peak"], rel=1e-6)
-    m = d["mcts_stub_reward"]
+    m = d["mcts"]
     assert "error" not in m, m
-    assert m["rollouts"] == 8 and m["trees_per_gpu"] == 4
+    assert m["parallel"]["rollouts"] == 8 and m["parallel"]["trees_per_gpu"] == 4
+    assert m["sequential"]["rollouts"] == 3 and m["sequential"]["trees_per_gpu"] == 1      # one tree: the unmodified search
+    assert d["mcts_rollouts_per_sec"] == m["parallel"]["rollouts_per_sec"] > 0
+    assert d["mcts_rollouts_per_sec_sequential"] == m["sequential"]["rollouts_per_sec"] > 0
+    assert d["ranks"] == [d["ranks"][0]] and d["ranks"][0]["world"] == 1
 
 
 def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):
     d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
                                          "--batch", "4", "--skip-batched", "--mcts-trees", "2", "--mcts-expansions", "1",
                                          "--probe-tokens", "2"])
-    assert "batched_rollouts" not in d and d["mcts_stub_reward"]["rollouts"] == 2
+    assert "batched_rollouts" not in d and d["mcts"]["parallel"]["rollouts"] == 2 and d["mcts"]["sequential"]["rollouts"] == 3
     d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
-                                         "--batch", "0", "--probe-tokens", "2", "--sample"])
-    assert "batched_rollouts" not in d and "mcts_stub_reward" not in d and d["value"] > 0
+                                         "--batch", "0", "--probe-tokens", "2", "--sample", "--mcts-seq-expansions", "0"])
+    assert "batched_rollouts" not in d and "mcts" not in d and d["value"] > 0
 
 
 def _rank_main(rank, world, port, outdir):
@@ -121,3 +125,6 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["value"] == pytest.approx(2 * 2 * 16 / (2 * d["ms_per_step"] / 1e3), rel=0.2)   # both ranks' tokens / max time
     assert d["batched_rollouts"]["rollouts_per_sec"] > 0
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["backend"] == "gloo" for r in d["ranks"])
+    assert d["mcts"]["sequential"]["rollouts"] == 2 * 3 and d["mcts"]["sequential"]["merged_on_rank0"] >= 1   # root-parallel over the ranks
+    assert d["mcts"]["parallel"]["rollouts"] == 2 * 4 * 2

@@ -339,24 +339,95 @@ def test_graph_replay_equals_plain_launches(tiny):
 
 def test_attention_variants_agree(tiny):
     """decode attention: one-block-per-head (short contexts) vs split-K + combine kernel vs split-K with
-    consumer-side / in-kernel combine — identical greedy tokens, logits within the single-op bound"""
+    consumer-side / in-kernel combine, and the tile-interleaved kernel (256 / 512 / 1024 threads, 1..16 splits, own-kernel or
+    consumer-side combine, direct output at one split) — identical greedy tokens, logits within the single-op bound"""
     model, proc = tiny
     enc = proc(images=sketch_image(9, 96), return_tensors="pt")
     ids, px = enc.input_ids[0], enc.pixel_values
     outs, logs = {}, {}
+    configs = [("head", dict(attn_threads=0, attn_splits=4, attn_full_max=4096, attn_combine=2)),
+               ("split", dict(attn_threads=0, attn_splits=4, attn_full_max=0, attn_combine=2)),
+               ("consumer", dict(attn_threads=0, attn_splits=4, attn_full_max=0, attn_combine=0)),
+               ("inkernel", dict(attn_threads=0, attn_splits=4, attn_full_max=0, attn_combine=1))]
+    for threads in (256, 512, 1024):
+        for splits in (1, 2, 4, 16):
+            for combine in (2, 0):
+                configs.append((f"tile{threads}/s{splits}/c{combine}",
+                                dict(attn_threads=threads, attn_splits=splits, attn_full_max=0, attn_combine=combine)))
     try:
-        for name, opts in (("head", dict(attn_full_max=4096, attn_combine=2)), ("split", dict(attn_full_max=0, attn_combine=2)),
-                           ("consumer", dict(attn_full_max=0, attn_combine=0)), ("inkernel", dict(attn_full_max=0, attn_combine=1))):
+        for name, opts in configs:
             for k, v in opts.items():
                 model.set_option(k, v)
             outs[name] = run_greedy(model, ids, px, 40)
             logs[name] = model.get_logits()
     finally:
-        model.set_option("attn_combine", 2)
-        model.set_option("attn_full_max", 0)
-    for name in ("split", "consumer", "inkernel"):
+        for k, v in dict(attn_combine=2, attn_full_max=0, attn_threads=0, attn_splits=4).items():
+            model.set_option(k, v)          # TINY's configuration (attn_splits 4)
+    for name, _ in configs[1:]:
         assert outs[name] == outs["head"], name
         assert rel_l2(logs[name], logs["head"]) < 5e-3, name
+
+
+def test_long_context_attention_tiles_wrap_around(tiny):
+    """contexts longer than splits x rows-per-tile: a block of the tile-interleaved attention walks several tiles (tile t
+    belongs to split t % S); every geometry must agree with the contiguous-range kernel at 150 keys"""
+    model, proc = tiny
+    enc = proc(images=sketch_image(3, 96), return_tensors="pt")
+    ids = torch.cat([enc.input_ids[0], torch.arange(20, 20 + 120) % 500 + 3])       # 12 + 120 tokens of context
+    ref, got = None, {}
+    try:
+        for threads, splits in ((0, 4), (256, 1), (256, 2), (512, 1), (1024, 1), (256, 16)):
+            model.set_option("attn_threads", threads)
+            model.set_option("attn_splits", splits)
+            toks = run_greedy(model, ids, enc.pixel_values, 24)
+            lg = model.get_logits()
+            if ref is None:
+                ref = (toks, lg)
+            got[(threads, splits)] = (toks, lg)
+    finally:
+        model.set_option("attn_threads", 0)
+        model.set_option("attn_splits", 4)
+    for key, (toks, lg) in got.items():
+        assert toks == ref[0], key
+        assert rel_l2(lg, ref[1]) < 5e-3, key
+
+
+def test_gemv_variants_agree(tiny):
+    """every tuned shape of the decode GEMVs (rows per wave, waves per block, persistent grids, split-K over the waves of
+    a block, the o_proj that reduces the attention partials in its prologue) computes the same step: identical greedy
+    tokens, logits within the single-op bound of the default shapes"""
+    model, proc = tiny
+    enc = proc(images=sketch_image(4, 96), return_tensors="pt")
+    ids, px = enc.input_ids[0], enc.pixel_values
+    lib, ctx = model.lib, model._ctx
+    base = run_greedy(model, ids, px, 24)
+    base_logits = model.get_logits()
+    EPI_RESID, EPI_QKV, EPI_SWIGLU, EPI_LOGITS, O_PROJ, O_PROJ_ATTN = 1, 2, 3, 4, 5, 6
+    sweeps = [(EPI_QKV, range(0, 12)), (EPI_SWIGLU, range(0, 12)), (EPI_LOGITS, range(0, 5)),
+              (EPI_RESID, list(range(0, 13)) + list(range(13, 23))), (O_PROJ, [13, 14, 18, 20, 10])]
+    try:
+        for slot, variants in sweeps:
+            for v in variants:
+                model._check(lib.dtk_set_gemv_variant(ctx, slot, v), "dtk_set_gemv_variant")
+                toks = run_greedy(model, ids, px, 24)
+                assert toks == base, (slot, v)
+                assert rel_l2(model.get_logits(), base_logits) < 5e-3, (slot, v)
+            model._check(lib.dtk_set_gemv_variant(ctx, slot, -1 if slot == O_PROJ else 0), "dtk_set_gemv_variant")
+        model.set_option("attn_combine", 0)         # partials reduced by o_proj's prologue
+        for threads, splits in ((0, 4), (512, 2)):
+            model.set_option("attn_threads", threads)
+            model.set_option("attn_splits", splits)
+            for v in range(0, 9):
+                model._check(lib.dtk_set_gemv_variant(ctx, O_PROJ_ATTN, v), "dtk_set_gemv_variant")
+                toks = run_greedy(model, ids, px, 24)
+                assert toks == base, ("o_proj+combine", threads, splits, v)
+                assert rel_l2(model.get_logits(), base_logits) < 5e-3, ("o_proj+combine", threads, splits, v)
+    finally:
+        for slot in (EPI_RESID, EPI_QKV, EPI_SWIGLU, EPI_LOGITS, O_PROJ_ATTN):
+            lib.dtk_set_gemv_variant(ctx, slot, 0)
+        lib.dtk_set_gemv_variant(ctx, O_PROJ, -1)
+        for k, v in dict(attn_combine=2, attn_threads=0, attn_splits=4).items():
+            model.set_option(k, v)
 
 
 def test_prefix_and_image_reuse_is_output_identical(tiny):
@@ -833,8 +904,10 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
                 model_max_length=TINY.max_positions, vit_dim=TINY.vit_dim, vit_depth=TINY.vit_depth, vit_heads=TINY.vit_heads,
                 vit_mlp=TINY.vit_mlp, vit_patch=TINY.vit_patch, vit_image=TINY.vit_image, attn_splits=TINY.attn_splits)
     (tmp_path / "config.json").write_text(json.dumps(cfgj))
-    with pytest.warns(UserWarning):
-        model, proc = load(str(tmp_path))
+    with pytest.raises(Exception):          # a checkpoint directory must carry its tokenizer, as the reference's loader requires
+        load(str(tmp_path))
+    with pytest.warns(UserWarning, match="GELU"):       # a v1 config.json does not record the tower's activation: say which is used
+        model, proc = load(str(tmp_path), synthetic_tokenizer=True)
     ref, _ = tiny
     for name in ("model.layers.1.self_attn.k_proj.weight", "vision_model.blocks.0.attn.qkv.weight",
                  "vision_model.patch_embed.proj.weight", "model.mm_projector.bias", "lm_head.weight"):
@@ -842,8 +915,8 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
     enc = proc(images=sketch_image(4, 96), return_tensors="pt")
     assert run_greedy(model, enc.input_ids[0], enc.pixel_values, 24) == run_greedy(ref, enc.input_ids[0], enc.pixel_values, 24)
     (tmp_path / "vision_tower.safetensors").unlink()
-    with pytest.raises(KeyError), pytest.warns(UserWarning):
-        load(str(tmp_path))
+    with pytest.raises(KeyError):
+        load(str(tmp_path), synthetic_tokenizer=True)
 
 
 # ------------------------------------------------------------------------------------------ v2 models (f2)
@@ -983,9 +1056,9 @@ def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
             "vision_config": {"hidden_size": c.vit_dim, "intermediate_size": c.vit_mlp, "num_hidden_layers": c.vit_depth,
                               "num_attention_heads": c.vit_heads, "image_size": c.vit_image, "patch_size": c.vit_patch,
                               "hidden_act": "gelu_pytorch_tanh"}}
+    cfgj["synthetic_tokenizer"] = True         # weight-only fixture: opt into the byte-level stand-in tokenizer
     (tmp_path / "config.json").write_text(json.dumps(cfgj))
-    with pytest.warns(UserWarning):
-        model, proc = load(str(tmp_path))
+    model, proc = load(str(tmp_path))
     assert model.config.arch == "v2" and model.config.num_kv_heads == 2 and not model.config.proj_bias
     for name in ("model.layers.1.self_attn.v_proj.weight", "vision_model.blocks.1.attn.qkv.weight", "vision_model.attn_pool.kv.bias",
                  "vision_model.pos_embed", "model.mm_projector.weight", "lm_head.weight", "rope.cos"):
