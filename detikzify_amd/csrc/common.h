@@ -69,7 +69,12 @@ struct DecState {
 struct BatchState {
   int32_t active[DTK_MAX_BATCH];
   int32_t step;      // global step counter (token ring index)
-  int32_t pad[15];
+  // the prefix most active slots share (chosen by the host per step): slot `pfx_src` holds it in its first `pfx_len` rows.
+  // k_attn_prefix_b scores it ONCE for all slots on the matrix cores; a slot is a member iff it reads those rows from
+  // pfx_src (share_src == pfx_src, share_len >= pfx_len) or is pfx_src itself.  pfx_len == 0: no such prefix this step.
+  int32_t pfx_src;
+  int32_t pfx_len;
+  int32_t pad[13];
   // forked slots (dtk_kv_fork) hold a bit-identical copy of their source's first share_len keys: attention reads those
   // rows from the SOURCE slot's cache instead (-1 = none), so the 32 rollouts of one image stream the 243-key image
   // prefix from HBM once per layer and hit the XCD's L2 afterwards
@@ -81,6 +86,9 @@ struct BatchState {
 // the MFMA B-operand fragment order: tile (slot/16, k/32) is 1 KiB, lane = ((k%32)/8)*16 + slot%16 holds 8
 // consecutive k.  A wave's x load is then 1 KiB contiguous (8 full cache lines) instead of 16 rows x 64 B
 // (16 half-used lines): measured gate/up at 32 slots 48.3 -> 35.2 us.
+__device__ __forceinline__ bool pfx_member(const BatchState* bs, int slot) {
+  return bs->pfx_len > 0 && (slot == bs->pfx_src || (bs->share_src[slot] == bs->pfx_src && bs->share_len[slot] >= bs->pfx_len));
+}
 __device__ __forceinline__ size_t xtile_off(int slot, int k, int nsteps) {
   return ((size_t)((slot >> 4) * nsteps + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (slot & 15)) * 8 + (k & 7);
 }

@@ -95,7 +95,7 @@ struct dtk_ctx {
   float *logits, *pm, *pl, *po;
   bf16_t* attn_out = nullptr;        // combined attention output [d] (in-kernel combine)
   unsigned* attn_ctr = nullptr;      // [H] arrival tickets
-  int attn_combine = 2;              // 0: consumer (o_proj prologue), 1: last-arriver in k_attn_decode, 2: own kernel
+  int attn_combine = 0;              // 0: consumer (o_proj prologue), 1: last-arriver in k_attn_decode, 2: own kernel
   DecState* st = nullptr;
   SamplingDev* sp = nullptr;
   int64_t* tok_ring_dev = nullptr;   // device ring
@@ -129,6 +129,11 @@ struct dtk_ctx {
   size_t kv_slot_stride = 0;
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
   float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
+  float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
+  int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
+  int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
+  int pfx_splits = 2;                // key splits of that kernel
+  int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4)
   DecState* st_b = nullptr;          // [16]
   SamplingDev* sp_b = nullptr;       // [16]
   BatchState* bs_dev = nullptr;
@@ -414,6 +419,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pmb = P.take<float>((size_t)c->nb * c->H * c->Sb);
     c->plb = P.take<float>((size_t)c->nb * c->H * c->Sb);
     c->pob = P.take<float>((size_t)c->nb * c->H * c->Sb * 128);
+    c->pfx_m = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
+    c->pfx_l = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
+    c->pfx_o = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4 * 128);
     c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
     c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
     c->smb_b = P.take<SampleMB>(DTK_MAX_BATCH + 1);
@@ -591,6 +599,8 @@ void batch_step_launches(dtk_ctx* c) {
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
     ad.scale = scale;
+    ad.impl = c->attn_b_impl; ad.use_prefix = c->attn_b_impl == 1 && c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads;
+    ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
     launch_gemv_b(EPI_RESID, g, s);
@@ -763,7 +773,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   // split-K factor of the decode attention: an explicit config value applies to both paths; auto = 16 for one sequence
   // (ds-7b 369.6 -> 373.0, ds-1.3b 1092 -> 1111, v2-8b 343.4 -> 345.1 tok/s over 8) and 8 for the batched step
   // (32 slots already give 8192 blocks: 4.53 ms/step vs 4.69 with 16)
-  c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 16;
+  c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 4;     // tile-interleaved splits: 4 x 128 rows cover 512 keys per memory round trip
   c->Sb = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = c->Sb = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
@@ -779,7 +789,11 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   const char* gm = getenv("DTK_GEMM");
   c->gemm_naive = gm && !strcmp(gm, "naive");
   const char* ac = getenv("DTK_ATTN_COMBINE");
-  c->attn_combine = !ac ? 2 : (!strcmp(ac, "consumer") ? 0 : (!strcmp(ac, "inkernel") ? 1 : 2));
+  // measured default (tools/tune_decode.py, profiles/r02_tune_decode_*.log): 512-thread tile kernel, 4 splits, partials reduced in
+  // o_proj's prologue — one launch less per layer (ds-7b 384.2 -> 387.0 tok/s, ds-1.3b 1137 -> 1174)
+  c->attn_combine = !ac ? 0 : (!strcmp(ac, "consumer") ? 0 : (!strcmp(ac, "inkernel") ? 1 : 2));
+  c->attn_threads = 512;
+  if (const char* at = getenv("DTK_ATTN_THREADS")) c->attn_threads = atoi(at);
   if (c->S > 16) c->S = 16;
   if (c->Sb > 16) c->Sb = 16;
   if (const char* fm = getenv("DTK_ATTN_FULL_MAX")) c->attn_full_max = atoi(fm);
@@ -844,6 +858,19 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * kvd * 2;
   c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * (c->wfmt == 1 ? 1 : 2);
   *out = c;
+  if (const char* opts = getenv("DTK_OPTIONS")) {   // "name=value,name=value": dtk_set_option at create (profiling runs of unmodified tools)
+    std::string all(opts);
+    size_t at = 0;
+    while (at < all.size()) {
+      size_t end = all.find(',', at);
+      if (end == std::string::npos) end = all.size();
+      const std::string item = all.substr(at, end - at);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos && dtk_set_option(c, item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != DTK_OK)
+        fprintf(stderr, "DTK_OPTIONS: %s rejected (%s)\n", item.c_str(), c->err.c_str());
+      at = end + 1;
+    }
+  }
   return DTK_OK;
 }
 
@@ -1203,6 +1230,24 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     hb->share_len[j] = sh_ok ? c->bseq[(size_t)j].share_len : 0;
   }
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
+  // the prefix most ACTIVE slots read from one source slot (forks of one image): scored once for all of them by
+  // k_attn_prefix_b; its length is the shortest share among those slots (what lies beyond is per-slot work)
+  hb->pfx_src = -1; hb->pfx_len = 0;
+  if (c->prefix_mfma && c->attn_b_impl == 1) {
+    int count[DTK_MAX_BATCH + 1] = {0};
+    for (int j = 0; j < DTK_MAX_BATCH; ++j) {
+      if (!active[j]) continue;
+      if (hb->share_src[j] >= 0 && hb->share_src[j] <= DTK_MAX_BATCH) count[hb->share_src[j]]++;
+    }
+    int best = -1;
+    for (int sidx = 0; sidx <= DTK_MAX_BATCH; ++sidx) if (count[sidx] > (best < 0 ? 0 : count[best])) best = sidx;
+    if (best >= 0 && count[best] + (best < DTK_MAX_BATCH && active[best] ? 1 : 0) >= 2) {
+      int len = 1 << 30;
+      for (int j = 0; j < DTK_MAX_BATCH; ++j)
+        if (active[j] && hb->share_src[j] == best) len = hb->share_len[j] < len ? hb->share_len[j] : len;
+      if (len >= 4 && len < (1 << 30)) { hb->pfx_src = best; hb->pfx_len = len; }
+    }
+  }
   int hi = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) if (active[j]) hi = j;
   c->nt_step = hi < 16 ? 1 : (hi < 32 ? 2 : 4);      // column tiles this step needs (per-column results do not depend on it)
@@ -1414,7 +1459,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   if (!c || !avg_us || reps < 1) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  if (role == 5) {  // batched gate/up kernel, experiment modes (variant = mode)
+  if (role == 5 || role == 6) {  // batched gate/up kernel, experiment modes (variant = mode; role 6: k_gemm_b, variant = shape * 16 + mode)
     if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
     ensure_tiled_weights(c);
     BatchState hb{}; for (int j = 0; j < c->nb; ++j) hb.active[j] = 1;
@@ -1425,7 +1470,8 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
         GemvBArgs g{};
         g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt;
         g.W = c->layers[l].t_wgu; g.W8 = c->layers[l].t8_wgu; g.wscale = c->layers[l].s_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
-        launch_gemv_b_mode(variant, g, s);
+        if (role == 6) launch_gemm_b_mode(variant >> 4, variant & 15, g, s);
+        else launch_gemv_b_mode(variant, g, s);
       }
     };
     pass();
@@ -1489,6 +1535,16 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     set_gemm_tile(value);
   }
   else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;
+  else if (!strcmp(name, "attn_b_impl") || !strcmp(name, "prefix_mfma") || !strcmp(name, "pfx_splits") || !strcmp(name, "gemv_b_wide") ||
+           !strcmp(name, "tail_threads") || !strcmp(name, "gemm_b")) {
+    if (!strcmp(name, "attn_b_impl")) { if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "attn_b_impl must be 0 or 1"); c->attn_b_impl = value; }
+    else if (!strcmp(name, "prefix_mfma")) c->prefix_mfma = value != 0;
+    else if (!strcmp(name, "gemm_b")) { if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_b must be 0..4"); set_gemm_b_shape(value); }
+    else if (!strcmp(name, "tail_threads")) { if (value != 256 && value != 512) return fail(c, DTK_ERR_ARG, "tail_threads must be 256 or 512"); c->tail_threads = value; }
+    else if (!strcmp(name, "pfx_splits")) { if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "pfx_splits must be 1..4"); c->pfx_splits = value; }
+    else { if (value < 0 || value > 6) return fail(c, DTK_ERR_ARG, "gemv_b_wide must be 0..6"); set_gemv_b_wide(value); }
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "gemm_bk")) {
     if (value != 64 && value != 128) return fail(c, DTK_ERR_ARG, "gemm_bk must be 64 or 128");
     set_gemm_bk(value);

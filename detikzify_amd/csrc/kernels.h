@@ -108,6 +108,10 @@ struct GemvBArgs {
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
+bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s);   // kernels_batch_gemm.hip; false = not covered, use k_gemv_b
+void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);   // timing experiments
+void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)
+void set_gemv_b_wide(int v);   // row tiles per block of the batched kernels: 0 round-1 shapes, 1 twice as many, 2 auto (wide from 32 slots)
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
 static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 31) >> 5) * 512; }
 // fp8: a 1 KiB tile covers 16 rows x 64 k (two MFMA k-steps): lane l holds row l&15, bytes 0..7 = k0 + (l>>4)*8 + 0..7,
@@ -124,7 +128,12 @@ struct AttnDecBArgs {
   bf16_t* out;                         // [16][d]
   int H; int S; int T_max; int d; float scale;
   int G;                               // query heads per kv head (1 = MHA)
-  int nslots;                          // grid z: 16 or 32
+  int nslots;                          // grid z: 16, 32 or 64
+  int impl;                            // 0: split-K per slot + combine kernel; 1: k_attn_tail_b (+ k_attn_prefix_b when use_prefix)
+  int use_prefix;                      // score BatchState's shared prefix once for all slots on the matrix cores
+  int pfx_splits;                      // key splits of the prefix kernel (its grid y)
+  int tail_threads;                    // k_attn_tail_b block: 512 (default) | 256
+  float* pfx_m; float* pfx_l; float* pfx_o;   // [slots][H][pfx_splits], ..., [slots][H][pfx_splits][128]: un-normalised prefix states
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 

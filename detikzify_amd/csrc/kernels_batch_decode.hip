@@ -21,12 +21,17 @@
 #define GB_KSTEP 32
 #define GB_UNROLL 4
 
-// rows of tile t of a block for the paired epilogues: QKV -> (i, i+64) RoPE partners; SWIGLU -> (gate, up)
+// rows of tile t of a block.  Paired epilogues own P = T / 2 pairs of 16-row tiles: tile p and its partner p + P
+// (QKV: RoPE partners i, i + 64; SWIGLU: gate row i, up row ff + i).  More tiles per block = more weight rows per x
+// fragment read from L2: at 64 slots a k-step needs 4 KiB of x per KiB of weights and row tile.
 template <int EPI, int T>
 __device__ __forceinline__ int gb_tile_row0(const GemvBArgs& a, int blk, int t) {
-  if (EPI == EPI_QKV)    // block = 16 dims i0..i0+15 (< 64) of head block blk/4 over [H q | KVH k | KVH v]
-    return (blk >> 2) * 128 + (blk & 3) * 16 + t * 64;
-  if (EPI == EPI_SWIGLU) return blk * 16 + t * a.ff;
+  constexpr int P = T >= 2 ? T / 2 : 1;
+  if (EPI == EPI_QKV) {  // block = 16 * P dims (< 64) of one head block over [H q | KVH k | KVH v]; 64 / (16 P) blocks per head block
+    constexpr int BPH = 4 / P;
+    return (blk / BPH) * 128 + (blk % BPH) * 16 * P + (t % P) * 16 + (t / P) * 64;
+  }
+  if (EPI == EPI_SWIGLU) return blk * 16 * P + (t % P) * 16 + (t / P) * a.ff;
   return (blk * T + t) * 16;
 }
 
@@ -116,8 +121,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
         for (int t = 0; t < T; ++t) {
           const bf16x8_t af = F8 ? f8x8_to_bf16x8(w[t][i][2 * h], w[t][i][2 * h + 1]) : __builtin_bit_cast(bf16x8_t, w[t][i]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt) {
+            if (MODE & 2) {   // timing experiment: no MFMA, the operands are folded in with integer ops so their loads stay live
+              const u32x4 wa = __builtin_bit_cast(u32x4, af), xa = x[F8 ? 2 * i + h : i][nt];
+              acc[t][nt][0] = __uint_as_float(__float_as_uint(acc[t][nt][0]) ^ wa[0] ^ wa[1] ^ wa[2] ^ wa[3] ^ xa[0] ^ xa[1] ^ xa[2] ^ xa[3]);
+            } else
             acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, x[F8 ? 2 * i + h : i][nt]), acc[t][nt], 0, 0, 0);
+          }
         }
   };
   if (F8) {   // two stages in flight (measured: fp8 step 3.24 -> 2.99 ms at B=16)
@@ -179,36 +189,54 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
         if (row < a.N) a.Y[(size_t)n * a.ldy + row] = f2bf(v[t]);
       }
     } else if (EPI == EPI_SWIGLU) {
-      const int i = blk * 16 + m;
-      if (i < a.ff) {
-        const float gte = rbf(v[0]), up = rbf(v[T - 1]);
-        const float sl = rbf(gte / (1.f + expf(-gte)));
-        a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
+      constexpr int P = T >= 2 ? T / 2 : 1;
+  #pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = blk * 16 * P + p * 16 + m;
+        if (i < a.ff) {
+          const float gte = rbf(v[p]), up = rbf(v[p + P]);
+          const float sl = rbf(gte / (1.f + expf(-gte)));
+          a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
+        }
       }
     } else if (EPI == EPI_QKV) {
-      const int hb = blk >> 2, i = (blk & 3) * 16 + m;
+      constexpr int P = T >= 2 ? T / 2 : 1, BPH = 4 / P;
+      const int hb = blk / BPH;
       const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
       const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
       const int pos = a.st[n].pos;
-      const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
       const size_t slot_kv = (size_t)n * a.kv_slot_stride;
-      if (sec == 2) {
-        bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
-        dst[i] = f2bf(x1);
-        dst[i + 64] = f2bf(x2);
-      } else {
-        const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-        const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
-        const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
-        const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
-        bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
-                                 : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
-        dst[i] = f2bf(o1);
-        dst[i + 64] = f2bf(o2);
+  #pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = (blk % BPH) * 16 * P + p * 16 + m;
+        const float x1 = rbf(v[p]), x2 = rbf(v[p + P]);
+        if (sec == 2) {
+          bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
+          dst[i] = f2bf(x1);
+          dst[i + 64] = f2bf(x2);
+        } else {
+          const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+          const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+          const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+          const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+          bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                                   : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
+          dst[i] = f2bf(o1);
+          dst[i + 64] = f2bf(o2);
+        }
       }
     }
 
   };
+  if (MODE & 4) {   // timing experiment: no cross-wave reduction, no epilogue (one store keeps the accumulators live)
+    float sacc = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sacc += acc[t][nt][0] + acc[t][nt][1] + acc[t][nt][2] + acc[t][nt][3];
+    if (sacc == 1.2345f) a.Y[tid] = 0;
+    return;
+  }
 #pragma unroll
   for (int p0 = 0; p0 < NT; p0 += NP) {
     if (p0) __syncthreads();   // the previous pass's reads of `red` are done
@@ -219,27 +247,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][t][q][lane * 4 + r] = acc[t][p0 + q][r];
     __syncthreads();
-    if (tid < 256 * NP) finish(tid >> 8, p0 + (tid >> 8), tid & 255);
+    for (int it = tid; it < 256 * NP; it += WAVES * 64) finish(it >> 8, p0 + (it >> 8), it & 255);
   }
 }
 
-void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments
+void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments (mode bits: 1 no x loads, 2 no MFMA, 4 no reduction / epilogue)
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
-  if (a.nt >= 3) {
-    if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1, false, GB_WAVES, 4>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, false, GB_WAVES, 4>), g, b, 0, s, a);
+#define GBM(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV>), g, b, 0, s, a)
+#define GBMS(NTV) switch (mode) { case 1: GBM(1, NTV); break; case 2: GBM(2, NTV); break; case 3: GBM(3, NTV); break; case 4: GBM(4, NTV); break; \
+                                  case 5: GBM(5, NTV); break; case 6: GBM(6, NTV); break; case 7: GBM(7, NTV); break; default: GBM(0, NTV); }
+  if (a.W8) {
+    if (a.nt >= 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
+    else if (a.nt == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true>), g, b, 0, s, a);
     return;
   }
-  if (a.nt == 2) {
-    if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1, false, GB_WAVES, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, false, GB_WAVES, 2>), g, b, 0, s, a);
-    return;
-  }
-  if (a.W8) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true>), g, b, 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 1>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0>), g, b, 0, s, a);
+  if (a.nt >= 3) { GBMS(4) }
+  else if (a.nt == 2) { GBMS(2) }
+  else { GBMS(1) }
+#undef GBMS
+#undef GBM
 }
 
 // waves per block of the N = d kernels (o_proj, down: only N/16 = 256 blocks, so the K split is what fills a CU)
@@ -248,29 +275,60 @@ static int resid_waves() {
   if (!w) { const char* e = getenv("DTK_GB_RESID_WAVES"); w = (e && atoi(e) == 16) ? 16 : 8; }   // measured: 8 and 16 within 1-2 % (DTK_GB_RESID_WAVES=16 to try)
   return w;
 }
+// Row tiles per block.  mode 0 = the round-1 shapes (T = 2 for the paired / logits kernels, 1 for the N = d kernels);
+// 1 = twice the tiles, 8 waves; 3 = twice the tiles, 4 waves; 4 / 5 = as 1 / 3 but the N = d kernels keep one tile;
+// 6 = twice the tiles for qkv and lm_head only; 2 = auto = 6 at 64 slots, else 0.  Measured at 64 slots, ds-7b
+// (profiles/r02_batch_wide_kernel_stats.csv vs r02_batch_tail_kernel_stats.csv): qkv 33.1 -> 27.9 us (192 blocks: one round, half
+// the x fragments through L2), lm_head 67.9 -> 62.2, gate/up 48.5 -> 48.4 (344 blocks: 1.34 rounds on 256 CUs eat the gain),
+// o_proj / down 24.1 -> 29.2 (128 blocks).  Results are bit-identical across modes (a row's k order depends on the wave split
+// of K only).
+static int g_gb_wide = -1;
+void set_gemv_b_wide(int v) { g_gb_wide = v; }
+static int gb_wide(int nt, bool f8) {
+  if (g_gb_wide < 0) { const char* e = getenv("DTK_GB_WIDE"); g_gb_wide = e ? atoi(e) : 2; }
+  int m = g_gb_wide;
+  if (m == 2) m = nt >= 4 ? 6 : 0;
+  if (f8 && nt >= 4) m = 0;                   // fp8 at 64 slots: four tiles do not fit the register file (spills)
+  return m;
+}
 template <bool F8, int NT>
 static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
+  const int mode = gb_wide(NT, F8);
+  const bool wide_qkv_logits = mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 6;
+  const bool wide = epi == EPI_SWIGLU ? (wide_qkv_logits && mode != 6) : wide_qkv_logits, w4 = mode == 3 || mode == 5;
+  const bool wide_resid = mode == 1 || mode == 3;
   if (epi == EPI_QKV) {
-    const int grid = (a.H + 2 * a.KVH) * 4;   // 4 blocks of 16 RoPE pairs per head block
-    hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2, 0, F8, GB_WAVES, NT>), dim3(grid), dim3(GB_THREADS), 0, s, a);
+    const int hb = a.H + 2 * a.KVH;
+    if (wide && w4) hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 4, 0, F8, 4, NT>), dim3(hb * 2), dim3(256), 0, s, a);
+    else if (wide) hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 4, 0, F8, GB_WAVES, NT>), dim3(hb * 2), dim3(GB_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_QKV, 2, 0, F8, GB_WAVES, NT>), dim3(hb * 4), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_SWIGLU) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8, GB_WAVES, NT>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
+    if (wide && w4) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 4, 0, F8, 4, NT>), dim3((a.ff + 31) / 32), dim3(256), 0, s, a);
+    else if (wide) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 4, 0, F8, GB_WAVES, NT>), dim3((a.ff + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, F8, GB_WAVES, NT>), dim3((a.ff + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_RESID) {
-    // N = d: only N/16 = 256 blocks of one 16-row tile.  Measured: 8 k-steps per stage (DTK_GB_RESID_KS=8) or 16 waves
-    // (DTK_GB_RESID_WAVES=16) change nothing (within 1-2 %) — with T = 1 these kernels read 2 KiB of x fragments from L2
-    // per KiB of weights at 32 slots, which is what bounds them (o_proj 9.3 us, down 26.8 us at B = 32)
+    // N = d: only N/16 = 256 one-tile blocks.  Measured in round 1: 8 k-steps per stage (DTK_GB_RESID_KS=8) or 16 waves
+    // (DTK_GB_RESID_WAVES=16) change nothing — what bounds them is the 2 KiB (32 slots) / 4 KiB (64) of x fragments read
+    // from L2 per KiB of weights, which two tiles per block halve (at the price of 128 blocks)
     static int ks = 0;
     if (!ks) { const char* e = getenv("DTK_GB_RESID_KS"); ks = (e && atoi(e) == 8) ? 8 : 4; }
-    if (resid_waves() == 16) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
+    if (wide_resid) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    else if (resid_waves() == 16 && NT < 4 && !F8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
     else if (ks == 8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT, 8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   } else if (epi == EPI_LOGITS) {
-    hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    if (wide && w4) hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 4, 0, F8, 4, NT>), dim3((a.N + 63) / 64), dim3(256), 0, s, a);
+    else if (wide) hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 4, 0, F8, GB_WAVES, NT>), dim3((a.N + 63) / 64), dim3(GB_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_gemv_b<EPI_LOGITS, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
   } else {
     hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
 }
+static int g_gemm_b_shape = -1;
+void set_gemm_b_shape(int v) { g_gemm_b_shape = v; }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (g_gemm_b_shape < 0) { const char* e = getenv("DTK_GEMM_B"); g_gemm_b_shape = e ? atoi(e) : 0; }
+  if (launch_gemm_b(epi, g_gemm_b_shape, a, s)) return;     // x staged through LDS (kernels_batch_gemm.hip); false: not covered
   if (a.nt >= 3) { if (a.W8) launch_gemv_b_impl<true, 4>(epi, a, s); else launch_gemv_b_impl<false, 4>(epi, a, s); }
   else if (a.nt == 2) { if (a.W8) launch_gemv_b_impl<true, 2>(epi, a, s); else launch_gemv_b_impl<false, 2>(epi, a, s); }
   else { if (a.W8) launch_gemv_b_impl<true, 1>(epi, a, s); else launch_gemv_b_impl<false, 1>(epi, a, s); }
@@ -447,7 +505,277 @@ __global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
   a.out[xtile_off(slot, h * 128 + t, (a.d + 31) >> 5)] = f2bf(o / L);   // o_proj's B operand: fragment-major
 }
 
+// ------------------------------------------------------------------------------------------
+// Shared prefix on the matrix cores.  The rollouts of one image hold bit-identical copies of the image prefix (dtk_kv_fork):
+// scoring it per slot on the VALU re-read the same 243 rows 64 times from L2 — 64 x 32 x 8 tiny blocks, 36 us per layer at
+// 64 slots.  k_attn_prefix_b does it ONCE per head as a 64-query flash attention (queries = slots) over the source slot's rows
+// [0, pfx_len): S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_16x16x32_bf16, computed transposed so a lane's MFMA column is its
+// own query (the scheme of k_attention_mfma, kernels_batched.hip), fp32 online softmax, P as a bf16 hi + lo pair.  It leaves
+// every slot's UN-normalised state (m, l, o[128]) per key split; k_attn_tail_b starts from it and continues over the slot's
+// private keys.  Grid (H, NPS): block z scans the 64-key tiles [z * tps, (z + 1) * tps).
+#define PFX_HDP 136   // LDS row stride of a 128-dim K / V row (elements): 68 dwords, conflict-free 16-byte fragment reads
+__global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PFX_HDP];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PFX_HDP];
+  const int Tk = a.bs->pfx_len;
+  if (Tk <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, z = blockIdx.y, NPS = gridDim.y;
+  const int kvh = h / a.G;
+  const int slot = wave * 16 + lq;                      // this lane's query
+  const bool real = slot < a.nslots;
+  const size_t src_off = (size_t)a.bs->pfx_src * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const bf16_t* Kp = a.kcache + src_off;
+  const bf16_t* Vp = a.vcache + src_off;
+  const int tiles = (Tk + 63) >> 6, tps = (tiles + NPS - 1) / NPS;
+  const int j_begin = z * tps * 64, j_end = min(Tk, (z + 1) * tps * 64);
+
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qp = a.q + (size_t)(real ? slot : 0) * a.d + h * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(qp + (ks * 4 + g) * 8));
+  }
+  float m = -1e30f, l = 0.f;
+  f32x4 o[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rk[4], rv[4];
+  auto tile_load = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 4, c = idx & 15;     // 64 rows x 16 chunks of 16 bytes
+      int j = j0 + r; if (j >= Tk) j = Tk - 1;
+      rk[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)j * 128 + c * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)j * 128 + c * 8);
+    }
+  };
+  if (j_begin < j_end) tile_load(j_begin);
+  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 4, c = idx & 15;
+      *reinterpret_cast<u32x4*>(&Ks[r * PFX_HDP + c * 8]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vs[r * PFX_HDP + c * 8]) = rv[i];
+    }
+    __syncthreads();
+    if (j0 + 64 < j_end) tile_load(j0 + 64);
+    f32x4 sc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(&Ks[(t * 16 + lq) * PFX_HDP + (ks * 4 + g) * 8]);
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kv), qf[ks], sc[t], 0, 0, 0);
+      }
+    }
+    float tmax = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + t * 16 + g * 4 + r;
+        const float v = key < j_end ? sc[t][r] * a.scale : -1e30f;
+        sc[t][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m, tmax);
+    const float corr = __expf(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + t * 16 + g * 4 + r;
+        const float p = key < j_end ? __expf(sc[t][r] - mn) : 0.f;
+        sc[t][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * corr + psum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] *= corr;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4 pw, pl;   // p = hi + lo (two bf16): the fp32 probabilities of the VALU path to ~16 mantissa bits
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const float p0 = sc[2 * s2 + half][2 * pr], p1 = sc[2 * s2 + half][2 * pr + 1];
+          const uint32_t hi = pack2(p0, p1);
+          pw[half * 2 + pr] = hi;
+          pl[half * 2 + pr] = pack2(p0 - pk_lo(hi), p1 - pk_hi(hi));
+        }
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw), pfl = __builtin_bit_cast(bf16x8_t, pl);
+      const bf16_t* v0 = Vs + ((2 * s2) * 16 + g * 4) * PFX_HDP + lq;
+      const bf16_t* v1 = v0 + 16 * PFX_HDP;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u32x4 vw;
+        vw[0] = (uint32_t)v0[dt * 16] | ((uint32_t)v0[dt * 16 + PFX_HDP] << 16);
+        vw[1] = (uint32_t)v0[dt * 16 + 2 * PFX_HDP] | ((uint32_t)v0[dt * 16 + 3 * PFX_HDP] << 16);
+        vw[2] = (uint32_t)v1[dt * 16] | ((uint32_t)v1[dt * 16 + PFX_HDP] << 16);
+        vw[3] = (uint32_t)v1[dt * 16 + 2 * PFX_HDP] | ((uint32_t)v1[dt * 16 + 3 * PFX_HDP] << 16);
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vw);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (real) {   // un-normalised state of (slot, head, key split z): lane holds dims dt * 16 + g * 4 + 0..3 of its query
+    const size_t rec = ((size_t)slot * a.H + h) * NPS + z;
+    float* po = a.pfx_o + rec * 128;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16 + g * 4) = o[dt];
+    if (g == 0) { a.pfx_m[rec] = m; a.pfx_l[rec] = l; }
+  }
+}
+
+// Per-slot remainder: block (h, slot) walks the slot's keys that are not covered by the shared prefix — [pfx_len, n) for a
+// member, [0, n) otherwise — in tiles of 16 * WAVES rows with the next tile in flight, starting from the prefix state, and
+// writes the normalised bf16 head output in o_proj's fragment-major order: no split partials, no combine kernel (64 slots x
+// 32 heads are 2048 blocks already).  Rows below a fork's share_len still come from its source slot (one copy in L2).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
+  constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
+  const int h = blockIdx.x, slot = blockIdx.y;
+  if (!a.bs->active[slot]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int kvh = h / a.G;
+  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const int ssrc = a.bs->share_src[slot];
+  const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
+  const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;
+  const bool member = a.use_prefix && pfx_member(a.bs, slot);
+  const int start = member ? a.bs->pfx_len : 0;
+  const int n = a.st[slot].pos + 1;
+  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + h * 128)[sub];
+
+  u32x4 kv[4], vv[4];
+  auto load_tile = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
+      j = min(j, a.T_max - 1);
+      const size_t off = (size_t)j * 128 + (j < slen ? sdelta : (size_t)0);
+      kv[i] = reinterpret_cast<const u32x4*>(kbase + off)[sub];
+      vv[i] = reinterpret_cast<const u32x4*>(vbase + off)[sub];
+    }
+  };
+  if (start < n) load_tile(start);
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  if (member && wave == 0 && grp == 0) {   // the prefix state (its key splits merged in order) seeds one of the block's streams
+    const size_t rec0 = ((size_t)slot * a.H + h) * a.pfx_splits;
+    for (int zsp = 0; zsp < a.pfx_splits; ++zsp) {
+      const float m2 = a.pfx_m[rec0 + zsp], l2 = a.pfx_l[rec0 + zsp];
+      const f32x4* po4 = reinterpret_cast<const f32x4*>(a.pfx_o + (rec0 + zsp) * 128 + sub * 8);
+      const f32x4 p0 = po4[0], p1 = po4[1];
+      const float mn = fmaxf(m, m2);
+      const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+      l = l * c1 + l2 * c2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = o[e] * c1 + p0[e] * c2;
+        o[4 + e] = o[4 + e] * c1 + p1[e] * c2;
+      }
+      m = mn;
+    }
+  }
+  for (int j0 = start; j0 < n; j0 += ROWS) {
+    u32x4 kc[4], vc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { kc[i] = kv[i]; vc[i] = vv[i]; }
+    if (j0 + ROWS < n) load_tile(j0 + ROWS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
+      float s = dot8(qv, kc[i], 0.f);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s *= a.scale;
+      if (j < n) {
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn);
+        const float p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = o[2 * e] * corr + p * pk_lo(vc[i][e]);
+          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vc[i][e]);
+        }
+        m = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64);
+    const float l2 = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, m2);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o2 = __shfl_xor(o[e], off, 64);
+      o[e] = o[e] * c1 + o2 * c2;
+    }
+    m = mn;
+  }
+  __shared__ float sm_m[WAVES][16], sm_l[WAVES][16], sm_o[WAVES][16][8];
+  if (grp == 0) {
+    sm_m[wave][sub] = m;
+    sm_l[wave][sub] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float M = sm_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[w][tid]);
+    float L = 0.f;
+    float oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const float c = __expf(sm_m[w][tid] - M);
+      L += c * sm_l[w][tid];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+    }
+    const float invL = 1.f / L;
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack2(oo[2 * e] * invL, oo[2 * e + 1] * invL);
+    *reinterpret_cast<u32x4*>(a.out + xtile_off(slot, h * 128 + tid * 8, (a.d + 31) >> 5)) = ov;   // 8 consecutive k of one fragment lane
+  }
+}
+
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
+  if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
+    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
+    // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
+    if (a.tail_threads == 256) hipLaunchKernelGGL(k_attn_tail_b<256>, dim3(a.H, a.nslots), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_attn_tail_b<512>, dim3(a.H, a.nslots), dim3(512), 0, s, a);
+    return;
+  }
   hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, a.nslots), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, a.nslots), dim3(128), 0, s, a);
 }

@@ -1,0 +1,297 @@
+// kernels_batch_gemm.hip — the batched decode GEMVs with the slots' input vectors streamed through LDS by the LDS-DMA path.
+//
+// Measured (tools/probe_batch.py, profiles/r02_probe_batch.txt; ds-7b gate/up, dtk_bench_gemv role 5): k_gemv_b streams its
+// weights at 6.2-6.4 TB/s when its x-fragment loads are removed — at 16, 32 AND 64 slots — and loses 2 / 6.5 / 19.6 us to them
+// (30.5 / 35.0 / 48.8 us for the full kernel); neither the MFMAs nor the reduction + epilogue cost anything measurable.  A k-step
+// needs 1 KiB of x per 16 slots and row tile, read from L2 through the CU's vector-memory path by every wave: at 64 slots that is
+// 352 MB per launch next to 180 MB of weights.  Here
+//   * a block is KQ x RP waves: RP row groups walk the SAME k-steps, so a 1 KiB x fragment is fetched ONCE per block and stage
+//     (L2 -> CU traffic for x / RP) while KQ splits of K keep enough waves on the weight stream;
+//   * x never touches a VGPR: each wave issues `global_load_lds_dwordx4` (1 KiB per instruction, straight into a ring of XA + 1
+//     LDS slots) XA stages ahead; the MFMA B operand is a ds_read_b128 of the landed fragment;
+//   * the weights (fragment-major tiles, non-temporal loads into the A operand registers) run XA stages ahead as well, in a
+//     register ring of XA + 1 stages.
+// K order per accumulator: k-steps in order inside each of the KQ splits, the splits added in order through LDS — fixed per
+// (role, shape), independent of the number of column tiles: a slot's result does not depend on how many slots are active.
+// Epilogues and rounding points as in kernels_batch_decode.hip / kernels_decode.hip.
+#include "kernels.h"
+
+// rows of tile t of row group g (a group = the T tiles one wave owns)
+template <int EPI, int T>
+__device__ __forceinline__ int gg_tile_row0(const GemvBArgs& a, int g, int t) {
+  if (EPI == EPI_QKV) return (g >> 2) * 128 + (g & 3) * 16 + t * 64;   // 16 RoPE pairs (i, i + 64) of one head block
+  if (EPI == EPI_SWIGLU) return g * 16 + t * a.ff;                     // gate rows, up rows
+  return (g * T + t) * 16;
+}
+template <int EPI, int T>
+__host__ __device__ __forceinline__ int gg_groups(int N, int ff, int H, int KVH) {
+  if (EPI == EPI_QKV) return (H + 2 * KVH) * 4;
+  if (EPI == EPI_SWIGLU) return (ff + 15) / 16;
+  return (N + 16 * T - 1) / (16 * T);
+}
+
+// one output element set: slot n, row m of the group's tiles, v[t] = reduced fp32 sums
+template <int EPI, int T>
+__device__ __forceinline__ void gg_epilogue(const GemvBArgs& a, int g, int n, int m, const float (&v)[T]) {
+  if (EPI == EPI_RESID) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gg_tile_row0<EPI, T>(a, g, t) + m;
+      if (row < a.N) {
+        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
+        *y = f2bf(bf2f(*y) + rbf(v[t]));
+      }
+    }
+  } else if (EPI == EPI_LOGITS) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gg_tile_row0<EPI, T>(a, g, t) + m;
+      if (row < a.N) a.logits[(size_t)n * a.N + row] = rbf(v[t]);
+    }
+  } else if (EPI == EPI_SWIGLU) {
+    const int i = g * 16 + m;
+    if (i < a.ff) {
+      const float gte = rbf(v[0]), up = rbf(v[T - 1]);
+      const float sl = rbf(gte / (1.f + expf(-gte)));
+      a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
+    }
+  } else if (EPI == EPI_QKV) {
+    const int hb = g >> 2, i = (g & 3) * 16 + m;
+    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
+    const int pos = a.st[n].pos;
+    const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
+    const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+    if (sec == 2) {
+      bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
+      dst[i] = f2bf(x1);
+      dst[i + 64] = f2bf(x2);
+    } else {
+      const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
+      const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
+      const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+      const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+      bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                               : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
+      dst[i] = f2bf(o1);
+      dst[i + 64] = f2bf(o2);
+    }
+  }
+}
+
+// One 1 KiB fragment, global -> LDS, no VGPR: lane l's 16 bytes land at lds_byte + 16 l (guides/cdna_hip_programming.md §5.7:
+// M0 carries the wave-uniform LDS address and is restored; the load is invisible to the compiler's vmcnt bookkeeping).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// T tiles per wave, KQ splits of K x RP row groups per block, NT column tiles of 16 slots, SK k-steps per stage, both streams
+// XA stages ahead.  Iteration t issues stage u = t + XA of both streams — weights first, then the x fragments — and computes
+// stage t; the prologue is iterations -XA .. -1.
+// MODE (timing experiments, dtk_bench_gemv role 6): 1 no x DMA, 2 no MFMA, 4 no barriers / waits, 8 no weight loads
+template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA, int MODE = 0>
+__global__ __launch_bounds__(KQ * RP * 64) void k_gemm_b(GemvBArgs a) {
+  constexpr int WAVES = KQ * RP, THREADS = WAVES * 64;
+  constexpr int SF = KQ * SK * NT;                  // 1 KiB x fragments of one stage (all K splits)
+  constexpr int FPW = (SF + WAVES - 1) / WAVES;     // fragments (LDS-DMA instructions) per staging wave and stage; with fewer
+  static_assert(SF % FPW == 0, "a wave stages FPW fragments or none");   // fragments than waves the last waves stage nothing
+  constexpr int RING = XA + 1;                      // LDS slots = weight register stages
+  constexpr int PER_STAGE = T * SK + FPW;           // vector-memory instructions a wave issues per stage
+  static_assert((XA - 1) * PER_STAGE < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // max(RING x SF, KQ x RP x T x NT) KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = wave / RP, r = wave % RP;
+  const int K = a.K;
+  const int nsteps = (K + 31) >> 5;
+  const int per = (nsteps + KQ - 1) / KQ;           // k-steps per K split (the last split may be shorter)
+  const int nstages = (per + SK - 1) / SK;
+  const int s0 = min(nsteps, q * per), s1 = min(nsteps, s0 + per);
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+  const int g = blockIdx.x * RP + r;
+  const int gc = g < groups ? g : groups - 1;       // clamped: a surplus row group streams valid memory and stores nothing
+  const unsigned lds0 = __builtin_amdgcn_groupstaticsize();   // byte address of the dynamic region
+  const bool stager = wave * FPW < SF;              // wave-uniform: this wave has fragments to fetch
+
+  const unsigned char* wrow[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
+    const int tn_max = ((a.N + 15) >> 4) - 1;
+    if (tn > tn_max) tn = tn_max;
+    wrow[t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+  }
+  const bf16_t* xlane = a.X + lane * 8;
+
+  f32x4 acc[T][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Stage u of this wave's weights -> registers.  A k-step past the end of the split is loaded from a valid tile and ZEROED:
+  // its x fragment (also fetched, from a clamped k-step: the instruction counts stay exact) then contributes nothing.
+  auto load_w = [&](u32x4 (&w)[T][SK], int u) {
+#pragma unroll
+    for (int i = 0; i < SK; ++i) {
+      const int st = s0 + u * SK + i;
+      const int stc = st < s1 ? st : (s1 > s0 ? s1 - 1 : 0);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        u32x4 v = (MODE & 8) ? (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)stc} : ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)stc * 1024));
+        if (st >= s1) v = (u32x4){0u, 0u, 0u, 0u};
+        w[t][i] = v;
+      }
+    }
+  };
+  // This wave's FPW fragments of stage u -> LDS slot.  Fragment f = ((qq * NT) + nt) * SK + i: the FPW fragments of a wave are
+  // consecutive k-steps of one (split, column tile) wherever FPW divides SK — consecutive KiB in memory.
+  auto dma_x = [&](int u, int slot) {
+    if (!stager || (MODE & 1)) return;
+#pragma unroll
+    for (int j = 0; j < FPW; ++j) {
+      const int f = wave * FPW + j;
+      const int qq = f / (NT * SK), nt = (f / SK) % NT, i = f % SK;
+      const int b0 = min(nsteps, qq * per);
+      int st = b0 + u * SK + i;
+      if (st >= nsteps) st = nsteps - 1;            // valid memory; the matching weights are zero
+      const unsigned dst = lds0 + (unsigned)((slot * SF + f) * 1024);
+      glds16(xlane + ((size_t)nt * nsteps + st) * 512, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  auto compute = [&](const u32x4 (&w)[T][SK], int slot) {
+    const unsigned char* xb = smem + ((size_t)slot * SF + (size_t)q * NT * SK) * 1024 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < SK; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * SK + i) * 1024));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (MODE & 2) {
+            const u32x4 xa = __builtin_bit_cast(u32x4, bf);
+            acc[t][nt][0] = __uint_as_float(__float_as_uint(acc[t][nt][0]) ^ w[t][i][0] ^ w[t][i][1] ^ w[t][i][2] ^ w[t][i][3] ^ xa[0] ^ xa[1] ^ xa[2] ^ xa[3]);
+          } else
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][i]), bf, acc[t][nt], 0, 0, 0);
+        }
+      }
+  };
+
+  u32x4 w[RING][T][SK];
+#pragma unroll
+  for (int u = 0; u < XA; ++u)
+    if (u < nstages) { load_w(w[u], u); dma_x(u, u); }
+  for (int sg = 0; sg < nstages; sg += RING) {
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {        // unrolled: ring slot j holds stage sg + j, stage sg + j + XA goes to slot (j + XA) % RING
+      const int st = sg + j;
+      if (st < nstages) {                    // block-uniform
+        // this wave's fragments of stage st have landed once at most the (XA - 1) younger stages are outstanding; near the end
+        // fewer were issued, so drain
+        if (!(MODE & 4)) {
+          if (stager && !(MODE & 1)) { if (st + XA - 1 < nstages) wait_vmcnt<(XA - 1) * PER_STAGE>(); else wait_vmcnt<0>(); }
+          __syncthreads();                   // everybody's fragments of stage st are in LDS; everybody is done with stage st - 1
+        }
+        if (st + XA < nstages) { load_w(w[(j + XA) % RING], st + XA); dma_x(st + XA, (j + XA) % RING); }
+        compute(w[j], j);
+      }
+    }
+  }
+  // ---- the KQ partial sums of a row group meet in LDS (aliasing the staging buffers), summed in split order
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);     // [q][r][t][nt][256]
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[((((size_t)q * RP + r) * T + t) * NT + nt) * 256 + lane * 4 + e] = acc[t][nt][e];
+  __syncthreads();
+  for (int it = tid; it < RP * NT * 256; it += THREADS) {
+    const int ti = it & 255, nt = (it >> 8) % NT, rr = it / (256 * NT);
+    const int l2 = ti >> 2, r2 = ti & 3;
+    const int n = nt * 16 + (l2 & 15);     // slot: C/D layout col = lane & 15
+    const int m = (l2 >> 4) * 4 + r2;      // row inside the tile
+    float v[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float sum = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < KQ; ++qq) sum += red[((((size_t)qq * RP + rr) * T + t) * NT + nt) * 256 + ti];
+      v[t] = sum;
+    }
+    const int gg = blockIdx.x * RP + rr;
+    if (gg < groups && a.bs->active[n]) gg_epilogue<EPI, T>(a, gg, n, m, v);
+  }
+}
+
+template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
+static void launch_one(const GemvBArgs& a, hipStream_t s) {
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+  constexpr size_t staging = (size_t)(XA + 1) * KQ * SK * NT * 1024, reduction = (size_t)KQ * RP * T * NT * 1024;
+  const size_t lds = staging > reduction ? staging : reduction;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a);
+}
+
+// shape (K splits x row groups, k-steps per stage, stages ahead); 8 waves per block:
+//        rows >> d roles (qkv, gate/up, lm_head)                       |   N = d roles (o_proj, down: 256 row tiles)
+//   1    2 x 4, 4, 3   172 blocks for gate/up, x traffic / 4           |   4 x 2, 2, 3  (128 blocks, x traffic / 2)
+//   2    4 x 2, 2, 3   344 blocks, x traffic / 2                       |   4 x 2, 2, 3
+//   3    2 x 4, 4, 2                                                   |   4 x 2, 2, 2
+//   4    2 x 4, 2, 3   shorter stages                                  |   8 x 1, 2, 1  (256 blocks, no sharing)
+template <int EPI, int T, int NT>
+static bool launch_shape(int shape, const GemvBArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_RESID) {
+    switch (shape) {
+      case 1: case 2: launch_one<EPI, T, 4, 2, NT, 2, 3>(a, s); return true;
+      case 3: launch_one<EPI, T, 4, 2, NT, 2, 2>(a, s); return true;
+      case 4: launch_one<EPI, T, 8, 1, NT, 2, 1>(a, s); return true;
+      default: return false;
+    }
+  } else {
+    switch (shape) {
+      case 1: launch_one<EPI, T, 2, 4, NT, 4, 3>(a, s); return true;
+      case 2: launch_one<EPI, T, 4, 2, NT, 2, 3>(a, s); return true;
+      case 3: launch_one<EPI, T, 2, 4, NT, 4, 2>(a, s); return true;
+      case 4: launch_one<EPI, T, 2, 4, NT, 2, 3>(a, s); return true;
+      default: return false;
+    }
+  }
+}
+template <int NT>
+static bool launch_nt(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
+  if (epi == EPI_QKV) return launch_shape<EPI_QKV, 2, NT>(shape, a, s);
+  if (epi == EPI_SWIGLU) return launch_shape<EPI_SWIGLU, 2, NT>(shape, a, s);
+  if (epi == EPI_RESID) return launch_shape<EPI_RESID, 1, NT>(shape, a, s);
+  if (epi == EPI_LOGITS) return launch_shape<EPI_LOGITS, 2, NT>(shape, a, s);
+  return false;
+}
+// timing experiments: the gate/up role at 64 slots, shape 1 or 2, with parts of the kernel removed (MODE bits above)
+void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s) {
+  const int groups = gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH);
+#define GMM(KQ, RP, SK, XA, M) do { const size_t lds = (size_t)(XA + 1) * KQ * SK * 4 * 1024; \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a); } while (0)
+#define GMS(KQ, RP, SK, XA) switch (mode) { case 1: GMM(KQ, RP, SK, XA, 1); break; case 2: GMM(KQ, RP, SK, XA, 2); break; case 4: GMM(KQ, RP, SK, XA, 4); break; \
+    case 5: GMM(KQ, RP, SK, XA, 5); break; case 8: GMM(KQ, RP, SK, XA, 8); break; case 9: GMM(KQ, RP, SK, XA, 9); break; case 13: GMM(KQ, RP, SK, XA, 13); break; \
+    case 7: GMM(KQ, RP, SK, XA, 7); break; default: GMM(KQ, RP, SK, XA, 0); }
+  if (shape == 2) { GMS(4, 2, 2, 3) } else { GMS(2, 4, 4, 3) }
+#undef GMS
+#undef GMM
+}
+
+// returns false when this path does not cover the request (fp8 weights, EPI_STORE, shape 0): the caller uses k_gemv_b
+bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
+  if (a.W8 || shape <= 0) return false;
+  if (a.nt >= 3) return launch_nt<4>(epi, shape, a, s);
+  if (a.nt == 2) return launch_nt<2>(epi, shape, a, s);
+  return launch_nt<1>(epi, shape, a, s);
+}

@@ -1,0 +1,140 @@
+"""
+Compile worker pool: LaTeX runs of finished rollouts in worker PROCESSES, overlapped with decoding.
+
+The reward of a rollout is dominated by `TikzDocument.compile` — latexmk (seconds), keep-last-page, crop, rasterise
+(reference detikzify/infer/tikz.py:89-156).  The reference overlaps that work only in its RL example, with a process pool
+and `imap` over a batch of completions (examples/refine.py:151-185: `RewardFunc.compile` returns the rasterised image from
+the worker).  Same pattern here, wired into the inference path:
+
+  * `CompilePool(workers)`            N spawned worker processes (spawn, not fork: the parent holds a HIP runtime and
+                                      threads); a job = (code, timeout) -> status, log, PNG of the raster, PDF bytes.
+  * `pool.imap(codes)`                results in input order, all jobs in flight (the refine.py pattern).
+  * `pooled_document_class(pool)`     a TikzDocument type whose compile() runs in the pool: pass it as `document_class` to
+                                      DetikzifyPipeline / DetikzifyGenerator.  The trees of `simulate_parallel` (one thread
+                                      each) then wait for their LaTeX run in a blocking `Future.result()` — no GIL, no more
+                                      than `workers` TeX processes at once — while the other trees' rollouts keep decoding
+                                      in the batched step.  `doc.prefetch()` starts a compile without waiting for it.
+
+Within ONE tree nothing can be overlapped without changing the search: expansion k+1 selects on the reward of expansion k
+(reference mcts/montecarlo.py:63-66).  The overlap is across trees (root parallelisation) and across the
+documents of a batch (`imap`).
+"""
+from __future__ import annotations
+
+import os
+from concurrent.futures import Future, ProcessPoolExecutor
+from io import BytesIO
+from multiprocessing import get_context
+from typing import Iterable, Iterator, List, NamedTuple, Optional, Type
+
+from PIL import Image
+
+from .tikz import Output, TikzDocument
+
+
+class CompiledFigure(NamedTuple):
+    """what travels back from a worker (picklable)"""
+    status: int
+    log: str
+    png: Optional[bytes]        # raster of the cropped last page, `raster_size` px on the long side (None: nothing to rasterise)
+    pdf: Optional[bytes]
+
+
+def _compile_job(code: str, timeout: Optional[int], raster_size: int, engines: Optional[List[str]]) -> CompiledFigure:
+    """runs in a worker process: the unchanged TikzDocument compile + rasterise"""
+    if engines is not None:
+        TikzDocument.set_engines(engines)
+    doc = TikzDocument(code, timeout=timeout)
+    out = doc.compile()
+    png = pdf = None
+    if out.pdf:
+        image = doc.rasterize(size=raster_size, expand_to_square=False)
+        if image is not None:
+            buf = BytesIO()
+            image.save(buf, format="PNG")
+            png = buf.getvalue()
+        try:
+            pdf = out.pdf.tobytes()
+        except Exception:  # noqa: BLE001  (a toolchain without byte export: the raster is what the reward needs)
+            pdf = None
+    return CompiledFigure(out.status, out.log, png, pdf)
+
+
+def _warm_job(seconds: float) -> int:
+    import time
+    time.sleep(seconds)
+    return os.getpid()
+
+
+class _PooledPdf:
+    """stands where TikzDocument keeps its pymupdf document: truthy, serialisable, carries the raster"""
+
+    def __init__(self, fig: CompiledFigure):
+        self._fig = fig
+
+    def tobytes(self) -> bytes:
+        if self._fig.pdf is None:
+            raise ValueError("the worker's toolchain did not export the PDF bytes")
+        return self._fig.pdf
+
+    def image(self) -> Image.Image:
+        return Image.open(BytesIO(self._fig.png)).convert("RGB")
+
+
+class CompilePool:
+    def __init__(self, workers: Optional[int] = None, raster_size: int = 420, engines: Optional[List[str]] = None):
+        self.workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
+        self.raster_size, self.engines = raster_size, engines
+        self._pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
+
+    def warm(self) -> int:
+        """start every worker now (a spawned worker imports this package, ~seconds) instead of under the first rollouts;
+        returns the number of distinct worker processes that answered"""
+        return len({f.result() for f in [self._pool.submit(_warm_job, 0.3) for _ in range(self.workers)]})
+
+    def submit(self, code: str, timeout: Optional[int] = 60) -> "Future[CompiledFigure]":
+        return self._pool.submit(_compile_job, code, timeout, self.raster_size, self.engines)
+
+    def imap(self, codes: Iterable[str], timeout: Optional[int] = 60) -> Iterator[CompiledFigure]:
+        """all documents in flight at once, results in input order (multiprocessing.Pool.imap, refine.py:176)"""
+        futures = [self.submit(code, timeout) for code in codes]
+        for f in futures:
+            yield f.result()
+
+    def close(self):
+        self._pool.shutdown(wait=True, cancel_futures=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def pooled_document_class(pool: CompilePool) -> Type[TikzDocument]:
+    """TikzDocument whose compile runs in `pool` (same interface, same status / log / errors / raster)"""
+
+    class PooledTikzDocument(TikzDocument):
+        _future: Optional[Future] = None
+
+        def prefetch(self) -> "PooledTikzDocument":
+            if self._compiled is None and self._future is None:
+                self._future = pool.submit(self.code, self.timeout)
+            return self
+
+        def _compile(self) -> Output:
+            fig = self.prefetch()._future.result()
+            return Output(pdf=_PooledPdf(fig) if fig.png is not None else None, status=fig.status, log=fig.log)
+
+        def rasterize(self, size: int = 420, expand_to_square: bool = True, **_) -> Optional[Image.Image]:
+            pdf = self.pdf
+            if not pdf:
+                return None
+            from ..util import expand
+            image = pdf.image()
+            if max(image.size) != size:         # the worker rasterised at pool.raster_size
+                scale = size / max(image.size)
+                image = image.resize((max(1, round(image.width * scale)), max(1, round(image.height * scale))), Image.LANCZOS)
+            return expand(image, size) if expand_to_square else image
+
+    return PooledTikzDocument

@@ -1,0 +1,192 @@
+"""Row a·X / f3 end to end with REAL child processes: `latexmk` is an executable on PATH (a script that behaves like the
+TeX driver as far as TikzDocument can tell: reads the .tex, writes <tex>.pdf and a -file-line-error log, exit status,
+optionally hangs with a grandchild), started by fork/exec through util.check_output with its timeout and process-group
+kill — not an injected toolchain object.  The three Python-side tools that are absent offline (pymupdf, pdfCropMargins,
+pdf2image) are tiny stand-in MODULES on PYTHONPATH, so the spawned workers of the compile pool import them like the real
+ones.  Reference: detikzify/infer/tikz.py:89-156 (compile / rasterize), examples/refine.py:151-185 (process pool + imap)."""
+import os
+import stat
+import sys
+import textwrap
+import time
+from pathlib import Path
+
+import pytest
+
+FAKE_LATEXMK = r'''#!/usr/bin/env python3
+import os, subprocess, sys, time
+tex = sys.argv[-1]
+engine = [a[1:] for a in sys.argv[1:] if a in ("-pdflatex", "-lualatex", "-xelatex")][0]
+assert "-file-line-error" in sys.argv and "-interaction=nonstopmode" in sys.argv and os.environ.get("max_print_line") == "1000"
+code = open(tex).read()
+lines = code.split("\n")
+print(f"Latexmk: fake run of {engine}\n({tex}")
+if "HANG" in code:                      # a run that never ends and has a child of its own (TeX spawns helpers)
+    child = subprocess.Popen(["sleep", "600"])
+    open(os.path.join(os.environ["FAKE_TEX_STATE"], "grandchild.pid"), "w").write(str(child.pid))
+    time.sleep(600)
+if "SLOW" in code:
+    time.sleep(0.4)
+bad = [i + 1 for i, l in enumerate(lines) if "\\undefinedmacro" in l]
+only = [l for l in lines if l.startswith("%ENGINE ")]
+if only and engine not in only[0]:      # this document only compiles with another engine
+    print(f"{tex}:1: Engine {engine} cannot do this.")
+    sys.exit(12)
+open(tex + ".pdf", "w").write("PDF " + engine + " " + str(sum(map(ord, code)) % 9973) + " pages=2")
+if bad:
+    print(f"{tex}:{bad[0]}: Undefined control sequence.")
+    if "FATAL" in code:
+        os.remove(tex + ".pdf")
+    sys.exit(12)
+'''
+
+FAKE_MODULES = {
+    "pymupdf.py": '''
+        import builtins
+        class _Doc:
+            def __init__(self, path):
+                self.text = builtins.open(path).read()
+            def __len__(self):
+                return int(self.text.rsplit("pages=", 1)[1]) if "pages=" in self.text else 1
+            def select(self, pages):
+                self.text = self.text.split(" pages=")[0] + f" lastpage={pages[0]}"
+            def save(self, path):
+                builtins.open(path, "w").write(self.text)
+            def tobytes(self):
+                return self.text.encode()
+            def __bool__(self):
+                return True
+        def open(path):
+            return _Doc(path)
+    ''',
+    "pdfCropMargins.py": '''
+        import shutil
+        def crop(args, quiet=False):
+            shutil.copy(args[-1], args[args.index("-o") + 1])
+    ''',
+    "pdf2image/__init__.py": "",
+    "pdf2image/pdf2image.py": '''
+        from PIL import Image, ImageDraw
+        def convert_from_bytes(data, size=420, single_file=True):
+            seed = sum(data) % 251
+            img = Image.new("RGB", (size, size * 2 // 3), "white")
+            d = ImageDraw.Draw(img)
+            d.line([seed, 5, size - 5, (seed * 7) % (size * 2 // 3)], fill="black", width=4)
+            d.text((10, 10), data.decode()[:40], fill="black")
+            return [img]
+    ''',
+}
+
+
+@pytest.fixture()
+def tex_box(tmp_path, monkeypatch):
+    """a directory with the fake TeX driver first on PATH and the stand-in modules first on PYTHONPATH"""
+    bindir, moddir, state = tmp_path / "bin", tmp_path / "mods", tmp_path / "state"
+    for d in (bindir, moddir / "pdf2image", state):
+        d.mkdir(parents=True)
+    exe = bindir / "latexmk"
+    exe.write_text(FAKE_LATEXMK)
+    exe.chmod(exe.stat().st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
+    for name, body in FAKE_MODULES.items():
+        (moddir / name).write_text(textwrap.dedent(body))
+    monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}{os.environ['PATH']}")
+    monkeypatch.setenv("PYTHONPATH", f"{moddir}{os.pathsep}{os.environ.get('PYTHONPATH', '')}")
+    monkeypatch.setenv("FAKE_TEX_STATE", str(state))
+    monkeypatch.syspath_prepend(str(moddir))
+    for m in ("pymupdf", "pdfCropMargins", "pdf2image", "pdf2image.pdf2image"):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    return state
+
+
+GOOD = "\\documentclass{standalone}\n\\begin{document}\n\\draw (0,0) -- (1,1);\n\\end{document}\n"
+BROKEN = "\\documentclass{standalone}\n\\begin{document}\n\\undefinedmacro\n\\draw (0,0);\n\\end{document}\n"
+FATAL = BROKEN + "% FATAL\n"
+LUA_ONLY = "%ENGINE lualatex\n" + GOOD
+
+
+def _pid_alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:        # a zombie still answers signal 0: read its state
+        return Path(f"/proc/{pid}/stat").read_text().split(") ")[1][0] != "Z"
+    except OSError:
+        return False
+
+
+def test_tikz_document_compiles_through_a_real_latexmk_process(tex_box):
+    from detikzify_amd.infer import TikzDocument
+    good = TikzDocument(GOOD)
+    assert good.status == 0 and not good.compiled_with_errors and good.errors == {}
+    assert good.is_rasterizable and good.has_content and good.rasterize().size == (420, 420)
+    assert good.pdf.tobytes().decode().startswith("PDF pdflatex") and "lastpage=1" in good.pdf.tobytes().decode()   # last of 2 pages kept
+    broken = TikzDocument(BROKEN)                  # recoverable error: a PDF is still produced (latexmk -f)
+    assert broken.status == 12 and broken.compiled_with_errors and broken.is_rasterizable
+    assert list(broken.errors) == [4] and "Undefined control sequence" in broken.errors[4]    # line 3 of the code + the inserted pagestyle line
+    fatal = TikzDocument(FATAL)
+    assert fatal.status == 12 and not fatal.is_rasterizable and list(fatal.errors) == [4]
+    lua = TikzDocument(LUA_ONLY)                   # engine fallback: pdflatex fails, lualatex succeeds (tikz.py:28,111-131)
+    assert lua.status == 0 and lua.pdf.tobytes().decode().startswith("PDF lualatex")
+
+
+def test_a_hanging_tex_run_is_killed_with_its_children(tex_box):
+    from detikzify_amd.infer import TikzDocument
+    TikzDocument.set_engines("pdflatex")
+    try:
+        t0 = time.perf_counter()
+        doc = TikzDocument(GOOD + "% HANG\n", timeout=1)
+        assert doc.status == -1 and not doc.is_rasterizable          # TimeoutExpired: no return code, nothing produced
+        assert time.perf_counter() - t0 < 20
+        pid = int((tex_box / "grandchild.pid").read_text())
+        for _ in range(50):
+            if not _pid_alive(pid):
+                break
+            time.sleep(0.1)
+        assert not _pid_alive(pid), "the TeX run's own child survived the timeout"
+    finally:
+        TikzDocument.set_engines(["pdflatex", "lualatex", "xelatex"])
+
+
+def test_compile_pool_runs_latex_in_worker_processes(tex_box):
+    from detikzify_amd.infer import TikzDocument
+    from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
+    codes = [GOOD, BROKEN, FATAL, LUA_ONLY] + [GOOD + f"% SLOW {i}\n" for i in range(6)]
+    direct = [TikzDocument(c) for c in codes[:4]]
+    with CompilePool(workers=3) as pool:
+        assert 1 <= pool.warm() <= 3                                  # workers up (spawn + imports) before timing
+        t0 = time.perf_counter()
+        figs = list(pool.imap(codes))
+        dt = time.perf_counter() - t0
+        assert [f.status for f in figs] == [0, 12, 12, 0] + [0] * 6
+        assert [f.png is not None for f in figs] == [True, True, False, True] + [True] * 6
+        assert [f.log for f in figs[:4]] != [d.log for d in direct]   # temp-file names differ ...
+        assert dt < 6 * 0.4 + 1.0, f"6 slow documents took {dt:.2f} s on 3 workers: no overlap"
+        # the document class that compiles in the pool: same verdicts as the in-process document
+        Pooled = pooled_document_class(pool)
+        docs = [Pooled(c).prefetch() for c in codes[:4]]              # all four in flight before the first result is read
+        for d, ref in zip(docs, direct):
+            assert (d.status, d.is_rasterizable, list(d.errors), d.compiled_with_errors) == \
+                   (ref.status, ref.is_rasterizable, list(ref.errors), ref.compiled_with_errors)
+            if ref.is_rasterizable:
+                assert d.rasterize().size == ref.rasterize().size == (420, 420)
+                assert d.rasterize().tobytes() == ref.rasterize().tobytes()
+        assert docs[0].pdf.tobytes() == direct[0].pdf.tobytes()
+
+
+def test_parallel_trees_compile_in_the_pool_while_the_others_decode(tex_box):
+    """the MCTS with the real reward path: three trees on the scripted device, every rollout's document goes through the
+    fake TeX driver in a pool worker; scores are compiler diagnostics (metric "fast"), so they are in {-1, 0, 1}"""
+    from detikzify_amd.infer import DetikzifyPipeline
+    from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
+
+    from .helpers import fake_processor, sketch_image
+    from .test_generate_loop import NIMG, VOCAB, ScriptedDevice
+    with CompilePool(workers=2) as pool:
+        pipe = DetikzifyPipeline(ScriptedDevice(slots=4), fake_processor(VOCAB, NIMG), metric="fast", max_length=NIMG + 30,
+                                 document_class=pooled_document_class(pool), compile_timeout=20)
+        out = list(pipe.simulate(sketch_image(9, 96), expansions=2, trees=3))
+        assert len(out) == 6 and all(s in (-1, 0, 1) for s, _ in out)
+        assert all(d.status in (0, 12) for _, d in out)
+        seq = list(pipe.simulate(sketch_image(9, 96), expansions=2))           # one tree: the same class works sequentially
+        assert len(seq) == 2

@@ -361,8 +361,8 @@ def test_attention_variants_agree(tiny):
             outs[name] = run_greedy(model, ids, px, 40)
             logs[name] = model.get_logits()
     finally:
-        for k, v in dict(attn_combine=2, attn_full_max=0, attn_threads=0, attn_splits=4).items():
-            model.set_option(k, v)          # TINY's configuration (attn_splits 4)
+        for k, v in dict(attn_combine=0, attn_full_max=0, attn_threads=512, attn_splits=4).items():
+            model.set_option(k, v)          # the defaults (TINY: attn_splits 4)
     for name, _ in configs[1:]:
         assert outs[name] == outs["head"], name
         assert rel_l2(logs[name], logs["head"]) < 5e-3, name
@@ -385,7 +385,7 @@ def test_long_context_attention_tiles_wrap_around(tiny):
                 ref = (toks, lg)
             got[(threads, splits)] = (toks, lg)
     finally:
-        model.set_option("attn_threads", 0)
+        model.set_option("attn_threads", 512)
         model.set_option("attn_splits", 4)
     for key, (toks, lg) in got.items():
         assert toks == ref[0], key
@@ -426,7 +426,7 @@ def test_gemv_variants_agree(tiny):
         for slot in (EPI_RESID, EPI_QKV, EPI_SWIGLU, EPI_LOGITS, O_PROJ_ATTN):
             lib.dtk_set_gemv_variant(ctx, slot, 0)
         lib.dtk_set_gemv_variant(ctx, O_PROJ, -1)
-        for k, v in dict(attn_combine=2, attn_threads=0, attn_splits=4).items():
+        for k, v in dict(attn_combine=0, attn_threads=512, attn_splits=4).items():
             model.set_option(k, v)
 
 
@@ -648,8 +648,14 @@ def test_rccl_coexists_with_the_library(tmp_path):
 # ------------------------------------------------------------------------------------------ batched decode
 @pytest.fixture(scope="module")
 def tiny_batched():
+    """the bit-identity tests below compare a slot decoded in a batch with the same sequence decoded alone / forked / in
+    another slot count: they pin the PER-SLOT path, so the one batch-dependent kernel — the shared prefix scored once for
+    all its forks on the matrix cores (default on) — is switched off here and has its own test
+    (test_shared_prefix_on_matrix_cores_tracks_the_per_slot_path)"""
     from detikzify_amd.model import load
-    return load("detikzify-tiny", synthetic=1234, batch_slots=5)
+    model, proc = load("detikzify-tiny", synthetic=1234, batch_slots=5)
+    model.set_option("prefix_mfma", 0)
+    return model, proc
 
 
 def _batch_prompts(proc):
@@ -783,6 +789,62 @@ def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched):
             engine.close()
         results[share] = res
     assert results[True] == results[False]
+
+
+@pytest.mark.parametrize("family", ["v1", "v2"])
+def test_shared_prefix_on_matrix_cores_tracks_the_per_slot_path(family, tiny_batched, request):
+    """Batched attention with `prefix_mfma` on (optional: measured no faster than the per-slot walk at 64 slots, off by default):
+    the prefix most active slots share (forks of one image) is scored ONCE per head for all
+    slots by k_attn_prefix_b (MFMA, 64 queries = slots), k_attn_tail_b continues over each slot's private keys.  Against the
+    per-slot path (prefix_mfma 0): same greedy tokens, logits within 1e-2 (fp32 summation order + the bf16 hi/lo split of
+    the probabilities; NOT bit-identical: a slot's rounding now depends on whether it shares a prefix — DESIGN §3.1b).
+    Covered: 1..4 key splits, a prefix that is not a multiple of the 64-key tile, a source slot that decodes itself, a slot
+    of ANOTHER image in the same step (not a member), both block shapes of the tail kernel, every wide-tile GEMV mode."""
+    model, proc = tiny_batched if family == "v1" else request.getfixturevalue("tiny_v2")
+    img_tok = model.config.image_token_id
+    (ids, px), (ids_b, px_b), _ = _batch_prompts(proc)
+    if family == "v2":
+        enc, enc_b = proc(images=sketch_image(10, 84), return_tensors="pt"), proc(images=sketch_image(11, 84), return_tensors="pt")
+        (ids, px), (ids_b, px_b) = (enc.input_ids[0], enc.pixel_values), (enc_b.input_ids[0], enc_b.pixel_values)
+    tail = torch.tensor([70, 300, 41] + [9] * 70 + [33, 12])                 # prefix of 12 (36) + 75 tokens: 87 / 111 keys, not a tile multiple
+    long_ids = torch.cat([ids, tail])
+
+    def run(prefix_on, splits=2, threads=512, wide=0, steps=14):
+        model.set_option("prefix_mfma", prefix_on)
+        model.set_option("pfx_splits", splits)
+        model.set_option("tail_threads", threads)
+        model.set_option("gemv_b_wide", wide)
+        for s_ in range(5):
+            model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=s_)
+        model.prefill(long_ids, px, slot=0)                                   # the source: decodes too
+        for dst in (1, 2):
+            model.kv_fork(0, dst, long_ids.numel())                           # whole-sequence forks: decode at once
+        model.kv_fork(0, 3, ids.numel() + 20)                                 # shorter share, then its own tail
+        model.prefill(torch.cat([long_ids[:ids.numel() + 20], torch.tensor([15, 6, 7])]), px, slot=3, reuse=True)
+        model.prefill(ids_b, px_b, slot=4)                                    # another image: not a member
+        toks, logits = [], None
+        for _ in range(steps):
+            model.decode_batch_launch([0, 1, 2, 3, 4])
+            toks.append(model.decode_batch_wait()[:5])
+        logits = [model.get_logits_slot(s_) for s_ in range(5)]
+        return toks, logits
+
+    try:
+        ref_t, ref_l = run(0)
+        assert all(t[0] == t[1] == t[2] for t in ref_t)                        # identical sequences, per-slot path: identical tokens
+        for kw in (dict(splits=1), dict(splits=2), dict(splits=4), dict(splits=3, threads=256), dict(wide=1), dict(wide=3)):
+            t, lg = run(1, **kw)
+            assert t == ref_t, kw
+            for s_ in range(5):
+                assert rel_l2(lg[s_], ref_l[s_]) < 1e-2, (kw, s_)         # a few bf16 flips (4e-3 on an element each) through 2 layers
+            assert torch.equal(lg[4], ref_l[4]) or kw.get("wide") or kw.get("threads") == 256, kw   # the non-member never sees the prefix kernel
+        for wide in (1, 3, 4, 5):                                              # wide tiles alone: the per-slot path is unchanged up to summation order
+            t, lg = run(0, wide=wide)
+            assert t == ref_t, wide
+            assert all(rel_l2(lg[s_], ref_l[s_]) < 1e-2 for s_ in range(5)), wide
+    finally:
+        for k, v in dict(prefix_mfma=0, pfx_splits=2, tail_threads=256, gemv_b_wide=2).items():
+            model.set_option(k, v)
 
 
 def test_simulate_parallel_trees(tiny_batched):
@@ -925,6 +987,7 @@ def test_safetensors_checkpoint_loader_matches_synthetic_fill(tmp_path, tiny):
 def tiny_v2():
     from detikzify_amd.model import load
     model, proc = load("detikzify-tiny-v2", synthetic=4321, batch_slots=5)
+    model.set_option("prefix_mfma", 0)      # bit-identity of the per-slot path (see tiny_batched)
     return model, proc
 
 
@@ -1078,15 +1141,50 @@ def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
 
 
 # ------------------------------------------------------------------------------------------ 32 slots (two MFMA column tiles)
-@pytest.mark.parametrize("nslots", [32, 64])
-def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots):
+@pytest.mark.parametrize("nslots,gemm_b", [(32, 0), (64, 0), (32, 1), (64, 1), (64, 2), (64, 3), (64, 4)])
+def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots, gemm_b):
     """load(batch_slots=33 | 65): slots 0..31 | 0..63 decode in one step (two | four 16-column MFMA tiles reuse each
     weight fragment).  Every slot's tokens and logits equal the same sequence decoded on the 16-slot build: the
-    per-column arithmetic (k order, reduction order) does not depend on the tile count."""
+    per-column arithmetic (k order, reduction order) does not depend on the tile count — for the register-operand kernels
+    (gemm_b 0) and for every block shape of the LDS-staged ones (gemm_b 1..4, kernels_batch_gemm.hip)."""
     from detikzify_amd.model import load
     m16, proc = tiny_batched
     m32, _ = load("detikzify-tiny", synthetic=1234, batch_slots=nslots + 1)
     assert m32.num_slots() == nslots + 1
+    m16.set_option("gemm_b", gemm_b)          # process-wide switch; each context drops its captured graphs
+    m32.set_option("gemm_b", gemm_b)
+    try:
+        _check_slot_count_invariance(m16, m32, proc, nslots)
+    finally:
+        m16.set_option("gemm_b", 0)
+        m32.set_option("gemm_b", 0)
+
+
+def test_lds_staged_batched_gemm_tracks_the_register_kernels(tiny_batched):
+    """k_gemm_b (x through LDS, K split 4 / 8 ways) vs k_gemv_b (x in registers, K split 8 ways): same greedy tokens, logits
+    within fp32 summation order"""
+    model, proc = tiny_batched
+    prompts = _batch_prompts(proc)
+    runs = {}
+    try:
+        for shape in (0, 1, 2, 3, 4):
+            model.set_option("gemm_b", shape)
+            for s_, (ids, px) in enumerate(prompts):
+                model.set_sampling(do_sample=False, bad_ids=[1], slot=s_)
+                model.prefill(ids, px, slot=s_)
+            toks = []
+            for _ in range(20):
+                model.decode_batch_launch([0, 1, 2])
+                toks.append(model.decode_batch_wait()[:3])
+            runs[shape] = (toks, [model.get_logits_slot(s_) for s_ in range(3)])
+    finally:
+        model.set_option("gemm_b", 0)
+    for shape in (1, 2, 3, 4):
+        assert runs[shape][0] == runs[0][0], shape
+        assert all(rel_l2(a, b) < 2e-3 for a, b in zip(runs[shape][1], runs[0][1])), shape
+
+
+def _check_slot_count_invariance(m16, m32, proc, nslots):
     enc = [proc(images=sketch_image(40 + i % 3, 96), return_tensors="pt") for i in range(3)]
     prompts = [torch.cat([enc[i % 3].input_ids[0], torch.tensor([10 + i, 3 * i + 5][: 1 + i % 2])]) for i in range(nslots)]
     n = 24

@@ -1,12 +1,31 @@
-"""Batched gate/up GEMV with and without its x-fragment loads, for 16 and 32 slots (dtk_bench_gemv role 5)."""
+"""Differential timing of the batched gate/up GEMV (dtk_bench_gemv role 5): what the kernel costs without its x-fragment
+loads (mode bit 1), without its MFMAs (bit 2), without its cross-wave reduction + epilogue (bit 4), at 16 / 32 / 64 slots."""
 import ctypes as C, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from detikzify_amd.model import load
-for slots in (16, 32):
+NAMES = {0: "full kernel", 1: "no x loads", 2: "no MFMA", 4: "no reduction / epilogue", 3: "no x, no MFMA", 6: "no MFMA, no epilogue",
+         5: "no x, no epilogue", 7: "weights stream only"}
+for slots in (64,):
     model, _ = load("detikzify-ds-7b", synthetic=1234, batch_slots=slots)
-    for mode, name in ((0, "correct"), (1, "no x loads")):
+    for mode in (0, 1, 2, 4, 3, 5, 6, 7):
         us = C.c_float()
-        model._check(model.lib.dtk_bench_gemv(model._ctx, 5, mode, 4, C.byref(us)), "bench")
-        print(f"slots {slots}: gate/up batched mode {mode} ({name}): {us.value:.2f} us  {2*model.config.ffn*model.config.hidden*2/us.value/1e3:.0f} GB/s")
+        best = 1e9
+        for _ in range(2):
+            model._check(model.lib.dtk_bench_gemv(model._ctx, 5, mode, 4, C.byref(us)), "bench")
+            best = min(best, us.value)
+        print(f"slots {slots}: gate/up mode {mode} ({NAMES[mode]:24s}): {best:6.2f} us  {2*model.config.ffn*model.config.hidden*2/best/1e3:5.0f} GB/s", flush=True)
     del model
+
+# the LDS-DMA kernel (role 6): shape 1 = 2 K splits x 4 row groups, shape 2 = 4 x 2; mode bits 1 no x DMA, 2 no MFMA, 4 no barriers, 8 no weight loads
+model, _ = load("detikzify-ds-7b", synthetic=1234, batch_slots=64)
+N6 = {0: "full kernel", 1: "no x DMA", 2: "no MFMA", 4: "no barriers / waits", 5: "no DMA, no barriers", 8: "no weight loads", 9: "no weights, no DMA",
+      13: "MFMA + LDS reads only", 7: "weights only (no DMA, MFMA, barriers)"}
+for shape in (1, 2):
+    for mode in (0, 1, 2, 4, 5, 7, 8, 9, 13):
+        us = C.c_float()
+        best = 1e9
+        for _ in range(2):
+            model._check(model.lib.dtk_bench_gemv(model._ctx, 6, shape * 16 + mode, 4, C.byref(us)), "bench")
+            best = min(best, us.value)
+        print(f"slots 64: k_gemm_b shape {shape} mode {mode:2d} ({N6[mode]:38s}): {best:6.2f} us  {2*model.config.ffn*model.config.hidden*2/best/1e3:5.0f} GB/s", flush=True)
