@@ -1545,6 +1545,14 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     else { if (value < 0 || value > 6) return fail(c, DTK_ERR_ARG, "gemv_b_wide must be 0..6"); set_gemv_b_wide(value); }
     drop_batch_graphs(c);
   }
+  else if (!strcmp(name, "gemm_impl")) {
+    if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
+    set_gemm_impl(value);
+  }
+  else if (!strcmp(name, "gemm_ring")) {
+    if (value < 2 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_ring must be 2..4");
+    set_gemm_ring(value);
+  }
   else if (!strcmp(name, "gemm_bk")) {
     if (value != 64 && value != 128) return fail(c, DTK_ERR_ARG, "gemm_bk must be 64 or 128");
     set_gemm_bk(value);

@@ -200,12 +200,22 @@ int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
 int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
 
 /* Tuning aids (tools/, bench): time one decode GEMV role (0 qkv, 1 o_proj, 2 gate/up, 3 down,
- * 4 lm_head) in kernel variant `variant` over all layers with HIP events (clobbers the decode
- * state); select the variant the decode step uses for an epilogue class. */
+ * 4 lm_head; 5 / 6 = the batched gate/up kernel / its LDS-DMA twin with parts switched off, tools/probe_batch.py) in kernel
+ * variant `variant` over all layers with HIP events (clobbers the decode state); select the variant the decode step uses for a
+ * role: epi 1 = residual roles (down, and o_proj unless slot 5 is set), 2 qkv, 3 gate/up, 4 lm_head, 5 = o_proj alone (-1: as
+ * epi 1), 6 = o_proj with the attention-partials prologue.  Variant 0 = the measured default of the model's width. */
 int  dtk_bench_gemv(dtk_ctx* ctx, int role, int variant, int reps, float* avg_us);
 int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
-int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);   /* "attn_full_max", "attn_combine", "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
-                                                                     "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32) */
+/* Tuning switches; every default is the measured-best setting.  Single-sequence decode: "attn_threads" (0 =
+ * contiguous key range per split | 256 | 512 | 1024 = tile-interleaved splits), "attn_splits" (1..16), "attn_combine" (0 = the
+ * split partials are reduced in o_proj's prologue, 1 = by the last-arriving split block, 2 = by an own kernel),
+ * "attn_full_max" (contexts below it use the one-block-per-head kernel).  Batched decode: "attn_b_impl" (0 = split-K per slot +
+ * combine kernel, 1 = one block per (head, slot)), "tail_threads" (256 | 512), "prefix_mfma" (score the prefix most slots share
+ * once on the matrix cores), "pfx_splits" (1..4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
+ * registers, 1..4 = x through LDS by LDS-DMA), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
+ * "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages" (1..4).
+ * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create. */
+int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the
  * hot path on host buffers.  All matrices row-major; bf16 as uint16.  They exist so a

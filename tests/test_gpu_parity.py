@@ -118,7 +118,7 @@ def test_op_gemm(tiny, M, N, K, flags, naive):
     assert rl2 < 1e-3 and ulps <= 2.01 and frac < 0.05
 
 
-@pytest.mark.parametrize("M,N,K,flags", [(243, 512, 432, 5), (729, 400, 304, 3), (130, 77 * 8, 688, 0), (300, 1000, 1152, 1)])
+@pytest.mark.parametrize("M,N,K,flags", [(243, 512, 432, 5), (729, 400, 304, 3), (130, 77 * 8, 688, 0), (300, 1000, 1152, 1), (65, 40, 64, 7), (17, 130, 4304, 1)])
 def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
     """the 64x64 / 128x64 / 128x128 block tiles of k_gemm_mfma (chosen per shape by block count) keep the k order per
     output element, so they agree bit for bit with each other and with the naive one-thread-per-output twin"""
@@ -142,6 +142,16 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
     model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
     model.set_option("gemm_bk", 64); model.set_option("gemm_tile", 0)
     assert np.array_equal(out, outs[1])
+    # k_gemm_dma: operand tiles written to LDS by the LDS-DMA path in MFMA fragment order, ring of 2..4 stages — same k order
+    try:
+        model.set_option("gemm_impl", 1)
+        for tile, ring in ((1, 3), (1, 2), (1, 4), (2, 3), (3, 3), (3, 2), (4, 3), (0, 3)):
+            model.set_option("gemm_tile", tile); model.set_option("gemm_ring", ring)
+            out = np.empty((M, N), dtype=np.uint16)
+            model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
+            assert np.array_equal(out, outs[1]), (tile, ring)
+    finally:
+        model.set_option("gemm_impl", 0); model.set_option("gemm_tile", 0); model.set_option("gemm_ring", 3)
     assert all(np.array_equal(outs[1], outs[t]) for t in (2, 3, 4, 5))
     frac = float((outs[1] != outs["naive"]).mean())
     assert frac < 2e-3     # fmaf chain vs MFMA tree inside a 32-wide k-step: rare 1-ulp flips only
