@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU decode per baseline entry before it stops early")
     ap.add_argument("--no-cpu-config1", action="store_true", help="skip the BASELINE config 1 entry (ds-1.3b shape on the host CPU)")
     ap.add_argument("--probe-tokens", type=int, default=64)
+    ap.add_argument("--probe-chain-reps", type=int, default=8, help="passes over all layers of the dominant kernel timed between one HIP event pair")
     ap.add_argument("--weight-format", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = e4m3 decoder weights with per-row 2^e scales (BASELINE config 5, cl-7b)")
     ap.add_argument("--skip-batched", action="store_true", help="allocate the --batch slots (for the MCTS phase) but skip the "
@@ -503,6 +504,23 @@ def main():
         except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
             roof["error"] = repr(e)
             model.set_graph_mode(1)
+        # second live measurement, the one `achieved` is quoted on: the SAME kernel launched back to back over all layers'
+        # weights (distinct 180 MB per launch: nothing comes from L2 / Infinity Cache) between ONE pair of HIP events on the
+        # library's stream — average launch duration including the kernel boundary, without the ~4.6 us an event pair
+        # around every single launch adds (kept above as in_step_event_pair_us); this is the figure that has to agree with
+        # rocprofv3's average for the kernel
+        try:
+            import ctypes as C
+            us = C.c_float(0.0)
+            model._check(model.lib.dtk_bench_gemv(model._ctx, 2, 0xFF, args.probe_chain_reps, C.byref(us)), "dtk_bench_gemv")
+            if us.value > 0 and roof.get("bytes_per_launch"):
+                ach = roof["bytes_per_launch"] / (us.value * 1e-6) / 1e9
+                roof.update(in_step_event_pair_us=roof.get("avg_launch_us"), in_step_achieved=roof.get("achieved"),
+                            achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_us=float(us.value),
+                            launches_timed=args.probe_chain_reps * cfg.layers,
+                            method="HIP events around a back-to-back chain of this kernel over every layer's weights on the library's stream")
+        except Exception as e:  # noqa: BLE001
+            roof["chain_error"] = repr(e)
         # HBM traffic of that kernel: a counter pass cannot run inside this process, so the figure comes from the committed
         # rocprofv3 --pmc FETCH_SIZE summary (x2 gfx950 correction, guides/MI355X_MICROARCH.md §HBM) — but only while it
         # describes THIS kernel: profiles/dominant_kernel.json records the model and the sha256 of kernels_decode.hip it was

@@ -1487,6 +1487,8 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   const bool same_layer = (variant & 0x100) != 0;  // every launch re-reads layer 0 (Infinity Cache probe)
   const int plain = (variant >> 9) & 3;            // 0x200: same weights through PRO_COPY + EPI_STORE; 0x400: PRO_RMSNORM + EPI_STORE
   variant &= 0xff;
+  const bool shipped = variant == 0xff;            // 0xff: whatever launch_gemv picks for this role and model (the kernel a decode step runs)
+  auto launch = [&](int pro, int epi, const GemvArgs& g) { if (shipped) launch_gemv(pro, epi, g, s); else launch_gemv_variant(pro, epi, variant, g, s); };
   auto one_pass = [&]() {
     for (int l = 0; l < c->L; ++l) {
       const LayerW& w = c->layers[same_layer ? 0 : l];
@@ -1503,11 +1505,11 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
       }
       g.eps = c->cfg.rms_eps; g.st = c->st; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH;
       g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.pm = c->pm; g.pl = c->pl; g.po = c->po; g.S = c->S;
-      if (role == 0) { g.W = w.wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch_gemv_variant(PRO_RMSNORM, EPI_QKV, variant, g, s); }
-      else if (role == 1) { g.W = w.wo; g.N = c->d; g.K = c->d; g.x = c->attn_out; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
-      else if (role == 2) { g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act; launch_gemv_variant(PRO_RMSNORM, EPI_SWIGLU, variant, g, s); }
-      else if (role == 3) { g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->q; launch_gemv_variant(PRO_COPY, EPI_RESID, variant, g, s); }
-      else { g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm; g.logits = c->logits; launch_gemv_variant(PRO_RMSNORM, EPI_LOGITS, variant, g, s); }
+      if (role == 0) { g.W = w.wqkv; g.N = c->d + 2 * c->KVH * 128; g.K = c->d; g.x = c->x; g.norm_w = w.ln1; g.q_out = c->q; g.kcache = kcache(c, l); g.vcache = vcache(c, l); launch(PRO_RMSNORM, EPI_QKV, g); }
+      else if (role == 1) { g.W = w.wo; g.N = c->d; g.K = c->d; g.x = c->attn_out; g.y = c->q; launch(PRO_COPY, EPI_RESID, g); }
+      else if (role == 2) { g.W = w.wgu; g.N = 2 * c->ff; g.K = c->d; g.x = c->x; g.norm_w = w.ln2; g.y = c->act; launch(PRO_RMSNORM, EPI_SWIGLU, g); }
+      else if (role == 3) { g.W = w.wdown; g.N = c->d; g.K = c->ff; g.x = c->act; g.y = c->q; launch(PRO_COPY, EPI_RESID, g); }
+      else { g.W = c->lm_head; g.N = c->V; g.K = c->d; g.x = c->x; g.norm_w = c->final_norm; g.logits = c->logits; launch(PRO_RMSNORM, EPI_LOGITS, g); }
     }
   };
   one_pass();  // warm-up (code objects, clocks)

@@ -11,6 +11,8 @@ from PIL import Image, ImageChops, ImageOps
 
 
 def remove_alpha(image: Image.Image, bg="white") -> Image.Image:
+    if image.mode == "RGB":         # nothing to composite: an opaque image comes back unchanged from the RGBA round trip below
+        return image.copy()         # (3 ms per rendered figure on the reward path; pinned by tests/golden/image_prep.json)
     canvas = Image.new("RGBA", image.size, bg)
     return Image.alpha_composite(canvas, image.convert("RGBA")).convert("RGB")
 

@@ -203,7 +203,8 @@ int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
  * 4 lm_head; 5 / 6 = the batched gate/up kernel / its LDS-DMA twin with parts switched off, tools/probe_batch.py) in kernel
  * variant `variant` over all layers with HIP events (clobbers the decode state); select the variant the decode step uses for a
  * role: epi 1 = residual roles (down, and o_proj unless slot 5 is set), 2 qkv, 3 gate/up, 4 lm_head, 5 = o_proj alone (-1: as
- * epi 1), 6 = o_proj with the attention-partials prologue.  Variant 0 = the measured default of the model's width. */
+ * epi 1), 6 = o_proj with the attention-partials prologue.  Variant 0 = the measured default of the model's width;
+ * dtk_bench_gemv variant 0xff = whatever the decode step itself launches for that role (bench.py's roofline leg). */
 int  dtk_bench_gemv(dtk_ctx* ctx, int role, int variant, int reps, float* avg_us);
 int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
 /* Tuning switches; every default is the measured-best setting.  Single-sequence decode: "attn_threads" (0 =
