@@ -1551,9 +1551,22 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
     set_gemm_impl(value);
   }
+  else if (!strcmp(name, "gemv_bx")) {
+    if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemv_bx must be 0..4");
+    set_gemv_bx(value);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "gemm_ring")) {
     if (value < 2 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_ring must be 2..4");
     set_gemm_ring(value);
+  }
+  else if (!strcmp(name, "vit_feature_layer")) {   // diagnostic (per-block parity tests): which block's normed output dtk_vit_encode(feats) returns
+    if (value < 0 || value >= c->vDepth) return fail(c, DTK_ERR_ARG, "vit_feature_layer must be 0..%d", c->vDepth - 1);
+    HIPCHK(c, hipStreamSynchronize(c->stream_vit));
+    c->cfg.vit_feature_layer = value;
+    c->have_image = false; c->cached_image_key = 0;   // a cached image prefix was projected from the old layer's features
+    c->seq0.image_key = 0; c->seq0.cached_ids.clear();
+    for (SeqHost& sh : c->bseq) { sh.image_key = 0; sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
   }
   else if (!strcmp(name, "gemm_bk")) {
     if (value != 64 && value != 128) return fail(c, DTK_ERR_ARG, "gemm_bk must be 64 or 128");

@@ -110,6 +110,8 @@ void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
 bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s);   // kernels_batch_gemm.hip; false = not covered, use k_gemv_b
 void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);   // timing experiments
+bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
+void set_gemv_bx(int v);       // 0: off, 1: on (units per block from the CU count), 2..4: on with that many units per block
 void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)
 void set_gemv_b_wide(int v);   // row tiles per block of the batched kernels: 0 round-1 shapes, 1 twice as many, 2 auto (wide from 32 slots)
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);

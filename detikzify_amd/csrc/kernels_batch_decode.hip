@@ -51,7 +51,7 @@ __device__ __forceinline__ bf16x8_t f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
 // NT = 16-slot column tiles (1: up to 16 slots, 2: up to 32, 4: up to 64): the A (weight) fragment of a k-step is reused by NT
 // MFMAs.  The cross-wave reduction goes through LDS two column tiles at a time (NP), so NT = 4 needs no more LDS than NT = 2.
 template <int EPI, int T, int MODE = 0, bool F8 = false, int WAVES = GB_WAVES, int NT = 1, int KS = 4>   // KS = k-steps per register stage
-__global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (MODE & 8) ? 4 : 1) void k_gemv_b(GemvBArgs a) {
   constexpr int NP = NT > 2 ? 2 : NT;   // column tiles per reduction pass
   __shared__ float red[WAVES][T][NP][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
   const int per = (nsteps + WAVES - 1) / WAVES;
   const int s0 = min(nsteps, wave * per), s1 = min(nsteps, s0 + per);
 
-  // MODE (timing experiments only): 1 = no x loads
+  // MODE (timing experiments only): 1 = no x loads, 2 = no MFMA, 4 = no reduction / epilogue, 8 = at least 4 waves per SIMD (<= 128
+  // VGPRs: two 8-wave blocks per CU), 16 = two register stages in flight, 32 = one x fragment per k-step feeds all NT column
+  // tiles (x traffic / NT: what perfect reuse of x would buy; wrong results), 64 = non-temporal x loads
   const int koff = (lane >> 4) * 8;
   // this lane's 16 bytes of tile 0 of the block's t-th row tile.  bf16: 1 KiB tile = one k-step; fp8: 1 KiB
   // pair tile = two k-steps.  A load "unit" below is one such tile.
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
           u32x4 xv;
           if (MODE & 1) xv = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          else if ((MODE & 32) && nt > 0) xv = x[F8 ? 2 * i + h : i][0];
+          else if (MODE & 64) xv = ld_nt(reinterpret_cast<const u32x4*>(xlane + ((size_t)nt * nsteps + (ok ? st : 0)) * 512));
           else xv = *reinterpret_cast<const u32x4*>(xlane + ((size_t)nt * nsteps + (ok ? st : 0)) * 512);
           if (!ok) xv = (u32x4){0u, 0u, 0u, 0u};
           x[F8 ? 2 * i + h : i][nt] = xv;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
           }
         }
   };
-  if (F8) {   // two stages in flight (measured: fp8 step 3.24 -> 2.99 ms at B=16)
+  if (F8 || (MODE & 16)) {   // two stages in flight (measured: fp8 step 3.24 -> 2.99 ms at B=16)
     u32x4 wA[T][U], xA[XN][NT], wB[T][U], xB[XN][NT];
     if (u0 < u1) load(wA, xA, u0);
     for (int u = u0; u < u1; u += 2 * U) {
@@ -252,10 +256,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_b(GemvBArgs a) {
 }
 
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments (mode bits: 1 no x loads, 2 no MFMA, 4 no reduction / epilogue)
+  if (mode >= 128 && mode <= 131) { if (!launch_gemv_bx(EPI_SWIGLU, mode - 127, a, s)) launch_gemv_b(EPI_SWIGLU, a, s); return; }   // the x-once-per-CU kernel: 128 auto, 129..131 = 2..4 units per block
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
 #define GBM(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV>), g, b, 0, s, a)
+#define GBM2(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV, 2>), g, b, 0, s, a)   // 2 k-steps per stage
 #define GBMS(NTV) switch (mode) { case 1: GBM(1, NTV); break; case 2: GBM(2, NTV); break; case 3: GBM(3, NTV); break; case 4: GBM(4, NTV); break; \
-                                  case 5: GBM(5, NTV); break; case 6: GBM(6, NTV); break; case 7: GBM(7, NTV); break; default: GBM(0, NTV); }
+                                  case 5: GBM(5, NTV); break; case 6: GBM(6, NTV); break; case 7: GBM(7, NTV); break; \
+                                  case 8: GBM(8, NTV); break; case 16: GBM2(16, NTV); break; case 24: GBM2(24, NTV); break; case 17: GBM(16, NTV); break; \
+                                  case 32: GBM(32, NTV); break; case 40: GBM(40, NTV); break; case 48: GBM2(48, NTV); break; case 56: GBM2(56, NTV); break; \
+                                  case 64: GBM(64, NTV); break; default: GBM(0, NTV); }
   if (a.W8) {
     if (a.nt >= 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
     else if (a.nt == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
@@ -266,6 +275,7 @@ void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGL
   else if (a.nt == 2) { GBMS(2) }
   else { GBMS(1) }
 #undef GBMS
+#undef GBM2
 #undef GBM
 }
 
@@ -324,11 +334,15 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
 }
+static int g_gemv_bx = -1;
+void set_gemv_bx(int v) { g_gemv_bx = v; }
 static int g_gemm_b_shape = -1;
 void set_gemm_b_shape(int v) { g_gemm_b_shape = v; }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemm_b_shape < 0) { const char* e = getenv("DTK_GEMM_B"); g_gemm_b_shape = e ? atoi(e) : 0; }
   if (launch_gemm_b(epi, g_gemm_b_shape, a, s)) return;     // x staged through LDS (kernels_batch_gemm.hip); false: not covered
+  if (g_gemv_bx < 0) { const char* e = getenv("DTK_GEMV_BX"); g_gemv_bx = e ? atoi(e) : 1; }
+  if (launch_gemv_bx(epi, g_gemv_bx, a, s)) return;         // 64 slots, rows >> d roles: x once per CU (kernels_batch_gemm.hip); false: not covered
   if (a.nt >= 3) { if (a.W8) launch_gemv_b_impl<true, 4>(epi, a, s); else launch_gemv_b_impl<false, 4>(epi, a, s); }
   else if (a.nt == 2) { if (a.W8) launch_gemv_b_impl<true, 2>(epi, a, s); else launch_gemv_b_impl<false, 2>(epi, a, s); }
   else { if (a.W8) launch_gemv_b_impl<true, 1>(epi, a, s); else launch_gemv_b_impl<false, 1>(epi, a, s); }

@@ -228,6 +228,201 @@ __global__ __launch_bounds__(KQ * RP * 64) void k_gemm_b(GemvBArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemv_bx — the rows >> d roles (qkv, gate/up, lm_head) at 49..64 slots with the x operand read ONCE PER CU.
+//
+// What the probes say (tools/probe_batch.py, profiles/r02_probe_batch_x_traffic.txt): k_gemv_b's weights stream at 6.4 TB/s, its
+// MFMAs and epilogue are free, neither occupancy nor deeper register staging changes anything — and feeding all four column
+// tiles from ONE x fragment (x traffic / 4, wrong results) takes it from 48.8 to 32.6 us.  The kernel is bound by the bytes of x
+// it pulls through the CU's vector-memory path: 688 blocks x 8 waves each read their K slice of all 64 slots = 352 MB per
+// launch.  k_gemm_b shared x between waves through LDS with a barrier every 2-4 k-steps and lost the weight stream to the
+// barriers (and to the compiler's vmcnt(0) in front of every stage: its waitcnt pass gives up on branchy loops).  Here:
+//   * ONE block per CU: UNITS compute waves + one loader wave.  A compute wave owns one unit (= the T = 2 paired row tiles
+//     k_gemv_b gives a block) over the FULL K, so there is no cross-wave reduction and the epilogue runs from the accumulator
+//     registers;
+//   * K is walked in phases of 8 k-steps; the 32 KiB of x fragments of a phase sit in LDS, double buffered, put there by the
+//     LOADER wave (phase q + 2 in flight in its registers while it parks phase q + 1): one barrier per phase.  x traffic = one
+//     pass over x per CU = 118 MB for gate/up (230 CUs), a third of k_gemv_b's;
+//   * the compute waves' vector-memory queue holds nothing but weights — a register ring two phases (16 k-steps, 32 KiB per
+//     wave) deep, non-temporal 1 KiB loads, refilled as it is consumed across phases and barriers.  vmcnt completes in order:
+//     with x fetched by the same wave (the first version of this kernel: 35.2 us) every wait for an x fragment also waited
+//     for the younger half of the weight ring; role-specialised waves keep the two streams' waits apart.  The phase bodies
+//     are branch-free (the last two phases are peeled): the compiler's waitcnt pass gives up (vmcnt(0)) on branchy loops;
+//   * grid = ceil(units / UNITS) <= CU count: every block is resident at once, a CU streams at most UNITS x K x 64 B of weights
+//     (768 KiB for gate/up, 9 % above the fair share) — the launch is HBM-bound as a whole, not per CU.
+// K order per accumulator: the k-steps of one k_gemv_b wave slice (CHP phases = nsteps / 8 k-steps) are summed by MFMA
+// accumulation from zero in k order, the slice sums are added in slice order in fp32 — the same chains and the same order as
+// k_gemv_b's 8 wave slices and their reduction, so the results are BIT-IDENTICAL to k_gemv_b (tested): a slot's tokens do not
+// depend on which of the two kernels served the step.
+template <bool B> struct bx_flag { static constexpr bool value = B; };
+template <int EPI, int UNITS, int CHP>
+__global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
+  constexpr int T = 2, NT = 4, PH = 8, RING = 2 * PH;           // k-steps per phase; weight ring = two phases
+  constexpr int FR = PH * NT;                                   // 1 KiB x fragments of one phase
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x FR KiB
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = a.K >> 5;                                  // the launcher guarantees K = 32 * 8 * PH * CHP
+  const int NPH = nsteps / PH;                                  // 8 * CHP phases (even); a chain (one k_gemv_b wave slice) = CHP phases
+
+  if (wave == UNITS) {
+    // ---- the loader wave: x fragments only.  Phase q + 2 is in flight (registers) while phase q + 1 is parked in the buffer
+    // nobody reads; its vector-memory queue holds nothing but L2 hits, the compute waves' queues nothing but weights, so
+    // neither stream's in-order waits ever touch the other
+    const bf16_t* xlane = a.X + lane * 8;
+    u32x4 xr[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(xlane + ((size_t)(f / PH) * nsteps + (f % PH)) * 512);
+#pragma unroll
+    for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(smem + (size_t)f * 1024 + lane * 16) = xr[f];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(xlane + ((size_t)(f / PH) * nsteps + PH + (f % PH)) * 512);
+    __syncthreads();
+    for (int q = 0; q < NPH; ++q) {
+      if (q + 1 < NPH) {
+        unsigned char* xn = smem + (size_t)((q + 1) & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(xn + (size_t)f * 1024) = xr[f];
+      }
+      if (q + 2 < NPH) {
+#pragma unroll
+        for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(xlane + ((size_t)(f / PH) * nsteps + (size_t)(q + 2) * PH + (f % PH)) * 512);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- compute waves: one unit each over the full K
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+  const int g = blockIdx.x * UNITS + wave;
+  const int gc = g < groups ? g : groups - 1;                   // a surplus wave streams valid memory and stores nothing
+  const unsigned char* wrow[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
+    const int tn_max = ((a.N + 15) >> 4) - 1;
+    if (tn > tn_max) tn = tn_max;
+    wrow[t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+  }
+  u32x4 wr[RING][T];
+#pragma unroll
+  for (int i = 0; i < RING; ++i)
+#pragma unroll
+    for (int t = 0; t < T; ++t) wr[i][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)i * 1024));
+  f32x4 tot[T][NT], c[T][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { tot[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+
+  // phase q (q & 1 == H): x from buffer H, weights from ring slots H * PH + j; REFILL loads the weights of phase q + 2 into them
+  auto phase = [&](int q, auto half_tag, auto refill_tag) {
+    constexpr int H = decltype(half_tag)::value ? 1 : 0;
+    constexpr bool REFILL = decltype(refill_tag)::value;
+    const unsigned char* xb = smem + (size_t)H * FR * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[H * PH + j][t]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
+      }
+      if (REFILL) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) wr[H * PH + j][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)((q + 2) * PH + j) * 1024));
+      }
+    }
+    __syncthreads();   // the loader has parked the next phase; everybody is done reading this one
+  };
+  auto close_chain = [&]() {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { tot[t][nt] += c[t][nt]; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  };
+  constexpr bx_flag<true> yes{};
+  constexpr bx_flag<false> no{};
+  for (int q = 0; q + 2 < NPH; q += 2) {                        // both phases have two phases after them
+    phase(q, no, yes);
+    if (CHP == 1) close_chain();
+    phase(q + 1, yes, yes);
+    close_chain();
+  }
+  phase(NPH - 2, no, no);
+  if (CHP == 1) close_chain();
+  phase(NPH - 1, yes, no);
+  close_chain();
+  if (g >= groups) return;
+  // C/D layout: lane holds rows (lane >> 4) * 4 + r, column (slot) nt * 16 + (lane & 15) of each tile
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    if (!a.bs->active[n]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
+    }
+  }
+}
+
+static int g_cu_count = 0;
+static int cu_count() {
+  if (!g_cu_count) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_cu_count = n;
+  }
+  return g_cu_count;
+}
+template <int EPI, int UNITS, int CHP>
+static void launch_bx_one(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * 8 * 4 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
+  hipLaunchKernelGGL((k_gemv_bx<EPI, UNITS, CHP>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a);
+}
+template <int EPI, int CHP>
+static bool launch_bx_units(int units, const GemvBArgs& a, hipStream_t s) {
+  switch (units) {
+    case 1: case 2: launch_bx_one<EPI, 2, CHP>(a, s); return true;   // (one unit per block would share nothing)
+    case 3: launch_bx_one<EPI, 3, CHP>(a, s); return true;
+    case 4: launch_bx_one<EPI, 4, CHP>(a, s); return true;
+    default: return false;                                           // more than 4 units per CU (128 k-token vocabularies): k_gemv_b
+  }
+}
+// variant > 0 = on; `units` waves per block = units per CU (variant 2..4 force that many: tuning).  false = not covered (fp8
+// weights, fewer than 49 slots, N = d roles, K other than 2048 / 4096, more than 4 units per CU): the caller uses k_gemv_b
+bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
+  if (a.W8 || a.nt < 3 || variant <= 0) return false;
+  if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
+  if (a.K != 4096 && a.K != 2048) return false;
+  if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
+  if (epi == EPI_LOGITS && (a.N & 31)) return false;
+  const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
+                   : epi == EPI_SWIGLU ? gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH) : gg_groups<EPI_LOGITS, 2>(a.N, a.ff, a.H, a.KVH);
+  int units = (groups + cu_count() - 1) / cu_count();
+  // measured at 64 slots, ds-7b (profiles/r02_batch64_bx_kernel_stats.csv vs r02_batch64_kernel_stats.csv): gate/up (3 units per CU)
+  // 48.7 -> 36.3 us, lm_head (4) 60.3 -> 49.5, qkv (1.5 -> 2 units: 192 blocks of 2 compute waves) 28.1 -> 31.3: with fewer than
+  // 3 units a CU has too few weight streams in flight, k_gemv_b keeps those roles
+  if (variant == 1 && units < 3) return false;
+  if (variant >= 2 && variant <= 4) units = variant;
+#define BX(E) (a.K == 4096 ? launch_bx_units<E, 2>(units, a, s) : launch_bx_units<E, 1>(units, a, s))
+  if (epi == EPI_QKV) return BX(EPI_QKV);
+  if (epi == EPI_SWIGLU) return BX(EPI_SWIGLU);
+  return BX(EPI_LOGITS);
+#undef BX
+}
+
 template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
 static void launch_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);

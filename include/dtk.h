@@ -215,6 +215,8 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * once on the matrix cores), "pfx_splits" (1..4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
  * registers, 1..4 = x through LDS by LDS-DMA), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
  * "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages" (1..4).
+ * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
+ * the tower block by block with it); every cached image prefix is dropped.
  * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create. */
 int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 

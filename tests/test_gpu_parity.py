@@ -626,6 +626,87 @@ def test_headline_models_match_cpu_oracle(name, weight_format):
     _against_cpu_oracle(name, n_greedy=16, n_sampled=12, weight_format=weight_format)
 
 
+def test_vit_error_grows_block_by_block_like_the_reference_dtype_policy():
+    """The real 27-block tower, one block at a time ("vit_feature_layer" walks the feature tap through the tower): at EVERY
+    depth the device is no further from the fp32 oracle than 1.5 x the bf16-policy oracle (+1e-3), after the first block it
+    is within rounding flips of the bf16-policy oracle (a wrong kernel shows up at block 0, it cannot hide in the depth-27
+    envelope), and no single block adds more than twice the policy's own worst per-block growth."""
+    import gc
+    from detikzify_amd.model import load
+    from oracle.vit import VitOracle
+    model, proc = load("detikzify-ds-1.3b", synthetic=1234, max_positions=512)
+    try:
+        cfg = model.config.oracle_dict()
+        depth = cfg["vit_depth"]
+        w = {k: v for k, v in weights_from_device(model, cfg).items() if k.startswith("vision_model.")}
+        px = proc(images=sketch_image(0, 224), return_tensors="pt").pixel_values
+        _, o16, _ = VitOracle(cfg, w, "bf16").intermediate(px[0], depth - 1, return_all=True)
+        v32 = VitOracle(cfg, w, "fp32")
+        _, o32, _ = v32.intermediate(px[0], depth - 1, return_all=True)
+        n16 = VitOracle(cfg, w, "bf16")
+        e_dev, e_orc, r_dev = [], [], []
+        for i in range(depth):
+            model.set_option("vit_feature_layer", i)
+            feats, _ = model.vit_encode(px, want_pooled=False)
+            truth, policy = v32.final_norm(o32[i]), n16.final_norm(o16[i])
+            e_dev.append(rel_l2(feats[0].float(), truth))
+            e_orc.append(rel_l2(policy, truth))
+            r_dev.append(rel_l2(feats[0].float(), policy))
+        model.set_option("vit_feature_layer", cfg["vit_feature_layer"])
+        print("ViT per-block rel-L2 vs fp32, device / bf16 oracle: " + " ".join(f"{a:.1e}/{b:.1e}" for a, b in zip(e_dev, e_orc)))
+        print("ViT per-block rel-L2 device vs bf16 oracle: " + " ".join(f"{a:.1e}" for a in r_dev))
+        # patch embedding + block 0 + final norm: the bf16 policy itself is 4.7e-3 from fp32 here; two correct bf16
+        # pipelines differ by rounding flips only (~1e-3)
+        assert r_dev[0] < 3e-3, f"block 0 alone is {r_dev[0]:.2e} away from the reference dtype policy"
+        for i in range(depth):
+            assert e_dev[i] < 1.5 * e_orc[i] + 1e-3, (i, e_dev[i], e_orc[i])
+        worst_policy_step = max(max(e_orc[i + 1] - e_orc[i] for i in range(depth - 1)), 1e-3)
+        for i in range(depth - 1):
+            assert e_dev[i + 1] - e_dev[i] < 2.0 * worst_policy_step, (i, e_dev[i], e_dev[i + 1], worst_policy_step)
+    finally:
+        del model
+        gc.collect()
+
+
+@pytest.mark.parametrize("layers", [1, 2, 4, 8, 16])
+def test_decoder_error_grows_with_depth_like_the_reference_dtype_policy(layers):
+    """The headline decoder width (ds-7b: d 4096, ff 11008, 32 heads) cut to 1..16 layers, text-only prompt of 48 tokens:
+    prefill logits and 4 decode steps against the CPU oracle at every depth.  At depth 1 the envelope is a single layer's
+    bf16 rounding, so a kernel that is wrong by more than that fails here whatever the full-depth envelope allows."""
+    import gc
+    from detikzify_amd.model.config import preset
+    from detikzify_amd.model.modeling import DetikzifyForCausalLM
+    cfg_dev = preset("detikzify-ds-7b")
+    cfg_dev.layers, cfg_dev.max_positions = layers, 256
+    model = DetikzifyForCausalLM(cfg_dev, 0)
+    try:
+        model.fill_synthetic(77 + layers)
+        cfg = model.config.oracle_dict()
+        w = {k: v for k, v in weights_from_device(model, cfg).items() if not k.startswith("vision_model.")}
+        g = torch.Generator().manual_seed(layers)
+        ids = torch.randint(3, cfg["vocab"] - 1, (48,), generator=g)
+        ids = ids[ids != cfg["image_token_id"]]
+        o16, o32 = DetikzifyOracle(cfg, w, precision="bf16"), DetikzifyOracle(cfg, w, precision="fp32")
+        dev = model.prefill(ids, None, return_logits=True)
+        ref, truth = o16.prefill(ids, None), o32.prefill(ids, None)
+        e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
+        assert e_dev < 1.5 * e_orc + 1e-3, (layers, e_dev, e_orc)
+        model.set_sampling(do_sample=False)
+        worst = 0.0
+        for _ in range(4):                      # the decode kernels at this depth, teacher-forced with the device's own tokens
+            model.decode_launch()
+            t = model.decode_wait()
+            lg = model.get_logits()
+            r32, r16 = o32.step(t), o16.step(t)
+            d, o = rel_l2(lg, r32), rel_l2(r16, r32)
+            worst = max(worst, d / (1.5 * o + 1e-3))
+            assert d < 1.5 * o + 1e-3, (layers, d, o)
+        print(f"decoder depth {layers}: prefill logits vs fp32: device {e_dev:.2e}, bf16 oracle {e_orc:.2e}; decode steps worst ratio to the envelope {worst:.2f}")
+    finally:
+        del model
+        gc.collect()
+
+
 def test_rccl_coexists_with_the_library(tmp_path):
     """torch.distributed nccl (= RCCL) in the same process as libdtk_hip.so (one HIP runtime):
     world_size 1 on this box — init, barrier, all_reduce, the string gather of detikzify_amd.dist."""
@@ -1192,6 +1273,42 @@ def test_lds_staged_batched_gemm_tracks_the_register_kernels(tiny_batched):
     for shape in (1, 2, 3, 4):
         assert runs[shape][0] == runs[0][0], shape
         assert all(rel_l2(a, b) < 2e-3 for a, b in zip(runs[shape][1], runs[0][1])), shape
+
+
+@pytest.mark.parametrize("name,layers", [("detikzify-ds-7b", 2), ("detikzify-ds-1.3b", 3)])
+def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, layers):
+    """k_gemv_bx (64 slots: the x fragments of a phase shared through LDS, one wave per row-tile pair over the full K) against
+    k_gemv_b at the real widths (K = 4096: chains of two phases, K = 2048: one), a few layers deep: same K order per
+    accumulator by construction, so tokens AND logits must be bit-identical — for every block shape."""
+    import gc
+    from detikzify_amd.model.config import preset
+    from detikzify_amd.model.modeling import DetikzifyForCausalLM
+    cfg = preset(name)
+    cfg.layers, cfg.max_positions, cfg.batch_slots = layers, 256, 64
+    model = DetikzifyForCausalLM(cfg, 0)
+    try:
+        model.fill_synthetic(99)
+        g = torch.Generator().manual_seed(5)
+        prompts = [torch.randint(3, cfg.vocab - 1, (6 + (i % 5),), generator=g) for i in range(64)]
+        slots = list(range(64))
+        runs = {}
+        for variant in (0, 1, 2, 3, 4):
+            model.set_option("gemv_bx", variant)
+            for s_, ids in enumerate(prompts):
+                model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
+                model.prefill(ids, None, slot=s_)
+            toks = []
+            for _ in range(6):
+                model.decode_batch_launch(slots)
+                toks.append(model.decode_batch_wait()[:64])
+            runs[variant] = (toks, torch.stack([model.get_logits_slot(s_) for s_ in (0, 17, 40, 63)]))
+        model.set_option("gemv_bx", 0)
+        for variant in (1, 2, 3, 4):
+            assert runs[variant][0] == runs[0][0], (name, variant)
+            assert torch.equal(runs[variant][1], runs[0][1]), (name, variant)
+    finally:
+        del model
+        gc.collect()
 
 
 def _check_slot_count_invariance(m16, m32, proc, nslots):
