@@ -129,6 +129,7 @@ struct dtk_ctx {
   size_t kv_slot_stride = 0;
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
   float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
+  float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk partial sums + arrival counters
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
@@ -422,6 +423,8 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pfx_m = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_l = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_o = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4 * 128);
+    c->kpart = P.take<float>((size_t)8 * ((size_t)(d + 15) / 16) * 4 * 256);   // k_gemv_bk: 8 K-slice partials of every row tile x 64 slots
+    c->kctr = P.take<unsigned>((size_t)(d + 15) / 16);                              // arrival counters (the arena is zeroed once; the last arrival resets)
     c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
     c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
     c->smb_b = P.take<SampleMB>(DTK_MAX_BATCH + 1);
@@ -591,7 +594,7 @@ void batch_step_launches(dtk_ctx* c) {
     bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
     GemvBArgs g{};
     g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt_step;
-    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
+    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride; g.kpart = c->kpart; g.kctr = c->kctr;
     launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
     g.W = w.t_wqkv; g.W8 = w.t8_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
@@ -1542,7 +1545,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (!strcmp(name, "attn_b_impl")) { if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "attn_b_impl must be 0 or 1"); c->attn_b_impl = value; }
     else if (!strcmp(name, "prefix_mfma")) c->prefix_mfma = value != 0;
     else if (!strcmp(name, "gemm_b")) { if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_b must be 0..4"); set_gemm_b_shape(value); }
-    else if (!strcmp(name, "tail_threads")) { if (value != 256 && value != 512) return fail(c, DTK_ERR_ARG, "tail_threads must be 256 or 512"); c->tail_threads = value; }
+    else if (!strcmp(name, "tail_threads")) { if (value != 64 && value != 128 && value != 256 && value != 512) return fail(c, DTK_ERR_ARG, "tail_threads must be 64, 128, 256 or 512"); c->tail_threads = value; }
     else if (!strcmp(name, "pfx_splits")) { if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "pfx_splits must be 1..4"); c->pfx_splits = value; }
     else { if (value < 0 || value > 6) return fail(c, DTK_ERR_ARG, "gemv_b_wide must be 0..6"); set_gemv_b_wide(value); }
     drop_batch_graphs(c);
@@ -1550,6 +1553,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemm_impl")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
     set_gemm_impl(value);
+  }
+  else if (!strcmp(name, "gemv_bk")) {
+    if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemv_bk must be 0 or 1");
+    set_gemv_bk(value);
+    drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bx")) {
     if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemv_bx must be 0..4");

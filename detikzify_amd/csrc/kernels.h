@@ -105,12 +105,15 @@ struct GemvBArgs {
   const uint8_t* W8;                   // fp8 (e4m3) pair-tiled copy of the weights, or null; then wscale[N] = per-row 2^e scales
   const float* wscale;
   int nt;                              // 16-slot column tiles: 1 (<= 16 slots), 2 (<= 32) or 4 (<= 64)
+  float* kpart; unsigned* kctr;        // k_gemv_bk: K-split partials [8][N / 16][4][256] fp32, one arrival counter per row tile (zero between launches)
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
 bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s);   // kernels_batch_gemm.hip; false = not covered, use k_gemv_b
 void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);   // timing experiments
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
+bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: N = d roles at 64 slots, K split over 8 CUs per row group; false = not covered
+void set_gemv_bk(int v);       // 0: off, 1: on
 void set_gemv_bx(int v);       // 0: off, 1: on (units per block from the CU count), 2..4: on with that many units per block
 void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)
 void set_gemv_b_wide(int v);   // row tiles per block of the batched kernels: 0 round-1 shapes, 1 twice as many, 2 auto (wide from 32 slots)

@@ -334,6 +334,8 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
 }
+static int g_gemv_bk = -1;
+void set_gemv_bk(int v) { g_gemv_bk = v; }
 static int g_gemv_bx = -1;
 void set_gemv_bx(int v) { g_gemv_bx = v; }
 static int g_gemm_b_shape = -1;
@@ -341,6 +343,8 @@ void set_gemm_b_shape(int v) { g_gemm_b_shape = v; }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemm_b_shape < 0) { const char* e = getenv("DTK_GEMM_B"); g_gemm_b_shape = e ? atoi(e) : 0; }
   if (launch_gemm_b(epi, g_gemm_b_shape, a, s)) return;     // x staged through LDS (kernels_batch_gemm.hip); false: not covered
+  if (g_gemv_bk < 0) { const char* e = getenv("DTK_GEMV_BK"); g_gemv_bk = e ? atoi(e) : 0; }
+  if (launch_gemv_bk(epi, g_gemv_bk, a, s)) return;         // 64 slots, N = d roles: K split over the CUs of a row group (kernels_batch_gemm.hip)
   if (g_gemv_bx < 0) { const char* e = getenv("DTK_GEMV_BX"); g_gemv_bx = e ? atoi(e) : 1; }
   if (launch_gemv_bx(epi, g_gemv_bx, a, s)) return;         // 64 slots, rows >> d roles: x once per CU (kernels_batch_gemm.hip); false: not covered
   if (a.nt >= 3) { if (a.W8) launch_gemv_b_impl<true, 4>(epi, a, s); else launch_gemv_b_impl<false, 4>(epi, a, s); }
@@ -786,7 +790,9 @@ void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
     if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
-    if (a.tail_threads == 256) hipLaunchKernelGGL(k_attn_tail_b<256>, dim3(a.H, a.nslots), dim3(256), 0, s, a);
+    if (a.tail_threads == 64) hipLaunchKernelGGL(k_attn_tail_b<64>, dim3(a.H, a.nslots), dim3(64), 0, s, a);
+    else if (a.tail_threads == 128) hipLaunchKernelGGL(k_attn_tail_b<128>, dim3(a.H, a.nslots), dim3(128), 0, s, a);
+    else if (a.tail_threads == 256) hipLaunchKernelGGL(k_attn_tail_b<256>, dim3(a.H, a.nslots), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_attn_tail_b<512>, dim3(a.H, a.nslots), dim3(512), 0, s, a);
     return;
   }

@@ -423,6 +423,172 @@ bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
 #undef BX
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemv_bk — the N = d roles (o_proj, down: 256 row tiles) at 49..64 slots: K split over the CUs of a row group.
+//
+// k_gemv_b gives each of the 256 one-tile blocks the whole K (8 waves x 1/8 of K): every block reads all of x — 1.4 MB for the
+// down projection at 64 slots, 360 MB per launch next to 90 MB of weights (o_proj: 131 MB next to 33.5).  Here the grid is
+// 32 row groups x 8 K slices = 256 blocks, one per CU:
+//   * block (rg, ks): TPG = 8 compute waves, wave w owns row tile rg * 8 + w over K slice ks — exactly the k-steps wave ks of the
+//     k_gemv_b block of that tile owns, accumulated the same way (MFMA accumulation from zero in k order), so the partial it
+//     produces is bit-identical to that wave's;
+//   * x: only the slice's fragments, through LDS in phases of 8 k-steps filled by a loader wave as in k_gemv_bx: x traffic =
+//     one pass over x per ROW GROUP = 32 x 1.4 MB = 45 MB for down (1/8);
+//   * the 8 partials of a tile meet in memory: a wave publishes its 16 x 64 fp32 tile with 8-byte agent-scope stores, drains
+//     them, draws a ticket from the tile's counter; the wave that draws the last ticket reads the 8 partials back with
+//     agent-scope loads, adds them in slice order 0..7 (the order of k_gemv_b's LDS reduction: bit-identical result) and runs
+//     the residual epilogue.  Nobody ever waits for another block (no spinning), so residency plays no role in correctness;
+//     8 MB of partials per launch; the 8 blocks of a row group are given consecutive-mod-8 block indices so that they land on
+//     one XCD (a placement hint only: correctness rests on the agent-scope accesses).
+// A chain of `per` k-steps is walked in phases of 8 with a ragged tail: the steady phases are branch-free (refills clamped to
+// the chain's last k-step, re-read from L2), the last phase zeroes the weights of the k-steps past the end.
+template <int TPG>
+__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bk(GemvBArgs a) {
+  constexpr int NT = 4, PH = 8, FR = PH * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x FR KiB
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = (a.K + 31) >> 5;
+  const int per = (nsteps + 7) >> 3;
+  const int ntiles = (a.N + 15) >> 4;
+  const int b = blockIdx.x, idx = b >> 3;
+  const int rgs_per_xcd = (int)(gridDim.x >> 6);                // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
+  const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
+  const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
+  const int Lc = s1 - s0;                                       // >= 1 (launcher)
+  const int nph = (Lc + PH - 1) / PH;
+
+  if (wave == TPG) {   // ---- loader wave
+    const bf16_t* xlane = a.X + lane * 8;
+    auto src = [&](int q, int f) { return xlane + ((size_t)(f / PH) * nsteps + min(s0 + q * PH + (f % PH), s1 - 1)) * 512; };
+    u32x4 xr[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(0, f));
+#pragma unroll
+    for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(smem + (size_t)f * 1024 + lane * 16) = xr[f];
+    if (nph > 1) {
+#pragma unroll
+      for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(1, f));
+    }
+    __syncthreads();
+    for (int q = 0; q < nph; ++q) {
+      if (q + 1 < nph) {
+        unsigned char* xn = smem + (size_t)((q + 1) & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(xn + (size_t)f * 1024) = xr[f];
+      }
+      if (q + 2 < nph) {
+#pragma unroll
+        for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(q + 2, f));
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- compute waves
+  const int tn = rg * TPG + wave;                               // < ntiles (launcher: ntiles = row groups x TPG)
+  const unsigned char* wrow = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16 + (size_t)s0 * 1024;
+  u32x4 wr[PH];
+#pragma unroll
+  for (int i = 0; i < PH; ++i) wr[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(i, Lc - 1) * 1024));
+  f32x4 c[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int p = 0; p + 1 < nph; ++p) {                            // steady phases: all 8 k-steps inside the chain
+    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[j]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
+      wr[j] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min((p + 1) * PH + j, Lc - 1) * 1024));
+    }
+    __syncthreads();
+  }
+  {                                                              // last phase: k-steps past the end contribute nothing
+    const int p = nph - 1;
+    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+      u32x4 w = wr[j];
+      if (p * PH + j >= Lc) w = (u32x4){0u, 0u, 0u, 0u};
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- publish the partial, draw a ticket, the last arrival reduces in slice order and applies the epilogue
+  typedef unsigned long long u64;
+  u64* mine = reinterpret_cast<u64*>(a.kpart) + (((size_t)ks * ntiles + tn) * NT) * 128 + lane * 2;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    __hip_atomic_store(mine + nt * 128, (u64)__float_as_uint(c[nt][0]) | ((u64)__float_as_uint(c[nt][1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + nt * 128 + 1, (u64)__float_as_uint(c[nt][2]) | ((u64)__float_as_uint(c[nt][3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing lane is in this wave
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.kctr + tn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __shfl(ticket, 0, 64);
+  if (ticket != 7u) return;
+  f32x4 sum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) sum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < 8; ++s) {
+    const u64* src = reinterpret_cast<const u64*>(a.kpart) + (((size_t)s * ntiles + tn) * NT) * 128 + lane * 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const u64 lo = __hip_atomic_load(src + nt * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 hi = __hip_atomic_load(src + nt * 128 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sum[nt][0] += __uint_as_float((unsigned)lo); sum[nt][1] += __uint_as_float((unsigned)(lo >> 32));
+      sum[nt][2] += __uint_as_float((unsigned)hi); sum[nt][3] += __uint_as_float((unsigned)(hi >> 32));
+    }
+  }
+  if (lane == 0) __hip_atomic_store(a.kctr + tn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    if (!a.bs->active[n]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tn * 16 + (lane >> 4) * 4 + r;
+      if (row < a.N) {
+        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
+        *y = f2bf(bf2f(*y) + rbf(sum[nt][r]));
+      }
+    }
+  }
+}
+
+// false = not covered: fp8 weights, fewer than 49 slots, other roles, a tile count that is not 32 row groups of 4 or 8 tiles,
+// a K that leaves one of the 8 slices empty, no partial buffer
+bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
+  if (a.W8 || a.nt < 3 || variant <= 0 || epi != EPI_RESID || !a.kpart || !a.kctr) return false;
+  const int ntiles = (a.N + 15) >> 4, nsteps = (a.K + 31) >> 5, per = (nsteps + 7) >> 3;
+  if ((a.N & 15) || (a.K & 31) || 7 * per >= nsteps) return false;
+  constexpr int lds = 2 * 8 * 4 * 1024;
+  if (ntiles == 256) {
+    static bool attr8 = false;
+    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    hipLaunchKernelGGL((k_gemv_bk<8>), dim3(256), dim3(9 * 64), lds, s, a);
+    return true;
+  }
+  if (ntiles == 128) {
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    hipLaunchKernelGGL((k_gemv_bk<4>), dim3(256), dim3(5 * 64), lds, s, a);
+    return true;
+  }
+  return false;
+}
+
 template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
 static void launch_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);

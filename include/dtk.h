@@ -211,9 +211,10 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * contiguous key range per split | 256 | 512 | 1024 = tile-interleaved splits), "attn_splits" (1..16), "attn_combine" (0 = the
  * split partials are reduced in o_proj's prologue, 1 = by the last-arriving split block, 2 = by an own kernel),
  * "attn_full_max" (contexts below it use the one-block-per-head kernel).  Batched decode: "attn_b_impl" (0 = split-K per slot +
- * combine kernel, 1 = one block per (head, slot)), "tail_threads" (256 | 512), "prefix_mfma" (score the prefix most slots share
+ * combine kernel, 1 = one block per (head, slot)), "tail_threads" (64 | 128 | 256 | 512), "prefix_mfma" (score the prefix most slots share
  * once on the matrix cores), "pfx_splits" (1..4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
- * registers, 1..4 = x through LDS by LDS-DMA), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
+ * registers, 1..4 = x through LDS by LDS-DMA), "gemv_bx" (0 off, 1 = x once per CU for gate/up + lm_head at 49..64 slots, 2..4 =
+ * forced units per block), "gemv_bk" (K split across CUs for o_proj / down; slower, off), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
  * "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages" (1..4).
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.

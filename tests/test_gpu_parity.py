@@ -1277,7 +1277,8 @@ def test_lds_staged_batched_gemm_tracks_the_register_kernels(tiny_batched):
 
 @pytest.mark.parametrize("name,layers", [("detikzify-ds-7b", 2), ("detikzify-ds-1.3b", 3)])
 def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, layers):
-    """k_gemv_bx (64 slots: the x fragments of a phase shared through LDS, one wave per row-tile pair over the full K) against
+    """k_gemv_bx (64 slots: the x fragments of a phase shared through LDS, one wave per row-tile pair over the full K) and
+    k_gemv_bk (N = d roles: K split over the 8 CUs of a row group, partials met in memory by the last arrival) against
     k_gemv_b at the real widths (K = 4096: chains of two phases, K = 2048: one), a few layers deep: same K order per
     accumulator by construction, so tokens AND logits must be bit-identical — for every block shape."""
     import gc
@@ -1292,8 +1293,9 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         prompts = [torch.randint(3, cfg.vocab - 1, (6 + (i % 5),), generator=g) for i in range(64)]
         slots = list(range(64))
         runs = {}
-        for variant in (0, 1, 2, 3, 4):
-            model.set_option("gemv_bx", variant)
+        for variant in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (1, 1)):
+            model.set_option("gemv_bx", variant[0])
+            model.set_option("gemv_bk", variant[1])
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1302,11 +1304,12 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                 model.decode_batch_launch(slots)
                 toks.append(model.decode_batch_wait()[:64])
             runs[variant] = (toks, torch.stack([model.get_logits_slot(s_) for s_ in (0, 17, 40, 63)]))
-        model.set_option("gemv_bx", 0)
-        for variant in (1, 2, 3, 4):
-            assert runs[variant][0] == runs[0][0], (name, variant)
-            assert torch.equal(runs[variant][1], runs[0][1]), (name, variant)
+        for variant in runs:
+            assert runs[variant][0] == runs[(0, 0)][0], (name, variant)
+            assert torch.equal(runs[variant][1], runs[(0, 0)][1]), (name, variant)
     finally:
+        model.set_option("gemv_bx", 1)      # process-wide switches: back to the defaults
+        model.set_option("gemv_bk", 0)
         del model
         gc.collect()
 

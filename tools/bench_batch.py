@@ -18,14 +18,22 @@ ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--weight-format", default="bf16")
 ap.add_argument("--slots", type=int, default=0, help="KV slots to allocate (default: --batch): partial-occupancy timing")
+ap.add_argument("--ctx", type=int, default=0, help="text-only prompt of this many tokens instead of the image prompt (attention cost vs context)")
+ap.add_argument("--private", action="store_true", help="with --ctx: every slot prefills its own prompt (no shared prefix)")
 ap.add_argument("--fork", action="store_true", help="prefill slot 0 only and fork its KV into the other slots (fewer dispatches: profiling runs)")
 args = ap.parse_args()
 model, proc = load(args.model, synthetic=1234, batch_slots=max(args.batch, args.slots), weight_format=args.weight_format)
 model.set_graph_mode(args.graph)
 enc = proc(images=sketch_image(0, 224), return_tensors="pt")
 ids, px = enc.input_ids[0], enc.pixel_values
+if args.ctx:
+    import torch
+    ids, px = torch.randint(3, model.config.vocab - 1, (args.ctx,), generator=torch.Generator().manual_seed(1)), None
 for s in range(args.batch):
     model.set_sampling(do_sample=False, bad_ids=[model.config.image_token_id], slot=s)
+    if args.ctx and args.private:
+        model.prefill((ids + s) % (model.config.vocab - 1), None, slot=s, reuse=False)
+        continue
     if args.fork and s > 0:
         model.kv_fork(0, s, ids.numel())
     else:
