@@ -9,6 +9,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
 DTK_ABI_VERSION = 3          # include/dtk.h DTK_ABI_VERSION
+DTK_VIT_BATCH = 8            # include/dtk.h: images per pass of dtk_vit_encode
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
 DTK_PREFILL_REUSE_PREFIX, DTK_PREFILL_REUSE_IMAGE = 1, 2
@@ -83,6 +84,9 @@ SYMBOLS = {
     "dtk_kv_fork": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "dtk_get_logits_slot": (C.c_int, [_P, C.c_int, _P]),
     "dtk_context_len_slot": (C.c_int, [_P, C.c_int]),
+    "dtk_slot_lcp": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_uint64, C.POINTER(C.c_int)]),
+    "dtk_slot_cached_ids": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "dtk_resume_slot": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_uint64]),
     "dtk_bench_gemv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "dtk_set_gemv_variant": (C.c_int, [_P, C.c_int, C.c_int]),
     "dtk_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),

@@ -58,7 +58,7 @@ struct DecState {
   int32_t next_pos;  // number of tokens that have KV after this step
   int32_t token;     // token sampled this step (input of the forward)
   uint32_t draw;     // number of tokens sampled since dtk_set_sampling
-  int32_t prompt_len_unused;
+  int32_t force_plus1;   // != 0: this step forwards token force_plus1 - 1 instead of sampling one (dtk_resume_slot); cleared by the sampler
   int32_t pad[3];
 };
 

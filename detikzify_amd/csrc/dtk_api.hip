@@ -142,6 +142,8 @@ struct dtk_ctx {
   uint8_t* t8_lm_head = nullptr;     // fp8 pair-tiled copy of lm_head (weight_format fp8)
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
+  SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_BATCH + 1]: per-slot set_sampling uploads queued on the stream
+  DecState* st_stage = nullptr;      // pinned [DTK_MAX_BATCH + 1]: dtk_resume_slot's state upload (no stream sync: a slot is resumed again only sequences later)
   int64_t* tokb_dev = nullptr;       // [DTK_MAX_INFLIGHT][16]
   int64_t* tokb_host = nullptr;      // pinned mirror
   uint64_t blaunched = 0, bwaited = 0;
@@ -376,22 +378,25 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->smb = P.take<SampleMB>(1);
   c->tok_ring_dev = P.take<int64_t>(DTK_MAX_INFLIGHT);
   c->probs_dev = P.take<float>(V);
-  c->pixels_dev = P.take<float>((size_t)3 * c->cfg.vit_image * c->cfg.vit_image);
-  c->patches = P.take<bf16_t>((size_t)N * c->vPatchLd);
-  c->VX = P.take<bf16_t>((size_t)N * D);
-  c->VN = P.take<bf16_t>((size_t)N * D);
-  c->VQKV = P.take<bf16_t>((size_t)N * 3 * D);
-  c->VAO = P.take<bf16_t>((size_t)N * D);
-  c->VH = P.take<bf16_t>((size_t)N * mlp);
-  c->feats = P.take<bf16_t>((size_t)N * D);
-  c->last_hidden = P.take<bf16_t>((size_t)N * D);
+  // the tower's activations hold DTK_VIT_BATCH images: dtk_vit_encode(batch) runs them as ONE pass (GEMM rows = images x
+  // patches: the M = 729 GEMMs of a single image leave the matrix cores 93 % idle), the prefill uses the first image's share
+  const size_t VB = DTK_VIT_BATCH;
+  c->pixels_dev = P.take<float>(VB * 3 * c->cfg.vit_image * c->cfg.vit_image);
+  c->patches = P.take<bf16_t>(VB * N * c->vPatchLd);
+  c->VX = P.take<bf16_t>(VB * N * D);
+  c->VN = P.take<bf16_t>(VB * N * D);
+  c->VQKV = P.take<bf16_t>(VB * N * 3 * D);
+  c->VAO = P.take<bf16_t>(VB * N * D);
+  c->VH = P.take<bf16_t>(VB * N * mlp);
+  c->feats = P.take<bf16_t>(VB * N * D);
+  c->last_hidden = P.take<bf16_t>(VB * N * D);
   c->pq = P.take<bf16_t>(D);
-  c->pkv = P.take<bf16_t>((size_t)N * 2 * D);
-  c->pao = P.take<bf16_t>(D);
-  c->px = P.take<bf16_t>(D);
-  c->pn = P.take<bf16_t>(D);
-  c->ph = P.take<bf16_t>(mlp);
-  c->pooled = P.take<bf16_t>(D);
+  c->pkv = P.take<bf16_t>(VB * N * 2 * D);
+  c->pao = P.take<bf16_t>(VB * D);
+  c->px = P.take<bf16_t>(VB * D);
+  c->pn = P.take<bf16_t>(VB * D);
+  c->ph = P.take<bf16_t>(VB * mlp);
+  c->pooled = P.take<bf16_t>(VB * D);
   c->IMG = P.take<bf16_t>((size_t)c->nImg * d);
   if (c->wfmt == 1) {
     for (int i = 0; i < L; ++i) {
@@ -470,55 +475,68 @@ bf16_t* kcache(dtk_ctx* c, int layer) { return c->kv + (size_t)layer * 2 * c->KV
 bf16_t* vcache(dtk_ctx* c, int layer) { return kcache(c, layer) + (size_t)c->KVH * c->Tmax * 128; }
 
 // ViT trunk + (optionally) MAP head for the image already in pixels_dev.
-void vit_forward(dtk_ctx* c, bool want_pooled, hipStream_t s) {
+void vit_forward(dtk_ctx* c, bool want_pooled, hipStream_t s, int B = 1) {
+  // B images (<= DTK_VIT_BATCH) in one pass: every row-wise op (LayerNorm, the Linear layers) sees B x N rows, attention and the
+  // position-embedding add run per image.  Per row the arithmetic is the single-image arithmetic (a GEMM row does not depend on
+  // the other rows of its tile), so image b's features are bit-identical to encoding it alone (tested).
   const int D = c->vD, N = c->vN, mlp = c->vMlp, Hh = c->vH, hd = c->vHd;
+  const int R = B * N;
   struct StreamScope { dtk_ctx* c; hipStream_t prev; ~StreamScope() { c->cur_stream = prev; } } scope{c, c->cur_stream};
   c->cur_stream = s;
-  launch_im2col(c->pixels_dev, c->patches, c->cfg.vit_image, c->cfg.vit_patch, c->vPatchLd, s);
-  // conv(patch)+bias -> bf16, then + pos_embed -> bf16 (timm PatchEmbed, _pos_embed)
-  gemm(c, c->patches, c->vPatchLd, c->pe_w, c->vPatchLd, c->pe_b, c->pos_embed, D, c->VX, D, N, D,
-       c->vPatchLd, GEMM_BIAS | GEMM_RESIDUAL);
+  const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
+  for (int b = 0; b < B; ++b) {
+    launch_im2col(c->pixels_dev + (size_t)b * img, c->patches + (size_t)b * N * c->vPatchLd, c->cfg.vit_image, c->cfg.vit_patch, c->vPatchLd, s);
+    // conv(patch)+bias -> bf16, then + pos_embed -> bf16 (timm PatchEmbed, _pos_embed): the residual operand is per patch
+    gemm(c, c->patches + (size_t)b * N * c->vPatchLd, c->vPatchLd, c->pe_w, c->vPatchLd, c->pe_b, c->pos_embed, D,
+         c->VX + (size_t)b * N * D, D, N, D, c->vPatchLd, GEMM_BIAS | GEMM_RESIDUAL);
+  }
   const float scale = 1.0f / sqrtf((float)hd);
   const int fl = c->cfg.vit_feature_layer;
   const int last = want_pooled ? c->vDepth - 1 : fl;
   for (int i = 0; i <= last; ++i) {
     const VitBlockW& w = c->vblocks[i];
-    launch_layernorm_rows(c->VX, D, w.n1w, w.n1b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
-    gemm(c, c->VN, D, w.qkvw, D, w.qkvb, nullptr, 0, c->VQKV, 3 * D, N, 3 * D, D, GEMM_BIAS);
-    AttnArgs a;
-    a.Q = c->VQKV; a.q_sh = hd; a.q_st = 3 * D;
-    a.K = c->VQKV + D; a.k_sh = hd; a.k_st = 3 * D;
-    a.V = c->VQKV + 2 * D; a.v_sh = hd; a.v_st = 3 * D;
-    a.O = c->VAO; a.o_sh = hd; a.o_st = D;
-    a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
-    launch_attention(a, s);
-    gemm(c, c->VAO, D, w.projw, D, w.projb, c->VX, D, c->VX, D, N, D, D, GEMM_BIAS | GEMM_RESIDUAL);
-    launch_layernorm_rows(c->VX, D, w.n2w, w.n2b, c->VN, D, N, D, c->cfg.vit_ln_eps, s);
-    gemm(c, c->VN, D, w.fc1w, D, w.fc1b, nullptr, 0, c->VH, mlp, N, mlp, D, GEMM_BIAS | gelu_flag(c));
-    gemm(c, c->VH, mlp, w.fc2w, mlp, w.fc2b, c->VX, D, c->VX, D, N, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
+    launch_layernorm_rows(c->VX, D, w.n1w, w.n1b, c->VN, D, R, D, c->cfg.vit_ln_eps, s);
+    gemm(c, c->VN, D, w.qkvw, D, w.qkvb, nullptr, 0, c->VQKV, 3 * D, R, 3 * D, D, GEMM_BIAS);
+    for (int b = 0; b < B; ++b) {
+      const bf16_t* qkv = c->VQKV + (size_t)b * N * 3 * D;
+      AttnArgs a;
+      a.Q = qkv; a.q_sh = hd; a.q_st = 3 * D;
+      a.K = qkv + D; a.k_sh = hd; a.k_st = 3 * D;
+      a.V = qkv + 2 * D; a.v_sh = hd; a.v_st = 3 * D;
+      a.O = c->VAO + (size_t)b * N * D; a.o_sh = hd; a.o_st = D;
+      a.H = Hh; a.Tq = N; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
+      launch_attention(a, s);
+    }
+    gemm(c, c->VAO, D, w.projw, D, w.projb, c->VX, D, c->VX, D, R, D, D, GEMM_BIAS | GEMM_RESIDUAL);
+    launch_layernorm_rows(c->VX, D, w.n2w, w.n2b, c->VN, D, R, D, c->cfg.vit_ln_eps, s);
+    gemm(c, c->VN, D, w.fc1w, D, w.fc1b, nullptr, 0, c->VH, mlp, R, mlp, D, GEMM_BIAS | gelu_flag(c));
+    gemm(c, c->VH, mlp, w.fc2w, mlp, w.fc2b, c->VX, D, c->VX, D, R, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
     if (i == fl)  // get_intermediate_layers(n=[layer], norm=True)
-      launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->feats, D, N, D, c->cfg.vit_ln_eps, s);
+      launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->feats, D, R, D, c->cfg.vit_ln_eps, s);
   }
   if (!want_pooled) return;
   // forward_features -> final norm; forward_head -> AttentionPoolLatent ('map')
   const bf16_t* lh = c->feats;
   if (fl != c->vDepth - 1) {
-    launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->last_hidden, D, N, D, c->cfg.vit_ln_eps, s);
+    launch_layernorm_rows(c->VX, D, c->vnorm_w, c->vnorm_b, c->last_hidden, D, R, D, c->cfg.vit_ln_eps, s);
     lh = c->last_hidden;
   }
   gemm(c, c->ap_latent, D, c->ap_qw, D, c->ap_qb, nullptr, 0, c->pq, D, 1, D, D, GEMM_BIAS);
-  gemm(c, lh, D, c->ap_kvw, D, c->ap_kvb, nullptr, 0, c->pkv, 2 * D, N, 2 * D, D, GEMM_BIAS);
-  AttnArgs a;
-  a.Q = c->pq; a.q_sh = hd; a.q_st = D;
-  a.K = c->pkv; a.k_sh = hd; a.k_st = 2 * D;
-  a.V = c->pkv + D; a.v_sh = hd; a.v_st = 2 * D;
-  a.O = c->pao; a.o_sh = hd; a.o_st = D;
-  a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
-  launch_attention(a, s);
-  gemm(c, c->pao, D, c->ap_pw, D, c->ap_pb, nullptr, 0, c->px, D, 1, D, D, GEMM_BIAS);
-  launch_layernorm_rows(c->px, D, c->ap_nw, c->ap_nb, c->pn, D, 1, D, c->cfg.vit_ln_eps, s);
-  gemm(c, c->pn, D, c->ap_f1w, D, c->ap_f1b, nullptr, 0, c->ph, mlp, 1, mlp, D, GEMM_BIAS | gelu_flag(c));
-  gemm(c, c->ph, mlp, c->ap_f2w, mlp, c->ap_f2b, c->px, D, c->pooled, D, 1, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
+  gemm(c, lh, D, c->ap_kvw, D, c->ap_kvb, nullptr, 0, c->pkv, 2 * D, R, 2 * D, D, GEMM_BIAS);
+  for (int b = 0; b < B; ++b) {
+    const bf16_t* kv = c->pkv + (size_t)b * N * 2 * D;
+    AttnArgs a;
+    a.Q = c->pq; a.q_sh = hd; a.q_st = D;
+    a.K = kv; a.k_sh = hd; a.k_st = 2 * D;
+    a.V = kv + D; a.v_sh = hd; a.v_st = 2 * D;
+    a.O = c->pao + (size_t)b * D; a.o_sh = hd; a.o_st = D;
+    a.H = Hh; a.Tq = 1; a.Tk = N; a.hd = hd; a.causal = 0; a.q_offset = 0; a.scale = scale; a.impl = c->attn_impl; a.kv_group = 1;
+    launch_attention(a, s);
+  }
+  gemm(c, c->pao, D, c->ap_pw, D, c->ap_pb, nullptr, 0, c->px, D, B, D, D, GEMM_BIAS);
+  launch_layernorm_rows(c->px, D, c->ap_nw, c->ap_nb, c->pn, D, B, D, c->cfg.vit_ln_eps, s);
+  gemm(c, c->pn, D, c->ap_f1w, D, c->ap_f1b, nullptr, 0, c->ph, mlp, B, mlp, D, GEMM_BIAS | gelu_flag(c));
+  gemm(c, c->ph, mlp, c->ap_f2w, mlp, c->ap_f2b, c->px, D, c->pooled, D, B, D, mlp, GEMM_BIAS | GEMM_RESIDUAL);
 }
 
 void project_image(dtk_ctx* c) {
@@ -836,6 +854,9 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   if (c->nb > 0) {
     CCHK(hipHostMalloc((void**)&c->bs_host, sizeof(BatchState) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
     CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->st_stage, sizeof(DecState) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->sp_stage, sizeof(SamplingDev) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->draw_stage, sizeof(uint32_t) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
     for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->bstep_done[i], hipEventDisableTiming));
   }
   CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
@@ -889,6 +910,9 @@ void dtk_destroy(dtk_ctx* c) {
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->bstep_done[i]) (void)hipEventDestroy(c->bstep_done[i]);
   if (c->bs_host) (void)hipHostFree(c->bs_host);
   if (c->tokb_host) (void)hipHostFree(c->tokb_host);
+  if (c->st_stage) (void)hipHostFree(c->st_stage);
+  if (c->sp_stage) (void)hipHostFree(c->sp_stage);
+  if (c->draw_stage) (void)hipHostFree(c->draw_stage);
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) if (c->step_done[i]) (void)hipEventDestroy(c->step_done[i]);
   hipEvent_t evs[] = {c->ev_a, c->ev_b, c->ev_c, c->probe_a, c->probe_b};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -1000,20 +1024,21 @@ int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, 
   // forward() semantics (pooled requested): last_hidden_state = forward_features = ALL blocks + final norm; without the
   // head: get_intermediate_layers(n=[feature_layer], norm=True).  The two differ when feature_layer != depth - 1.
   const bf16_t* hidden = (pooled_out && c->cfg.vit_feature_layer != c->vDepth - 1) ? c->last_hidden : c->feats;
-  for (int b = 0; b < batch; ++b) {
-    HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b * img, img * 4, hipMemcpyHostToDevice, sv));
+  for (int b0 = 0; b0 < batch; b0 += DTK_VIT_BATCH) {
+    const int B = std::min(batch - b0, (int)DTK_VIT_BATCH);
+    HIPCHK(c, hipMemcpyAsync(c->pixels_dev, pixels + (size_t)b0 * img, (size_t)B * img * 4, hipMemcpyHostToDevice, sv));
     HIPCHK(c, hipEventRecord(c->ev_va, sv));
-    vit_forward(c, pooled_out != nullptr, sv);
+    vit_forward(c, pooled_out != nullptr, sv, B);
     HIPCHK(c, hipEventRecord(c->ev_vb, sv));
     if (feats_out)
-      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b * c->vN * c->vD, hidden, (size_t)c->vN * c->vD * 2, hipMemcpyDeviceToHost, sv));
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)feats_out + (size_t)b0 * c->vN * c->vD, hidden, (size_t)B * c->vN * c->vD * 2, hipMemcpyDeviceToHost, sv));
     if (pooled_out)
-      HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b * c->vD, c->pooled, (size_t)c->vD * 2, hipMemcpyDeviceToHost, sv));
+      HIPCHK(c, hipMemcpyAsync((bf16_t*)pooled_out + (size_t)b0 * c->vD, c->pooled, (size_t)B * c->vD * 2, hipMemcpyDeviceToHost, sv));
     HIPCHK(c, hipStreamSynchronize(sv));
     HIPCHK(c, hipGetLastError());
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev_va, c->ev_vb) == hipSuccess) c->stats.last_vit_ms = ms;
-    c->stats.vit_images++;
+    if (hipEventElapsedTime(&ms, c->ev_va, c->ev_vb) == hipSuccess) c->stats.last_vit_ms = ms / (float)B;
+    c->stats.vit_images += (uint64_t)B;
   }
   return DTK_OK;  // IMG (the projected prefix of the cached prefill image) is left untouched
 }
@@ -1163,10 +1188,21 @@ static int set_sampling_impl(dtk_ctx* c, const dtk_sampling* sp, SamplingDev* sp
   for (int i = 0; i < 8; ++i) {
     dv.bad_ids[i] = sp->bad_ids[i]; dv.begin_ids[i] = sp->begin_suppress_ids[i]; dv.always_ids[i] = sp->always_suppress_ids[i];
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(sp_dst, &dv, sizeof dv, hipMemcpyHostToDevice));
-  const uint32_t zero = 0;
-  HIPCHK(c, hipMemcpy(&st_dst->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
+  if (!is_single && c->sp_stage) {
+    // a slot's parameters change between two of ITS sequences, while a step of the OTHER slots may be in flight: the upload is
+    // queued behind that step from a pinned per-slot staging record (rewritten only at the slot's next set_sampling, sequences
+    // later) instead of draining the stream — a drain per join cost the batch a ~5 ms bubble (128 joins: 0.57 s of a 8 s search)
+    const int slot = (int)(sp_dst - c->sp_b);
+    c->sp_stage[slot] = dv;
+    c->draw_stage[slot] = 0;
+    HIPCHK(c, hipMemcpyAsync(sp_dst, &c->sp_stage[slot], sizeof dv, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st_dst->draw, &c->draw_stage[slot], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(sp_dst, &dv, sizeof dv, hipMemcpyHostToDevice));
+    const uint32_t zero = 0;
+    HIPCHK(c, hipMemcpy(&st_dst->draw, &zero, sizeof zero, hipMemcpyHostToDevice));
+  }
   if (is_single) { c->sampling = *sp; c->launched = c->waited = 0; }
   // which sampler the captured graphs must contain: the multi-block chain serves large vocabularies unless a
   // configuration needs top-k; a change of kind drops the graph (re-captured by the next launch)
@@ -1330,12 +1366,75 @@ int dtk_kv_fork(dtk_ctx* c, int src, int dst, int n_tokens) {
   if ((size_t)n_tokens == a.cached_ids.size() && a.have_logits && a.host_next_pos == n_tokens) {
     HIPCHK(c, hipMemcpyAsync(c->logits_b + (size_t)dst * c->V, c->logits_b + (size_t)src * c->V, (size_t)c->V * 4,
                              hipMemcpyDeviceToDevice, c->stream));
-    DecState st0{};
+    DecState& st0 = c->st_stage[dst];             // pinned per-slot record: queued behind the step in flight, no drain
+    st0 = DecState{};
     st0.pos = n_tokens - 1; st0.next_pos = n_tokens; st0.token = (int32_t)a.cached_ids[(size_t)n_tokens - 1]; st0.draw = 0;
     HIPCHK(c, hipMemcpyAsync(c->st_b + dst, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // st0 lives on this stack frame
     b.have_logits = true;
   }
+  return DTK_OK;
+}
+
+// Longest common prefix of `ids` with what slot's KV cache holds (prefilled AND decoded tokens), under the rules of
+// DTK_PREFILL_REUSE_PREFIX: an image prompt only matches a cache computed with the same image key.  The engine uses it to give
+// a returning MCTS tree the slot that still holds its previous rollout.
+int dtk_slot_lcp(dtk_ctx* c, int slot, const int64_t* ids, int T, uint64_t image_key, int* lcp_out) {
+  if (!c || !ids || !lcp_out || T < 1 || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_slot_lcp: bad argument");
+  const SeqHost& sh = c->bseq[(size_t)slot];
+  int img_count = 0;
+  for (int t = 0; t < T; ++t) img_count += ids[t] == c->cfg.image_token_id;
+  const bool has_img = img_count > 0;
+  const bool same_image = !has_img ? !sh.cached_with_image : (sh.cached_with_image && image_key != 0 && sh.image_key == image_key);
+  int n = 0;
+  if (same_image) {
+    const int lim = (int)std::min<size_t>(sh.cached_ids.size(), (size_t)T);
+    while (n < lim && sh.cached_ids[(size_t)n] == ids[n]) ++n;
+  }
+  *lcp_out = n;
+  return DTK_OK;
+}
+
+// Diagnostic: the token ids slot's cache is known to hold (-1 = a decoded token whose step has not been read yet); returns the
+// number of ids written (at most n_max).
+int dtk_slot_cached_ids(dtk_ctx* c, int slot, int64_t* out, int n_max) {
+  if (!c || !out || slot < 0 || slot >= c->nb || n_max < 0) return -1;
+  const SeqHost& sh = c->bseq[(size_t)slot];
+  const int n = (int)std::min<size_t>(sh.cached_ids.size(), (size_t)n_max);
+  for (int i = 0; i < n; ++i) out[i] = sh.cached_ids[(size_t)i];
+  return n;
+}
+
+// Resume decoding in place: the slot's cache already holds ids[0, T-1) (dtk_slot_lcp >= T - 1) — typically the path to an MCTS
+// node inside the slot's own previous rollout.  No prefill: the context is cut back to T - 1 tokens and the NEXT batched step
+// forwards ids[T-1] for this slot instead of sampling (DecState.force_plus1), returning ids[T-1] as that step's token; the step
+// after it samples the first new token (draw 0: begin-suppress applies there).  The rows [0, T-1) stay as they were written
+// (by the prefill GEMMs and / or the decode kernels of the earlier sequence), like any DTK_PREFILL_REUSE_PREFIX hit.
+int dtk_resume_slot(dtk_ctx* c, int slot, const int64_t* ids, int T, uint64_t image_key) {
+  if (!c || !ids || T < 2 || slot < 0 || slot >= c->nb) return fail(c, DTK_ERR_ARG, "dtk_resume_slot: bad argument");
+  if (T > c->Tmax) return fail(c, DTK_ERR_RANGE, "prompt of %d tokens exceeds max_positions %d", T, c->Tmax);
+  if (ids[T - 1] == c->cfg.image_token_id) return fail(c, DTK_ERR_ARG, "dtk_resume_slot: the last prompt token is an image position (its input is a patch feature, not an embedding)");
+  int lcp = 0;
+  const int rc = dtk_slot_lcp(c, slot, ids, T, image_key, &lcp);
+  if (rc) return rc;
+  if (lcp < T - 1) return fail(c, DTK_ERR_STATE, "dtk_resume_slot: slot %d holds %d of the %d prompt tokens (needs %d)", slot, lcp, T, T - 1);
+  for (uint64_t q = c->bwaited; q < c->blaunched; ++q)
+    if (c->bs_host[q % DTK_MAX_INFLIGHT].active[slot]) return fail(c, DTK_ERR_STATE, "dtk_resume_slot: slot %d is part of a step in flight", slot);
+  HIPCHK(c, hipSetDevice(c->device));
+  SeqHost& sh = c->bseq[(size_t)slot];
+  for (int j = 0; j < c->nb; ++j) {        // forks that read rows >= T - 1 from this slot would see them overwritten
+    SeqHost& o = c->bseq[(size_t)j];
+    if (o.share_src == slot && o.share_len > T - 1) { o.share_src = -1; o.share_len = 0; }
+  }
+  if (sh.share_len > T - 1) sh.share_len = T - 1;
+  if (sh.share_len <= 0) { sh.share_src = -1; sh.share_len = 0; }
+  sh.cached_ids.resize((size_t)T - 1);
+  sh.host_next_pos = T - 1;
+  sh.have_logits = true;                   // "may decode": the first step does not read the logits buffer
+  sh.last_reuse_start = T - 1;
+  DecState& st0 = c->st_stage[slot];
+  st0 = DecState{};
+  st0.pos = T - 2; st0.next_pos = T - 1; st0.token = (int32_t)ids[T - 2]; st0.draw = 0; st0.force_plus1 = (int32_t)ids[T - 1] + 1;
+  HIPCHK(c, hipMemcpyAsync(c->st_b + slot, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));   // ordered behind the step in flight
   return DTK_OK;
 }
 

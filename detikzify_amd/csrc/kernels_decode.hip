@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
   __syncthreads();
   const SamplingDev* sp = &s_sp;
   const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
+  const int forced = a.advance ? a.st->force_plus1 : 0;
   const bool first = (draw == 0);
   const bool sampling = sp->do_sample != 0;
   const float invT = sampling ? 1.f / sp->temperature : 1.f;
@@ -1303,14 +1304,17 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(SampleArgs a) {
     for (int i = tid; i < V; i += SAMPLE_THREADS) a.probs_out[i] = (i == s_token) ? 1.f : 0.f;
   }
 
-  const int tok = s_token;
+  // a resumed slot (dtk_resume_slot) forwards the last token of its prompt instead of a sampled one: the draw counter (and
+  // with it the begin-suppress rule of the first SAMPLED token) does not move
+  const int tok = forced > 0 ? forced - 1 : s_token;
   if (tid == 0) {
     a.tok_ring[a.bs ? 0u : draw % (uint32_t)a.ring] = (int64_t)tok;
     if (a.advance) {
       a.st->token = tok;
       a.st->pos = a.st->next_pos;
       a.st->next_pos = a.st->next_pos + 1;
-      a.st->draw = draw + 1;
+      a.st->draw = forced > 0 ? draw : draw + 1;
+      if (forced > 0) a.st->force_plus1 = 0;
     }
   }
   if (a.advance) {
@@ -1362,6 +1366,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
   __syncthreads();
   const SamplingDev* sp = &s_sp;
   const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
+  const int forced = a.advance ? a.st->force_plus1 : 0;
   const bool first = (draw == 0);
   const bool sampling = sp->do_sample != 0;
   const float invT = sampling ? 1.f / sp->temperature : 1.f;
@@ -1543,14 +1548,17 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
     for (int k = 0; k < SF_PER; ++k) if (i0 + k < V) a.probs_out[i0 + k] = (i0 + k == s_token) ? 1.f : 0.f;
   }
 
-  const int tok = s_token;
+  // a resumed slot (dtk_resume_slot) forwards the last token of its prompt instead of a sampled one: the draw counter (and
+  // with it the begin-suppress rule of the first SAMPLED token) does not move
+  const int tok = forced > 0 ? forced - 1 : s_token;
   if (tid == 0) {
     a.tok_ring[a.bs ? 0u : draw % (uint32_t)a.ring] = (int64_t)tok;
     if (a.advance) {
       a.st->token = tok;
       a.st->pos = a.st->next_pos;
       a.st->next_pos = a.st->next_pos + 1;
-      a.st->draw = draw + 1;
+      a.st->draw = forced > 0 ? draw : draw + 1;
+      if (forced > 0) a.st->force_plus1 = 0;
     }
   }
   if (a.advance) {

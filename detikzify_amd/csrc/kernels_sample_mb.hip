@@ -275,6 +275,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_draw(SampleArgs a, int nblk)
   const int tid = threadIdx.x, blk = blockIdx.x;
   mb_common(a, nblk, &cm);
   const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
+  const int forced = a.advance ? a.st->force_plus1 : 0;
   const bool sampling = cm.sp.do_sample != 0;
   if (tid == 0) s_token = -1;
   __syncthreads();
@@ -332,15 +333,19 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_draw(SampleArgs a, int nblk)
     }
   }
   __syncthreads();
+  if (forced > 0) owner = blk == 0;     // nothing was asked of the (stale) logits: exactly one block writes the token
   if (!owner) return;
-  const int tok = s_token;
+  // a resumed slot (dtk_resume_slot) forwards the last token of its prompt instead of a sampled one: the draw counter (and
+  // with it the begin-suppress rule of the first SAMPLED token) does not move
+  const int tok = forced > 0 ? forced - 1 : s_token;
   if (tid == 0) {
     a.tok_ring[a.bs ? 0u : draw % (uint32_t)a.ring] = (int64_t)tok;
     if (a.advance) {
       a.st->token = tok;
       a.st->pos = a.st->next_pos;
       a.st->next_pos = a.st->next_pos + 1;
-      a.st->draw = draw + 1;
+      a.st->draw = forced > 0 ? draw : draw + 1;
+      if (forced > 0) a.st->force_plus1 = 0;
     }
   }
   if (a.advance) {

@@ -12,6 +12,7 @@ simulate_parallel / simulate_parallel_images   independent DetikzifyGenerator tr
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 import time
@@ -58,7 +59,7 @@ class BatchEngine:
     The SelfSim ViT passes do not take `cv`: they run on their own stream under the model's ViT lock."""
 
     def __init__(self, model, max_batch: Optional[int] = None, share_prefix: bool = True, pipeline: bool = True,
-                 gather: int = 0, gather_timeout: float = 0.5, prefix_slots: Optional[int] = None):
+                 gather: int = 0, gather_timeout: float = 0.5, prefix_slots: Optional[int] = None, resume_in_place: bool = True):
         n = model.num_slots()
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
@@ -79,6 +80,15 @@ class BatchEngine:
         self.prefix_cache: "OrderedDict[Tuple[int, int], int]" = OrderedDict()     # (image key, prefix length) -> prefix slot, LRU order
         self.slot_img: Dict[int, Tuple[int, int]] = {}      # slot -> (image key, prefix length) whose KV prefix it still holds
         self.joins = 0
+        # A sequence whose prompt (all but its last token) is still in a free slot's KV cache — an MCTS tree coming back to a node
+        # of its own previous rollout — continues there without a prefill: the slot joins the batch at once and its first step
+        # forwards the last prompt token instead of sampling (dtk_resume_slot).  The reused rows are the ones the earlier
+        # sequence wrote (prefill GEMMs or decode kernels), as with any same-slot prefix reuse; resume_in_place=False makes
+        # every join fork the image prefix and prefill what follows, which stalls the batch ~10 ms per join.
+        self.resume_in_place = resume_in_place
+        self.resumes = 0
+        self.last_slot: Dict[int, int] = {}                  # sequence owner -> the slot its last sequence used
+        self.skip_first: set = set()                         # resumed slots whose next token is the forced prompt token: not emitted
         self.inplace_reuses = 0                              # joins that found their image prefix already in their slot
         self.prefix_encodes = 0                              # ViT + prefix prefills run for the prefix cache (diagnostics)
         self.pipeline = pipeline
@@ -99,6 +109,9 @@ class BatchEngine:
         self.tokens_out = 0
         self.t_wait = self.t_launch = self.t_prefill = 0.0     # seconds inside the native calls (diagnostics)
         self.host_bound_steps = 0
+        self.t_idle = 0.0                               # seconds with sequences alive but no step in flight (joins, rewards, warm start)
+        self.slot_steps_short = 0                       # steps that ran with fewer than half of the decode slots active
+        self._t_free_since = time.perf_counter()        # stamp of the last moment nothing was in flight (start, or a collect)
         self.t_first_launch = self.t_last_collect = None        # perf_counter stamps (diagnostics; reset by expect())
         # warm start: hold the first step until `gather` sequences have joined (rollouts started together should not
         # trickle in one pipeline flush at a time); gives up after gather_timeout seconds
@@ -126,11 +139,13 @@ class BatchEngine:
             self.gather_left = min(int(n), self.capacity)
             self.gather_deadline = time.perf_counter() + timeout
             self.t_first_launch = self.t_last_collect = None
+            self._t_free_since = time.perf_counter()
 
     def stats(self) -> Dict[str, Any]:
         return {"steps": self.steps, "tokens_out": self.tokens_out, "wait_s": round(self.t_wait, 3), "launch_s": round(self.t_launch, 3),
                 "prefill_s": round(self.t_prefill, 3), "host_bound_steps": self.host_bound_steps, "prefix_encodes": self.prefix_encodes,
-                "inplace_reuses": self.inplace_reuses, "joins": self.joins}
+                "inplace_reuses": self.inplace_reuses, "joins": self.joins, "resumed_in_place": self.resumes, "idle_between_steps_s": round(self.t_idle, 3),
+                "steps_below_half_occupancy": self.slot_steps_short}
 
     def close(self):
         with self._locked():
@@ -138,7 +153,9 @@ class BatchEngine:
         self.model.batch_engine = None
 
     @contextmanager
-    def sequence(self, ids, pixel_values, sampling: Dict[str, Any]) -> Iterator[_Sequence]:
+    def sequence(self, ids, pixel_values, sampling: Dict[str, Any], owner: Optional[int] = None) -> Iterator[_Sequence]:
+        """`owner`: whoever starts sequence after sequence (an MCTS tree: generate(sequence_owner=t)) — a join that cannot
+        resume takes the slot its owner used last, so it does not overwrite a rollout ANOTHER owner may come back to"""
         want = self._prefix_key(ids, pixel_values) if (self.share_prefix and pixel_values is not None) else None
         with self._locked():
             while not self.free:
@@ -153,12 +170,26 @@ class BatchEngine:
             # (re-used in place); else evict the prefix of some other image
             # (lowest index first: a step only runs the 16-slot column tiles up to its highest active slot)
             order = sorted(self.free)
-            slot = next((f for f in order if f not in self.slot_img), None)
+            slot, resume = None, False
+            n_ids = int(ids.numel())
+            # (an image position takes the projected patch feature, not a token embedding: the forced token must be text)
+            if (self.resume_in_place and n_ids >= 2 and (want is not None or pixel_values is None)
+                    and int(ids.reshape(-1)[-1]) != self.model.config.image_token_id):
+                key = want[0] if want is not None else 0
+                best = self.model.best_lcp_slot(order, ids, key)
+                if best is not None and best[1] >= n_ids - 1:
+                    slot, resume = best[0], True
+            if slot is None and owner is not None and self.last_slot.get(owner) in self.free:
+                slot = self.last_slot[owner]
+            if slot is None:
+                slot = next((f for f in order if f not in self.slot_img), None)
             if slot is None and want is not None:
                 slot = next((f for f in order if self.slot_img.get(f) == want), None)
             if slot is None:
                 slot = order[0]
             self.free.remove(slot)
+            if owner is not None:
+                self.last_slot[owner] = slot
         joined = False
         try:
             with self._locked():   # prefill needs the context exclusively (same stream as the decode steps)
@@ -169,9 +200,15 @@ class BatchEngine:
                     raise self.error
                 t0 = time.perf_counter()
                 self.model.set_sampling(slot=slot, **sampling)
-                forked = self._fork_prefix(slot, ids, pixel_values, want) if want is not None else 0
-                if want is None:
-                    self.slot_img.pop(slot, None)
+                if resume:
+                    self.model.resume_slot(slot, ids, want[0] if want is not None else 0)
+                    self.skip_first.add(slot)
+                    self.resumes += 1
+                    forked = 2
+                else:
+                    forked = self._fork_prefix(slot, ids, pixel_values, want) if want is not None else 0
+                    if want is None:
+                        self.slot_img.pop(slot, None)
                 if forked == 2:
                     pass    # the prompt IS the prefix (rollout from the root): KV and logits were forked, nothing to run
                 elif forked:
@@ -191,6 +228,7 @@ class BatchEngine:
             yield _Sequence(self, slot)
         finally:
             with self._locked():
+                self.skip_first.discard(slot)
                 if joined:
                     self.active.discard(slot)
                     self.ready.discard(slot)
@@ -267,6 +305,11 @@ class BatchEngine:
             t0 = time.perf_counter()
             if self.t_first_launch is None:
                 self.t_first_launch = t0
+            if self._t_free_since is not None:
+                self.t_idle += t0 - self._t_free_since
+                self._t_free_since = None
+            if 2 * len(slots) < self.capacity:
+                self.slot_steps_short += 1
             self.model.decode_batch_launch(slots)
             self.t_launch += time.perf_counter() - t0
             self.inflight = slots
@@ -295,6 +338,9 @@ class BatchEngine:
                 self.host_bound_steps += 1      # the GPU had already finished: this step waited for the host
             for s in self.inflight:
                 if s in self.active:
+                    if s in self.skip_first:        # the forced last prompt token of a resumed slot: already part of the prompt
+                        self.skip_first.discard(s)
+                        continue
                     if s in self.sinks:
                         pushed.append((s, toks[s]))
                     else:
@@ -308,6 +354,7 @@ class BatchEngine:
                 self.zombies.discard(s)
                 self.free.append(s)
         self.inflight = None
+        self._t_free_since = time.perf_counter()      # cleared by the next launch (pipelined steps: microseconds later)
         self.cv.notify_all()
         if dispatch:
             self._dispatch(pushed)
@@ -419,29 +466,35 @@ class BatchEngine:
 
 
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
-                      seeds: Optional[List[int]] = None, **gen_kwargs) -> Iterator[Tuple[float, Any]]:
+                      seeds: Optional[List[int]] = None, resume_in_place: bool = True, **gen_kwargs) -> Iterator[Tuple[float, Any]]:
     """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (tree t draws its sampling seeds
     from a torch generator seeded seeds[t], default seed_base + t) decoded as one batch.  Yields (score, document)
     pairs in completion order.  trees == 1 is the unmodified sequential search."""
     for _, score, doc in simulate_parallel_images(pipeline, [image], trees, expansions_per_tree, seed_base, seeds=seeds,
-                                                  **gen_kwargs):
+                                                  resume_in_place=resume_in_place, **gen_kwargs):
         yield score, doc
 
 
 def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_per_tree: int, seed_base: int = 1000,
-                             seeds: Optional[List[int]] = None, **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
+                             seeds: Optional[List[int]] = None, resume_in_place: bool = True,
+                             **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
     """Several images in flight on one GPU (BASELINE config 5: 8 images x 4 rollouts): len(images) * trees_per_image
     independent searches decoded as one batch; the engine encodes every image once and forks its KV prefix into the
-    slots of that image's trees.  Yields (image index, score, document) in completion order.  Tree k (image k //
+    slots of that image's trees.  A tree that comes back to a node of its own previous rollout continues in the slot that still
+    holds it, without a prefill (BatchEngine resume_in_place; False = fork the image prefix + prefill the path on every join).  Yields (image index, score, document) in completion order.  Tree k (image k //
     trees_per_image) samples with the seed stream seeds[k] (default seed_base + k)."""
     import torch
     imgs = [pipeline.load(im) for im in images]
+    with torch.inference_mode():    # what every generator of an image would compute for itself (generate.py: _processed)
+        encs = [pipeline.processor(images=im, text=None, text_kwargs={"truncation": True}, return_tensors="pt") for im in imgs]
     trees = len(imgs) * trees_per_image
     if seeds is None:
         seeds = [seed_base + t for t in range(trees)]
     assert len(seeds) == trees, "one seed per tree"
-    engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees) if trees > 1 else None
+    engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees, resume_in_place=resume_in_place) if trees > 1 else None
     out: "queue.Queue" = queue.Queue()
+    trace_path = os.environ.get("DTK_TRACE_MCTS")
+    trace: Optional[List[Tuple[float, int, str]]] = [(time.perf_counter(), -1, "start")] if trace_path else None
     cancelled = threading.Event()
     generators: List[Any] = [None] * trees
 
@@ -449,15 +502,27 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
         try:
             gen = torch.Generator().manual_seed(int(seeds[t]))
             draws = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
-            g = generators[t] = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric, **gen_kwargs)
+            g = generators[t] = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric,
+                                                    processed=encs[t // trees_per_image], **gen_kwargs)
             base_generate = g.generate
 
             def generate(input_ids, **kw):      # per-tree RNG stream; a cancelled search starts no further rollout
                 if cancelled.is_set():
                     raise InterruptedError("search cancelled")
-                return base_generate(input_ids, seed=next(draws), **kw)
+                return base_generate(input_ids, seed=next(draws), sequence_owner=t, **kw)
 
             g.generate = generate
+            if trace is not None:               # DTK_TRACE_MCTS=<file>: wall-clock of every tree's phases (tools/mcts_timeline.py)
+                def timed(f, name):
+                    def w(*a, **k):
+                        trace.append((time.perf_counter(), t, name + "_start"))
+                        try:
+                            return f(*a, **k)
+                        finally:
+                            trace.append((time.perf_counter(), t, name + "_end"))
+                    return w
+                g.generate, g.score = timed(g.generate, "rollout"), timed(g.score, "reward")
+                trace.append((time.perf_counter(), t, "tree_ready"))
             for score, doc in g.simulate(expansions=expansions_per_tree):
                 if cancelled.is_set():
                     break
@@ -503,6 +568,11 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
         if engine is not None and not alive:
             engine.close()
             pipeline.model.last_batch_stats = engine.stats()
+        if trace is not None:
+            trace.append((time.perf_counter(), -1, "end"))
+            import json
+            with open(trace_path, "w") as f:
+                json.dump(trace, f)
         if alive:
             raise RuntimeError(f"{len(alive)} search threads did not stop within 120 s of the cancellation; "
                                "the batch engine is left attached so they cannot interleave with other sequences")

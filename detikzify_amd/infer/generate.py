@@ -63,7 +63,7 @@ class DetikzifyGenerator:
     def __init__(self, model, processor, image: Optional[Image.Image], text: Optional[str] = None,
                  metric=None, compile_timeout: Optional[int] = 60, mcts_timeout: Optional[int] = None,
                  streamer=None, control: Optional[ExplicitAbort] = None, exploration: float = 0.6,
-                 strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, **gen_kwargs):
+                 strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, processed=None, **gen_kwargs):
         self.model, self.processor = model, processor
         self.metric, self.image, self.text = metric, image, text
         self.compile_timeout, self.mcts_timeout = compile_timeout, mcts_timeout
@@ -71,12 +71,16 @@ class DetikzifyGenerator:
         self.document_class = document_class
         self.gen_kwargs = gen_kwargs
 
-        self._processed = None      # processor output for (image, text), built on first use
+        # processor output for (image, text): built on first use — or handed in by a caller that starts many generators on
+        # the same image (simulate_parallel: one resize + normalise per image instead of two per tree, all under the GIL
+        # right when every tree wants to start)
+        assert processed is None or text is None, "a shared processor output is for image-only prompts"
+        self._processed = processed
         self.solution: deque = deque(maxlen=1)
         self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}
         self.norm = DynMinMaxNorm()
         self.control = control or ExplicitAbort()
-        root_ids = processor(images=self.image, text=self.text, return_tensors="pt").input_ids
+        root_ids = (processed if processed is not None else processor(images=self.image, text=self.text, return_tensors="pt")).input_ids
         self.montecarlo = MonteCarlo(root_node=WideNode(root_ids.to(model.device).squeeze(),
                                                         exploration=self.exploration))
         self.montecarlo.child_finder = self.child_finder

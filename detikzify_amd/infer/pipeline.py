@@ -23,7 +23,9 @@ class DetikzifyPipeline:
                  metric: Union[Literal["model", "fast"], Any] = "model", **gen_kwargs):
         self.model, self.processor = model, processor
         if metric == "model":      # SelfSim
-            self.metric = ImageSim.from_detikzify(model, processor, sync_on_compute=False)
+            # the features of the input image are the same for every rollout: memoised by image bytes (the
+            # reference recomputes them per reward, detikzify/evaluate/imagesim.py:91-125 — same value, one ViT pass less)
+            self.metric = ImageSim.from_detikzify(model, processor, sync_on_compute=False, cache_reference=True)
         elif metric == "fast":     # compiler diagnostics
             self.metric = None
         else:

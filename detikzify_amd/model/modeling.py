@@ -18,7 +18,7 @@ import threading
 import ctypes as C
 import hashlib
 from types import SimpleNamespace
-from typing import Any, Dict, Iterable, List, Optional
+from typing import Any, Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -62,6 +62,9 @@ class DetikzifyVisionModel:
 
     def __init__(self, owner: "DetikzifyForCausalLM"):
         self._owner = owner
+        self._pool_lock = threading.Lock()
+        self._pool_queue: List[Any] = []        # [pixels, done event, result | exception] of threads waiting for a pooled output
+        self._pool_leader = False
 
     def __call__(self, pixel_values: torch.Tensor, **_) -> VisionOutput:
         return self.forward(pixel_values)
@@ -71,8 +74,43 @@ class DetikzifyVisionModel:
         return VisionOutput(last_hidden_state=feats, pooler_output=pooled)
 
     def pooled_only(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        """pooler_output without copying the 729 x 1152 patch features back (SelfSim "cos": the reward's hot call)"""
-        return self._owner.vit_encode(pixel_values, want_pooled=True, want_feats=False)[1]
+        """pooler_output without copying the 729 x 1152 patch features back (SelfSim "cos": the reward's hot call).
+
+        Calls that arrive from several threads at once (the trees of a parallel search scoring their rollouts) are combined:
+        the first caller becomes the leader and encodes whatever has queued up — up to DTK_VIT_BATCH images per pass over the
+        tower, 2.7 ms per image instead of 4.1 — until the queue is empty; the others sleep until their result is in.  Per image
+        the result is bit-identical to a call of its own (dtk_vit_encode's batch rows are independent)."""
+        px = pixel_values.detach().to("cpu", torch.float32)
+        if px.dim() == 3:
+            px = px[None]
+        if px.shape[0] != 1:
+            return self._owner.vit_encode(px, want_pooled=True, want_feats=False)[1]
+        item = [px, threading.Event(), None]
+        with self._pool_lock:
+            self._pool_queue.append(item)
+            lead = not self._pool_leader
+            if lead:
+                self._pool_leader = True
+        if lead:
+            while True:
+                with self._pool_lock:
+                    batch, self._pool_queue = self._pool_queue[:_lib.DTK_VIT_BATCH], self._pool_queue[_lib.DTK_VIT_BATCH:]
+                    if not batch:
+                        self._pool_leader = False
+                        break
+                try:
+                    out = self._owner.vit_encode(torch.cat([it[0] for it in batch]), want_pooled=True, want_feats=False)[1]
+                    for k, it in enumerate(batch):
+                        it[2] = out[k:k + 1].clone()
+                except BaseException as e:  # noqa: BLE001  (every waiter gets the error; the leader re-raises its own below)
+                    for it in batch:
+                        it[2] = e
+                for it in batch:
+                    it[1].set()
+        item[1].wait()
+        if isinstance(item[2], BaseException):
+            raise item[2]
+        return item[2]
 
     def get_intermediate_layers(self, pixel_values: torch.Tensor, *_, **__):
         feats, _ = self._owner.vit_encode(pixel_values, want_pooled=False)
@@ -291,7 +329,7 @@ class DetikzifyForCausalLM:
                 px = px[0]
             self._px_keepalive = px
             px_ptr = px.numpy().ctypes.data_as(C.c_void_p)
-            key = int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
+            key = self.image_key(pixel_values)
         reuse = self.reuse_prefix if reuse is None else reuse
         flags = (_lib.DTK_PREFILL_REUSE_PREFIX | _lib.DTK_PREFILL_REUSE_IMAGE) if reuse else 0
         logits = np.empty(self.config.vocab, dtype=np.float32) if return_logits else None
@@ -343,10 +381,53 @@ class DetikzifyForCausalLM:
     def kv_fork(self, src_slot: int, dst_slot: int, n_tokens: int):
         self._check(self.lib.dtk_kv_fork(self._ctx, int(src_slot), int(dst_slot), int(n_tokens)), "dtk_kv_fork")
 
-    @staticmethod
-    def image_key(pixel_values: torch.Tensor) -> int:
+    _image_keys: Dict[Tuple[int, int, int], Tuple[Any, int]] = {}     # (storage address, elements, tensor version) -> (tensor, key)
+
+    @classmethod
+    def image_key(cls, pixel_values: torch.Tensor) -> int:
+        """content hash of the pixels (the C side keys cached image prefixes by it).  Hashing 1.8 MB costs ~2 ms under the GIL and
+        the 64 trees of a parallel search all present the SAME tensor object: memoised per tensor (the entry keeps the tensor
+        alive, so its address cannot be reused by another one; the version counter catches in-place edits)"""
+        # (inference-mode tensors keep no version counter: an in-place edit of one between two calls would go unnoticed —
+        # processor outputs are never edited)
+        ident = (pixel_values.data_ptr(), pixel_values.numel(), -1 if pixel_values.is_inference() else pixel_values._version)
+        hit = cls._image_keys.get(ident)
+        if hit is not None and hit[0] is pixel_values:
+            return hit[1]
         px = pixel_values.detach().to("cpu", torch.float32).contiguous()
-        return int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
+        key = int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
+        if len(cls._image_keys) >= 64:
+            cls._image_keys.pop(next(iter(cls._image_keys)))
+        cls._image_keys[ident] = (pixel_values, key)
+        return key
+
+    def slot_lcp(self, slot: int, ids: torch.Tensor, key: int = 0) -> int:
+        ids = ids.detach().to("cpu", torch.int64).reshape(-1).contiguous()
+        out = C.c_int(0)
+        self._check(self.lib.dtk_slot_lcp(self._ctx, int(slot), ids.numpy().ctypes.data_as(C.c_void_p), ids.numel(), C.c_uint64(key),
+                                          C.byref(out)), "dtk_slot_lcp")
+        return int(out.value)
+
+    def best_lcp_slot(self, slots: Iterable[int], ids: torch.Tensor, key: int = 0) -> Optional[Tuple[int, int]]:
+        """(slot, lcp) of the slot among `slots` whose cache shares the longest prefix with ids (lowest index on ties), None if
+        none shares a token"""
+        ids = ids.detach().to("cpu", torch.int64).reshape(-1).contiguous()
+        ptr, n, out, best = ids.numpy().ctypes.data_as(C.c_void_p), ids.numel(), C.c_int(0), None
+        for s_ in slots:
+            self._check(self.lib.dtk_slot_lcp(self._ctx, int(s_), ptr, n, C.c_uint64(key), C.byref(out)), "dtk_slot_lcp")
+            if out.value > (best[1] if best else 0):
+                best = (int(s_), int(out.value))
+        return best
+
+    def cached_ids(self, slot: int, n_max: int = 4096) -> List[int]:
+        out = (C.c_int64 * n_max)()
+        n = self.lib.dtk_slot_cached_ids(self._ctx, int(slot), out, n_max)
+        return [int(out[i]) for i in range(max(0, n))]
+
+    def resume_slot(self, slot: int, ids: torch.Tensor, key: int = 0):
+        ids = ids.detach().to("cpu", torch.int64).reshape(-1).contiguous()
+        self._check(self.lib.dtk_resume_slot(self._ctx, int(slot), ids.numpy().ctypes.data_as(C.c_void_p), ids.numel(), C.c_uint64(key)),
+                    "dtk_resume_slot")
 
     def get_logits_slot(self, slot: int) -> torch.Tensor:
         out = np.empty(self.config.vocab, dtype=np.float32)
@@ -396,7 +477,7 @@ class DetikzifyForCausalLM:
                  temperature: Optional[float] = None, top_p: Optional[float] = None,
                  top_k: Optional[int] = None, max_length: Optional[int] = None,
                  max_new_tokens: Optional[int] = None, eos_token_id=None, seed: Optional[int] = None,
-                 inputs: Optional[torch.Tensor] = None, **hf_kwargs) -> torch.Tensor:
+                 inputs: Optional[torch.Tensor] = None, sequence_owner: Optional[int] = None, **hf_kwargs) -> torch.Tensor:
         """One sequence of HF GenerationMixin.generate/_sample semantics (generation/utils.py
         :2783-2950): streamer.put(prompt) once, then per token: processors -> argmax|draw ->
         append -> streamer.put(token) -> stopping criteria (max length, EOS, user criteria);
@@ -477,7 +558,8 @@ class DetikzifyForCausalLM:
             # sequences (infer/batching.py); one pass over the weights serves all of them
             with engine.sequence(ids[0], pixel_values, dict(
                     do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k, seed=seed, bad_ids=bad,
-                    begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ())) as seq:
+                    begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ()),
+                    owner=sequence_owner) as seq:
                 seq.run(emit)       # emit() is called per token by the thread that drives the batch (no per-token hand-off)
         elif n_new_max > 0:
             # the context has ONE un-slotted sequence: a second generate() on it from another thread would interleave its

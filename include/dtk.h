@@ -168,6 +168,7 @@ int  dtk_set_sampling(dtk_ctx* ctx, const dtk_sampling* s);
  * waiting; dtk_decode_wait returns the oldest un-read token (at most
  * DTK_MAX_INFLIGHT steps may be pending).  dtk_decode = launch + wait. */
 #define DTK_MAX_INFLIGHT 4
+#define DTK_VIT_BATCH 8      /* images dtk_vit_encode runs as one pass over the tower (larger batches: several passes) */
 int  dtk_decode_launch(dtk_ctx* ctx);
 int  dtk_decode_wait(dtk_ctx* ctx, int64_t* token_out);
 int  dtk_decode(dtk_ctx* ctx, int64_t* token_out);
@@ -196,6 +197,14 @@ int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
 int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active /* [DTK_MAX_BATCH] */);
 int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out /* [DTK_MAX_BATCH] */);
 int  dtk_kv_fork(dtk_ctx* ctx, int src_slot, int dst_slot, int n_tokens);   /* share a prefix's KV (f1) */
+/* f1, same-slot reuse for returning MCTS trees (reference infer/generate.py:305-353 re-prefills the path to the selected node
+ * on every rollout): dtk_slot_lcp = how many leading tokens of `ids` the slot's KV cache still holds (prefilled or decoded, same
+ * image key); dtk_resume_slot = continue from there WITHOUT a prefill when all but the last prompt token are cached — the next
+ * batched step forwards ids[T-1] for this slot instead of sampling and returns it as that step's token (the caller drops it),
+ * the step after samples the first new token. */
+int  dtk_slot_lcp(dtk_ctx* ctx, int slot, const int64_t* ids, int n_tokens, uint64_t image_key, int* lcp_out);
+int  dtk_resume_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int n_tokens, uint64_t image_key);
+int  dtk_slot_cached_ids(dtk_ctx* ctx, int slot, int64_t* ids_out, int n_max);   /* diagnostic: what the slot's cache holds; returns the count */
 int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
 int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
 

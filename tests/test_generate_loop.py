@@ -68,12 +68,16 @@ class ScriptedDevice(DetikzifyForCausalLM):
         self.ctx, self.img, self.samp, self.gen0 = {}, {}, {}, {}
         self.pending, self.bpending = [], []
         self.max_in_flight = self.launches = self.prefills = self.forks = self.tail_prefills = 0
+        self.forced, self.resumes = {}, 0
         tok = fake_processor(VOCAB, NIMG).tokenizer
         self.newline = [i for i, t in enumerate(tok._id2tok) if "\n" in t and i > 2]
         self.plain = [i for i, t in enumerate(tok._id2tok) if "\n" not in t and i > 2]
 
     # ---- the toy LM ---------------------------------------------------------------------------------------------
     def _next(self, s):
+        if s in self.forced:            # a resumed slot forwards the last token of its prompt instead of sampling
+            self.ctx[s].append(self.forced.pop(s))
+            return self.ctx[s][-1]
         sp, ctx = self.samp[s], self.ctx[s]
         seed = sp.get("seed", 0) if sp.get("do_sample") else 0
         h = zlib.crc32(repr((self.img[s], ctx, seed)).encode())
@@ -117,6 +121,23 @@ class ScriptedDevice(DetikzifyForCausalLM):
         self.ctx[dst_slot], self.img[dst_slot] = self.ctx[src_slot][:n_tokens], self.img[src_slot]
         self.gen0[dst_slot] = n_tokens
         self.forks += 1
+
+    def best_lcp_slot(self, slots, ids, key=0):
+        ids, best = [int(t) for t in ids.reshape(-1)], None
+        for s in slots:
+            if s not in self.ctx or self.img.get(s) != key:
+                continue
+            n = next((i for i, (a, b) in enumerate(zip(self.ctx[s], ids)) if a != b), min(len(self.ctx[s]), len(ids)))
+            if n > (best[1] if best else 0):
+                best = (s, n)
+        return best
+
+    def resume_slot(self, slot, ids, key=0):
+        ids = [int(t) for t in ids.reshape(-1)]
+        assert self.img.get(slot) == key and self.ctx[slot][:len(ids) - 1] == ids[:-1], "resume without the prompt in the slot"
+        assert not any(slot in step for step in self.bpending), "resume of a slot that is part of an un-collected step"
+        self.ctx[slot], self.gen0[slot], self.forced[slot] = ids[:-1], len(ids), ids[-1]
+        self.resumes += 1
 
     def decode_launch(self):
         assert len(self.ctx[self.SINGLE]) < self.config.max_positions
@@ -259,7 +280,7 @@ def test_sequences_in_engine_slots_decode_exactly_as_alone():
     st = eng.stats()
     # every join got its image prefix without a full prefill: one ViT + prefix prefill per image CHANGE of the prefix
     # cache at most, everything else forked / reused in place; the scripted device has checked every reuse claim
-    assert st["joins"] == 18 and dev.forks + st["inplace_reuses"] == 18
+    assert st["joins"] == 18 and dev.forks + st["inplace_reuses"] + st["resumed_in_place"] == 18
     assert dev.prefills == st["prefix_encodes"] + dev.tail_prefills and st["prefix_encodes"] <= 18
 
 
@@ -292,6 +313,44 @@ def test_parallel_trees_share_one_metric_but_never_a_score():
     seq = list(simulate_parallel(pipe, image, trees=1, expansions_per_tree=4))
     gen = DetikzifyGenerator(dev, proc, image=ref_img, metric=pipe.metric, **pipe.gen_kwargs)
     assert len(seq) == 4 and len(list(gen.simulate(expansions=2))) == 2
+
+
+def test_returning_sequences_resume_in_the_slot_that_holds_their_prompt():
+    """A sequence whose prompt is a path inside an earlier sequence of the same image (an MCTS tree returning to a node of its
+    previous rollout) finds the free slot whose cache still holds that path and continues there: no fork, no tail prefill; the
+    first token of its first step is the forced last prompt token and never reaches the caller.  Token for token what the same
+    prompt and seed produce alone; resume_in_place=False takes the fork + prefill path to the same tokens."""
+    proc = fake_processor(VOCAB, NIMG)
+    kw = dict(bad_words_ids=[[IMG]], begin_suppress_tokens=[EOS], do_sample=True, max_length=NIMG + 60)
+    firsts = [(*_prompt(proc, j % 2, extra=[60 + j]), 300 + j) for j in range(4)]
+    alone_dev = ScriptedDevice()
+    out1 = [alone_dev.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0] for i, p, s in firsts]
+    seconds = [(o[: NIMG + 1 + max(1, (o.numel() - NIMG - 1) // 2)], p, 400 + j) for j, (o, (_, p, _)) in enumerate(zip(out1, firsts))]
+    out2 = [alone_dev.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0] for i, p, s in seconds]
+    for resume in (True, False):
+        dev = ScriptedDevice(slots=5)
+        eng = BatchEngine(dev, max_batch=4, resume_in_place=resume)
+        got, errs = {}, []
+
+        def worker(j):
+            try:
+                for wave, (i, p, s) in enumerate((firsts[j], seconds[j])):
+                    got[(j, wave)] = dev.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0]
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(j,)) for j in range(4)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert not any(t.is_alive() for t in ths) and not errs, errs[:1]
+        eng.close()
+        for j in range(4):
+            assert torch.equal(got[(j, 0)], out1[j]) and torch.equal(got[(j, 1)], out2[j]), (resume, j)
+        st = eng.stats()
+        if resume:      # every second-wave prompt was still cached in a free slot (4 slots, 4 threads: nobody evicted it)
+            assert st["resumed_in_place"] == dev.resumes == 4 and dev.tail_prefills <= 4
+        else:
+            assert st["resumed_in_place"] == dev.resumes == 0 and dev.tail_prefills >= 4
 
 
 def test_device_error_surfaces_from_every_layer_without_hanging():
@@ -356,9 +415,9 @@ def test_several_images_in_flight_keep_their_own_prefix_and_reward(slots):
     st = dev.last_batch_stats
     if slots >= 13:
         assert st["prefix_encodes"] == 4        # every image encoded once (prefix cache, then donors / in place)
-    if slots == 16:                             # a prefix-cache slot per image: every join is a fork
-        assert dev.forks == st["joins"] and dev.prefills == 4 + dev.tail_prefills      # tails: rollouts from inner nodes
-    assert st["prefix_encodes"] + dev.forks + st["inplace_reuses"] >= st["joins"]
+    if slots == 16:                             # a prefix-cache slot per image: every join is a fork — or a resume in place
+        assert dev.forks + st["resumed_in_place"] == st["joins"] and dev.prefills == 4 + dev.tail_prefills      # tails: rollouts from inner nodes
+    assert st["prefix_encodes"] + dev.forks + st["inplace_reuses"] + st["resumed_in_place"] >= st["joins"]
 
 
 def test_a_failing_streamer_or_criterion_frees_its_slot_and_leaves_the_others_alone():

@@ -159,6 +159,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.dtk_abi_version() == _lib.DTK_ABI_VERSION
     hdr = (Path(__file__).resolve().parents[1] / "include" / "dtk.h").read_text()
     assert f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION} " in hdr or f"#define DTK_ABI_VERSION {_lib.DTK_ABI_VERSION}\n" in hdr
+    for name in ("DTK_MAX_BATCH", "DTK_MAX_INFLIGHT", "DTK_VIT_BATCH"):      # constants the Python side mirrors
+        assert re.search(rf"#define {name}\s+{getattr(_lib, name)}\b", hdr), name
     # struct layouts: the ctypes mirrors against the C compiler's own sizeof / offsetof (exported by the library)
     assert lib.dtk_abi_struct_size(0) == ctypes.sizeof(_lib.DtkConfig) == 29 * 4
     assert lib.dtk_abi_struct_size(1) == ctypes.sizeof(_lib.DtkSampling) == 4 * 4 + 8 + 3 * 4 + 24 * 4 + 4
