@@ -45,6 +45,9 @@ class _FakeModel:
         self.pos[b], self.cnt[b] = n, 0
         self.forks += 1
 
+    def best_lcp_slot(self, slots, ids, key=0):
+        return None        # this device remembers no token ids: nothing to resume in place
+
     def decode_batch_launch(self, slots):
         assert len(self.launched) < 2 and slots == sorted(slots) and all(0 <= s < 64 for s in slots)
         assert all(self.pos[s] < self.config.max_positions for s in slots)
