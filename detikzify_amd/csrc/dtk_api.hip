@@ -130,9 +130,6 @@ struct dtk_ctx {
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
   float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
   float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk partial sums + arrival counters
-  bf16_t* At = nullptr; size_t At_elems = 0;           // k_gemm_px: the prefill's activations in fragment-major order
-  const bf16_t* At_of = nullptr; int At_rows = 0;      // what At currently holds (invalidated whenever the source is rewritten)
-  int gemm_px = 1, gemm_px_min_rows = 33;              // k_gemm_px on / off; prompts shorter than this stay on k_gemm_mfma
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
@@ -431,8 +428,6 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pfx_m = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_l = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_o = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4 * 128);
-    c->At_elems = (size_t)((T + 15) / 16) * 16 * (size_t)d;
-    c->At = P.take<bf16_t>(c->At_elems);                                           // k_gemm_px: retiled prefill activations
     c->kpart = P.take<float>((size_t)8 * ((size_t)(d + 15) / 16) * 4 * 256);   // k_gemv_bk: 8 K-slice partials of every row tile x 64 slots
     c->kctr = P.take<unsigned>((size_t)(d + 15) / 16);                              // arrival counters (the arena is zeroed once; the last arrival resets)
     c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
@@ -464,24 +459,14 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->scratch = P.take<unsigned char>(c->scratch_bytes);
 }
 
-// Wt: the fragment-major copy of W (the batched decode's tiled weights), or null.  With it the rows >> d GEMMs of the prefill go
-// to k_gemm_px (weights streamed once); the activations are retiled into c->At first.  Same bits as k_gemm_mfma either way.
 void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
-          const bf16_t* res, int ldr, bf16_t* C, int ldc, int M, int N, int K, int flags, const bf16_t* Wt = nullptr) {
+          const bf16_t* res, int ldr, bf16_t* C, int ldc, int M, int N, int K, int flags) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags;
   hipStream_t s = c->cur_stream ? c->cur_stream : c->stream;
-  if (c->gemm_naive) { launch_gemm_naive(g, s); return; }
-  if (Wt && c->At && c->gemm_px && M >= c->gemm_px_min_rows && (size_t)((M + 15) / 16) * 16 * K <= c->At_elems) {
-    if (c->At_of != A || c->At_rows != M) {           // qkv and gate/up of one layer read different tensors; q / k / v never re-tile
-      launch_retile_ld(A, lda, c->At, M, K, s);
-      c->At_of = A; c->At_rows = M;
-    }
-    g.At = c->At; g.Wt = Wt;
-    if (launch_gemm_px(g, s)) return;
-  }
-  launch_gemm_mfma(g, s);
+  if (c->gemm_naive) launch_gemm_naive(g, s);
+  else launch_gemm_mfma(g, s);
 }
 
 int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
@@ -1069,7 +1054,6 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   // drain pending decode steps (their tokens are dropped)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   ensure_fp8_weights(c);
-  if (c->nb > 0 && c->gemm_px) ensure_tiled_weights(c);   // the prefill's rows >> d GEMMs stream the fragment-major copies (k_gemm_px)
   if (is_single) c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
   else c->bwaited = c->blaunched;
   // ---- locate the image placeholder run (reference v1/modeling_detikzify.py:179-184)
@@ -1129,8 +1113,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     const LayerW& w = c->layers[l];
     launch_rmsnorm_rows(c->X, d, w.ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
     const int qkvn = d + 2 * c->KVH * 128;
-    c->At_of = nullptr;     // Xn was just rewritten by the RMSNorm
-    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0, c->tiled_ready && c->wfmt == 0 ? w.t_wqkv : nullptr);
+    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0);
     launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
     AttnArgs a;
     a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
@@ -1141,8 +1124,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     launch_attention(a, s);
     gemm(c, c->AO, d, w.wo, d, nullptr, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL);
     launch_rmsnorm_rows(c->X, d, w.ln2, c->Xn, d, n, d, c->cfg.rms_eps, s);
-    c->At_of = nullptr;
-    gemm(c, c->Xn, d, w.wgu, d, nullptr, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, c->tiled_ready && c->wfmt == 0 ? w.t_wgu : nullptr);
+    gemm(c, c->Xn, d, w.wgu, d, nullptr, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0);
     launch_silu_mul(c->GU, ff, c->ACT, n, s);
     gemm(c, c->ACT, ff, w.wdown, ff, nullptr, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL);
   }
@@ -1670,11 +1652,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemm_impl")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
     set_gemm_impl(value);
-  }
-  else if (!strcmp(name, "gemm_px")) {
-    if (value < 0) return fail(c, DTK_ERR_ARG, "gemm_px must be 0 (off) or the smallest prompt (rows) that uses it");
-    c->gemm_px = value != 0; c->gemm_px_min_rows = value > 1 ? value : 33;
-    set_gemm_px(c->gemm_px);
   }
   else if (!strcmp(name, "gemv_bk")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemv_bk must be 0 or 1");

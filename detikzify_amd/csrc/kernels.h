@@ -155,13 +155,8 @@ struct GemmArgs {
   bf16_t* C; int ldc;            // [M][N]
   int M, N, K;                   // K multiple of 8
   int flags;
-  const bf16_t* At = nullptr;    // k_gemm_px: A in fragment-major order (k_retile of the M x K activations)
-  const bf16_t* Wt = nullptr;    // k_gemm_px: W in fragment-major order (the batched decode's tiled copy)
 };
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
-void set_gemm_px(int v);      // 0 off, 1 on
-bool launch_gemm_px(const GemmArgs& a, hipStream_t s);   // rows >> d weights streamed once, x through LDS phases (M <= 256 per pass); false = not covered
-void launch_retile_ld(const bf16_t* src, int ld, bf16_t* dst, int N, int K, hipStream_t s);   // row-major [N][ld] -> fragment-major
 void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4
 void set_gemm_tile(int v);   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32

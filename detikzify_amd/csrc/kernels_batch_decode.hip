@@ -802,7 +802,7 @@ void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
 
 // Row-major [N][K] bf16 -> fragment-major tiles (see the header): storage = ceil(N/16)*ceil(K/32) tiles
 // of 512 elements, zero padded.  One thread per 16-byte lane slot.
-__global__ void k_retile(const bf16_t* src, bf16_t* dst, int N, int K, int ld) {
+__global__ void k_retile(const bf16_t* src, bf16_t* dst, int N, int K) {
   const int K32 = (K + 31) >> 5, N16 = (N + 15) >> 4;
   const long total = (long)N16 * K32 * 64;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -811,7 +811,7 @@ __global__ void k_retile(const bf16_t* src, bf16_t* dst, int N, int K, int ld) {
     const int tk = (int)(tile % K32), tn = (int)(tile / K32);
     const int n = tn * 16 + (lane & 15), k = tk * 32 + (lane >> 4) * 8;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (n < N && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * ld + k);
+    if (n < N && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * K + k);
     reinterpret_cast<u32x4*>(dst)[i] = v;
   }
 }
@@ -840,10 +840,5 @@ void launch_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K, hipStream_
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s) {
   const long total = (long)((N + 15) >> 4) * ((K + 31) >> 5) * 64;
   long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, N, K, K);
-}
-void launch_retile_ld(const bf16_t* src, int ld, bf16_t* dst, int N, int K, hipStream_t s) {
-  const long total = (long)((N + 15) >> 4) * ((K + 31) >> 5) * 64;
-  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, N, K, ld);
+  hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, N, K);
 }

@@ -8,7 +8,6 @@
 // tile's loads issued before the current tile's MFMAs (T14 split), padded LDS rows.
 // Epilogue fuses bias / GELU / residual exactly where timm / HF round to bf16.
 #include "kernels.h"
-#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -283,186 +282,6 @@ static void launch_gemm_dma_t(const GemmArgs& a, hipStream_t s, dim3 grid) {
     attr_set = true;
   }
   hipLaunchKernelGGL((k_gemm_dma<BM, BN, RING>), grid, dim3(256), lds, s, a);
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// k_gemm_px — the prefill's rows >> d GEMMs (qkv, gate/up) with the weights streamed ONCE: the batched decode's x-once-per-CU
-// kernel (kernels_batch_gemm.hip: k_gemv_bx) with the prompt's rows as the MFMA N dimension.
-//
-// k_gemm_mfma at M = 243 is a 4 x N/64 grid of 64 x 64 tiles: every weight tile is read by four row blocks and every block
-// re-reads its 64 rows of A for all 64 k-tiles through the 128-byte-row access pattern (10-12 TB/s from L2): 330 TFLOP/s on the
-// gate/up GEMM (140 us), 13.8 % MFMA-busy.  Here a compute wave owns two 16-row weight tiles over the full K and ALL NT column
-// tiles of the prompt (NT = 16: 256 rows): 2 x NT accumulator tiles (128 AGPRs), 2 KiB of weights per k-step straight from the
-// fragment-major copy into the A operand (register ring, non-temporal), NT KiB of x fragments from LDS for 2 NT MFMAs.  The
-// prompt's activations are retiled once per GEMM (k_retile: 2 MB) and walk through LDS in phases of PH k-steps, double
-// buffered, fetched by a loader wave (one phase ahead in registers); UNITS compute waves per block,
-// grid = ceil(N / 32 / UNITS) <= CU count.  Per output element the k-steps are accumulated in order in ONE MFMA chain — the
-// arithmetic of k_gemm_mfma (and of the naive twin), so the results are bit-identical (tested) and the choice of kernel may
-// depend on M.
-template <int NT, int UNITS, int PH, int RING>
-__global__ __launch_bounds__((UNITS + 1) * 64) void k_gemm_px(GemmArgs a, int mt0) {
-  constexpr int T = 2, FR = PH * NT, HALF = FR;      // one loader wave fetches all FR fragments of a phase (UNITS + 1 <= 4 waves: a wave per
-  static_assert(RING % PH == 0, "ring slots line up with phases");   // SIMD, the whole 512-register file each)
-  constexpr int RP = RING / PH;                                  // phases the weight ring spans
-  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];   // 2 x FR KiB
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nsteps = a.K >> 5;                                  // the launcher guarantees K % (32 PH RP) == 0
-  const int NPH = nsteps / PH;
-  const int mtiles = (a.M + 15) >> 4;
-
-  if (wave >= UNITS) {   // ---- the loader wave: fragment f = nt * PH + i of every phase, one phase ahead in registers
-    const int h = 0;
-    const bf16_t* xlane = a.At + lane * 8;
-    size_t base[HALF];
-#pragma unroll
-    for (int k = 0; k < HALF; ++k) {
-      const int f = h * HALF + k;
-      int mt = mt0 + f / PH;
-      if (mt > mtiles - 1) mt = mtiles - 1;                     // a column tile past the prompt: valid memory, never stored
-      base[k] = ((size_t)mt * nsteps + (f % PH)) * 512;
-    }
-    u32x4 xr[HALF];
-#pragma unroll
-    for (int k = 0; k < HALF; ++k) xr[k] = *reinterpret_cast<const u32x4*>(xlane + base[k]);
-#pragma unroll
-    for (int k = 0; k < HALF; ++k) *reinterpret_cast<u32x4*>(psm + (size_t)(h * HALF + k) * 1024 + lane * 16) = xr[k];
-    if (NPH > 1) {
-#pragma unroll
-      for (int k = 0; k < HALF; ++k) xr[k] = *reinterpret_cast<const u32x4*>(xlane + base[k] + (size_t)PH * 512);
-    }
-    __syncthreads();
-    for (int q = 0; q < NPH; ++q) {
-      if (q + 1 < NPH) {
-        unsigned char* xn = psm + (size_t)((q + 1) & 1) * FR * 1024 + (size_t)h * HALF * 1024 + lane * 16;
-#pragma unroll
-        for (int k = 0; k < HALF; ++k) *reinterpret_cast<u32x4*>(xn + (size_t)k * 1024) = xr[k];
-      }
-      if (q + 2 < NPH) {
-#pragma unroll
-        for (int k = 0; k < HALF; ++k) xr[k] = *reinterpret_cast<const u32x4*>(xlane + base[k] + (size_t)(q + 2) * PH * 512);
-      }
-      __syncthreads();
-    }
-    return;
-  }
-
-  // ---- compute waves: weight rows [32 g, 32 g + 32)
-  const int groups = (a.N + 31) >> 5;
-  const int g = blockIdx.x * UNITS + wave;
-  const int gc = g < groups ? g : groups - 1;
-  const unsigned char* wrow[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    int tn = gc * 2 + t;
-    const int tn_max = ((a.N + 15) >> 4) - 1;
-    if (tn > tn_max) tn = tn_max;
-    wrow[t] = reinterpret_cast<const unsigned char*>(a.Wt) + ((size_t)tn * nsteps * 64 + lane) * 16;
-  }
-  u32x4 wr[RING][T];
-#pragma unroll
-  for (int i = 0; i < RING; ++i)
-#pragma unroll
-    for (int t = 0; t < T; ++t) wr[i][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)i * 1024));
-  f32x4 acc[T][NT];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  // phase q uses LDS buffer q & 1 and ring slots (q % RP) * PH + j; REFILL loads phase q + RP into them
-  auto phase = [&](int q, auto slot_tag, auto refill_tag) {
-    constexpr int S = decltype(slot_tag)::value;                // q % RP
-    constexpr bool REFILL = decltype(refill_tag)::value;
-    const unsigned char* xb = psm + (size_t)(q & 1) * FR * 1024 + lane * 16;
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      constexpr int NH = NT > 8 ? 8 : NT;                      // x fragments held at a time
-#pragma unroll
-      for (int n0 = 0; n0 < NT; n0 += NH) {
-        bf16x8_t xf[NH];
-#pragma unroll
-        for (int nt = 0; nt < NH; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)((n0 + nt) * PH + j) * 1024));
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[S * PH + j][t]);
-#pragma unroll
-          for (int nt = 0; nt < NH; ++nt) acc[t][n0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], acc[t][n0 + nt], 0, 0, 0);
-        }
-      }
-      if (REFILL) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) wr[S * PH + j][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)((q + RP) * PH + j) * 1024));
-      }
-    }
-    __syncthreads();
-  };
-  static_assert(RP == 2, "the peeling below assumes a ring of two phases");
-  for (int q = 0; q + 2 < NPH; q += 2) {
-    phase(q, std::integral_constant<int, 0>{}, std::true_type{});
-    phase(q + 1, std::integral_constant<int, 1>{}, std::true_type{});
-  }
-  phase(NPH - 2, std::integral_constant<int, 0>{}, std::false_type{});
-  phase(NPH - 1, std::integral_constant<int, 1>{}, std::false_type{});
-  if (g >= groups) return;
-  // C/D layout: lane holds weight rows (= output columns n) (lane >> 4) * 4 + r of tile t, prompt row (= m) (lane & 15) of column tile nt
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int m = (mt0 + nt) * 16 + (lane & 15);
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int n0 = (g * 2 + t) * 16 + (lane >> 4) * 4;
-      if (n0 + 3 < a.N) {
-        const uint32_t lo = pack2(gemm_epilogue(acc[t][nt][0], m, n0, a), gemm_epilogue(acc[t][nt][1], m, n0 + 1, a));
-        const uint32_t hi = pack2(gemm_epilogue(acc[t][nt][2], m, n0 + 2, a), gemm_epilogue(acc[t][nt][3], m, n0 + 3, a));
-        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n0) = make_uint2(lo, hi);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n0 + r < a.N) a.C[(size_t)m * a.ldc + n0 + r] = f2bf(gemm_epilogue(acc[t][nt][r], m, n0 + r, a));
-      }
-    }
-  }
-}
-
-static int g_px_cus = 0;
-template <int NT, int UNITS, int PH, int RING>
-static void launch_px_one(const GemmArgs& a, int mt0, hipStream_t s) {
-  constexpr int lds = 2 * PH * NT * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_px<NT, UNITS, PH, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  const int groups = (a.N + 31) >> 5;
-  hipLaunchKernelGGL((k_gemm_px<NT, UNITS, PH, RING>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a, mt0);
-}
-static int g_gemm_px = -1;       // 0 off, 1 on (dtk_set_option "gemm_px" / DTK_GEMM_PX)
-void set_gemm_px(int v) { g_gemm_px = v; }
-// false = not covered: no fragment-major operands, K that is not a whole number of ring spans, fewer than 3 units per CU (N = d
-// roles: one tile per CU would make every CU read all of A), ldc / N not 8-byte friendly
-bool launch_gemm_px(const GemmArgs& a, hipStream_t s) {
-  if (g_gemm_px < 0) { const char* e = getenv("DTK_GEMM_PX"); g_gemm_px = e ? atoi(e) : 1; }
-  if (!g_gemm_px || !a.At || !a.Wt || a.M < 1 || (a.N & 31) || (a.ldc & 3)) return false;
-  if (!g_px_cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    g_px_cus = n;
-  }
-  const int groups = a.N >> 5;
-  const int units = (groups + g_px_cus - 1) / g_px_cus;
-  if (units < 2 || units > 4 || (a.K & 255)) return false;       // K % (32 * PH * RP) with PH = 4, RP = 2
-  if (units == 4 && a.M > 128) return false;                     // 5 waves cap a wave at 256 registers: 2 x 16 accumulator tiles do not fit
-  const int mtiles = (a.M + 15) >> 4;
-  for (int mt0 = 0; mt0 < mtiles; mt0 += 16) {                   // 256 prompt rows per pass (each pass streams the weights again)
-    const int left = mtiles - mt0;
-#define PX(NTV) do { if (units == 2) launch_px_one<NTV, 2, 4, 8>(a, mt0, s); else if (units == 3) launch_px_one<NTV, 3, 4, 8>(a, mt0, s); \
-                     else launch_px_one<NTV, 4, 4, 8>(a, mt0, s); } while (0)
-    if (left > 8) PX(16); else if (left > 4) PX(8); else PX(4);
-#undef PX
-  }
-  return true;
 }
 
 static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
