@@ -134,6 +134,7 @@ struct dtk_ctx {
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
   int pfx_splits = 2;                // key splits of that kernel
+  int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
   int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4)
   DecState* st_b = nullptr;          // [16]
   SamplingDev* sp_b = nullptr;       // [16]
@@ -620,7 +621,7 @@ void batch_step_launches(dtk_ctx* c) {
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
     ad.scale = scale;
-    ad.impl = c->attn_b_impl; ad.use_prefix = c->attn_b_impl == 1 && c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads;
+    ad.impl = c->attn_b_impl; ad.use_prefix = c->attn_b_impl == 1 && c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused;
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
@@ -1652,6 +1653,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemm_impl")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
     set_gemm_impl(value);
+  }
+  else if (!strcmp(name, "gqa_fused")) {
+    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gqa_fused must be 0 (a block per query head), 1 (per K/V head) or 2 (per pair of query heads)");
+    c->gqa_fused = value;
+    drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bk")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemv_bk must be 0 or 1");

@@ -662,14 +662,19 @@ __global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
 // member, [0, n) otherwise — in tiles of 16 * WAVES rows with the next tile in flight, starting from the prefix state, and
 // writes the normalised bf16 head output in o_proj's fragment-major order: no split partials, no combine kernel (64 slots x
 // 32 heads are 2048 blocks already).  Rows below a fork's share_len still come from its source slot (one copy in L2).
-template <int THREADS>
+// GQ = query heads per block: 1, or the GQA group (H / KVH = 4 for the v2 models): the heads of a group attend over the SAME
+// K / V rows, so the block loads a row once and scores it against GQ queries.  Per head the arithmetic — which lane owns which
+// keys, the order of the online-softmax updates, the cross-lane and cross-wave merges — is exactly that of GQ = 1 (the compiler
+// contracts the multiply-adds differently in the two instantiations: equal to fp32 rounding, tested, not bit for bit); the key /
+// value traffic through L2 drops by GQ (ds-7b has no groups: GQ = 1).  A slot's result still does not depend on the other slots.
+template <int THREADS, int GQ = 1>
 __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
-  const int h = blockIdx.x, slot = blockIdx.y;
+  const int h0 = blockIdx.x * GQ, slot = blockIdx.y;
   if (!a.bs->active[slot]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 15, grp = lane >> 4;
-  const int kvh = h / a.G;
+  const int kvh = h0 / a.G;
   const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   const int ssrc = a.bs->share_src[slot];
@@ -678,7 +683,9 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   const bool member = a.use_prefix && pfx_member(a.bs, slot);
   const int start = member ? a.bs->pfx_len : 0;
   const int n = a.st[slot].pos + 1;
-  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + h * 128)[sub];
+  u32x4 qv[GQ];
+#pragma unroll
+  for (int g = 0; g < GQ; ++g) qv[g] = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + (h0 + g) * 128)[sub];
 
   u32x4 kv[4], vv[4];
   auto load_tile = [&](int j0) {
@@ -692,25 +699,31 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
     }
   };
   if (start < n) load_tile(start);
-  float m = -1e30f, l = 0.f;
-  float o[8];
+  float m[GQ], l[GQ], o[GQ][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int g = 0; g < GQ; ++g) {
+    m[g] = -1e30f; l[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+  }
   if (member && wave == 0 && grp == 0) {   // the prefix state (its key splits merged in order) seeds one of the block's streams
-    const size_t rec0 = ((size_t)slot * a.H + h) * a.pfx_splits;
-    for (int zsp = 0; zsp < a.pfx_splits; ++zsp) {
-      const float m2 = a.pfx_m[rec0 + zsp], l2 = a.pfx_l[rec0 + zsp];
-      const f32x4* po4 = reinterpret_cast<const f32x4*>(a.pfx_o + (rec0 + zsp) * 128 + sub * 8);
-      const f32x4 p0 = po4[0], p1 = po4[1];
-      const float mn = fmaxf(m, m2);
-      const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
-      l = l * c1 + l2 * c2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = o[e] * c1 + p0[e] * c2;
-        o[4 + e] = o[4 + e] * c1 + p1[e] * c2;
+    for (int g = 0; g < GQ; ++g) {
+      const size_t rec0 = ((size_t)slot * a.H + h0 + g) * a.pfx_splits;
+      for (int zsp = 0; zsp < a.pfx_splits; ++zsp) {
+        const float m2 = a.pfx_m[rec0 + zsp], l2 = a.pfx_l[rec0 + zsp];
+        const f32x4* po4 = reinterpret_cast<const f32x4*>(a.pfx_o + (rec0 + zsp) * 128 + sub * 8);
+        const f32x4 p0 = po4[0], p1 = po4[1];
+        const float mn = fmaxf(m[g], m2);
+        const float c1 = __expf(m[g] - mn), c2 = __expf(m2 - mn);
+        l[g] = l[g] * c1 + l2 * c2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[g][e] = o[g][e] * c1 + p0[e] * c2;
+          o[g][4 + e] = o[g][4 + e] * c1 + p1[e] * c2;
+        }
+        m[g] = mn;
       }
-      m = mn;
     }
   }
   for (int j0 = start; j0 < n; j0 += ROWS) {
@@ -721,68 +734,78 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
-      float s = dot8(qv, kc[i], 0.f);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 8, 64);
-      s *= a.scale;
-      if (j < n) {
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn);
-        const float p = __expf(s - mn);
-        l = l * corr + p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[2 * e] = o[2 * e] * corr + p * pk_lo(vc[i][e]);
-          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vc[i][e]);
+      for (int g = 0; g < GQ; ++g) {
+        float s = dot8(qv[g], kc[i], 0.f);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        s *= a.scale;
+        if (j < n) {
+          const float mn = fmaxf(m[g], s);
+          const float corr = __expf(m[g] - mn);
+          const float p = __expf(s - mn);
+          l[g] = l[g] * corr + p;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[g][2 * e] = o[g][2 * e] * corr + p * pk_lo(vc[i][e]);
+            o[g][2 * e + 1] = o[g][2 * e + 1] * corr + p * pk_hi(vc[i][e]);
+          }
+          m[g] = mn;
         }
-        m = mn;
       }
     }
   }
 #pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {
-    const float m2 = __shfl_xor(m, off, 64);
-    const float l2 = __shfl_xor(l, off, 64);
-    const float mn = fmaxf(m, m2);
-    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
-    l = l * c1 + l2 * c2;
+  for (int g = 0; g < GQ; ++g) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float o2 = __shfl_xor(o[e], off, 64);
-      o[e] = o[e] * c1 + o2 * c2;
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float m2 = __shfl_xor(m[g], off, 64);
+      const float l2 = __shfl_xor(l[g], off, 64);
+      const float mn = fmaxf(m[g], m2);
+      const float c1 = __expf(m[g] - mn), c2 = __expf(m2 - mn);
+      l[g] = l[g] * c1 + l2 * c2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float o2 = __shfl_xor(o[g][e], off, 64);
+        o[g][e] = o[g][e] * c1 + o2 * c2;
+      }
+      m[g] = mn;
     }
-    m = mn;
   }
-  __shared__ float sm_m[WAVES][16], sm_l[WAVES][16], sm_o[WAVES][16][8];
+  __shared__ float sm_m[GQ][WAVES][16], sm_l[GQ][WAVES][16], sm_o[GQ][WAVES][16][8];
   if (grp == 0) {
-    sm_m[wave][sub] = m;
-    sm_l[wave][sub] = l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
+    for (int g = 0; g < GQ; ++g) {
+      sm_m[g][wave][sub] = m[g];
+      sm_l[g][wave][sub] = l[g];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm_o[g][wave][sub][e] = o[g][e];
+    }
   }
   __syncthreads();
-  if (tid < 16) {
-    float M = sm_m[0][tid];
+  if (tid < 16 * GQ) {
+    const int g = tid >> 4, t16 = tid & 15;
+    float M = sm_m[g][0][t16];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[w][tid]);
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[g][w][t16]);
     float L = 0.f;
     float oo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) oo[e] = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
-      const float c = __expf(sm_m[w][tid] - M);
-      L += c * sm_l[w][tid];
+      const float c = __expf(sm_m[g][w][t16] - M);
+      L += c * sm_l[g][w][t16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
+      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[g][w][t16][e];
     }
     const float invL = 1.f / L;
     u32x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = pack2(oo[2 * e] * invL, oo[2 * e + 1] * invL);
-    *reinterpret_cast<u32x4*>(a.out + xtile_off(slot, h * 128 + tid * 8, (a.d + 31) >> 5)) = ov;   // 8 consecutive k of one fragment lane
+    *reinterpret_cast<u32x4*>(a.out + xtile_off(slot, (h0 + g) * 128 + t16 * 8, (a.d + 31) >> 5)) = ov;   // 8 consecutive k of one fragment lane
   }
 }
 
@@ -790,6 +813,23 @@ void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
     if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
+    if (a.G == 4 && a.gqa_fused == 2) {   // pairs of query heads: half the sharing, twice the blocks
+      hipLaunchKernelGGL((k_attn_tail_b<256, 2>), dim3(a.H / 2, a.nslots), dim3(256), 0, s, a);
+      return;
+    }
+    if (a.G == 4 && a.gqa_fused) {   // GQA: the four query heads of a K / V head in one block (same arithmetic per head, a quarter of the K / V reads)
+      if (a.tail_threads == 64) hipLaunchKernelGGL((k_attn_tail_b<64, 4>), dim3(a.H / 4, a.nslots), dim3(64), 0, s, a);
+      else if (a.tail_threads == 128) hipLaunchKernelGGL((k_attn_tail_b<128, 4>), dim3(a.H / 4, a.nslots), dim3(128), 0, s, a);
+      else if (a.tail_threads == 512) hipLaunchKernelGGL((k_attn_tail_b<512, 4>), dim3(a.H / 4, a.nslots), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_attn_tail_b<256, 4>), dim3(a.H / 4, a.nslots), dim3(256), 0, s, a);
+      return;
+    }
+    if (a.G == 2 && a.gqa_fused) {
+      if (a.tail_threads == 64) hipLaunchKernelGGL((k_attn_tail_b<64, 2>), dim3(a.H / 2, a.nslots), dim3(64), 0, s, a);
+      else if (a.tail_threads == 128) hipLaunchKernelGGL((k_attn_tail_b<128, 2>), dim3(a.H / 2, a.nslots), dim3(128), 0, s, a);
+      else hipLaunchKernelGGL((k_attn_tail_b<256, 2>), dim3(a.H / 2, a.nslots), dim3(256), 0, s, a);
+      return;
+    }
     if (a.tail_threads == 64) hipLaunchKernelGGL(k_attn_tail_b<64>, dim3(a.H, a.nslots), dim3(64), 0, s, a);
     else if (a.tail_threads == 128) hipLaunchKernelGGL(k_attn_tail_b<128>, dim3(a.H, a.nslots), dim3(128), 0, s, a);
     else if (a.tail_threads == 256) hipLaunchKernelGGL(k_attn_tail_b<256>, dim3(a.H, a.nslots), dim3(256), 0, s, a);

@@ -223,7 +223,8 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * combine kernel, 1 = one block per (head, slot)), "tail_threads" (64 | 128 | 256 | 512), "prefix_mfma" (score the prefix most slots share
  * once on the matrix cores), "pfx_splits" (1..4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
  * registers, 1..4 = x through LDS by LDS-DMA), "gemv_bx" (0 off, 1 = x once per CU for gate/up + lm_head at 49..64 slots, 2..4 =
- * forced units per block), "gemv_bk" (K split across CUs for o_proj / down; slower, off), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
+ * forced units per block), "gemv_bk" (K split across CUs for o_proj / down; slower, off), "gqa_fused" (GQA models: 0 = an attention block per query
+ * head, 1 = per K/V head, 2 = per pair of query heads), "share_prefix_reads".  Prefill / ViT: "attn_impl" (0 auto, 1 VALU, 2 MFMA flash),
  * "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages" (1..4).
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.
