@@ -255,7 +255,19 @@ __global__ __launch_bounds__(KQ * RP * 64) void k_gemm_b(GemvBArgs a) {
 // k_gemv_b's 8 wave slices and their reduction, so the results are BIT-IDENTICAL to k_gemv_b (tested): a slot's tokens do not
 // depend on which of the two kernels served the step.
 template <bool B> struct bx_flag { static constexpr bool value = B; };
-template <int EPI, int UNITS, int CHP>
+// two e4m3 words (8 weights of one row) -> the bf16 A fragment of one k-step (exact; as in kernels_batch_decode.hip)
+__device__ __forceinline__ bf16x8_t gg_f8x8_to_bf16x8(uint32_t w0, uint32_t w1) {
+  u32x4 o;
+  o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false));
+  o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, true));
+  o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, false));
+  o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, true));
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+// F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps), are widened to bf16 in registers and
+// fed to the same MFMAs in the same k order; the per-row power-of-two scale multiplies the finished sum — bit-identical to the
+// fp8 k_gemv_b kernels (whose four-tile variants spill at 64 slots: here a compute wave has the whole register file)
+template <int EPI, int UNITS, int CHP, bool F8 = false>
 __global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
   constexpr int T = 2, NT = 4, PH = 8, RING = 2 * PH;           // k-steps per phase; weight ring = two phases
   constexpr int FR = PH * NT;                                   // 1 KiB x fragments of one phase
@@ -302,11 +314,13 @@ __global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
     int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
     const int tn_max = ((a.N + 15) >> 4) - 1;
     if (tn > tn_max) tn = tn_max;
-    wrow[t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+    wrow[t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                 : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
   }
-  u32x4 wr[RING][T];
+  constexpr int WS = F8 ? 2 : 1;                                 // k-steps per 1 KiB weight tile
+  u32x4 wr[RING / WS][T];
 #pragma unroll
-  for (int i = 0; i < RING; ++i)
+  for (int i = 0; i < RING / WS; ++i)
 #pragma unroll
     for (int t = 0; t < T; ++t) wr[i][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)i * 1024));
   f32x4 tot[T][NT], c[T][NT];
@@ -326,15 +340,18 @@ __global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
       bf16x8_t xf[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+      constexpr int slot_base = H * PH / WS;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[H * PH + j][t]);
+        const u32x4 wv = wr[slot_base + j / WS][t];
+        const bf16x8_t af = F8 ? gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]) : __builtin_bit_cast(bf16x8_t, wv);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
       }
-      if (REFILL) {
+      if (REFILL && (j % WS) == WS - 1) {                       // the tile just used up
 #pragma unroll
-        for (int t = 0; t < T; ++t) wr[H * PH + j][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)((q + 2) * PH + j) * 1024));
+        for (int t = 0; t < T; ++t)
+          wr[slot_base + j / WS][t] = ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)(((q + 2) * PH + j) / WS) * 1024));
       }
     }
     __syncthreads();   // the loader has parked the next phase; everybody is done reading this one
@@ -365,7 +382,15 @@ __global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
     if (!a.bs->active[n]) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      if (F8) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
+          if (row >= a.N) row = a.N - 1;
+          v[t] *= a.wscale[row];                                // power of two: exact
+        }
+      }
       gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
     }
   }
@@ -385,11 +410,13 @@ static void launch_bx_one(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = 2 * 8 * 4 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  hipLaunchKernelGGL((k_gemv_bx<EPI, UNITS, CHP>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a);
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bx<EPI, UNITS, CHP, true>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bx<EPI, UNITS, CHP, false>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a);
 }
 template <int EPI, int CHP>
 static bool launch_bx_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -400,10 +427,10 @@ static bool launch_bx_units(int units, const GemvBArgs& a, hipStream_t s) {
     default: return false;                                           // more than 4 units per CU (128 k-token vocabularies): k_gemv_b
   }
 }
-// variant > 0 = on; `units` waves per block = units per CU (variant 2..4 force that many: tuning).  false = not covered (fp8
-// weights, fewer than 49 slots, N = d roles, K other than 2048 / 4096, more than 4 units per CU): the caller uses k_gemv_b
+// variant > 0 = on; `units` waves per block = units per CU (variant 2..4 force that many: tuning).  false = not covered (fewer
+// than 49 slots, N = d roles, K other than 2048 / 4096, more than 4 units per CU): the caller uses k_gemv_b
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
-  if (a.W8 || a.nt < 3 || variant <= 0) return false;
+  if (a.nt < 3 || variant <= 0) return false;
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
   if (a.K != 4096 && a.K != 2048) return false;
   if (epi == EPI_SWIGLU && (a.ff & 15)) return false;

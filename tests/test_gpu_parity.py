@@ -1356,8 +1356,8 @@ def test_lds_staged_batched_gemm_tracks_the_register_kernels(tiny_batched):
         assert all(rel_l2(a, b) < 2e-3 for a, b in zip(runs[shape][1], runs[0][1])), shape
 
 
-@pytest.mark.parametrize("name,layers", [("detikzify-ds-7b", 2), ("detikzify-ds-1.3b", 3)])
-def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, layers):
+@pytest.mark.parametrize("name,layers,weight_format", [("detikzify-ds-7b", 2, "bf16"), ("detikzify-ds-1.3b", 3, "bf16"), ("detikzify-cl-7b", 2, "fp8")])
+def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, layers, weight_format):
     """k_gemv_bx (64 slots: the x fragments of a phase shared through LDS, one wave per row-tile pair over the full K) and
     k_gemv_bk (N = d roles: K split over the 8 CUs of a row group, partials met in memory by the last arrival) against
     k_gemv_b at the real widths (K = 4096: chains of two phases, K = 2048: one), a few layers deep: same K order per
@@ -1366,7 +1366,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
     from detikzify_amd.model.config import preset
     from detikzify_amd.model.modeling import DetikzifyForCausalLM
     cfg = preset(name)
-    cfg.layers, cfg.max_positions, cfg.batch_slots = layers, 256, 64
+    cfg.layers, cfg.max_positions, cfg.batch_slots, cfg.weight_format = layers, 256, 64, weight_format
     model = DetikzifyForCausalLM(cfg, 0)
     try:
         model.fill_synthetic(99)
