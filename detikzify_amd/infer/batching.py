@@ -166,6 +166,9 @@ class BatchEngine:
                 finally:
                     with self._plock:
                         self.pending += 1
+            if self.zombies and self.error is None:
+                self._collect()     # a slot left while its last step was in flight is free once that step is read — and it may
+                                    # be the very slot whose cache holds this prompt (a tree returning right after its rollout)
             # slot choice: a free slot that holds no prefix worth keeping; else one that already holds THIS image's prefix
             # (re-used in place); else evict the prefix of some other image
             # (lowest index first: a step only runs the 16-slot column tiles up to its highest active slot)
