@@ -709,3 +709,60 @@ def test_load_builds_the_processor_of_every_preset(monkeypatch):
         assert set(enc.input_ids[0].tolist()) == {model.config.image_token_id}, name
     with pytest.raises(FileNotFoundError):
         dm.load("nllg/detikzify-ds-7b")            # no local checkpoint, no network: say so
+
+
+def test_concurrent_pooled_calls_are_combined_and_every_caller_gets_its_own_row():
+    """vision_model.pooled_only from many threads (the trees of a parallel search scoring their rollouts): leader / follower
+    batching into passes of at most DTK_VIT_BATCH images, each caller receives the row of ITS image, a failing pass reaches
+    exactly the callers that were in it, and the next callers find a working leader again."""
+    import threading
+    import time
+    from detikzify_amd.model.modeling import DetikzifyVisionModel
+
+    class Owner:
+        def __init__(self):
+            self.batches, self.fail_next = [], False
+
+        def vit_encode(self, px, want_pooled=True, want_feats=True):
+            time.sleep(0.005)                       # the device pass: callers pile up behind it
+            self.batches.append(px.shape[0])
+            if self.fail_next:
+                self.fail_next = False
+                raise RuntimeError("device error")
+            return None, px.reshape(px.shape[0], -1)[:, :4] * 2.0     # "pooled" = a function of the image alone
+
+    owner = Owner()
+    vm = DetikzifyVisionModel(owner)
+    imgs = [torch.full((1, 3, 4, 4), float(i)) for i in range(40)]
+    got, errs = [None] * 40, []
+
+    def worker(i):
+        try:
+            got[i] = vm.pooled_only(imgs[i])
+        except RuntimeError as e:
+            errs.append((i, str(e)))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(40)]
+    [t.start() for t in ths]
+    [t.join(timeout=30) for t in ths]
+    assert not errs and sum(owner.batches) == 40 and max(owner.batches) <= _lib.DTK_VIT_BATCH and len(owner.batches) < 40
+    for i in range(40):
+        assert got[i].shape == (1, 4) and torch.equal(got[i], torch.full((1, 4), 2.0 * i))
+    # a failing pass: its callers get the error, later callers are served
+    owner.batches.clear()
+    owner.fail_next = True
+    got2, errs2 = [None] * 12, []
+
+    def worker2(i):
+        try:
+            got2[i] = vm.pooled_only(imgs[i])
+        except RuntimeError as e:
+            errs2.append(i)
+
+    ths = [threading.Thread(target=worker2, args=(i,)) for i in range(12)]
+    [t.start() for t in ths]
+    [t.join(timeout=30) for t in ths]
+    assert 1 <= len(errs2) <= _lib.DTK_VIT_BATCH and len(errs2) == owner.batches[0]
+    assert all(torch.equal(got2[i], torch.full((1, 4), 2.0 * i)) for i in range(12) if i not in errs2)
+    assert torch.equal(vm.pooled_only(imgs[3]), torch.full((1, 4), 6.0))     # and the model still answers afterwards
+    assert vm.pooled_only(torch.cat(imgs[:3])).shape == (3, 4)                # an explicit batch goes straight through
