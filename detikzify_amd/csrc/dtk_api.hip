@@ -1659,6 +1659,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     c->gqa_fused = value;
     drop_batch_graphs(c);
   }
+  else if (!strcmp(name, "resid_split")) {
+    set_resid_split(value != 0);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "gemv_bk")) {
     if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemv_bk must be 0 or 1");
     set_gemv_bk(value);

@@ -55,7 +55,13 @@ __global__ __launch_bounds__(WAVES * 64, (MODE & 8) ? 4 : 1) void k_gemv_b(GemvB
   constexpr int NP = NT > 2 ? 2 : NT;   // column tiles per reduction pass
   __shared__ float red[WAVES][T][NP][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x;
+  // MODE & 128 (N = d roles at 64 slots): a block owns T row tiles and HALF of the slots (NT = 2 of the 4 column tiles); the two
+  // blocks of a row-tile group are given ids b and b + 8 — the same XCD, dispatched together — so the second one finds the weights
+  // in that XCD's L2.  x traffic halves (each block reads 32 slots' worth), the K split and its reduction order are unchanged.
+  constexpr bool SPLIT = (MODE & 128) != 0;
+  const int b0 = blockIdx.x;
+  const int blk = SPLIT ? (((b0 >> 4) << 3) | (b0 & 7)) : b0;
+  const int nt0 = SPLIT ? ((b0 >> 3) & 1) * NT : 0;
   const int K = a.K;
   // K slice of this wave, in k-steps of 32 (the last step may be partial: K % 8 == 0)
   const int nsteps = (K + GB_KSTEP - 1) / GB_KSTEP;
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(WAVES * 64, (MODE & 8) ? 4 : 1) void k_gemv_b(GemvB
           u32x4 xv;
           if (MODE & 1) xv = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
           else if ((MODE & 32) && nt > 0) xv = x[F8 ? 2 * i + h : i][0];
-          else if (MODE & 64) xv = ld_nt(reinterpret_cast<const u32x4*>(xlane + ((size_t)nt * nsteps + (ok ? st : 0)) * 512));
-          else xv = *reinterpret_cast<const u32x4*>(xlane + ((size_t)nt * nsteps + (ok ? st : 0)) * 512);
+          else if (MODE & 64) xv = ld_nt(reinterpret_cast<const u32x4*>(xlane + ((size_t)(nt0 + nt) * nsteps + (ok ? st : 0)) * 512));
+          else xv = *reinterpret_cast<const u32x4*>(xlane + ((size_t)(nt0 + nt) * nsteps + (ok ? st : 0)) * 512);
           if (!ok) xv = (u32x4){0u, 0u, 0u, 0u};
           x[F8 ? 2 * i + h : i][nt] = xv;
         }
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64, (MODE & 8) ? 4 : 1) void k_gemv_b(GemvB
   auto finish = [&](int q, int nt, int ti) {
     // thread -> (m, n) of a 16x16 tile: C/D layout col n = lane&15, row m = (lane>>4)*4 + reg
     const int l2 = ti >> 2, r2 = ti & 3;
-    const int n = nt * 16 + (l2 & 15);  // slot
+    const int n = (nt0 + nt) * 16 + (l2 & 15);  // slot
     const int m = (l2 >> 4) * 4 + r2;   // row inside the tile
     float v[T];
   #pragma unroll
@@ -292,6 +298,8 @@ static int resid_waves() {
 // the x fragments through L2), lm_head 67.9 -> 62.2, gate/up 48.5 -> 48.4 (344 blocks: 1.34 rounds on 256 CUs eat the gain),
 // o_proj / down 24.1 -> 29.2 (128 blocks).  Results are bit-identical across modes (a row's k order depends on the wave split
 // of K only).
+static int g_resid_split = 1;   // 1 (default): N = d roles at 64 slots as 2 row tiles x 32 slots per block (dtk_set_option "resid_split"): o_proj + down 24.0 -> 22.5 us avg
+void set_resid_split(int v) { g_resid_split = v; }
 static int g_gb_wide = -1;
 void set_gemv_b_wide(int v) { g_gb_wide = v; }
 static int gb_wide(int nt, bool f8) {
@@ -322,7 +330,9 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
     // from L2 per KiB of weights, which two tiles per block halve (at the price of 128 blocks)
     static int ks = 0;
     if (!ks) { const char* e = getenv("DTK_GB_RESID_KS"); ks = (e && atoi(e) == 8) ? 8 : 4; }
-    if (wide_resid) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
+    if (NT == 4 && !F8 && g_resid_split && ((a.N + 31) / 32) % 8 == 0)
+      hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 128, false, GB_WAVES, 2>), dim3(2 * ((a.N + 31) / 32)), dim3(GB_THREADS), 0, s, a);
+    else if (wide_resid) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
     else if (resid_waves() == 16 && NT < 4 && !F8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
     else if (ks == 8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT, 8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
