@@ -26,6 +26,7 @@ ap.add_argument("--synthetic", type=int, default=None)
 ap.add_argument("--trees", type=int, default=32, help="independent trees per GPU (<= 64: one batched decode)")
 ap.add_argument("--expansions", type=int, default=4, help="rollouts per tree")
 ap.add_argument("--no-latex", action="store_true")
+ap.add_argument("--tex-workers", type=int, default=16, help="LaTeX worker processes per rank (compile pool); 0 = compile in the tree's own thread")
 ap.add_argument("--keep", type=int, default=5)
 args = ap.parse_args()
 
@@ -34,9 +35,22 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     torch.cuda.set_device(local_rank)
     ddist.init_process_group(os.environ.get("DTK_DIST_BACKEND"))      # default nccl (= RCCL); "gloo" for a control-flow test
 model, processor = load(args.model, synthetic=args.synthetic, device_map=local_rank, batch_slots=min(64, args.trees) + 1)
-kw = dict(document_class=SyntheticTikzDocument) if args.no_latex else {}
+pool = None
+if args.no_latex:
+    kw = dict(document_class=SyntheticTikzDocument)
+elif args.tex_workers > 0:      # latexmk / crop / rasterise of finished rollouts in worker processes while the other trees decode
+    from detikzify_amd.infer import CompilePool, pooled_document_class
+    pool = CompilePool(workers=args.tex_workers)
+    pool.warm()
+    kw = dict(document_class=pooled_document_class(pool))
+else:
+    kw = {}
 pipe = DetikzifyPipeline(model, processor, **kw)
-best = ddist.root_parallel_search(pipe, args.image, trees=args.trees, expansions_per_tree=args.expansions)
+try:
+    best = ddist.root_parallel_search(pipe, args.image, trees=args.trees, expansions_per_tree=args.expansions)
+finally:
+    if pool is not None:
+        pool.close()
 if ddist.rank() == 0:
     for score, code in best[-args.keep:][::-1]:      # merge_rollouts sorts ascending (eval.py:106)
         print(f"% score {score:.4f}\n{code}\n")
