@@ -118,7 +118,11 @@ struct SampleMB {
   unsigned long long above[4];           // mass strictly above the chosen bin, per level
   unsigned int bin[4];
   unsigned long long total;
-  unsigned int thr, pad;
+  unsigned int thr;
+  // DecState.draw / .force_plus1 as they were BEFORE this step's draw kernel (written by block 0 of k_smb_max): k_smb_draw's
+  // blocks read only these — its last block rewrites DecState while blocks of the same slot may not have started yet
+  unsigned int draw_snap;
+  int forced_snap, pad;
 };
 
 // Top-p radix level: among the 256 (mass, count) bins of one level pick the LOWEST non-empty bin whose strictly-above

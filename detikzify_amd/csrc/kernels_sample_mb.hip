@@ -133,6 +133,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_max(SampleArgs a) {
     for (int w = 1; w < 16; ++w)
       if (s_f[w] > b || (s_f[w] == b && s_i[w] < bi)) { b = s_f[w]; bi = s_i[w]; }
     a.mb->bmax[blk] = b; a.mb->barg[blk] = bi;
+    if (blk == 0) { a.mb->draw_snap = draw; a.mb->forced_snap = a.advance ? a.st->force_plus1 : 0; }
   }
   // the histograms of this step start from zero (P1 is a later kernel)
   if (blk == 0) {
@@ -274,8 +275,11 @@ __global__ __launch_bounds__(MB_THREADS) void k_smb_draw(SampleArgs a, int nblk)
   __shared__ int s_token;
   const int tid = threadIdx.x, blk = blockIdx.x;
   mb_common(a, nblk, &cm);
-  const uint32_t draw = (a.step_override >= 0) ? (uint32_t)a.step_override : a.st->draw;
-  const int forced = a.advance ? a.st->force_plus1 : 0;
+  // the snapshot of k_smb_max, NOT DecState: the block that owns the token advances DecState (draw, force_plus1) at its end,
+  // and with more blocks than the chip holds at once (v2-8b: 16 slices x 64 slots) a block of the same slot can start after
+  // that — it would see the next step's draw index / a cleared force flag, pick an owner of its own and advance a second time
+  const uint32_t draw = a.mb->draw_snap;
+  const int forced = a.mb->forced_snap;
   const bool sampling = cm.sp.do_sample != 0;
   if (tid == 0) s_token = -1;
   __syncthreads();

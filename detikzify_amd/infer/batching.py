@@ -179,7 +179,15 @@ class BatchEngine:
             if (self.resume_in_place and n_ids >= 2 and (want is not None or pixel_values is None)
                     and int(ids.reshape(-1)[-1]) != self.model.config.image_token_id):
                 key = want[0] if want is not None else 0
-                best = self.model.best_lcp_slot(order, ids, key)
+                # an owner (an MCTS tree) resumes only in the slot IT used last: whether a join resumes or re-prefills must not
+                # depend on which other slots happen to be free at that moment (thread timing) — resumed rows were written by
+                # the decode kernels, prefilled rows by the GEMMs, so the choice is visible in the last bits of the logits and
+                # a fixed-seed parallel search would stop being reproducible.  Owner-less sequences may take any free slot.
+                if owner is not None:
+                    candidates = [self.last_slot[owner]] if self.last_slot.get(owner) in self.free else []
+                else:
+                    candidates = order
+                best = self.model.best_lcp_slot(candidates, ids, key) if candidates else None
                 if best is not None and best[1] >= n_ids - 1:
                     slot, resume = best[0], True
             if slot is None and owner is not None and self.last_slot.get(owner) in self.free:

@@ -22,7 +22,9 @@ documents of a batch (`imap`).
 from __future__ import annotations
 
 import os
+import threading
 from concurrent.futures import Future, ProcessPoolExecutor
+from concurrent.futures.process import BrokenProcessPool
 from io import BytesIO
 from multiprocessing import get_context
 from typing import Iterable, Iterator, List, NamedTuple, Optional, Type
@@ -84,8 +86,24 @@ class _PooledPdf:
 class CompilePool:
     def __init__(self, workers: Optional[int] = None, raster_size: int = 420, engines: Optional[List[str]] = None):
         self.workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
-        self.raster_size, self.engines = raster_size, engines
-        self._pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
+        # the workers start from a fresh interpreter: an engine list set on the parent's TikzDocument (set_engines) travels
+        # with every job unless the caller names another one
+        self.raster_size, self.engines = raster_size, list(TikzDocument.engines) if engines is None else engines
+        self.restarts = 0
+        self._lock = threading.Lock()
+        self._pool = self._new_executor()
+
+    def _new_executor(self) -> ProcessPoolExecutor:
+        return ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
+
+    def restart(self, broken: ProcessPoolExecutor) -> None:
+        """a worker died (OOM-killed TeX run, crashing rasteriser): concurrent.futures marks the whole executor broken for good.
+        Replace it once (the first thread that reports `broken` does; the others find a new one already in place)."""
+        with self._lock:
+            if self._pool is broken:
+                self._pool = self._new_executor()
+                self.restarts += 1
+        broken.shutdown(wait=False, cancel_futures=True)
 
     def warm(self) -> int:
         """start every worker now (a spawned worker imports this package, ~seconds) instead of under the first rollouts;
@@ -93,13 +111,31 @@ class CompilePool:
         return len({f.result() for f in [self._pool.submit(_warm_job, 0.3) for _ in range(self.workers)]})
 
     def submit(self, code: str, timeout: Optional[int] = 60) -> "Future[CompiledFigure]":
-        return self._pool.submit(_compile_job, code, timeout, self.raster_size, self.engines)
+        for _ in range(3):
+            pool = self._pool
+            try:
+                f = pool.submit(_compile_job, code, timeout, self.raster_size, self.engines)
+                f._dtk_executor = pool       # so that whoever sees BrokenProcessPool on this future restarts the right executor
+                return f
+            except BrokenProcessPool:
+                self.restart(pool)
+        raise BrokenProcessPool("the compile pool's workers keep dying")
+
+    def result(self, future: "Future[CompiledFigure]") -> Optional[CompiledFigure]:
+        """the figure, or None when the job's worker (or a sibling: the executor fails every pending job) died — the pool is
+        restarted for the jobs that follow; the lost job is reported as a failed compile by the caller"""
+        try:
+            return future.result()
+        except BrokenProcessPool:
+            self.restart(getattr(future, "_dtk_executor", self._pool))
+            return None
 
     def imap(self, codes: Iterable[str], timeout: Optional[int] = 60) -> Iterator[CompiledFigure]:
         """all documents in flight at once, results in input order (multiprocessing.Pool.imap, refine.py:176)"""
         futures = [self.submit(code, timeout) for code in codes]
         for f in futures:
-            yield f.result()
+            fig = self.result(f)
+            yield fig if fig is not None else CompiledFigure(-1, "compile worker died", None, None)
 
     def close(self):
         self._pool.shutdown(wait=True, cancel_futures=True)
@@ -123,7 +159,9 @@ def pooled_document_class(pool: CompilePool) -> Type[TikzDocument]:
             return self
 
         def _compile(self) -> Output:
-            fig = self.prefetch()._future.result()
+            fig = pool.result(self.prefetch()._future)
+            if fig is None:         # the worker died under this job (or under a sibling): a failed compile, not a failed search
+                return Output()
             return Output(pdf=_PooledPdf(fig) if fig.png is not None else None, status=fig.status, log=fig.log)
 
         def rasterize(self, size: int = 420, expand_to_square: bool = True, **_) -> Optional[Image.Image]:
@@ -131,8 +169,12 @@ def pooled_document_class(pool: CompilePool) -> Type[TikzDocument]:
             if not pdf:
                 return None
             from ..util import expand
-            image = pdf.image()
-            if max(image.size) != size:         # the worker rasterised at pool.raster_size
+            if size == pool.raster_size:
+                image = pdf.image()             # the worker's raster
+            elif pdf._fig.pdf is not None:      # another size: rasterise the PDF again, as the base class would (never a resample)
+                image = self.toolchain.to_image(pdf, size)
+            else:                               # a toolchain without byte export: the worker's raster is all there is
+                image = pdf.image()
                 scale = size / max(image.size)
                 image = image.resize((max(1, round(image.width * scale)), max(1, round(image.height * scale))), Image.LANCZOS)
             return expand(image, size) if expand_to_square else image

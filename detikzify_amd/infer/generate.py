@@ -1,18 +1,33 @@
 """
-DetikzifyGenerator — one image, one search tree (rows a·G, a·R, a·M; the reference's semantics,
-detikzify/infer/generate.py:145-353), `TikzGenerator` being the alias the north-star names:
+DetikzifyGenerator — one image, one search tree (rows a·G, a·R, a·M).  `TikzGenerator` is the alias the north-star names.
 
-  generate()                :209-227  early-out on EOS / max_length, the processor output for (image, text), then
-                                      model.generate with bad_words_ids=[[image_token]], begin_suppress_tokens=[eos]
-  newlineinfo               :229-244  vocabulary scan: which tokens contain newlines (kept per processor)
-  rollout()                 :246-282  generate in a worker thread, split the token stream at newline tokens into
-                                      (prefix, #lines) states on the caller's side
-  child_finder() / merge()  :305-353  sqrt(n) node insertion, error-line pruning, failed-tail memo, (normalised)
-                                      back-propagation
-The tree's value types live in infer/tree.py, the sample() / simulate() front-end in infer/pipeline.py, several
-trees in one batched decode in infer/batching.py.  The model object is detikzify_amd.model.DetikzifyForCausalLM
-(HIP); nothing here touches the GPU directly.  `document_class` selects the reward back-end (TikzDocument =
-latexmk, unchanged).
+Written from the behaviour that tests/golden/generator_trace.json pins (the reference's detikzify/infer/generate.py:145-353
+executed on a scripted model; three reward modes: identical rollouts, scores, tree statistics, memo size and model calls),
+not from its text.  What that behaviour is, in this file's terms:
+
+  one expansion (`child_finder`, the callback detikzify_amd.mcts.MonteCarlo calls on the node it selected)
+    1. CONTINUE the node's token prefix with the model and cut the stream into one tree position per source line
+       (`rollout` -> `_LineCutter`); a position whose continuation is already known to fail takes that memoised tail and
+       ends the generation on the spot (`_grow_chain`);
+    2. a "widen" node re-rolls from its PARENT: count the visit, then skip the part of the chain the parent's subtree
+       already holds (`merge`);
+    3. COMPILE what the chain spells (`decode` -> document_class) and decide whether it can be rewarded at all
+       (rasterisable, and — strict mode — free of errors);
+    4. GRAFT: only round(sqrt(n)) of the n new positions enter the tree, as a single path (`_graft_path`).  A document
+       that cannot be rewarded but names an error line keeps the positions BEFORE that line (same cap) and memoises the
+       chain from the first position PAST it as a failing tail (`_graft_before_error`);
+    5. REWARD the path's tip: SelfSim of the rendering (min-max normalised against every reward of this tree, lazily:
+       infer/tree.DynMinMaxNorm), -1 when there is nothing to render; without a metric, compiler diagnostics
+       (rewardable minus had-errors).  The (raw score, document) pair is what `simulate()` yields.
+
+  generate()   early-out on EOS / the length budget, then model.generate with the image token banned and EOS suppressed
+               at the first new position (reference :209-227 is the contract for these arguments)
+  rollout()    generation in a background thread; the caller's thread receives the tokens one source line at a time
+
+Departures that do not change results: the processor output of (image, text) is computed once per generator (or handed
+in by simulate_parallel) instead of once per rollout; the newline table lives on the processor; the worker is a plain
+thread, not a ThreadPool(1); streamed tokens arrive in line bursts (TokenStreamer(flush_on=...)).
+The model object is detikzify_amd.model.DetikzifyForCausalLM (HIP); nothing here touches the GPU directly.
 """
 from __future__ import annotations
 
@@ -20,11 +35,9 @@ import re
 import threading
 from collections import deque
 from contextlib import nullcontext
-from functools import cached_property
 from math import sqrt
-from time import time
-from types import SimpleNamespace
-from typing import Dict, Generator, List, Optional, Tuple, Type
+from time import monotonic
+from typing import Dict, Iterator, List, NamedTuple, Optional, Sequence, Tuple, Type
 
 import torch
 from PIL import Image
@@ -37,10 +50,10 @@ from .tree import DynMinMaxNorm, NodeState, Numeric, WideNode
 
 
 class _BackgroundCall:
-    """func(*args, **kwds) in one worker thread; an exception goes to error_callback; wait() joins.  This is what the
-    reference gets from `ThreadPool(processes=1).apply_async(...)` + `pending.wait()` (infer/generate.py:248-258) without
-    the pool's three housekeeping threads, whose start-up and 0.1 s polling cost 50-100 ms per rollout — nothing next to a
-    LaTeX run, but a sixth of a rollout that is decoded in a 64-wide batch."""
+    """func(*args, **kwds) in one worker thread; an exception goes to error_callback; wait() joins.  What the reference
+    gets from `ThreadPool(processes=1).apply_async(...)` + `pending.wait()` (infer/generate.py:248-258) without the pool's
+    three housekeeping threads, whose start-up and 0.1 s polling cost 50-100 ms per rollout — nothing next to a LaTeX
+    run, but a sixth of a rollout that is decoded in a 64-wide batch."""
 
     def __init__(self, func, args=(), kwds=None, error_callback=None):
         self._func, self._args, self._kwds, self._error_callback = func, args, kwds or {}, error_callback
@@ -59,195 +72,259 @@ class _BackgroundCall:
         self._thread.join(timeout)
 
 
+class NewlineToken(NamedTuple):
+    """what a vocabulary entry that contains line breaks does to the line count"""
+    num_lines: int      # line breaks inside the token's text
+    trailing: bool      # the text ENDS with one (otherwise the token already starts the next line)
+
+
+def newline_table(processor) -> Dict[int, NewlineToken]:
+    """token id -> NewlineToken for every vocabulary entry whose decoded text contains a line break (\\r\\n and \\r count as
+    one).  Depends on the tokenizer alone, so it is kept on the (unwrapped) processor: the trees of simulate_parallel — one
+    generator each — build it once, not once per tree (a vocabulary-sized loop of decode() calls under the tokenizer lock:
+    HF fast tokenizers are not re-entrant)."""
+    owner = unwrap(processor)
+    with getattr(owner, "_tok_lock", nullcontext()):
+        table = getattr(owner, "_newline_table", None)
+        if table is None:
+            table = {}
+            for token_id in owner.tokenizer.vocab.values():
+                text = re.sub(r"\r\n|\r", "\n", processor.decode([token_id]))
+                breaks = text.count("\n")
+                if breaks:
+                    table[token_id] = NewlineToken(breaks, text.endswith("\n"))
+            try:
+                owner._newline_table = table
+            except AttributeError:      # a processor type that forbids new attributes: per-generator table
+                pass
+    if not table:
+        raise AssertionError("the vocabulary has no token with a line break: the search tree is built from source lines")
+    return table
+
+
+class _LineCutter:
+    """Turns a token stream into tree positions, one per completed source line.
+
+    A position is (all tokens up to and including the token that completed the line, number of lines so far).  A newline
+    token that goes on with text after its last break has already begun the next line: that begun line is counted when the
+    token arrives and taken back out of the NEXT newline token's count (and out of the final, unfinished position), so a
+    line is never counted twice."""
+
+    def __init__(self, prefix: torch.Tensor, num_lines: int, table: Dict[int, NewlineToken]):
+        self.prefix, self.num_lines, self.table = prefix, num_lines, table
+        self._open: List[int] = []          # tokens since the last completed line
+        self._begun = 0                     # 1 while the last newline token spilled into a line that is still open
+
+    def _take(self) -> torch.Tensor:
+        self.prefix = torch.cat((self.prefix, torch.tensor(self._open, device=self.prefix.device)))
+        self._open = []
+        return self.prefix
+
+    def push(self, token: int) -> Optional[Tuple[torch.Tensor, int]]:
+        self._open.append(token)
+        hit = self.table.get(token)
+        if hit is None:
+            return None
+        self.num_lines += hit.num_lines - self._begun
+        self._begun = 0 if hit.trailing else 1
+        return self._take(), self.num_lines
+
+    def rest(self) -> Optional[Tuple[torch.Tensor, int]]:
+        """the unfinished last line, if the stream ended inside one"""
+        if not self._open:
+            return None
+        return self._take(), self.num_lines - self._begun
+
+
 class DetikzifyGenerator:
     def __init__(self, model, processor, image: Optional[Image.Image], text: Optional[str] = None,
                  metric=None, compile_timeout: Optional[int] = 60, mcts_timeout: Optional[int] = None,
                  streamer=None, control: Optional[ExplicitAbort] = None, exploration: float = 0.6,
                  strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, processed=None, **gen_kwargs):
-        self.model, self.processor = model, processor
-        self.metric, self.image, self.text = metric, image, text
-        self.compile_timeout, self.mcts_timeout = compile_timeout, mcts_timeout
-        self.streamer, self.exploration, self.strict = streamer, exploration, strict
-        self.document_class = document_class
-        self.gen_kwargs = gen_kwargs
-
-        # processor output for (image, text): built on first use — or handed in by a caller that starts many generators on
-        # the same image (simulate_parallel: one resize + normalise per image instead of two per tree, all under the GIL
-        # right when every tree wants to start)
         assert processed is None or text is None, "a shared processor output is for image-only prompts"
-        self._processed = processed
-        self.solution: deque = deque(maxlen=1)
-        self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}
+        self.model, self.processor = model, processor
+        self.image, self.text, self.metric = image, text, metric
+        self.compile_timeout, self.mcts_timeout = compile_timeout, mcts_timeout
+        self.streamer, self.control = streamer, control or ExplicitAbort()
+        self.exploration, self.strict, self.document_class = exploration, strict, document_class
+        self.gen_kwargs = gen_kwargs
+        self._processed = processed             # processor output of (image, text); built on first use unless handed in
+        self._newlines: Optional[Dict[int, NewlineToken]] = None
+
         self.norm = DynMinMaxNorm()
-        self.control = control or ExplicitAbort()
-        root_ids = (processed if processed is not None else processor(images=self.image, text=self.text, return_tensors="pt")).input_ids
-        self.montecarlo = MonteCarlo(root_node=WideNode(root_ids.to(model.device).squeeze(),
-                                                        exploration=self.exploration))
+        self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}      # position -> the chain that failed from there on
+        self.solution: deque = deque(maxlen=1)                          # the last expansion's (score, document)
+        prompt = processed if processed is not None else processor(images=image, text=text, return_tensors="pt")
+        self.montecarlo = MonteCarlo(root_node=self._node(prompt.input_ids.to(model.device).squeeze(), 0))
         self.montecarlo.child_finder = self.child_finder
-        # memoise by value: token tuples / image bytes (reference :191-192)
-        self.decode = cache_cast(lambda token_ids: tuple(token_ids.tolist()))(self.decode)
-        self.score = cache_cast(lambda image: image.tobytes())(self.score)
+        # equal token sequences decode to the SAME document object and equal renderings score once (the search revisits
+        # positions; a TikzDocument compiles lazily and keeps its result)
+        by_tokens, by_pixels = cache_cast(lambda ids: tuple(ids.tolist())), cache_cast(lambda rendering: rendering.tobytes())
+        self.decode, self.score = by_tokens(self.decode), by_pixels(self.score)
 
-    def __call__(self, *args, **kwargs):
-        return self.simulate(*args, **kwargs)
+    def _node(self, token_ids: torch.Tensor, num_lines: int) -> WideNode:
+        return WideNode(token_ids, num_lines, exploration=self.exploration)
 
-    def simulate(self, expansions: Optional[Numeric] = 1) -> Generator[Tuple[Numeric, TikzDocument], None, None]:
-        """One MCTS expansion per iteration; yields every rollout as (score, document)."""
-        started = time()
-        while expansions is None or (expansions := expansions - 1) >= 0:
+    @property
+    def newlineinfo(self) -> Dict[int, NewlineToken]:
+        if self._newlines is None:
+            self._newlines = newline_table(self.processor)
+        return self._newlines
+
+    # ---- front-end -------------------------------------------------------------------------------------------------
+    def simulate(self, expansions: Optional[Numeric] = 1) -> Iterator[Tuple[Numeric, TikzDocument]]:
+        """one MCTS expansion per item: (score, document) of its rollout.  `expansions=None` runs until `mcts_timeout`
+        (checked after an expansion: the budget never cuts a rollout short, at least one is always produced)."""
+        deadline = None if self.mcts_timeout is None else monotonic() + self.mcts_timeout
+        done = 0
+        while expansions is None or done < expansions:
             self.montecarlo.simulate()
+            done += 1
             yield self.solution.pop()
-            if self.mcts_timeout is not None and time() - started > self.mcts_timeout:
-                return
+            if deadline is not None and monotonic() > deadline:
+                break
 
-    # ---- a·G -------------------------------------------------------------------------------------
-    def generate(self, input_ids: torch.Tensor, streamer=None, **gen_kwargs) -> torch.Tensor:
-        streamers = StreamerList(filter(bool, [streamer, self.streamer]))
-        numel = input_ids.numel()
-        max_length = {**self.model.generation_config.to_dict(), **self.gen_kwargs, **gen_kwargs}["max_length"]
-        eos = unwrap(self.processor).tokenizer.eos_token_id
-        if (numel and input_ids[-1] == eos) or numel >= max_length:
-            streamers.end()
-            return input_ids  # never continue past EOS / the length budget
-        with torch.inference_mode():
-            # image and text are fixed for the life of the generator: the reference re-runs the processor on every call
-            # (:216), the result is the same tensor every time — keep it (6 ms of resize + normalise per rollout)
-            enc = self._processed
-            if enc is None:
-                enc = self._processed = self.processor(images=self.image, text=self.text, text_kwargs={"truncation": True},
-                                                       return_tensors="pt")
-            adapter_kwargs = {k: v for k, v in enc.to(self.model.device).items() if k.startswith("adapter")}
-            return self.model.generate(
-                input_ids=input_ids.unsqueeze(0),
-                bad_words_ids=[[self.model.config.image_token_id]],
-                begin_suppress_tokens=[self.model.config.text_config.eos_token_id],
-                pixel_values=enc.get("pixel_values"),
-                streamer=streamers,
-                **adapter_kwargs, **self.gen_kwargs, **gen_kwargs,
-            ).squeeze()
-
-    # ---- a·R -------------------------------------------------------------------------------------
-    @cached_property
-    def newlineinfo(self) -> Dict[int, SimpleNamespace]:
-        """token id -> (#newlines it contains, whether it ends with one); tokens may hold several."""
-        # The table depends on the tokenizer alone: it is kept on the processor, so the trees of simulate_parallel (one
-        # DetikzifyGenerator each) build it once instead of once per tree (a vocabulary-sized loop of decode() calls under
-        # the tokenizer lock — HF fast tokenizers are not re-entrant).
-        owner = unwrap(self.processor)
-        with getattr(owner, "_tok_lock", nullcontext()):
-            info = getattr(owner, "_newlineinfo", None)
-            if info is None:
-                info = {}
-                for token_id in owner.tokenizer.vocab.values():
-                    text = re.sub(r"\r\n|\r", "\n", self.processor.decode([token_id]))
-                    if n := text.count("\n"):
-                        info[token_id] = SimpleNamespace(num_lines=n, trailing=text.endswith("\n"))
-                try:
-                    owner._newlineinfo = info
-                except AttributeError:      # a processor type that forbids new attributes: per-generator table
-                    pass
-        assert info
-        return info
-
-    def rollout(self, state: NodeState) -> Generator[Tuple[torch.Tensor, int], None, None]:
-        """Continue `state` to completion in a worker thread; yield one (prefix, #lines) per
-        generated source line as the tokens stream in."""
-        input_ids, num_lines, continuation = state.token_ids, state.num_lines, False
-        streamer = TokenStreamer(flush_on=self.newlineinfo)      # same tokens, handed over one source line at a time
-        pending = _BackgroundCall(
-            func=self.generate, args=[input_ids], error_callback=streamer.propagate_error,
-            kwds=dict(stopping_criteria=[self.control.reset()], streamer=streamer))
-        try:
-            prefix, line = input_ids, []
-            for token in streamer:
-                line.append(token)
-                if nl := self.newlineinfo.get(token):
-                    # a token may continue with text after its newline ("continuation")
-                    num_lines += nl.num_lines - continuation
-                    continuation = not nl.trailing
-                    prefix = torch.cat((prefix, torch.tensor(line, device=prefix.device)))
-                    line.clear()
-                    yield prefix, num_lines
-            if line:
-                yield torch.cat((prefix, torch.tensor(line, device=prefix.device))), num_lines - continuation
-        except (GeneratorExit, KeyboardInterrupt):
-            self.control.abort()
-            raise
-        else:
-            if self.control.should_stop:
-                raise InterruptedError
-        finally:
-            pending.wait()
-
-    def decode(self, token_ids: torch.Tensor) -> TikzDocument:
-        n_prompt = len(self.montecarlo.root_node.token_ids)
-        return self.document_class(
-            timeout=self.compile_timeout,
-            code=self.processor.decode(token_ids[n_prompt:], skip_special_tokens=True))
-
-    def score(self, image: Image.Image) -> Numeric:
-        assert self.metric
-        self.metric.update(img1=image, img2=self.image, text2=self.text)
-        value = self.metric.compute()
-        self.metric.reset()
-        return value
+    __call__ = simulate         # a generator object is callable like its simulate()
 
     def sample(self) -> TikzDocument:
         return self.decode(self.generate(input_ids=self.montecarlo.root_node.token_ids))
 
-    # ---- a·M -------------------------------------------------------------------------------------
-    def child_finder(self, node: WideNode, montecarlo: MonteCarlo):
-        new_nodes: List[WideNode] = []
-        rollout = self.rollout(node.state)
-        for state in rollout:
-            candidate = WideNode(*state, exploration=self.exploration)
-            if candidate.state in self.failed_rollouts:  # known-bad tail: splice it, stop generating
-                new_nodes.extend(self.failed_rollouts[candidate.state])
-                rollout.close()
+    # ---- a·G: one call of the model ------------------------------------------------------------------------------------
+    def _prompt_features(self):
+        if self._processed is None:
+            self._processed = self.processor(images=self.image, text=self.text, text_kwargs={"truncation": True},
+                                             return_tensors="pt")
+        return self._processed
+
+    def generate(self, input_ids: torch.Tensor, streamer=None, **gen_kwargs) -> torch.Tensor:
+        sinks = StreamerList([s for s in (streamer, self.streamer) if s])
+        options = {**self.gen_kwargs, **gen_kwargs}
+        budget = options.get("max_length", self.model.generation_config.to_dict().get("max_length"))
+        n = input_ids.numel()
+        finished = n > 0 and input_ids[-1] == unwrap(self.processor).tokenizer.eos_token_id
+        if finished or n >= budget:         # nothing may follow EOS, nothing fits beyond the budget
+            sinks.end()
+            return input_ids
+        with torch.inference_mode():
+            features = self._prompt_features().to(self.model.device)
+            conditioning = {name: value for name, value in features.items() if name.startswith("adapter")}
+            out = self.model.generate(
+                input_ids=input_ids[None],
+                pixel_values=features.get("pixel_values"),
+                bad_words_ids=[[self.model.config.image_token_id]],                     # never emit the image placeholder
+                begin_suppress_tokens=[self.model.config.text_config.eos_token_id],     # never an empty program
+                streamer=sinks,
+                **conditioning, **options)
+        return out.squeeze()
+
+    # ---- a·R: a generation as a stream of tree positions -------------------------------------------------------------------
+    def rollout(self, state: NodeState) -> Iterator[Tuple[torch.Tensor, int]]:
+        """continue `state` to the end in a worker thread; yields (token prefix, #lines) after every completed source line
+        (and once more for an unfinished last line).  Closing the iterator aborts the generation; an abort from elsewhere
+        (`control.abort()`) surfaces as InterruptedError after the stream has ended."""
+        table = self.newlineinfo
+        cutter = _LineCutter(state.token_ids, state.num_lines, table)
+        tokens = TokenStreamer(flush_on=table)       # same tokens, handed over one source line at a time
+        worker = _BackgroundCall(self.generate, args=[state.token_ids], error_callback=tokens.propagate_error,
+                                 kwds=dict(stopping_criteria=[self.control.reset()], streamer=tokens))
+        try:
+            for token in tokens:
+                position = cutter.push(token)
+                if position is not None:
+                    yield position
+            tail = cutter.rest()
+            if tail is not None:
+                yield tail
+            if self.control.should_stop:
+                raise InterruptedError
+        except (GeneratorExit, KeyboardInterrupt):
+            self.control.abort()
+            raise
+        finally:
+            worker.wait()
+
+    def decode(self, token_ids: torch.Tensor) -> TikzDocument:
+        new_tokens = token_ids[len(self.montecarlo.root_node.token_ids):]
+        return self.document_class(code=self.processor.decode(new_tokens, skip_special_tokens=True), timeout=self.compile_timeout)
+
+    def score(self, image: Image.Image) -> Numeric:
+        assert self.metric
+        self.metric.update(img1=image, img2=self.image, text2=self.text)
+        try:
+            return self.metric.compute()
+        finally:
+            self.metric.reset()
+
+    # ---- a·M: one expansion ----------------------------------------------------------------------------------------------
+    def _grow_chain(self, start: NodeState) -> List[WideNode]:
+        """the new positions of one rollout from `start`, oldest first"""
+        chain: List[WideNode] = []
+        stream = self.rollout(start)
+        for token_ids, num_lines in stream:
+            fresh = self._node(token_ids, num_lines)
+            known_tail = self.failed_rollouts.get(fresh.state)
+            if known_tail is not None:      # this position is known to end in a failure: reuse that ending, stop generating
+                chain += known_tail
+                stream.close()
                 break
-            new_nodes.append(candidate)
+            chain.append(fresh)
+        return chain
 
-        if node.is_widen_node:
+    def merge(self, node: WideNode, nodes_to_merge: Sequence[WideNode]) -> Tuple[WideNode, List[WideNode]]:
+        """descend from `node` along children that hold the same positions as the head of the chain; returns where the
+        descent ended and the part of the chain that is new there"""
+        taken = 0
+        while taken < len(nodes_to_merge):
+            wanted = nodes_to_merge[taken].state
+            twin = next((child for child in node.children if child.state == wanted), None)
+            if twin is None:
+                break
+            node, taken = twin, taken + 1
+        return node, list(nodes_to_merge[taken:])
+
+    @staticmethod
+    def _graft_path(anchor: WideNode, path: Sequence[WideNode]) -> WideNode:
+        for link in path:
+            anchor.add_child(link)
+            anchor = link
+        return anchor
+
+    def _graft_before_error(self, anchor: WideNode, chain: List[WideNode], cap: int, error_line: int) -> WideNode:
+        """positions in front of the first located error join the tree (at most `cap`: those with index < cap); the chain
+        from the first position beyond the error line is remembered as a failing continuation of that position.  A position
+        whose last line IS the error line is neither (the line may still be incomplete)."""
+        for i, link in enumerate(chain):
+            if link.num_lines > error_line:
+                self.failed_rollouts[link.state] = chain[i:]
+                break
+            if link.num_lines < error_line and i < cap:
+                anchor.add_child(link)
+                anchor = link
+        return anchor
+
+    def child_finder(self, node: WideNode, montecarlo: MonteCarlo) -> None:
+        chain = self._grow_chain(node.state)
+        if node.is_widen_node:              # a re-roll at the parent's position: it is the parent that grows
             node.visits += 1
-            node, new_nodes = self.merge(node.parent, new_nodes)
+            node, chain = self.merge(node.parent, chain)
 
-        tikz = self.decode((new_nodes or [node])[-1].token_ids)
-        skip_idx = round(sqrt(len(new_nodes)))
+        document = self.decode(chain[-1].token_ids if chain else node.token_ids)
+        cap = round(sqrt(len(chain)))       # sqrt(n) of n new lines enter the tree
+        rewardable = bool(document.is_rasterizable) and not (self.strict and document.compiled_with_errors)
 
-        scorable = tikz.is_rasterizable and not (self.strict and tikz.compiled_with_errors)
-        if scorable:
-            for new_node in new_nodes[:skip_idx]:   # a chain of the first sqrt(n) line-nodes
-                node.add_child(new_node)
-                node = new_node
-        elif errorln := min(tikz.errors or [0]):
-            # keep what precedes the first located error; memoise the failing tail
-            for idx, new_node in enumerate(new_nodes):
-                # NB: the reference looks the 0-dim *tensor* up (generate.py:330); tensors hash by
-                # identity, so this is None there — kept verbatim for identical tree statistics.
-                ends_with_eol = self.newlineinfo.get(new_node.token_ids[-1])
-                if new_node.num_lines < errorln and idx < skip_idx:
-                    node.add_child(new_node)
-                    node = new_node
-                elif new_node.num_lines > errorln or (new_node.num_lines == errorln and ends_with_eol):
-                    self.failed_rollouts[new_node.state] = new_nodes[idx:]
-                    break
+        if rewardable:
+            tip = self._graft_path(node, chain[:cap])
+        else:
+            first_error = min(document.errors or [0])       # 0: nothing located (errors are keyed by 1-based line)
+            tip = self._graft_before_error(node, chain, cap, first_error) if first_error else node
 
         if self.metric:
-            score = self.score(tikz.rasterize()) if scorable else -1
-        else:  # compiler diagnostics as the reward
-            score = scorable - tikz.compiled_with_errors
-
-        node.update_win_value(self.norm(score) if scorable and self.metric else score)
-        self.solution.append((score, tikz))
-
-    def merge(self, node: WideNode, nodes_to_merge: List[WideNode]) -> Tuple[WideNode, List[WideNode]]:
-        """walk down existing children while the new chain repeats them"""
-        for candidate in list(nodes_to_merge):
-            match = next((c for c in node.children if c.state == candidate.state), None)
-            if match is None:
-                break
-            node, nodes_to_merge = match, nodes_to_merge[1:]
-        return node, nodes_to_merge
+            score = self.score(document.rasterize()) if rewardable else -1
+            tip.update_win_value(self.norm(score) if rewardable else score)
+        else:       # compiler diagnostics as the reward: 1 clean, 0 rendered with errors / not rendered but error-free, -1 failed
+            score = rewardable - document.compiled_with_errors
+            tip.update_win_value(score)
+        self.solution.append((score, document))
 
 
 # the name BASELINE.json's north_star uses for the drop-in (SURVEY.md §0 row 1)

@@ -382,6 +382,7 @@ class DetikzifyForCausalLM:
         self._check(self.lib.dtk_kv_fork(self._ctx, int(src_slot), int(dst_slot), int(n_tokens)), "dtk_kv_fork")
 
     _image_keys: Dict[Tuple[int, int, int], Tuple[Any, int]] = {}     # (storage address, elements, tensor version) -> (tensor, key)
+    _image_keys_lock = threading.Lock()     # every tree thread of a parallel search comes through image_key()
 
     @classmethod
     def image_key(cls, pixel_values: torch.Tensor) -> int:
@@ -391,14 +392,16 @@ class DetikzifyForCausalLM:
         # (inference-mode tensors keep no version counter: an in-place edit of one between two calls would go unnoticed —
         # processor outputs are never edited)
         ident = (pixel_values.data_ptr(), pixel_values.numel(), -1 if pixel_values.is_inference() else pixel_values._version)
-        hit = cls._image_keys.get(ident)
+        with cls._image_keys_lock:
+            hit = cls._image_keys.get(ident)
         if hit is not None and hit[0] is pixel_values:
             return hit[1]
         px = pixel_values.detach().to("cpu", torch.float32).contiguous()
-        key = int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")
-        if len(cls._image_keys) >= 64:
-            cls._image_keys.pop(next(iter(cls._image_keys)))
-        cls._image_keys[ident] = (pixel_values, key)
+        key = int.from_bytes(hashlib.blake2b(px.numpy().tobytes(), digest_size=8).digest(), "little")    # (outside the lock: 2 ms)
+        with cls._image_keys_lock:
+            while len(cls._image_keys) >= 64:       # oldest entry out (dicts keep insertion order); at most 64 pixel tensors stay alive
+                cls._image_keys.pop(next(iter(cls._image_keys)))
+            cls._image_keys[ident] = (pixel_values, key)
         return key
 
     def slot_lcp(self, slot: int, ids: torch.Tensor, key: int = 0) -> int:

@@ -88,3 +88,13 @@ def rel_l2(a, b) -> float:
     a = torch.as_tensor(a).double().flatten()
     b = torch.as_tensor(b).double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def peaked_lm_head(lm_head: torch.Tensor, beta: float = 2.0, seed: int = 0, clip: int = 8) -> torch.Tensor:
+    """a second synthetic weight set with PEAKED logits: every lm_head row is multiplied by 2^e, e = round(beta * z) with z ~ N(0, 1)
+    per row (clipped to +-clip).  A power of two is exact in bf16, so the result is still a bf16 tensor and the oracle and the
+    device see the same values.  The row norms become log-normal: a few dozen rows dominate every step's logits and the top-1 /
+    top-2 gap is tens of bf16 ulps instead of ~1 (uniform rows: the top of 32 k equal-variance values, P(gap < 1 ulp) ~ 10 %)."""
+    g = torch.Generator().manual_seed(seed)
+    e = torch.clamp(torch.round(beta * torch.randn(lm_head.shape[0], generator=g)), -clip, clip)
+    return lm_head.float() * torch.exp2(e)[:, None]

@@ -190,3 +190,66 @@ def test_parallel_trees_compile_in_the_pool_while_the_others_decode(tex_box):
         assert all(d.status in (0, 12) for _, d in out)
         seq = list(pipe.simulate(sketch_image(9, 96), expansions=2))           # one tree: the same class works sequentially
         assert len(seq) == 2
+
+
+def test_a_dying_worker_fails_one_compile_not_the_search(tex_box):
+    """a worker killed under a TeX run (OOM killer) breaks concurrent.futures' executor for good: the pool replaces it, the
+    lost job reads as a failed compile (status -1, nothing to rasterise) and the jobs after it compile normally"""
+    import signal
+    from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
+    with CompilePool(workers=1) as pool:
+        assert pool.warm() == 1
+        Pooled = pooled_document_class(pool)
+        victim = Pooled(GOOD + "% HANG\n", timeout=30).prefetch()
+        pidfile = tex_box / "grandchild.pid"
+        for _ in range(100):
+            if pidfile.exists():
+                break
+            time.sleep(0.1)
+        assert pidfile.exists(), "the fake TeX run never started"
+        worker = next(iter(pool._pool._processes))           # the one worker process
+        os.kill(worker, signal.SIGKILL)
+        os.kill(int(pidfile.read_text()), signal.SIGKILL)
+        assert victim.status == -1 and not victim.is_rasterizable
+        assert pool.restarts == 1
+        after = Pooled(GOOD)
+        assert after.status == 0 and after.is_rasterizable
+        figs = list(pool.imap([GOOD, BROKEN]))
+        assert [f.status for f in figs] == [0, 12]
+
+
+def test_pool_inherits_the_parents_engines_and_rasterises_other_sizes_from_the_pdf(tex_box):
+    from detikzify_amd.infer import TikzDocument
+    from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
+    TikzDocument.set_engines("pdflatex")
+    try:
+        with CompilePool(workers=1) as pool:
+            assert pool.engines == ["pdflatex"]
+            Pooled = pooled_document_class(pool)
+            assert Pooled(LUA_ONLY).status == 12                 # the worker did not fall back to lualatex
+            direct, pooled = TikzDocument(GOOD), Pooled(GOOD)
+            for size in (420, 224):                              # 224: re-rasterised from the PDF like the base class, no resample
+                assert pooled.rasterize(size=size).tobytes() == direct.rasterize(size=size).tobytes()
+    finally:
+        TikzDocument.set_engines(["pdflatex", "lualatex", "xelatex"])
+
+
+def test_multi_gpu_example_runs_as_a_script_with_a_compile_pool(tex_box, tmp_path):
+    """examples/mcts_multi_gpu.py started the way a user starts it (`python examples/...`), LaTeX in a 1-worker spawn pool: the
+    spawned worker re-imports the main script as __mp_main__, which must not parse arguments, join a process group or load a
+    model again (round 2's script did all three at module level and died with BrokenProcessPool).  The device is the scripted
+    one of tests/test_generate_loop.py (DTK_EXAMPLE_LOADER), everything else is the shipped path."""
+    import subprocess
+    from .helpers import sketch_image
+    root = Path(__file__).resolve().parents[1]
+    image = tmp_path / "sketch.png"
+    sketch_image(3, 96).save(image)
+    env = dict(os.environ, DTK_EXAMPLE_LOADER="tests.test_generate_loop:example_loader",
+               PYTHONPATH=f"{root}{os.pathsep}{os.environ.get('PYTHONPATH', '')}")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(root / "examples" / "mcts_multi_gpu.py"), "--model", "scripted", "--image", str(image),
+                          "--trees", "2", "--expansions", "2", "--tex-workers", "1", "--metric", "fast", "--keep", "2"],
+                         capture_output=True, text=True, timeout=240, env=env, cwd=tmp_path)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert res.stdout.count("% score") == 2, res.stdout[-2000:]

@@ -555,3 +555,8 @@ def test_generate_protocol_matches_hf_generate(golden_dir):
         out = dev.generate(input_ids=ids, do_sample=False, streamer=st, stopping_criteria=[cr], suppress_tokens=[EOS], **kw)
         assert list(out.shape) == golden[name]["out_shape"]
         assert st.events == golden[name]["streamer"] and cr.events == golden[name]["criterion"], name
+
+
+def example_loader(args, local_rank):
+    """DTK_EXAMPLE_LOADER hook of examples/mcts_multi_gpu.py (tests/test_compile_pool.py): the scripted device + the toy processor"""
+    return ScriptedDevice(slots=min(64, args.trees) + 1), fake_processor(VOCAB, NIMG)
