@@ -71,7 +71,36 @@ def parse():
     ap.add_argument("--mcts-trees", type=int, default=-1, help="trees per GPU of the parallel MCTS phase (-1 = as many as --batch, 0 = skip)")
     ap.add_argument("--mcts-expansions", type=int, default=2, help="rollouts per tree in the parallel MCTS phase")
     ap.add_argument("--mcts-seq-expansions", type=int, default=3, help="rollouts of the sequential (one tree per GPU) search, 0 = skip")
+    ap.add_argument("--no-config4", action="store_true", help="skip mcts.config4 (BASELINE configs[3]: 16 rollouts of one image over the ranks)")
+    ap.add_argument("--no-config5", action="store_true", help="skip mcts.config5 (BASELINE configs[4]: cl-7b fp8, 8 images x 32 rollouts over the ranks)")
+    ap.add_argument("--config5-model", default="detikzify-cl-7b")
+    ap.add_argument("--config5-images", type=int, default=8)
+    ap.add_argument("--config5-trees", type=int, default=8, help="trees per image (x --config5-expansions = 32 rollouts per image)")
+    ap.add_argument("--config5-expansions", type=int, default=4)
+    ap.add_argument("--reward-latency", type=float, nargs="*", default=[], help="f3 measurement: emulate a LaTeX run of S seconds per reward "
+                    "(S values, e.g. 1 5) with and without the compile pool, 1 tree and --mcts-trees trees")
     return ap.parse_args()
+
+
+def ragged_pipeline_class(base, n_new, lo_frac=0.25):
+    """A pipeline whose rollouts stop after a pseudo-random number of new tokens in [lo_frac * n_new, n_new] (a function of the
+    rollout's sampling seed): real rollouts end at EOS at different lengths, synthetic weights practically never sample EOS,
+    and equal-length rollouts are the easiest schedule a batch engine can get (every tree hits its reward on the same step)."""
+    lo = max(1, int(n_new * lo_frac))
+
+    class RaggedPipeline(base):
+        def _generator(self, *a, **kw):
+            g = super()._generator(*a, **kw)
+            inner, budget = g.generate, {**self.gen_kwargs, **kw}.get("max_length")
+
+            def generate(input_ids, seed=0, **k):
+                h = (int(seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+                h ^= h >> 31
+                length = lo + h % (n_new - lo + 1)
+                return inner(input_ids, seed=seed, max_length=min(budget, int(input_ids.numel()) + length), **k)
+            g.generate = generate
+            return g
+    return RaggedPipeline
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
@@ -226,6 +255,7 @@ def cpu_baseline_config1(budget_s):
     from detikzify_amd.model.config import preset
     cfg = preset("detikzify-ds-1.3b").oracle_dict()
     g = torch.Generator().manual_seed(1234)
+    threads, probe_gbs = _pick_cpu_threads()          # chosen for THIS entry, not inherited from whatever ran before
     t0 = time.perf_counter()
     d, ff, V, L = cfg["hidden"], cfg["ffn"], cfg["vocab"], cfg["layers"]
 
@@ -253,6 +283,7 @@ def cpu_baseline_config1(budget_s):
             kv, logits, n = r.past_key_values, r.logits[0, -1], n + 1
         dt = time.perf_counter() - t1
     return {"value": n / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference", "prefill_s": round(t_prefill, 2),
+            "thread_choice": f"{threads} threads: fastest of 8..all cores on a 256 MB fp32 GEMV probe ({probe_gbs:.0f} GB/s)",
             "sample": f"BASELINE config 1: HuggingFace LlamaForCausalLM at the ds-1.3b shape, fp32, KV cache, seeded synthetic weights "
                       f"(built in {t_build:.0f} s), 243-position prefix (prefill {t_prefill:.1f} s, not timed), {n} greedy tokens"}
 
@@ -268,7 +299,7 @@ def main():
     import detikzify_amd.model as dmodel
     from detikzify_amd import dist as ddist
     from detikzify_amd.util import expand
-    from tests.helpers import sketch_image
+    from detikzify_amd.util.synthetic import sketch_image
 
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} (one rank per GPU)")
@@ -287,7 +318,7 @@ def main():
         gpus = {(p.get("cuda_device"), p.get("pci_bus_id"), p.get("device_uuid")) for p in placement}
         assert len(gpus) == world, f"{world} ranks on {len(gpus)} distinct GPUs: {placement}"
 
-    n_slots = min(65, min(64, args.batch) + max(1, args.batch_images)) if args.batch > 1 else 0   # + a prefix-cache slot per image
+    n_slots = min(64, args.batch) + min(8, max(1, args.batch_images)) if args.batch > 1 else 0   # + a prefix-cache slot per image (<= 8)
     model, proc = dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=n_slots, weight_format=args.weight_format)
     model.reuse_prefix = bool(args.reuse)
     cfg = model.config
@@ -398,7 +429,12 @@ def main():
                           "last_collect_to_end_ms": round(1e3 * (t_end - engine.t_last_collect), 1)}
                 tb = t_end - tb
             tb = max_over_ranks(tb)
-            bytes_step = W + args.batch * Kb * mean_ctx
+            # HBM bytes one step must move: the weights once, every slot's PRIVATE keys (its generated tokens), and the image
+            # prefix once per image — forked slots read the prefix rows from their source slot (share_prefix_reads), so it is
+            # not B copies.  (SURVEY §8d's formula W + sum_b K*t_b counts it B times: kept as frac_of_survey_formula.)
+            bytes_survey = W + args.batch * Kb * mean_ctx
+            shared = T0 if engine.share_prefix else 0
+            bytes_step = W + args.batch * Kb * (mean_ctx - shared) + n_img * Kb * shared
             result["batched_rollouts"] = {
                 "batch_per_gpu": args.batch, "images_in_flight": n_img, "prefix_encodes_both_passes": engine.prefix_encodes,
                 "rollouts_per_sec": world * args.batch / tb,
@@ -409,6 +445,10 @@ def main():
                 "achieved_GBps": bytes_step * n_new / tb / 1e9,
                 "frac_of_hbm_peak": bytes_step * n_new / tb / 1e9 / HBM_PEAK_GBS,
                 "roofline_rollouts_per_sec": world * args.batch * HBM_PEAK_GBS * 1e9 / (bytes_step * n_new),
+                "frac_of_survey_formula": bytes_survey * n_new / tb / 1e9 / HBM_PEAK_GBS,
+                "survey_formula_bytes_per_step": bytes_survey,
+                "bytes_note": "algorithmic_bytes_per_step = W + B*K*(mean context - prefix) + images*K*prefix: the shared image prefix is read once "
+                              "per image, not once per slot; frac_of_survey_formula keeps SURVEY 8d's W + sum_b K*t_b (rounds 1-2 quoted that)",
                 "prefix_sharing": bool(engine.share_prefix),
                 "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3),
                                    "host_bound_steps": engine.host_bound_steps, **phases},
@@ -423,62 +463,148 @@ def main():
 
     # ---- the MCTS metric: the search itself (detikzify_amd.infer: DetikzifyGenerator per tree, reference semantics)
     trees = min(args.batch, 64) if args.mcts_trees < 0 else min(args.mcts_trees, max(args.batch, 0))
-    if args.mcts_seq_expansions > 0 or trees > 1:
+    want_c4 = not args.no_config4 and args.batch >= 2
+    want_c5 = not args.no_config5
+    if args.mcts_seq_expansions > 0 or trees > 1 or want_c4 or want_c5 or args.reward_latency:
+        from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
+        from detikzify_amd.infer.batching import simulate_parallel_images
         mcts = {"reward": "SelfSim (device ViT, reference-image features cached) of SyntheticTikzDocument renderings — LaTeX is absent "
                           "offline: stub-reward numbers, not comparable with real-LaTeX runs",
                 "max_length": T0 + n_new, "sampling": "temperature .8, top-p .95 (DetikzifyPipeline defaults)",
-                "roofline_note": "bytes moved >= decode steps x W + generated tokens x K x prefix (every rollout's context is at least "
-                                 "the image prefix): the fractions are lower bounds of the decode-step HBM roofline share"}
+                "roofline_note": "frac_of_roofline = generated tokens/s over what the decode-step HBM roofline allows a batch of that many "
+                                 "slots: b * 8 TB/s / (W + b*K*n_new/2 + images*K*prefix) — the weights once per step, every slot's own "
+                                 "keys at the mean depth of a from-the-root rollout, the image prefix once per image"}
+
+        def search(the_model, the_proc, images, trees_per_image, expansions, ragged=False, pipe_kw=None, Wk=None):
+            """This rank's share of a root-parallel search: len(images) * trees_per_image trees as ONE batched decode (one tree:
+            the unmodified sequential search), then the path's single exchange — (score, code) records to rank 0 — timed on its
+            own.  Every rank calls this (the gather is a collective) even with no image of its own."""
+            base = ragged_pipeline_class(DetikzifyPipeline, n_new) if ragged else DetikzifyPipeline
+            pipe = base(the_model, the_proc, **{**dict(metric="model", document_class=SyntheticTikzDocument, max_length=T0 + n_new),
+                                                **(pipe_kw or {})})
+            if getattr(pipe, "metric", None) is not None and hasattr(pipe.metric, "cache_reference"):
+                pipe.metric.cache_reference = True           # f1: a reference image's features are computed once
+            n_trees = len(images) * trees_per_image
+            s0 = the_model.stats()
+            fence()
+            t_begin = time.perf_counter()
+            local = [[] for _ in images]
+            if n_trees:
+                for k, score, doc in simulate_parallel_images(pipe, images, trees_per_image, expansions,
+                                                              seeds=[ddist.tree_seed(1000, t) for t in range(n_trees)]):
+                    local[k].append([float(score), doc.code])
+            t_search = time.perf_counter() - t_begin
+            t_g = time.perf_counter()
+            gathered = ddist.gather_objects([len(images), sum(len(x) for x in local), t_search, local])
+            t_gather = time.perf_counter() - t_g
+            fence()
+            total_s = max_over_ranks(time.perf_counter() - t_begin)
+            s1 = the_model.stats()
+            eng = (getattr(the_model, "last_batch_stats", None) or {}) if n_trees > 1 else {}
+            tokens = eng.get("tokens_out") if n_trees > 1 else None
+            out = {"trees_per_gpu": n_trees, "images_per_gpu": len(images), "expansions_per_tree": expansions, "ragged_lengths": bool(ragged),
+                   "seconds": total_s, "search_seconds_this_rank": round(t_search, 3), "gather_seconds": round(max_over_ranks(t_gather), 4),
+                   "decode_steps_per_gpu": (eng.get("steps") if n_trees > 1 else s1["decode_steps"] - s0["decode_steps"]),
+                   "tokens_generated_per_gpu": tokens, "vit_passes_per_gpu": s1["vit_images"] - s0["vit_images"]}
+            if n_trees > 1:
+                out["engine"] = eng
+            if gathered is not None:            # rank 0: the whole job
+                n_roll = sum(g[1] for g in gathered)
+                rates = [g[1] / g[2] for g in gathered if g[2] > 0 and g[1] > 0]
+                out.update(rollouts=n_roll, rollouts_per_sec=n_roll / total_s,
+                           per_rank_rollouts_per_sec_min_max=[round(min(rates), 3), round(max(rates), 3)] if rates else None,
+                           merged_on_rank0=sum(len(ddist.merge_rollouts([img])) for g in gathered for img in g[3]))
+                scores = [r[0] for g in gathered for img in g[3] for r in img]
+                out["scores_min_max"] = [min(scores), max(scores)] if scores else None
+                if Wk is not None and tokens and n_trees > 1:
+                    Wm, Km = Wk
+                    roof = n_trees * HBM_PEAK_GBS * 1e9 / (Wm + n_trees * Km * n_new / 2.0 + len(images) * Km * T0)
+                    out.update(tokens_per_sec_this_gpu=tokens / t_search, roofline_tokens_per_sec_per_gpu=roof,
+                               frac_of_roofline=tokens / t_search / roof)
+            return out
+
+        img0 = sketch_image(0, 224)
         try:
-            from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
-            from detikzify_amd.infer.batching import simulate_parallel
-            pipe = DetikzifyPipeline(model, proc, metric="model", document_class=SyntheticTikzDocument, max_length=T0 + n_new)
-            pipe.metric.cache_reference = True           # f1: the reference image's features are computed once
-            img0 = sketch_image(0, 224)
             if args.mcts_seq_expansions > 0:
                 # ONE tree per GPU: the unmodified sequential search (selection k+1 depends on back-propagation k); over N ranks
-                # this is root parallelisation with seeds 1000 + rank (BASELINE config 4)
-                s0 = model.stats()
-                fence()
-                tm = time.perf_counter()
-                res = list(simulate_parallel(pipe, img0, trees=1, expansions_per_tree=args.mcts_seq_expansions,
-                                             seeds=[ddist.tree_seed(1000, 0)]))
-                records = ddist.gather_objects([[float(s), d.code] for s, d in res])
-                fence()
-                tm = max_over_ranks(time.perf_counter() - tm)
-                s1 = model.stats()
-                steps = s1["decode_steps"] - s0["decode_steps"]
-                moved = steps * (W + Kb * T0)
-                mcts["sequential"] = {
-                    "trees_per_gpu": 1, "expansions": args.mcts_seq_expansions, "rollouts": world * len(res),
-                    "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "decode_steps_per_gpu": steps,
-                    "vit_passes_per_gpu": s1["vit_images"] - s0["vit_images"],
-                    "frac_of_hbm_peak": moved / tm / 1e9 / HBM_PEAK_GBS,
-                    "roofline_rollouts_per_sec_at_512_tokens": world * HBM_PEAK_GBS * 1e9 / (bytes_per_token * n_new),
-                    "merged_on_rank0": len(ddist.merge_rollouts(records)) if records is not None else None}
+                # this is root parallelisation with seeds 1000 + rank (SURVEY §8d/e)
+                r = search(model, proc, [img0], 1, args.mcts_seq_expansions)
+                steps = r["decode_steps_per_gpu"]
+                r["frac_of_hbm_peak"] = steps * (W + Kb * T0) / r["seconds"] / 1e9 / HBM_PEAK_GBS
+                r["roofline_rollouts_per_sec_at_512_tokens"] = world * HBM_PEAK_GBS * 1e9 / (bytes_per_token * n_new)
+                mcts["sequential"] = r
             if trees > 1:
-                fence()
-                v0 = model.stats()["vit_images"]
-                tm = time.perf_counter()
-                res = list(simulate_parallel(pipe, img0, trees=trees, expansions_per_tree=args.mcts_expansions,
-                                             seeds=[ddist.tree_seed(1000, t) for t in range(trees)]))
-                records = ddist.gather_objects([[float(s), d.code] for s, d in res])
-                fence()
-                tm = max_over_ranks(time.perf_counter() - tm)
-                eng = getattr(model, "last_batch_stats", None) or {}
-                moved = eng.get("steps", 0) * W + eng.get("tokens_out", 0) * Kb * T0
-                mcts["parallel"] = {
-                    "trees_per_gpu": trees, "expansions_per_tree": args.mcts_expansions, "rollouts": world * len(res),
-                    "rollouts_per_sec": world * len(res) / tm, "seconds": tm, "engine": eng,
-                    "tokens_generated_per_gpu": eng.get("tokens_out"), "vit_passes_per_gpu": model.stats()["vit_images"] - v0,
-                    "frac_of_hbm_peak": moved / tm / 1e9 / HBM_PEAK_GBS if moved else None,
-                    "scores_min_max": [float(min(s for s, _ in res)), float(max(s for s, _ in res))] if res else None,
-                    "merged_on_rank0": len(ddist.merge_rollouts(records)) if records is not None else None}
+                mcts["parallel"] = search(model, proc, [img0], trees, args.mcts_expansions, Wk=(W, Kb))
+            if want_c4:
+                # BASELINE configs[3]: "ds-7b, MCTS refine (16 rollouts, LaTeX-compile reward) sharded across 8 MI355X" — 16 rollouts of ONE
+                # image in total: rank r grows shard_expansions(16, N)[r] trees of one expansion each as one batch (N=1: 16 trees,
+                # N=8: 2 per rank; reference examples/eval.py:108-137 is the per-image loop this shards)
+                mine = ddist.shard_expansions(16, world)[rank]
+                c4 = {"shape": "16 rollouts of one image over all ranks, root-parallel: 16/N trees x 1 expansion per rank",
+                      "fixed_length": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, Wk=(W, Kb)),
+                      "ragged": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, ragged=True, Wk=(W, Kb))}
+                mcts["config4"] = c4
+            for S in args.reward_latency:
+                # f3: what a reward that costs what LaTeX costs does to rollouts/s.  The renderer sleeps S seconds per document
+                # (DTK_SYNTH_COMPILE_SECONDS) either in the tree's own thread (pool off: what TikzDocument's subprocess call does
+                # to a tree) or in a CompilePool worker process (pool on); ragged rollout lengths so rewards do not all start at
+                # the same step.  Reference: examples/refine.py:151-185 (pool + imap), infer/tikz.py:89-147 (1-60 s per document).
+                from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
+                from detikzify_amd.infer.tikz import SleepingSyntheticTikzDocument
+                os.environ["DTK_SYNTH_COMPILE_SECONDS"] = str(S)
+                entry = {}
+                for n_t in (1, trees) if trees > 1 else (1,):
+                    for pooled in (False, True):
+                        pool = CompilePool(workers=min(64, max(1, n_t)), document_class=SleepingSyntheticTikzDocument) if pooled else None
+                        try:
+                            if pool is not None:
+                                pool.warm()
+                            doc_cls = pooled_document_class(pool) if pooled else SleepingSyntheticTikzDocument
+                            r = search(model, proc, [img0], n_t, 2, ragged=True, pipe_kw=dict(document_class=doc_cls), Wk=(W, Kb))
+                        finally:
+                            if pool is not None:
+                                pool.close()
+                        busy = (r.get("engine") or {}).get("wait_s")
+                        entry[f"{n_t}_trees_pool_{'on' if pooled else 'off'}"] = {
+                            k: r.get(k) for k in ("rollouts", "rollouts_per_sec", "seconds", "decode_steps_per_gpu", "tokens_generated_per_gpu",
+                                                  "frac_of_roofline")} | {"engine_wait_s": busy}
+                mcts.setdefault("reward_latency", {})[f"{S:g}s"] = entry
+                os.environ.pop("DTK_SYNTH_COMPILE_SECONDS", None)
         except Exception as e:  # noqa: BLE001
             mcts["error"] = repr(e)
+        if want_c5:
+            # BASELINE configs[4]: "cl-7b fp8 weights, batch=8 images, MCTS 32 rollouts on 8 MI355X": the images are striped over the
+            # ranks (images[r::N], exact reference sharding, examples/eval.py:80-83), every image gets --config5-trees trees x
+            # --config5-expansions expansions = 32 rollouts, all of a rank's trees decode as ONE batch, one gather to rank 0.
+            # N=1: 8 images x 8 trees = 64 slots + 8 prefix-cache slots on one GPU; N=8: one image, 8 slots per GPU.
+            try:
+                imgs5 = [sketch_image(200 + k, 224) for k in range(args.config5_images)]
+                mine5 = ddist.chunk(list(range(len(imgs5))), world)[rank]
+                slots5 = len(mine5) * args.config5_trees
+                t_load = time.perf_counter()
+                m5, p5 = dmodel.load(args.config5_model, synthetic=1234, device_map=local_rank, weight_format="fp8",
+                                     batch_slots=max(2, min(64, slots5) + min(8, max(1, len(mine5)))))
+                t_load = time.perf_counter() - t_load
+                st5 = m5.stats()
+                Wk5 = (st5["weight_bytes_per_token"], st5["kv_bytes_per_ctx_token"])
+                c5 = {"shape": f"{args.config5_model} fp8 weights, {len(imgs5)} images striped over the ranks, {args.config5_trees} trees x "
+                               f"{args.config5_expansions} expansions = {args.config5_trees * args.config5_expansions} rollouts per image",
+                      "model_load_seconds": round(t_load, 1), "weight_bytes_per_token": Wk5[0]}
+                try:
+                    for key, ragged in (("fixed_length", False), ("ragged", True)):
+                        c5[key] = search(m5, p5, [imgs5[i] for i in mine5], args.config5_trees, args.config5_expansions, ragged=ragged, Wk=Wk5)
+                finally:
+                    del m5
+                    import gc
+                    gc.collect()
+                mcts["config5"] = c5
+            except Exception as e:  # noqa: BLE001
+                mcts["config5"] = {"error": repr(e)}
         result["mcts"] = mcts
         result["mcts_rollouts_per_sec"] = (mcts.get("parallel") or {}).get("rollouts_per_sec")
         result["mcts_rollouts_per_sec_sequential"] = (mcts.get("sequential") or {}).get("rollouts_per_sec")
+        result["mcts_config4_rollouts_per_sec"] = ((mcts.get("config4") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
+        result["mcts_config5_rollouts_per_sec"] = ((mcts.get("config5") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
 
     if rank == 0:
         # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)

@@ -143,8 +143,8 @@ struct dtk_ctx {
   uint8_t* t8_lm_head = nullptr;     // fp8 pair-tiled copy of lm_head (weight_format fp8)
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
-  SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_BATCH + 1]: per-slot set_sampling uploads queued on the stream
-  DecState* st_stage = nullptr;      // pinned [DTK_MAX_BATCH + 1]: dtk_resume_slot's state upload (no stream sync: a slot is resumed again only sequences later)
+  SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_SLOTS]: per-slot set_sampling uploads queued on the stream
+  DecState* st_stage = nullptr;      // pinned [DTK_MAX_SLOTS]: dtk_resume_slot's state upload (no stream sync: a slot is resumed again only sequences later)
   int64_t* tokb_dev = nullptr;       // [DTK_MAX_INFLIGHT][16]
   int64_t* tokb_host = nullptr;      // pinned mirror
   uint64_t blaunched = 0, bwaited = 0;
@@ -160,8 +160,8 @@ struct dtk_ctx {
   SampleMB* smb_b = nullptr;
   bool mb_single = false;            // the captured single-sequence graph uses the multi-block sampler
   bool mb_batch = false;             // ... the batched graph
-  bool slot_topk[DTK_MAX_BATCH + 1] = {};   // slots whose sampling needs top-k (single-block sampler only)
-  bool slot_samples[DTK_MAX_BATCH + 1] = {}; // slots that sample (not greedy)
+  bool slot_topk[DTK_MAX_SLOTS] = {};   // slots whose sampling needs top-k (single-block sampler only)
+  bool slot_samples[DTK_MAX_SLOTS] = {}; // slots that sample (not greedy)
   uint64_t launched = 0, waited = 0;
   hipEvent_t step_done[DTK_MAX_INFLIGHT] = {};
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -431,9 +431,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->pfx_o = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4 * 128);
     c->kpart = P.take<float>((size_t)8 * ((size_t)(d + 15) / 16) * 4 * 256);   // k_gemv_bk: 8 K-slice partials of every row tile x 64 slots
     c->kctr = P.take<unsigned>((size_t)(d + 15) / 16);                              // arrival counters (the arena is zeroed once; the last arrival resets)
-    c->st_b = P.take<DecState>(DTK_MAX_BATCH + 1);
-    c->sp_b = P.take<SamplingDev>(DTK_MAX_BATCH + 1);
-    c->smb_b = P.take<SampleMB>(DTK_MAX_BATCH + 1);
+    c->st_b = P.take<DecState>(DTK_MAX_SLOTS);
+    c->sp_b = P.take<SamplingDev>(DTK_MAX_SLOTS);
+    c->smb_b = P.take<SampleMB>(DTK_MAX_SLOTS);
     c->bs_dev = P.take<BatchState>(1);
     if (c->wfmt == 1) {             // fp8: pair-tiled fp8 copies (+6.6 GB for cl-7b), no bf16 tiles
       for (int i = 0; i < L; ++i) {
@@ -799,8 +799,9 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->Sb = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
   if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = c->Sb = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
-  // up to 64 decoding slots (one, two or four 16-column MFMA tiles) + 1 slot that is only ever prefilled / forked (prefix cache)
-  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_BATCH + 1 ? DTK_MAX_BATCH + 1 : cfg->reserved[0]);
+  // up to 64 decoding slots (one, two or four 16-column MFMA tiles) + up to 8 slots that are only ever prefilled / forked from
+  // (prefix cache: one per image in flight, BASELINE config 5 = 8 images)
+  c->nb = cfg->reserved[0] < 0 ? 0 : (cfg->reserved[0] > DTK_MAX_SLOTS ? DTK_MAX_SLOTS : cfg->reserved[0]);
   c->nt = c->nb > 33 ? 4 : (c->nb > 17 ? 2 : 1);   // 17 / 33 / 65 = 16 / 32 / 64 decoding slots + the prefix slot
   c->bseq.resize((size_t)c->nb);
   c->vD = cfg->vit_dim; c->vDepth = cfg->vit_depth; c->vH = cfg->vit_heads; c->vHd = vhd;
@@ -855,9 +856,9 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   if (c->nb > 0) {
     CCHK(hipHostMalloc((void**)&c->bs_host, sizeof(BatchState) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
     CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipHostMallocDefault));
-    CCHK(hipHostMalloc((void**)&c->st_stage, sizeof(DecState) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
-    CCHK(hipHostMalloc((void**)&c->sp_stage, sizeof(SamplingDev) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
-    CCHK(hipHostMalloc((void**)&c->draw_stage, sizeof(uint32_t) * (DTK_MAX_BATCH + 1), hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->st_stage, sizeof(DecState) * (DTK_MAX_SLOTS), hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->sp_stage, sizeof(SamplingDev) * (DTK_MAX_SLOTS), hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->draw_stage, sizeof(uint32_t) * (DTK_MAX_SLOTS), hipHostMallocDefault));
     for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->bstep_done[i], hipEventDisableTiming));
   }
   CCHK(hipEventCreate(&c->ev_a)); CCHK(hipEventCreate(&c->ev_b)); CCHK(hipEventCreate(&c->ev_c));
@@ -1274,13 +1275,13 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   // k_attn_prefix_b; its length is the shortest share among those slots (what lies beyond is per-slot work)
   hb->pfx_src = -1; hb->pfx_len = 0;
   if (c->prefix_mfma && c->attn_b_impl == 1) {
-    int count[DTK_MAX_BATCH + 1] = {0};
+    int count[DTK_MAX_SLOTS] = {0};
     for (int j = 0; j < DTK_MAX_BATCH; ++j) {
       if (!active[j]) continue;
-      if (hb->share_src[j] >= 0 && hb->share_src[j] <= DTK_MAX_BATCH) count[hb->share_src[j]]++;
+      if (hb->share_src[j] >= 0 && hb->share_src[j] < DTK_MAX_SLOTS) count[hb->share_src[j]]++;
     }
     int best = -1;
-    for (int sidx = 0; sidx <= DTK_MAX_BATCH; ++sidx) if (count[sidx] > (best < 0 ? 0 : count[best])) best = sidx;
+    for (int sidx = 0; sidx < DTK_MAX_SLOTS; ++sidx) if (count[sidx] > (best < 0 ? 0 : count[best])) best = sidx;
     if (best >= 0 && count[best] + (best < DTK_MAX_BATCH && active[best] ? 1 : 0) >= 2) {
       int len = 1 << 30;
       for (int j = 0; j < DTK_MAX_BATCH; ++j)
@@ -1565,7 +1566,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   if (role == 5 || role == 6) {  // batched gate/up kernel, experiment modes (variant = mode; role 6: k_gemm_b, variant = shape * 16 + mode)
     if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
     ensure_tiled_weights(c);
-    BatchState hb{}; for (int j = 0; j < c->nb; ++j) hb.active[j] = 1;
+    BatchState hb{}; for (int j = 0; j < c->nb && j < DTK_MAX_BATCH; ++j) hb.active[j] = 1;
     for (int j = 0; j < DTK_MAX_BATCH; ++j) hb.share_src[j] = -1;
     HIPCHK(c, hipMemcpy(c->bs_dev, &hb, sizeof hb, hipMemcpyHostToDevice));
     auto pass = [&]() {

@@ -42,11 +42,12 @@ class CompiledFigure(NamedTuple):
     pdf: Optional[bytes]
 
 
-def _compile_job(code: str, timeout: Optional[int], raster_size: int, engines: Optional[List[str]]) -> CompiledFigure:
+def _compile_job(code: str, timeout: Optional[int], raster_size: int, engines: Optional[List[str]],
+                 document_class: Type[TikzDocument] = TikzDocument) -> CompiledFigure:
     """runs in a worker process: the unchanged TikzDocument compile + rasterise"""
     if engines is not None:
         TikzDocument.set_engines(engines)
-    doc = TikzDocument(code, timeout=timeout)
+    doc = document_class(code, timeout=timeout)
     out = doc.compile()
     png = pdf = None
     if out.pdf:
@@ -84,7 +85,11 @@ class _PooledPdf:
 
 
 class CompilePool:
-    def __init__(self, workers: Optional[int] = None, raster_size: int = 420, engines: Optional[List[str]] = None):
+    def __init__(self, workers: Optional[int] = None, raster_size: int = 420, engines: Optional[List[str]] = None,
+                 document_class: Type[TikzDocument] = TikzDocument):
+        """`document_class`: what a worker compiles with — TikzDocument (latexmk), or a module-level stand-in such as
+        SleepingSyntheticTikzDocument (it is pickled by reference: the workers import it)"""
+        self.document_class = document_class
         self.workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
         # the workers start from a fresh interpreter: an engine list set on the parent's TikzDocument (set_engines) travels
         # with every job unless the caller names another one
@@ -114,7 +119,7 @@ class CompilePool:
         for _ in range(3):
             pool = self._pool
             try:
-                f = pool.submit(_compile_job, code, timeout, self.raster_size, self.engines)
+                f = pool.submit(_compile_job, code, timeout, self.raster_size, self.engines, self.document_class)
                 f._dtk_executor = pool       # so that whoever sees BrokenProcessPool on this future restarts the right executor
                 return f
             except BrokenProcessPool:

@@ -240,3 +240,16 @@ class SyntheticTikzDocument(TikzDocument):
             x1, y1 = (v * 29 + 40) % size, (v * 31 + 90) % size
             d.line([x0, y0, x1, y1], fill="black", width=3)
         return img
+
+
+class SleepingSyntheticTikzDocument(SyntheticTikzDocument):
+    """SyntheticTikzDocument whose compile takes DTK_SYNTH_COMPILE_SECONDS of wall time (a sleep: like the wait for a latexmk
+    child process it holds neither the GIL nor a core) — bench.py --reward-latency measures what a reward that costs what
+    LaTeX costs (1-60 s, reference infer/tikz.py:89-147) does to rollouts/s.  Module level and configured through the
+    environment so that spawned compile-pool workers build the same class."""
+
+    def _compile(self) -> Output:
+        import os
+        import time
+        time.sleep(float(os.environ.get("DTK_SYNTH_COMPILE_SECONDS", "0") or 0))
+        return super()._compile()

@@ -182,14 +182,15 @@ int  dtk_synchronize(dtk_ctx* ctx);
 int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
 
 /* Batched decode for independent rollouts of one GPU: dtk_config.reserved[0] = number
- * of slots (<= DTK_MAX_BATCH + 1), each with its own KV cache, sampling state and logits.  One
+ * of slots (<= DTK_MAX_SLOTS), each with its own KV cache, sampling state and logits.  One
  * dtk_decode_batch_* step = one _sample iteration for every active slot with ONE pass over the weights
  * (bytes/step = W + sum_b K*t_b).  Up to 17 slots: slots 0..15 decode (one 16-column MFMA tile); 18..33 slots:
- * slots 0..31 decode (two tiles); 34..65 slots: slots 0..63 decode (four tiles); a further slot can only be
- * prefilled / forked from (prefix cache).
+ * slots 0..31 decode (two tiles); 34..72 slots: slots 0..63 decode (four tiles); slots beyond the decoding ones can only be
+ * prefilled / forked from (prefix cache: one per image in flight — BASELINE config 5 runs 8 images on one GPU).
  * The `active` / `tokens_out` arrays always have DTK_MAX_BATCH entries.
  * The image embeddings cache is shared (DTK_PREFILL_REUSE_IMAGE). */
 #define DTK_MAX_BATCH 64
+#define DTK_MAX_SLOTS (DTK_MAX_BATCH + 8)
 int  dtk_num_slots(const dtk_ctx* ctx);
 int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const float* pixels,
                       uint64_t image_key, int flags, float* logits_last_out);

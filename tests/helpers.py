@@ -12,22 +12,12 @@ from PIL import Image, ImageDraw
 from detikzify_amd.model.config import preset
 from detikzify_amd.model.processing import DetikzifyImageProcessor, DetikzifyProcessor
 from detikzify_amd.model.tokenizer import SyntheticTokenizer
+from detikzify_amd.util.synthetic import sketch_image  # noqa: F401  (the tests' seeded sketch: same input as bench.py / smoke())
 
 TINY = preset("detikzify-tiny")
 TINY_CFG = TINY.kernel_dict()
 TINY_V2 = preset("detikzify-tiny-v2")          # GQA 4/2, rope "llama3", bias-free connector, tanh GELU, dedicated image token
 TINY_V2_CFG = TINY_V2.oracle_dict()
-
-
-def sketch_image(seed: int = 0, size: int = 224) -> Image.Image:
-    """white canvas with 12 random black poly-lines, 2 px wide (SURVEY.md §8d synthetic input)"""
-    rng = np.random.default_rng(seed)
-    img = Image.new("RGB", (size, size), "white")
-    d = ImageDraw.Draw(img)
-    for _ in range(12):
-        pts = [tuple(int(v) for v in rng.integers(8, size - 8, 2)) for _ in range(int(rng.integers(2, 5)))]
-        d.line(pts, fill="black", width=2)
-    return img
 
 
 def fake_processor(vocab: int = 512, image_seq_len: int = 12, image_size: int = 84) -> DetikzifyProcessor:

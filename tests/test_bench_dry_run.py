@@ -50,7 +50,8 @@ def _run_bench(monkeypatch, capsys, argv):
 def test_bench_json_contract_and_phases(monkeypatch, capsys):
     d = _run_bench(monkeypatch, capsys, ["--steps", "2", "--warmup", "1", "--new-tokens", "24", "--no-cpu-baseline",
                                          "--batch", "8", "--batch-images", "3", "--mcts-trees", "4", "--mcts-expansions", "2",
-                                         "--probe-tokens", "2"])
+                                         "--probe-tokens", "2", "--config5-images", "3", "--config5-trees", "2", "--config5-expansions", "2",
+                                         "--reward-latency", "0.05"])
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict)):
@@ -64,6 +65,10 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert "error" not in b, b
     assert b["batch_per_gpu"] == 8 and b["images_in_flight"] == 3 and b["rollouts_per_sec"] > 0
     assert b["frac_of_hbm_peak"] == pytest.approx(b["achieved_GBps"] / 8000.0)
+    # the shared image prefix is counted once per image, not once per slot: fewer bytes than SURVEY 8d's formula
+    assert b["algorithmic_bytes_per_step"] < b["survey_formula_bytes_per_step"] and b["frac_of_hbm_peak"] < b["frac_of_survey_formula"]
+    prefix, kv = d["config"]["prefix_tokens"], 1.0e5
+    assert b["survey_formula_bytes_per_step"] - b["algorithmic_bytes_per_step"] == pytest.approx((8 - 3) * kv * prefix)
     assert b["roofline_rollouts_per_sec"] == pytest.approx(b["rollouts_per_sec"] / b["frac_of_hbm_peak"], rel=1e-6)
     m = d["mcts"]
     assert "error" not in m, m
@@ -72,6 +77,21 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert d["mcts_rollouts_per_sec"] == m["parallel"]["rollouts_per_sec"] > 0
     assert d["mcts_rollouts_per_sec_sequential"] == m["sequential"]["rollouts_per_sec"] > 0
     assert d["ranks"] == [d["ranks"][0]] and d["ranks"][0]["world"] == 1
+    # BASELINE configs[3] and [4] as stated: 16 rollouts of one image; N images x (trees x expansions) rollouts
+    c4, c5 = m["config4"], m["config5"]
+    for variant in ("fixed_length", "ragged"):
+        assert c4[variant]["rollouts"] == 8 and c4[variant]["trees_per_gpu"] == 8, c4      # 16 trees capped by --batch 8 here
+        assert c5[variant]["rollouts"] == 3 * 2 * 2 and c5[variant]["images_per_gpu"] == 3 and c5[variant]["trees_per_gpu"] == 6, c5
+        for c in (c4, c5):
+            assert c[variant]["gather_seconds"] >= 0 and c[variant]["rollouts_per_sec"] > 0 and c[variant]["ragged_lengths"] == (variant == "ragged")
+            lo, hi = c[variant]["per_rank_rollouts_per_sec_min_max"]
+            assert 0 < lo <= hi
+    assert c4["ragged"]["tokens_generated_per_gpu"] < c4["fixed_length"]["tokens_generated_per_gpu"]     # rollouts of different lengths
+    assert d["mcts_config4_rollouts_per_sec"] == c4["fixed_length"]["rollouts_per_sec"]
+    assert d["mcts_config5_rollouts_per_sec"] == c5["fixed_length"]["rollouts_per_sec"]
+    rl = m["reward_latency"]["0.05s"]                                                      # f3: reward latency x pool on / off x 1 / N trees
+    assert set(rl) == {"1_trees_pool_off", "1_trees_pool_on", "4_trees_pool_off", "4_trees_pool_on"}
+    assert all(v["rollouts"] == (2 if k.startswith("1_") else 8) and v["rollouts_per_sec"] > 0 for k, v in rl.items())
 
 
 def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):
@@ -81,7 +101,10 @@ def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):
     assert "batched_rollouts" not in d and d["mcts"]["parallel"]["rollouts"] == 2 and d["mcts"]["sequential"]["rollouts"] == 3
     d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
                                          "--batch", "0", "--probe-tokens", "2", "--sample", "--mcts-seq-expansions", "0"])
-    assert "batched_rollouts" not in d and "mcts" not in d and d["value"] > 0
+    assert "batched_rollouts" not in d and d["value"] > 0 and set(d["mcts"]) >= {"config5"} and "sequential" not in d["mcts"]
+    d = _run_bench(monkeypatch, capsys, ["--steps", "1", "--warmup", "0", "--new-tokens", "16", "--no-cpu-baseline",
+                                         "--batch", "0", "--probe-tokens", "2", "--mcts-seq-expansions", "0", "--no-config5"])
+    assert "mcts" not in d
 
 
 def _rank_main(rank, world, port, outdir):
@@ -102,7 +125,7 @@ def _rank_main(rank, world, port, outdir):
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.set_device = lambda *a, **k: None
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--new-tokens", "16", "--no-cpu-baseline",
-                "--batch", "4", "--probe-tokens", "2"]
+                "--batch", "4", "--probe-tokens", "2", "--config5-images", "4", "--config5-trees", "2", "--config5-expansions", "1"]
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.main()
@@ -128,3 +151,7 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["backend"] == "gloo" for r in d["ranks"])
     assert d["mcts"]["sequential"]["rollouts"] == 2 * 3 and d["mcts"]["sequential"]["merged_on_rank0"] >= 1   # root-parallel over the ranks
     assert d["mcts"]["parallel"]["rollouts"] == 2 * 4 * 2
+    # config 4: 16 rollouts of one image over 2 ranks = 8 trees each, capped by --batch 4; config 5: 8 images striped over the ranks
+    c4, c5 = d["mcts"]["config4"]["fixed_length"], d["mcts"]["config5"]["fixed_length"]
+    assert c4["rollouts"] == 2 * 4 and c4["trees_per_gpu"] == 4 and c4["gather_seconds"] >= 0
+    assert c5["rollouts"] == 4 * 2 * 1 and c5["images_per_gpu"] == 2 and len(c5["per_rank_rollouts_per_sec_min_max"]) == 2

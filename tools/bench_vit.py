@@ -6,7 +6,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from detikzify_amd.model import load
-from tests.helpers import sketch_image
+from detikzify_amd.util.synthetic import sketch_image
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")

@@ -15,7 +15,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch  # noqa: E402
 
 from detikzify_amd.model import load  # noqa: E402
-from tests.helpers import sketch_image  # noqa: E402
+from detikzify_amd.util.synthetic import sketch_image  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")

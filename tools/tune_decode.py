@@ -19,7 +19,7 @@ import torch  # noqa: E402
 
 from detikzify_amd.model import load  # noqa: E402
 from detikzify_amd.util import expand  # noqa: E402
-from tests.helpers import sketch_image  # noqa: E402
+from detikzify_amd.util.synthetic import sketch_image  # noqa: E402
 
 EPI_RESID, EPI_QKV, EPI_SWIGLU, EPI_LOGITS, O_PROJ, O_PROJ_ATTN = 1, 2, 3, 4, 5, 6
 

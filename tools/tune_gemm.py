@@ -7,7 +7,7 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from detikzify_amd.model import load  # noqa: E402
-from tests.helpers import sketch_image  # noqa: E402
+from detikzify_amd.util.synthetic import sketch_image  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")
