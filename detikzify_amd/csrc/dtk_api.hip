@@ -129,7 +129,8 @@ struct dtk_ctx {
   size_t kv_slot_stride = 0;
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
   float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
-  float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk partial sums + arrival counters
+  float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk / k_gemv_bkp partial sums + arrival counters
+  bool resid_kparts = false;   // batched N = d roles as two launches (k_gemv_bkp + k_resid_norm_b): dtk_set_option("resid_kparts")
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
@@ -607,6 +608,14 @@ void batch_step_launches(dtk_ctx* c) {
   if (c->mb_batch) launch_sample_mb(sa, s); else launch_sample_b(sa, s);
   const float scale = 1.0f / sqrtf(128.f);
   const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
+  bool kparts = false;
+  if (c->resid_kparts) {      // both N = d roles must be covered: the norm placement follows from it for the whole step
+    GemvBArgs t{};
+    t.nt = c->nt_step; t.kpart = c->kpart; t.W8 = c->layers[0].t8_wo; t.N = d; t.K = d;
+    kparts = resid_kparts_covers(t);
+    t.K = ff;
+    kparts = kparts && resid_kparts_covers(t);
+  }
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
     bf16_t* kc = c->kvb + (size_t)l * kv_layer;
@@ -614,7 +623,10 @@ void batch_step_launches(dtk_ctx* c) {
     GemvBArgs g{};
     g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt_step;
     g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride; g.kpart = c->kpart; g.kctr = c->kctr;
-    launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+    // resid_kparts (64 slots): an N = d role is k_gemv_bkp (K split over CUs, fp32 partials stored) and the RMSNorm that follows it
+    // is k_resid_norm_b, which first adds the partials + the residual — so the norm of layer l > 0 has already been produced by
+    // layer l - 1's down projection, and the final norm by the last layer's
+    if (l == 0 || !kparts) launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
     g.W = w.t_wqkv; g.W8 = w.t8_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xnb; g.ldx = d; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
@@ -625,14 +637,24 @@ void batch_step_launches(dtk_ctx* c) {
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
-    launch_gemv_b(EPI_RESID, g, s);
-    launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+    if (kparts) {
+      launch_gemv_bkp(g, s);
+      launch_resid_norm_b(c->kpart, c->xb, d, w.ln2, c->xnb, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+    } else {
+      launch_gemv_b(EPI_RESID, g, s);
+      launch_rmsnorm_b(c->xb, d, w.ln2, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+    }
     g.W = w.t_wgu; g.W8 = w.t8_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X = c->xnb; g.ldx = d; g.Y = c->actb; g.ldy = ff;
     launch_gemv_b(EPI_SWIGLU, g, s);
     g.W = w.t_wdown; g.W8 = w.t8_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X = c->actb; g.ldx = ff; g.Y = c->xb; g.ldy = d;
-    launch_gemv_b(EPI_RESID, g, s);
+    if (kparts) {
+      launch_gemv_bkp(g, s);
+      launch_resid_norm_b(c->kpart, c->xb, d, l + 1 < c->L ? c->layers[l + 1].ln1 : c->final_norm, c->xnb, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+    } else {
+      launch_gemv_b(EPI_RESID, g, s);
+    }
   }
-  launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
+  if (!kparts) launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
   GemvBArgs g{};
   g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.W8 = c->t8_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
   g.d = d; g.ff = ff; g.nt = c->nt_step;
@@ -1662,6 +1684,10 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   }
   else if (!strcmp(name, "resid_split")) {
     set_resid_split(value != 0);
+    drop_batch_graphs(c);
+  }
+  else if (!strcmp(name, "resid_kparts")) {     // batched N = d roles as k_gemv_bkp + k_resid_norm_b (64 slots, bf16 weights)
+    c->resid_kparts = value != 0;
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bk")) {

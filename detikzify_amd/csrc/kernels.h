@@ -114,6 +114,12 @@ void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
 bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: N = d roles at 64 slots, K split over 8 CUs per row group; false = not covered
 void set_gemv_bk(int v);       // 0: off, 1: on
+// N = d roles at 33..64 slots as two launches (kernels_batch_gemm.hip): k_gemv_bkp = K split over the CUs of a row group, plain stores
+// of the fp32 partials; k_resid_norm_b = reduce + residual + the RMSNorm that follows the role anyway (replaces k_rmsnorm_b there)
+bool resid_kparts_covers(const GemvBArgs& a);
+void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s);
+void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps, const BatchState* bs,
+                         int nslots, hipStream_t s);
 void set_resid_split(int v);   // batched N = d roles at 64 slots: 0 = one row tile x 64 slots per block, 1 = two row tiles x 32 slots
 void set_gemv_bx(int v);       // 0: off, 1: on (units per block from the CU count), 2..4: on with that many units per block
 void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)

@@ -375,10 +375,10 @@ __global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, con
   for (int c = tid; c < D8; c += 256) {
     const u32x4 v = x4[c];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e) {     // explicit fma: k_resid_norm_b (kernels_batch_gemm.hip) folds the squares in this exact order
       const float lo = pk_lo(v[e]), hi = pk_hi(v[e]);
-      ss += lo * lo;
-      ss += hi * hi;
+      ss = __builtin_fmaf(lo, lo, ss);
+      ss = __builtin_fmaf(hi, hi, ss);
     }
   }
   ss = wave_sum(ss);

@@ -616,6 +616,198 @@ bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemv_bkp + k_resid_norm_b — the N = d roles at 33..64 slots as TWO launches: K split over the CUs of a row group, the
+// partials met by the NEXT kernel of the step instead of inside this one.
+//
+// k_gemv_bk (above) has the right traffic shape — x / 8 — and lost to its in-kernel exchange: publish -> drain -> ticket ->
+// read-back -> residual read-modify-write is ~8 us of dependent memory round trips at the tail of every row tile
+// (profiles/r02_batch64_bk_kernel_stats.csv).  The step already HAS a kernel right behind each N = d role: the RMSNorm of the
+// residual stream it has just updated (post_attention_layernorm after o_proj, the next layer's input_layernorm — or the final
+// norm — after down), a 64-block launch that reads every x element anyway.  So:
+//   * k_gemv_bkp = k_gemv_bk's compute, bit for bit (same K slices, same MFMA chains), whose waves simply STORE their
+//     16 x 64 fp32 partial, slot-major ([slice][slot][row]: a lane's 4 rows are one 16-byte store, kernel B reads rows
+//     contiguously) — no atomics, no tickets, no fences: the kernel boundary is the hand-off;
+//   * k_resid_norm_b (one block per slot) adds the 8 partials of every row in slice order (k_gemv_b's LDS reduction order),
+//     applies the residual epilogue (x += bf16(sum), HF rounding), and normalises the updated row in the same pass — sum of
+//     squares in k_rmsnorm_b's exact order (chunk c by "virtual thread" c mod 256, chained through LDS across the block's
+//     256-thread rounds), so x, the scale and the fragment-major xn are BIT-IDENTICAL to k_gemv_b<RESID> + k_rmsnorm_b.
+// Launch count per layer is unchanged (7); the N = d kernels stop reading all of x in every block (down: 360 -> 45 MB through
+// L2) and lose their reduction + read-modify-write tail; the norm kernel reads 8 MB of partials (L2 / MALL resident) more.
+template <int TPG>
+__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkp(GemvBArgs a) {
+  constexpr int NT = 4, PH = 8, FR = PH * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x FR KiB
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = (a.K + 31) >> 5;
+  const int per = (nsteps + 7) >> 3;
+  const int b = blockIdx.x, idx = b >> 3;
+  const int rgs_per_xcd = (int)(gridDim.x >> 6);                // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
+  const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
+  const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
+  const int Lc = s1 - s0;                                       // >= 1 (launcher)
+  const int nph = (Lc + PH - 1) / PH;
+
+  if (wave == TPG) {   // ---- loader wave: the slice's x fragments, one phase (8 k-steps x 4 column tiles = 32 KiB) at a time
+    const bf16_t* xlane = a.X + lane * 8;
+    auto src = [&](int q, int f) { return xlane + ((size_t)(f / PH) * nsteps + min(s0 + q * PH + (f % PH), s1 - 1)) * 512; };
+    u32x4 xr[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(0, f));
+#pragma unroll
+    for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(smem + (size_t)f * 1024 + lane * 16) = xr[f];
+    if (nph > 1) {
+#pragma unroll
+      for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(1, f));
+    }
+    __syncthreads();
+    for (int q = 0; q < nph; ++q) {
+      if (q + 1 < nph) {
+        unsigned char* xn = smem + (size_t)((q + 1) & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(xn + (size_t)f * 1024) = xr[f];
+      }
+      if (q + 2 < nph) {
+#pragma unroll
+        for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(q + 2, f));
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
+  const int tn = rg * TPG + wave;
+  const unsigned char* wrow = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16 + (size_t)s0 * 1024;
+  u32x4 wr[PH];
+#pragma unroll
+  for (int i = 0; i < PH; ++i) wr[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(i, Lc - 1) * 1024));
+  f32x4 c[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int p = 0; p + 1 < nph; ++p) {                            // steady phases: all 8 k-steps inside the chain
+    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[j]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
+      wr[j] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min((p + 1) * PH + j, Lc - 1) * 1024));
+    }
+    __syncthreads();
+  }
+  {                                                              // last phase: k-steps past the end contribute nothing
+    const int p = nph - 1;
+    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+      u32x4 w = wr[j];
+      if (p * PH + j >= Lc) w = (u32x4){0u, 0u, 0u, 0u};
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
+    }
+  }
+  // ---- the partial of (slice ks, tile tn): lane holds rows tn*16 + (lane>>4)*4 + 0..3 of slot nt*16 + (lane&15)
+  float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
+}
+
+// false = not covered (fp8 weights, fewer than 33 slots, a tile count that is not 32 row groups of 4 or 8 tiles, a K that
+// leaves one of the 8 slices empty, a width k_resid_norm_b does not handle): the caller uses k_gemv_b<RESID> + k_rmsnorm_b
+bool resid_kparts_covers(const GemvBArgs& a) {
+  if (a.W8 || a.nt < 3 || !a.kpart) return false;
+  const int ntiles = (a.N + 15) >> 4, nsteps = (a.K + 31) >> 5, per = (nsteps + 7) >> 3;
+  if ((a.N & 15) || (a.K & 31) || 7 * per >= nsteps) return false;
+  if (ntiles != 256 && ntiles != 128) return false;
+  const int D8 = a.N >> 3;
+  return D8 == 256 || D8 == 512 || D8 == 1024;
+}
+void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * 8 * 4 * 1024;
+  if (((a.N + 15) >> 4) == 256) {
+    static bool attr8 = false;
+    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    hipLaunchKernelGGL((k_gemv_bkp<8>), dim3(256), dim3(9 * 64), lds, s, a);
+  } else {
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    hipLaunchKernelGGL((k_gemv_bkp<4>), dim3(256), dim3(5 * 64), lds, s, a);
+  }
+}
+
+// One block per slot, D / 8 threads (thread c owns rows 8c .. 8c+7).  part: [8 slices][64 slots][D] fp32 (k_gemv_bkp);
+// X: the residual streams [slot][ldx] (updated in place); Y: the normalised rows, fragment-major (the next GEMV's B operand).
+template <int ROUNDS>
+__global__ __launch_bounds__(ROUNDS * 256) void k_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps,
+                                                               const BatchState* bs) {
+  const int slot = blockIdx.x;
+  if (!bs->active[slot]) return;
+  __shared__ float chain[256];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, c = tid, round = tid >> 8;
+  // every load of the thread goes out before the first use: 16 partial pieces + x + the norm weight = one memory round trip
+  f32x4 p0[8], p1[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(part + ((size_t)ks * 64 + slot) * D + c * 8);
+    p0[ks] = src[0]; p1[ks] = src[1];
+  }
+  u32x4* xrow = reinterpret_cast<u32x4*>(X + (size_t)slot * ldx) + c;
+  const u32x4 xv = *xrow;
+  const u32x4 g = reinterpret_cast<const u32x4*>(w)[c];
+  float y[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float sum = 0.f;                                    // slice order 0..7 from zero: k_gemv_b's cross-wave reduction
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) sum += (e < 4 ? p0[ks][e] : p1[ks][e - 4]);
+    const float res = (e & 1) ? pk_hi(xv[e >> 1]) : pk_lo(xv[e >> 1]);
+    y[e] = rbf(res + rbf(sum));                         // HF: hidden = residual + proj(x), the projection a bf16 tensor
+  }
+  u32x4 yo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) yo[e] = pack2(y[2 * e], y[2 * e + 1]);
+  *xrow = yo;
+  // sum of squares in k_rmsnorm_b's order: its thread t folds chunk t, then chunk t + 256, ... into ONE accumulator
+  float ss = 0.f;
+  for (int r = 0; r < ROUNDS; ++r) {
+    if (round == r) {
+      if (r > 0) ss = chain[tid & 255];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ss = __builtin_fmaf(y[2 * e], y[2 * e], ss); ss = __builtin_fmaf(y[2 * e + 1], y[2 * e + 1], ss); }
+      if (r + 1 < ROUNDS) chain[tid & 255] = ss;
+    }
+    if (r + 1 < ROUNDS) __syncthreads();
+  }
+  if (round == ROUNDS - 1) {
+    ss = wave_sum(ss);
+    if (lane == 0) red[(tid >> 6) & 3] = ss;
+  }
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = pack2(pk_lo(g[e]) * rbf(y[2 * e] * inv), pk_hi(g[e]) * rbf(y[2 * e + 1] * inv));
+  *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, (D + 31) >> 5)) = o;
+}
+void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps, const BatchState* bs,
+                         int nslots, hipStream_t s) {
+  const int rounds = (D >> 3) >> 8;
+  if (rounds == 1) hipLaunchKernelGGL((k_resid_norm_b<1>), dim3(nslots), dim3(256), 0, s, part, X, ldx, w, Y, D, eps, bs);
+  else if (rounds == 2) hipLaunchKernelGGL((k_resid_norm_b<2>), dim3(nslots), dim3(512), 0, s, part, X, ldx, w, Y, D, eps, bs);
+  else hipLaunchKernelGGL((k_resid_norm_b<4>), dim3(nslots), dim3(1024), 0, s, part, X, ldx, w, Y, D, eps, bs);
+}
+
 template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
 static void launch_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);

@@ -1,7 +1,7 @@
 """Pick the lm_head row-scale seed of the PEAKED synthetic weight set (tests/helpers.py::peaked_lm_head) on the CPU oracle:
 for each candidate seed run ViT + prefill + 16 greedy steps of ds-7b (bf16 policy) and print the top-2 gaps in bf16 ulps.
 The GPU test (tests/test_gpu_parity_batched.py::test_peaked_logits_weight_set_is_token_identical) re-checks the gaps itself.
-Usage: python tools/peaked_seed_search.py [model] [n_steps] [seed ...]   (~27 GB of RAM for ds-7b)"""
+Usage: python tools/peaked_seed_search.py [model] [n_steps] [beta] [seed ...]   (~27 GB of RAM for ds-7b)"""
 import sys
 import time
 from pathlib import Path
@@ -18,7 +18,8 @@ from tests.helpers import peaked_lm_head, sketch_image  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "detikzify-ds-7b"
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-seeds = [int(s) for s in sys.argv[3:]] or [0, 1, 2, 3]
+beta = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+seeds = [int(s) for s in sys.argv[4:]] or [0, 1, 2, 3]
 c = preset(name)
 c.max_positions = 512
 cfg = c.oracle_dict()
@@ -39,7 +40,7 @@ h = o.llm.forward(o.input_embeds(ids, px[0]))
 snap = (list(o.llm.k), list(o.llm.v), o.llm.pos)
 print(f"prefill {time.perf_counter() - t0:.0f} s", flush=True)
 for seed in seeds:
-    w["lm_head.weight"] = peaked_lm_head(base_head, 2.0, seed)
+    w["lm_head.weight"] = peaked_lm_head(base_head, beta, seed)
     o.llm.k, o.llm.v, o.llm.pos = list(snap[0]), list(snap[1]), snap[2]
     logits = o.llm.logits(h[-1])
     gaps, toks = [], []
@@ -50,4 +51,4 @@ for seed in seeds:
         t = int(torch.argmax(m))
         toks.append(t)
         logits = o.step(t)
-    print(f"seed {seed}: min gap {min(gaps):.1f} ulps; gaps {' '.join(f'{g:.0f}' for g in gaps)}; tokens {toks}; {time.perf_counter() - t0:.0f} s", flush=True)
+    print(f"beta {beta} seed {seed}: distinct tokens {len(set(toks))}; min gap {min(gaps):.1f} ulps; gaps {' '.join(f'{g:.0f}' for g in gaps)}; tokens {toks}; {time.perf_counter() - t0:.0f} s", flush=True)
