@@ -313,6 +313,8 @@ def main():
         ddist.init_process_group(backend, timeout_s=1800)
         assert dist.get_backend() == backend and dist.get_world_size() == world
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    if world > 1 and backend == "nccl":
+        ddist.pin_to_gpu_numa_node(local_rank)      # each rank's tree / reward threads stay on its GPU's NUMA node (DTK_NO_PIN=1: off)
     placement = ddist.gather_objects(ddist.placement())         # rank 0: who drives which GPU
     if rank == 0 and world > 1 and backend == "nccl":
         gpus = {(p.get("cuda_device"), p.get("pci_bus_id"), p.get("device_uuid")) for p in placement}

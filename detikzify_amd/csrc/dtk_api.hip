@@ -1674,8 +1674,12 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemm_impl")) {
-    if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 or 1");
+    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma) or 2 (k_gemm_glds where the shape has the tiles)");
     set_gemm_impl(value);
+  }
+  else if (!strcmp(name, "gemm_glds_min_tiles")) {
+    if (value < 1) return fail(c, DTK_ERR_ARG, "gemm_glds_min_tiles must be >= 1");
+    set_gemm_glds_min_tiles(value);
   }
   else if (!strcmp(name, "gqa_fused")) {
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gqa_fused must be 0 (a block per query head), 1 (per K/V head) or 2 (per pair of query heads)");

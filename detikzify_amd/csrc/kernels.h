@@ -170,6 +170,7 @@ void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4
 void set_gemm_tile(int v);   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32
 void set_gemm_impl(int v);   // 0 = k_gemm_mfma (operands staged through registers), 1 = k_gemm_dma (LDS-DMA ring, fragment-major LDS)
 void set_gemm_ring(int v);   // LDS stages of k_gemm_dma: 2..4
+void set_gemm_glds_min_tiles(int v);   // gemm_impl 2: 128 x 128 tiles a shape needs to take k_gemm_glds
 void launch_gemm_naive(const GemmArgs& a, hipStream_t s);
 
 void launch_layernorm_rows(const bf16_t* X, int ldx, const bf16_t* w, const bf16_t* b,

@@ -269,7 +269,146 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs a) {
       }
 }
 
-static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
+// ------------------------------------------------------------------------------------------
+// k_gemm_glds: the GEMM for shapes with enough tiles to fill the chip at 128 x 128 (batched ViT M = images x 729, long prompts, the
+// prefill's N >> d GEMMs).  Round 2 showed that k_gemm_mfma saturates at ~246 TFLOP/s whatever its tile shape (4 waves, one LDS
+// k-tile in use, two barriers per k-tile, operands staged through registers in 16 rows x 64 B pieces) and that k_gemm_dma
+// (fragment-shaped LDS-DMA fills of the same structure) is no better.  This is the structure guides/cdna_hip_programming.md §5
+// measures at 874-912 TFLOP/s on 4096^3 ("step 3" + the glds table's first row):
+//   * 128 x 128 block tile, BK = 64, 4 waves in a 2 x 2 grid, each wave 64 x 64 = 4 x 4 MFMA tiles: per 32-wide k-step 8 fragment
+//     reads feed 16 MFMAs (k_gemm_mfma's 64 x 64 tile: 4 reads per 4 MFMAs);
+//   * BOTH operands go global -> LDS by `global_load_lds_dwordx4` in FULL 128-byte lines: one instruction = 8 tile rows x 128 B
+//     (lane l: row l >> 3, 16-byte chunk l & 7), no VGPR, no ds_write;
+//   * the LDS image is the plain [row][8 chunks] tile; bank conflicts of the fragment reads (rows 128 B apart: 4-way) are removed
+//     by XOR-swizzling the chunk index with (row >> 1) & 7 — applied on the SOURCE address of the fill (LDS-DMA writes are
+//     lane-linear) and on the read address (conflict-free for all four ds_read_b128 lane groups, brute-forced);
+//   * two LDS stages (2 x 32 KiB, 2 blocks per CU): the fill of k-tile t + 1 is in flight under the MFMAs of k-tile t, ONE barrier
+//     per k-tile (vmcnt(0) for the wave's own 8 fills, barrier, issue the next fill, compute).
+// A K that is not a multiple of 64 ends with one register-staged, zero-filled tile.  The k order per output element is
+// k_gemm_mfma's (32-wide k-steps in order, MFMA accumulation from zero): results are bit-identical to every other GEMM variant.
+__device__ __forceinline__ void glds16_row(const void* gsrc, unsigned lds_byte) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmArgs a) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  constexpr unsigned OPB = BM * BK * 2;            // bytes of one operand tile (16 KiB)
+  constexpr unsigned STB = 2 * OPB;                // one stage: A tile, then W tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];   // the kernel's only LDS object: LDS address 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int MB = (a.M + BM - 1) / BM, NB = (a.N + BN - 1) / BN;
+  const int b = blockIdx.x;
+  const int nt = (b & 7) + 8 * ((b >> 3) / MB), mb = (b >> 3) % MB;   // XCD-aware map (see k_gemm_mfma)
+  if (nt >= NB) return;
+  const int m0 = mb * BM, n0 = nt * BN;
+  const int K = a.K;
+
+  // fill map: a stage is 32 pieces of 1 KiB (16 of A, 16 of W); wave w issues pieces 8w .. 8w+7.  Piece p covers tile rows
+  // 8 (p & 15) .. +7 of operand p >> 4; lane l fills LDS chunk (row l >> 3, position l & 7) FROM source chunk (l & 7) ^ swz(row)
+  const bf16_t* src[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = wave * 8 + i, op = p >> 4, row = (p & 15) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (op == 0) { int am = m0 + row; if (am >= a.M) am = a.M - 1; src[i] = a.A + (size_t)am * a.lda + chunk * 8; }
+    else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; src[i] = a.W + (size_t)wn * a.ldw + chunk * 8; }
+  }
+  auto fill = [&](int t) {
+    const unsigned base = (unsigned)(t & 1) * STB + (unsigned)wave * 8u * 1024u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16_row(src[i] + (size_t)t * BK, base + (unsigned)i * 1024u);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fragment read addresses inside a stage: row r of the operand tile, k-chunk q = 4 ks + (lane >> 4)
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ra = (unsigned)(wr * 64 + i * 16 + (lane & 15)), rb = (unsigned)(wc * 64 + i * 16 + (lane & 15));
+    aoff[i] = ra * 128u; boff[i] = OPB + rb * 128u;
+  }
+  const unsigned swz = (unsigned)(((lane & 15) >> 1) & 7);          // (row >> 1) & 7: the tile rows of a fragment start at a multiple of 16
+  const unsigned q0 = (unsigned)(lane >> 4);
+  auto compute = [&](int stage) {
+    const unsigned char* st = gsm + (unsigned)stage * STB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned coff = (((unsigned)ks * 4u + q0) ^ swz) * 16u;
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i] + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + boff[j] + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = K / BK;                           // full k-tiles (LDS-DMA); K % 64 (a multiple of 8) goes through registers below
+  if (nk > 0) fill(0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tile t have landed
+    __syncthreads();                                        // ... and everybody's; all waves are done reading stage (t + 1) & 1
+    if (t + 1 < nk) fill(t + 1);
+    compute(t & 1);
+  }
+  if (K % BK) {                                    // ragged tail: register-staged, zero-filled, same image (swizzle included)
+    const int stage = nk & 1, k0 = nk * BK;
+    __syncthreads();                               // stage `stage` was last read by compute(nk - 2): everybody is past it
+    unsigned char* st = gsm + (unsigned)stage * STB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                  // 2 x 1024 chunks over 256 threads
+      const int c = tid + 256 * i, op = c >> 10, row = (c >> 3) & 127, pos = c & 7;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      const int k = k0 + chunk * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k < K) {
+        if (op == 0) { int am = m0 + row; if (am >= a.M) am = a.M - 1; v = *reinterpret_cast<const u32x4*>(a.A + (size_t)am * a.lda + k); }
+        else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; v = *reinterpret_cast<const u32x4*>(a.W + (size_t)wn * a.ldw + k); }
+      }
+      *reinterpret_cast<u32x4*>(st + (unsigned)op * OPB + (unsigned)row * 128u + (unsigned)pos * 16u) = v;
+    }
+    __syncthreads();
+    compute(stage);
+  }
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+        if (m < a.M && n < a.N)
+          a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
+      }
+}
+static int g_glds_min_tiles = 160;   // 128 x 128 tiles a shape must have for k_gemm_glds (gemm_impl 2 / 3); below that the small-tile kernel fills the chip better
+void set_gemm_glds_min_tiles(int v) { g_glds_min_tiles = v; }
+static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
+  if ((a.lda % 8) || (a.ldw % 8) || a.K < 64 || (a.K % 8)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
+  const long mbs = (a.M + 127) / 128, nbs = (a.N + 127) / 128;
+  if (mbs * nbs < g_glds_min_tiles) return false;
+  constexpr int lds = 2 * 2 * 128 * 64 * 2;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k_gemm_glds, dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(256), lds, s, a);
+  return true;
+}
+
+static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring), 2 = k_gemm_glds for shapes with >= g_glds_min_tiles 128 x 128 tiles (else k_gemm_mfma); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
 void set_gemm_ring(int v) { g_gemm_ring = v; }
@@ -309,6 +448,7 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   }
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
   if (g_gemm_impl < 0) { const char* e = getenv("DTK_GEMM_IMPL"); g_gemm_impl = e ? atoi(e) : 0; }
+  if (g_gemm_impl == 2 && !gemm_tile_override() && launch_gemm_glds(a, s)) return;     // 128 x 128 LDS-DMA kernel where the shape has the tiles for it
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
     const int ring = g_gemm_ring;
 #define DMA_LAUNCH(BM_, BN_) do { if (ring == 2) launch_gemm_dma_t<BM_, BN_, 2>(a, s, grid(BM_, BN_)); else if (ring == 4) launch_gemm_dma_t<BM_, BN_, 4>(a, s, grid(BM_, BN_)); \

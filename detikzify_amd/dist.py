@@ -115,7 +115,54 @@ def placement() -> Dict[str, Any]:
         props = torch.cuda.get_device_properties(i)
         info.update(cuda_device=i, device_name=props.name, device_uuid=str(getattr(props, "uuid", "")),
                     pci_bus_id=getattr(props, "pci_bus_id", None))
+    info["cpus_allowed"] = len(os.sched_getaffinity(0))        # after pin_to_gpu_numa_node(): the GPU's NUMA node
     return info
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/nodeN/cpulist)"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_cpus(pci_bdf: str, sysfs: str = "/sys") -> Optional[List[int]]:
+    """CPUs of the NUMA node the GPU at PCI address `pci_bdf` ("0000:c1:00.0") hangs off, None when the platform does not say
+    (no such device, numa_node -1 on single-node machines)"""
+    try:
+        node = int(open(f"{sysfs}/bus/pci/devices/{pci_bdf}/numa_node").read())
+        if node < 0:
+            return None
+        return parse_cpulist(open(f"{sysfs}/devices/system/node/node{node}/cpulist").read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys") -> Optional[List[int]]:
+    """One rank per GPU means 8 processes x (64 tree threads + reward work) on one host: keep each rank's threads on the NUMA
+    node of ITS GPU (PCIe root + memory local to the pinned staging buffers) instead of letting 8 x 64 threads roam over both
+    sockets.  Restricts this process (and every thread it starts later) to that node's CPUs, intersected with what the process
+    is allowed to use; returns the CPU list, or None when nothing was changed (unknown topology, DTK_NO_PIN=1)."""
+    if os.environ.get("DTK_NO_PIN") or not torch.cuda.is_available():
+        return None
+    i = torch.cuda.current_device() if device_index is None else device_index
+    props = torch.cuda.get_device_properties(i)
+    try:
+        bdf = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}.0"
+    except (AttributeError, TypeError, ValueError):
+        return None
+    cpus = gpu_numa_cpus(bdf, sysfs)
+    if not cpus:
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return allowed
 
 
 def merge_rollouts(per_rank: Sequence[Sequence[Sequence[Any]]]) -> List[List[Any]]:

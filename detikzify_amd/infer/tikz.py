@@ -17,7 +17,6 @@ from __future__ import annotations
 import hashlib
 import logging
 from collections import namedtuple
-from functools import cached_property
 from io import BytesIO
 from os import environ
 from os.path import isfile, join
@@ -123,14 +122,22 @@ class TikzDocument:
     def errors(self) -> Dict[int, str]:
         return located_errors(self.log) if self.compiled_with_errors else {}
 
-    @cached_property
+    # Memoised per document WITHOUT functools.cached_property: until Python 3.12 that descriptor computes under ONE lock shared by
+    # every instance of the class, and the first read of `is_rasterizable` is what runs latexmk (1-60 s) — the LaTeX runs of all
+    # the trees of a parallel search were serialised behind it (bench.py --reward-latency: 16 trees, 1 s per compile -> 1.0
+    # rollouts/s, pool or no pool).  The reference declares both as cached_property (infer/tikz.py); same values, no lock.
+    @property
     def is_rasterizable(self) -> bool:
-        return self.rasterize() is not None
+        if "is_rasterizable" not in self.__dict__:
+            self.__dict__["is_rasterizable"] = self.rasterize() is not None
+        return self.__dict__["is_rasterizable"]
 
-    @cached_property
+    @property
     def has_content(self) -> bool:
-        img = self.rasterize()
-        return img is not None and img.getcolors(1) is None
+        if "has_content" not in self.__dict__:
+            img = self.rasterize()
+            self.__dict__["has_content"] = img is not None and img.getcolors(1) is None
+        return self.__dict__["has_content"]
 
     @classmethod
     def set_engines(cls, engines: Union[str, list]):

@@ -65,6 +65,7 @@ def main(argv=None) -> int:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             torch.cuda.set_device(local_rank)
             ddist.init_process_group(os.environ.get("DTK_DIST_BACKEND"))      # default nccl (= RCCL); "gloo" for a control-flow test
+            ddist.pin_to_gpu_numa_node(local_rank)       # the rank's 64 tree threads + reward work stay on its GPU's NUMA node
         model, processor = load_model(args, local_rank)
         pipe = DetikzifyPipeline(model, processor, metric=args.metric, **kw)
         best = ddist.root_parallel_search(pipe, args.image, trees=args.trees, expansions_per_tree=args.expansions)

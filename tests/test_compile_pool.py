@@ -253,3 +253,26 @@ def test_multi_gpu_example_runs_as_a_script_with_a_compile_pool(tex_box, tmp_pat
                          capture_output=True, text=True, timeout=240, env=env, cwd=tmp_path)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert res.stdout.count("% score") == 2, res.stdout[-2000:]
+
+
+def test_documents_of_parallel_trees_compile_concurrently(monkeypatch):
+    """the first read of `is_rasterizable` is what runs the compile; as a functools.cached_property (Python < 3.12: one lock per
+    descriptor, shared by ALL instances) it serialised the LaTeX runs of every tree of a parallel search.  Eight documents whose
+    compile takes 0.4 s each, read from eight threads, must take about one compile, not eight."""
+    import threading
+    from detikzify_amd.infer.tikz import SleepingSyntheticTikzDocument
+    monkeypatch.setenv("DTK_SYNTH_COMPILE_SECONDS", "0.4")
+    docs = [SleepingSyntheticTikzDocument(f"\\draw (0,0) -- ({i},1);\nline {i}\n") for i in range(8)]
+    seen = [None] * 8
+
+    def read(i):
+        seen[i] = (docs[i].is_rasterizable, docs[i].has_content)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=read, args=(i,)) for i in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    assert dt < 1.6, f"8 concurrent 0.4 s compiles took {dt:.2f} s: serialised"
+    t0 = time.perf_counter()
+    assert [(d.is_rasterizable, d.has_content) for d in docs] == seen       # memoised: no second compile
+    assert time.perf_counter() - t0 < 0.2

@@ -108,3 +108,20 @@ def test_sharding_matches_the_reference_script():
         assert chunks == want["chunks"], key
         assert ddist.interleave(chunks) == want["interleaved"] == items, key
         assert ddist.interleave_all(chunks, n) == items, key
+
+
+def test_numa_pinning_helpers(tmp_path):
+    """dist.parse_cpulist / gpu_numa_cpus on a fake sysfs tree (the rank-to-NUMA-node pinning of N > 1 runs)"""
+    from detikzify_amd import dist as dd
+    assert dd.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and dd.parse_cpulist("") == []
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127\n")
+    assert dd.gpu_numa_cpus("0000:c1:00.0", str(tmp_path)) == list(range(64, 128))
+    (dev / "numa_node").write_text("-1\n")
+    assert dd.gpu_numa_cpus("0000:c1:00.0", str(tmp_path)) is None          # single-node machine: nothing to pin to
+    assert dd.gpu_numa_cpus("0000:00:00.0", str(tmp_path)) is None          # unknown device
+    assert dd.pin_to_gpu_numa_node() is None                                # no GPU here: a no-op

@@ -20,9 +20,11 @@ ap.add_argument("--weight-format", default="bf16")
 ap.add_argument("--slots", type=int, default=0, help="KV slots to allocate (default: --batch): partial-occupancy timing")
 ap.add_argument("--ctx", type=int, default=0, help="text-only prompt of this many tokens instead of the image prompt (attention cost vs context)")
 ap.add_argument("--private", action="store_true", help="with --ctx: every slot prefills its own prompt (no shared prefix)")
+ap.add_argument("--max-positions", type=int, default=0, help="KV rows allocated per slot and head (default: the preset's): locality experiment")
 ap.add_argument("--fork", action="store_true", help="prefill slot 0 only and fork its KV into the other slots (fewer dispatches: profiling runs)")
 args = ap.parse_args()
-model, proc = load(args.model, synthetic=1234, batch_slots=max(args.batch, args.slots), weight_format=args.weight_format)
+model, proc = load(args.model, synthetic=1234, batch_slots=max(args.batch, args.slots), weight_format=args.weight_format,
+                   max_positions=args.max_positions or None)
 model.set_graph_mode(args.graph)
 enc = proc(images=sketch_image(0, 224), return_tensors="pt")
 ids, px = enc.input_ids[0], enc.pixel_values

@@ -16,8 +16,9 @@ px = torch.cat([proc(images=sketch_image(i, 224), return_tensors="pt").pixel_val
 alone = [model.vit_encode(px[i:i + 1], want_pooled=True) for i in range(3)]
 f8, p8 = model.vit_encode(px[:8], want_pooled=True)
 print("batched == alone (features, pooled):", all(torch.equal(f8[i], alone[i][0][0]) for i in range(3)), all(torch.equal(p8[i], alone[i][1][0]) for i in range(3)))
-for tile, name in ((0, "auto"), (1, "64x64"), (2, "128x64"), (3, "128x128")):
-    model.set_option("gemm_tile", tile)
+ap_variants = ((0, "auto", 0), (1, "64x64", 0), (2, "128x64", 0), (3, "128x128", 0), (0, "glds128", 2))   # (gemm_tile, name, gemm_impl)
+for tile, name, impl in ap_variants:
+    model.set_option("gemm_tile", tile); model.set_option("gemm_impl", impl)
     for B in (1, 2, 4, 8, 16):
         model.vit_encode(px[:B], want_pooled=True, want_feats=False)
         t0 = time.perf_counter(); n = 4
@@ -25,4 +26,4 @@ for tile, name in ((0, "auto"), (1, "64x64"), (2, "128x64"), (3, "128x128")):
             model.vit_encode(px[:B], want_pooled=True, want_feats=False)
         dt = (time.perf_counter() - t0) / n
         print(f"tile {name:8s} {B:2d} images per call: {1e3 * dt / B:6.2f} ms per image ({666.5e-3 * B / dt:6.0f} TFLOP/s)", flush=True)
-model.set_option("gemm_tile", 0)
+model.set_option("gemm_tile", 0); model.set_option("gemm_impl", 0)

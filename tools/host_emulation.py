@@ -6,6 +6,11 @@ time; everything above the emulated time is host overhead (GIL hand-offs, reward
 
     python tools/host_emulation.py --trees 32 --step-ms 4.1
     python tools/host_emulation.py --trees 64 --step-ms 5.8
+    python tools/host_emulation.py --trees 64 --step-ms 6.2 --procs 8      # 8 ranks on one host (the N = 8 shape of bench.py)
+
+--procs N runs N such processes side by side (one per emulated GPU) and reports every process's rollouts/s and its HOST CPU
+seconds per rollout (user + system time of the whole stack): ranks x rollouts/s x CPU-seconds per rollout = the cores an
+8-GPU node must spare for the Python side.
 """
 import argparse
 import sys
@@ -26,7 +31,27 @@ ap.add_argument("--trees", type=int, default=32)
 ap.add_argument("--expansions", type=int, default=3)
 ap.add_argument("--step-ms", type=float, default=4.1, help="emulated duration of one batched decode step")
 ap.add_argument("--new-tokens", type=int, default=256)
+ap.add_argument("--procs", type=int, default=1, help="processes side by side, one per emulated GPU")
+ap.add_argument("--json", action="store_true", help="one JSON line (used by --procs)")
 args = ap.parse_args()
+
+if args.procs > 1:
+    import json
+    import os
+    import subprocess
+    cmd = [sys.executable, __file__, "--trees", str(args.trees), "--expansions", str(args.expansions), "--step-ms", str(args.step_ms),
+           "--new-tokens", str(args.new_tokens), "--json"]
+    t0 = time.perf_counter()
+    kids = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(args.procs)]
+    outs = [json.loads([ln for ln in k.communicate()[0].splitlines() if ln.startswith("{")][-1]) for k in kids]
+    wall = time.perf_counter() - t0
+    rates = [o["rollouts_per_sec"] for o in outs]
+    cpu = [o["cpu_seconds_per_rollout"] for o in outs]
+    ideal = outs[0]["emulated_gpu_rollouts_per_sec"]
+    print(f"{args.procs} processes x {args.trees} trees on {len(os.sched_getaffinity(0))} CPUs: per-process rollouts/s min {min(rates):.1f} / max {max(rates):.1f} "
+          f"(the emulated GPU alone allows {ideal:.1f}); whole host {sum(rates):.1f} rollouts/s; host CPU per rollout "
+          f"{1e3 * sum(cpu) / len(cpu):.1f} ms (user + sys) -> {sum(rates) * sum(cpu) / len(cpu):.1f} cores busy; {wall:.0f} s incl. start-up")
+    sys.exit(0)
 
 
 def pooled_only(self, pixel_values):
@@ -64,11 +89,21 @@ dev = T.ScriptedDevice(slots=args.trees + 1, max_positions=T.NIMG + args.new_tok
 pipe = DetikzifyPipeline(dev, proc, metric="model", document_class=SyntheticTikzDocument, max_length=T.NIMG + args.new_tokens,
                          compile_timeout=None)
 img = sketch_image(3, 224)
+import resource  # noqa: E402
 for rep in range(2):        # the first pass warms caches (newline table, reference features)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res = list(simulate_parallel(pipe, img, trees=args.trees, expansions_per_tree=args.expansions))
     dt = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
 st = dev.last_batch_stats
+cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+if args.json:
+    import json
+    print(json.dumps({"rollouts": len(res), "seconds": dt, "rollouts_per_sec": len(res) / dt, "cpu_seconds_per_rollout": cpu_s / max(1, len(res)),
+                      "steps": st["steps"], "wall_ms_per_step": 1e3 * dt / st["steps"],
+                      "emulated_gpu_rollouts_per_sec": len(res) / (st["steps"] * args.step_ms / 1e3)}))
+    sys.exit(0)
 print(f"{args.trees} trees x {args.expansions}: {len(res)} rollouts in {dt:.2f} s = {len(res) / dt:.1f} rollouts/s; {st['steps']} steps, "
       f"{1e3 * dt / st['steps']:.2f} ms wall per step for an emulated {args.step_ms} ms step ({st['steps'] * args.step_ms / 1e3:.2f} s of "
       f"'GPU' time); steps that found the 'GPU' idle: {st['host_bound_steps']}; tokens {st['tokens_out']}")
