@@ -130,7 +130,7 @@ struct dtk_ctx {
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
   float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
   float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk / k_gemv_bkp partial sums + arrival counters
-  bool resid_kparts = false;   // batched N = d roles as two launches (k_gemv_bkp + k_resid_norm_b): dtk_set_option("resid_kparts")
+  bool resid_kparts = true;    // batched N = d roles at 64 slots as two launches (k_gemv_bkp + k_resid_norm_b; measured 20.2 -> 21.2 rollouts/s): dtk_set_option("resid_kparts")
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)

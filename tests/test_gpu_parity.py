@@ -1406,6 +1406,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_bx", 1)      # process-wide switches: back to the defaults
         model.set_option("gemv_bk", 0)
         model.set_option("resid_split", 1)
+        model.set_option("resid_kparts", 1)
         del model
         gc.collect()
 
