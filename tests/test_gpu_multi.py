@@ -96,3 +96,27 @@ def test_single_gpu_world_one_needs_no_process_group():
     assert dd.sharded_sample(pipe, images, do_sample=False) == [pipe.sample(image=im, do_sample=False).code for im in images]
     best = dd.root_parallel_search(pipe, images[0], trees=2, expansions_per_tree=1)
     assert 1 <= len(best) <= 2 and dd.tree_seed(1000, 0) == 1000 and dd.placement()["world"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node (RCCL over xGMI)")
+def test_bench_two_gpus_runs_the_drivers_command(tmp_path):
+    """the exact command the driver's scaling run uses (`python -m torch.distributed.run ... bench.py --gpus N --steps K
+    --warmup W`) at N = 2 with the smallest model and short rollouts: one JSON line from rank 0, whole-job totals, both GPUs
+    distinct, the MCTS phases (config 4 = 16 rollouts over the ranks, config 5 = images striped over the ranks) present"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "1", "--model", "detikzify-ds-1.3b", "--config5-model", "detikzify-ds-1.3b", "--new-tokens", "48",
+                          "--batch", "16", "--config5-images", "4", "--config5-trees", "2", "--config5-expansions", "1", "--probe-tokens", "4"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=str(ROOT))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert len({(r["cuda_device"], r.get("device_uuid")) for r in d["ranks"]}) == 2 and all(r["backend"] == "nccl" for r in d["ranks"])
+    m = d["mcts"]
+    assert m["config4"]["fixed_length"]["rollouts"] == 16 and m["config4"]["fixed_length"]["trees_per_gpu"] == 8
+    assert m["config5"]["fixed_length"]["rollouts"] == 4 * 2 and m["config5"]["fixed_length"]["images_per_gpu"] == 2
+    lo, hi = m["config5"]["fixed_length"]["per_rank_rollouts_per_sec_min_max"]
+    assert 0 < lo <= hi and m["config5"]["fixed_length"]["gather_seconds"] >= 0

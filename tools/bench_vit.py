@@ -10,9 +10,14 @@ from detikzify_amd.util.synthetic import sketch_image
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="detikzify-ds-7b")
+ap.add_argument("--only", type=int, default=0, help="profiling runs: this many images per call only, GEMM variant from DTK_OPTIONS")
 args = ap.parse_args()
 model, proc = load(args.model, synthetic=1234)
 px = torch.cat([proc(images=sketch_image(i, 224), return_tensors="pt").pixel_values for i in range(16)])
+if args.only:
+    for _ in range(6):
+        model.vit_encode(px[:args.only], want_pooled=True, want_feats=False)
+    sys.exit(0)
 alone = [model.vit_encode(px[i:i + 1], want_pooled=True) for i in range(3)]
 f8, p8 = model.vit_encode(px[:8], want_pooled=True)
 print("batched == alone (features, pooled):", all(torch.equal(f8[i], alone[i][0][0]) for i in range(3)), all(torch.equal(p8[i], alone[i][1][0]) for i in range(3)))

@@ -105,6 +105,7 @@ struct EngineArgs {
   unsigned* err;           // != 0: a bounded spin gave up (code)
   int depth;               // fills (16 KiB) the loader keeps in flight: 1..3
   uint16_t* final_out;     // plain bf16 [D]: the last layer's down output (for the A == C check)
+  int mode;                // timing experiments (wrong results): 1 = no edges (nobody waits for an input vector), 2 = no dot products (loader alone)
 };
 
 // control words in LDS, behind the ring and the x buffer (byte offsets from the start of the dynamic LDS = LDS address 0: the kernel
@@ -122,20 +123,23 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_byte) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-// one fill = 16 consecutive pieces (16 KiB of the weight stream) into 16 consecutive ring pieces: ONE asm statement, ~4 issue
-// slots per piece (a per-piece C loop with its bookkeeping costs ~30 instructions per piece — more than the 0.64 us landing
-// cadence of a fill allows one wave)
-__device__ __forceinline__ void glds_fill16_nt(const unsigned char* g, unsigned lds_byte) {
+// one fill = 16 consecutive pieces (16 KiB of the weight stream) into 16 consecutive ring pieces: two asm statements of 8 pieces, ~4
+// issue slots per piece (a per-piece C loop with its bookkeeping costs ~30 instructions per piece — more than the 0.64 us
+// landing cadence of a fill allows one wave).  No instruction offsets: an `offset:` on global_load_lds moves the LDS destination
+// as well as the global source (LDS address = M0 + offset + 16 * lane; the first version of this probe added it on top of the M0
+// increments and scattered three pieces out of four), so every piece gets its own address register pair and M0 value.
+__device__ __forceinline__ void glds_fill8_nt(const unsigned char* g, unsigned lds_byte) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
-  const unsigned char *g1 = g + 4096, *g2 = g + 8192, *g3 = g + 12288;
-#define P4(G) "global_load_lds_dwordx4 " G ", off nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t" \
-              "global_load_lds_dwordx4 " G ", off offset:1024 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t" \
-              "global_load_lds_dwordx4 " G ", off offset:2048 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t" \
-              "global_load_lds_dwordx4 " G ", off offset:3072 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t" P4("%1") P4("%2") P4("%3") P4("%4") "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "v"(g1), "v"(g2), "v"(g3), "s"(dst) : "memory");
-#undef P4
+  const unsigned char *g1 = g + 1024, *g2 = g + 2048, *g3 = g + 3072, *g4 = g + 4096, *g5 = g + 5120, *g6 = g + 6144, *g7 = g + 7168;
+#define P1(G) "global_load_lds_dwordx4 " G ", off nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t" P1("%1") P1("%2") P1("%3") P1("%4") P1("%5") P1("%6") P1("%7") P1("%8") "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7), "s"(dst) : "memory");
+#undef P1
+}
+__device__ __forceinline__ void glds_fill16_nt(const unsigned char* g, unsigned lds_byte) {
+  glds_fill8_nt(g, lds_byte);
+  glds_fill8_nt(g + 8192, lds_byte + 8192u);
 }
 __device__ __forceinline__ unsigned lds_ld(unsigned off) {
   unsigned v;
@@ -275,7 +279,9 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
     // ---- the input vector: OUTPUT of the previous phase (layer 0, phase 0: vec[P_DOWN] tagged epoch0)
     const int psrc = (p + NPHASE - 1) % NPHASE;
     const unsigned tag_in = a.epoch0 + (unsigned)ph;
-    if (wave == 0) {
+    if (a.mode & 1) {
+      // timing experiment: no edge — the phase starts on whatever xbuf holds
+    } else if (wave == 0) {
       unsigned val[86];
       if (!sweep<86>(a.vec[psrc], K / 2, tag_in, val, lane)) { if (lane == 0) { lds_st(OFF_ABORT, 1u); atomicMax(a.err, 200u + (unsigned)p); } return; }
       // every producer has published => the other waves of THIS CU finished the previous phase => xbuf is free
@@ -316,9 +322,10 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
         __builtin_amdgcn_s_sleep(1);
       }
       const unsigned r0 = (unsigned)(((u64)b0x2 * 512ull) % (u64)RING_BYTES);
-      float a0, a1, a2 = 0.f, a3 = 0.f;
-      if (K8 == 512) row_pair<8>(ring, r0, K8, lane, xr, a0, a1); else row_pair<22>(ring, r0, K8, lane, xr, a0, a1);
-      if (p == P_GU) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (a.mode & 2) { /* timing experiment: the ring is released unread */ }
+      else if (K8 == 512) row_pair<8>(ring, r0, K8, lane, xr, a0, a1); else row_pair<22>(ring, r0, K8, lane, xr, a0, a1);
+      if (p == P_GU && !(a.mode & 2)) {
         unsigned r1 = r0 + 2u * (unsigned)K8 * 16u; if (r1 >= (unsigned)RING_BYTES) r1 -= RING_BYTES;
         row_pair<8>(ring, r1, K8, lane, xr, a2, a3);
       }
@@ -425,9 +432,12 @@ int main(int argc, char** argv) {
   printf("engine: %zu B LDS per block, occupancy %d block/CU, grid %d\n", lds, occ, cus);
   if (occ < 1) { printf("engine does not fit\n"); return 1; }
   unsigned epoch = 1;
-  for (int depth = 1; depth <= 3; ++depth) {
-    ea.depth = depth;
-    char nm[96]; snprintf(nm, sizeof nm, "C engine (1 loader + 3 consumers per CU), %d fills in flight", depth);
+  const int runs[][2] = {{2, 0}, {1, 0}, {3, 0}, {2, 1}, {2, 3}};      // (fills in flight, mode)
+  for (const auto& run : runs) {
+    const int depth = run[0];
+    ea.depth = depth; ea.mode = run[1];
+    char nm[112]; snprintf(nm, sizeof nm, "C engine, %d fills in flight%s", depth,
+                           run[1] == 0 ? "" : run[1] == 1 ? " [no edges: streaming rate]" : " [no edges, no dot products: loader alone]");
     auto go = [&] {
       ea.epoch0 = epoch;
       hipLaunchKernelGGL(k_publish_input, dim3(D / 2 / 256), dim3(256), 0, s, ea.vec[P_DOWN], x0, epoch);
