@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -105,6 +106,9 @@ struct EngineArgs {
   unsigned* err;           // != 0: a bounded spin gave up (code)
   int depth;               // fills (16 KiB) the loader keeps in flight: 1..3
   uint16_t* final_out;     // plain bf16 [D]: the last layer's down output (for the A == C check)
+  long long* trace;        // optional [ncu][phases][2] wall-clock stamps (100 MHz) of consumer wave 0: input vector ready, last item published
+  int sweepers;            // consumer waves that sweep an input vector: 3 (a third each) or 1 (wave 0 sweeps all of it)
+  int thin;                // 1: the loader keeps ONE fill in flight while a wave of its CU is sweeping (guide row gather-pass)
   int mode;                // timing experiments (wrong results): 1 = no edges (nobody waits for an input vector), 2 = no dot products (loader alone)
 };
 
@@ -115,7 +119,10 @@ constexpr unsigned OFF_FILLED = RING_BYTES + XBUF_BYTES;      // pieces landed i
 constexpr unsigned OFF_WPOS = OFF_FILLED + 4;                 // [3] absolute piece index below which consumer w no longer needs the ring
 constexpr unsigned OFF_XREADY = OFF_FILLED + 16;              // phases (absolute count) whose input vector is in xbuf
 constexpr unsigned OFF_ABORT = OFF_FILLED + 20;
-constexpr unsigned CTRL_BYTES = 32;
+constexpr unsigned OFF_XPARTS = OFF_FILLED + 24;             // sweep parts written into xbuf (3 per phase, absolute count)
+constexpr unsigned OFF_XCOPIED = OFF_FILLED + 28;
+constexpr unsigned OFF_GATHER = OFF_FILLED + 32;             // consumer waves of this CU that are sweeping right now (the loader thins its stream)            // consumer waves that have taken a phase's x into registers (3 per phase)
+constexpr unsigned CTRL_BYTES = 48;
 
 __device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_byte) {
   unsigned keep;
@@ -147,6 +154,7 @@ __device__ __forceinline__ unsigned lds_ld(unsigned off) {
   return v;
 }
 __device__ __forceinline__ void lds_st(unsigned off, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_add(unsigned off, unsigned v) { asm volatile("ds_add_u32 %0, %1" :: "v"(off), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // items of phase p owned by CU `cu`: [first, first + count) of N / rows_per_item items; an item = 2 rows (gu: 4 rows) -> ONE granule
@@ -161,32 +169,26 @@ __device__ __forceinline__ unsigned item_pieces_x2(int p) {   // ring bytes of o
   return p == P_ATTN ? 0u : (unsigned)(rows_per_item(p) * phase_K(p) * 2 / 512);
 }
 
-// sweep G granules (G % 64 == 0 or ragged) of `vec` until every tag == tag; lane l keeps granules l + 64 j in val[j]
+// sweep granule rows [row0, row1) (a row = 64 consecutive granules, one per lane) of `vec` until every tag == tag: EVERY load of
+// the range is in flight in each pass (the first version polled 16 loads at a time, chunk after chunk: two to six dependent
+// round trips after the last producer had published); lane l keeps granule 64 * (row0 + j) + l in val[j]
 template <int MAXJ>
-__device__ __forceinline__ bool sweep(const u64* vec, int G, unsigned tag, unsigned (&val)[MAXJ], int lane) {
-  const int nj = (G + 63) >> 6;
+__device__ __forceinline__ bool sweep_rows(const u64* vec, int row0, int row1, int G, unsigned tag, unsigned (&val)[MAXJ], int lane) {
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
 #pragma unroll
-  for (int j0 = 0; j0 < MAXJ; j0 += 16) {
-    if (j0 >= nj) break;
-    for (unsigned spins = 0;; ++spins) {
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j0 + j < MAXJ) {
-          const int g = lane + 64 * (j0 + j);
-          if (j0 + j < nj && g < G) {
-            const u64 x = __hip_atomic_load(vec + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[j0 + j] = (unsigned)x;
-            ok = ok && (unsigned)(x >> 32) == tag;
-          }
-        }
+    for (int j = 0; j < MAXJ; ++j) {
+      const int g = lane + 64 * (row0 + j);
+      if (row0 + j < row1 && g < G) {
+        const u64 x = __hip_atomic_load(vec + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        val[j] = (unsigned)x;
+        ok = ok && (unsigned)(x >> 32) == tag;
       }
-      if (__all(ok)) break;
-      if (spins > SPIN_LIMIT || lds_ld(OFF_ABORT)) return false;
-      __builtin_amdgcn_s_sleep(2);
     }
+    if (__all(ok)) return true;
+    if (spins > SPIN_LIMIT || lds_ld(OFF_ABORT)) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
-  return true;
 }
 
 // one row pair from the ring: rows at ring byte offsets r0, r0 + K * 2 (mod ring); x in registers (chunk c = lane + 64 i)
@@ -248,7 +250,11 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
         if (!wait_space(issued + SLOT, p)) return;
         glds_fill16_nt(src + (size_t)q * PIECE, (issued % RING_PIECES) * PIECE);
         issued += SLOT; ++fills_pending;
-        if (fills_pending >= depth) {       // keep `depth` fills in flight: the oldest has landed when (depth - 1) * 16 loads are outstanding
+        if (a.thin && lds_ld(OFF_GATHER) != 0u) {          // a sweep is queued behind this CU's own LDS-DMA burst: one fill at a time
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          fills_pending = 0;
+          lds_st(OFF_FILLED, issued);
+        } else if (fills_pending >= depth) {       // keep `depth` fills in flight: the oldest has landed when (depth - 1) * 16 loads are outstanding
           if (depth == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else if (depth == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -281,23 +287,43 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
     const unsigned tag_in = a.epoch0 + (unsigned)ph;
     if (a.mode & 1) {
       // timing experiment: no edge — the phase starts on whatever xbuf holds
-    } else if (wave == 0) {
-      unsigned val[86];
-      if (!sweep<86>(a.vec[psrc], K / 2, tag_in, val, lane)) { if (lane == 0) { lds_st(OFF_ABORT, 1u); atomicMax(a.err, 200u + (unsigned)p); } return; }
-      // every producer has published => the other waves of THIS CU finished the previous phase => xbuf is free
-#pragma unroll
-      for (int j = 0; j < 86; ++j) { const int g = lane + 64 * j; if (g < K / 2) reinterpret_cast<unsigned*>(xbuf)[g] = val[j]; }
-      lds_drain();                          // the wave's LDS stores execute in order; the flag goes last
-      if (lane == 0) lds_st(OFF_XREADY, (unsigned)ph + 1u);
     } else {
+      // every consumer wave sweeps a third of the vector (rows of 64 granules), parks it in xbuf, and all three meet on LDS counters
+      const int G = K / 2, rows = (G + 63) >> 6;
+      const int nsw = a.sweepers == 1 ? 1 : NCONS;
+      const int row0 = wave < nsw ? rows * wave / nsw : 0, row1 = wave < nsw ? rows * (wave + 1) / nsw : 0;
+      auto park = [&](auto& val, auto nj) {     // sweep this wave's rows, wait until xbuf is free, park the values there
+        constexpr int NJ = decltype(nj)::value;
+        if (a.thin && lane == 0) lds_add(OFF_GATHER, 1u);
+        const bool ok = sweep_rows<NJ>(a.vec[psrc], row0, row1, G, tag_in, val, lane);
+        if (a.thin && lane == 0) lds_add(OFF_GATHER, 0xffffffffu);
+        if (!ok) { if (lane == 0) { lds_st(OFF_ABORT, 1u); atomicMax(a.err, 200u + (unsigned)p); } return false; }
+        for (unsigned spins = 0;; ++spins) {     // xbuf still holds the previous phase's x until all three waves have it in registers
+          if (lds_ld(OFF_XCOPIED) >= (unsigned)NCONS * (unsigned)ph) break;
+          if (spins > SPIN_LIMIT || lds_ld(OFF_ABORT)) { if (lane == 0) atomicMax(a.err, 250u + (unsigned)p); return false; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int g = lane + 64 * (row0 + j); if (row0 + j < row1 && g < G) reinterpret_cast<unsigned*>(xbuf)[g] = val[j]; }
+        lds_drain();                          // the wave's LDS stores execute in order; the count goes last
+        if (lane == 0) lds_add(OFF_XPARTS, 1u);
+        return true;
+      };
+      if (nsw == 1) {
+        if (wave == 0) { unsigned val[86]; if (!park(val, std::integral_constant<int, 86>())) return; }
+      } else {
+        unsigned val[29]; if (!park(val, std::integral_constant<int, 29>())) return;
+      }
       for (unsigned spins = 0;; ++spins) {
-        if (lds_ld(OFF_XREADY) >= (unsigned)ph + 1u) break;
+        if (lds_ld(OFF_XPARTS) >= (unsigned)nsw * ((unsigned)ph + 1u)) break;
         if (spins > SPIN_LIMIT || lds_ld(OFF_ABORT)) { if (lane == 0) atomicMax(a.err, 300u + (unsigned)p); return; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
 #pragma unroll
     for (int i = 0; i < 22; ++i) { const int c = lane + 64 * i; if (c < K8) xr[i] = reinterpret_cast<const u32x4*>(xbuf)[c]; }
+    if (p != P_ATTN) { lds_drain(); if (lane == 0) lds_add(OFF_XCOPIED, 1u); }       // (attn reads xbuf in its items: counted after them)
+    if (a.trace && wave == 0 && lane == 0) a.trace[((size_t)cu * nph_total + ph) * 2] = (long long)wall_clock64();
 
     int first, count; cu_items(p, cu, ncu, first, count);
     if (p == P_ATTN) {
@@ -310,6 +336,8 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
           __hip_atomic_store(a.vec[p] + gi, ((u64)tag_out << 32) | o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      lds_drain(); if (lane == 0) lds_add(OFF_XCOPIED, 1u);
+      if (a.trace && wave == 0 && lane == 0) a.trace[((size_t)cu * nph_total + ph) * 2 + 1] = (long long)wall_clock64();
       continue;
     }
     const unsigned ipx2 = item_pieces_x2(p);
@@ -347,6 +375,7 @@ __global__ __launch_bounds__(256) void k_engine(EngineArgs a) {
         if (p == P_DOWN && l == a.nlayers - 1) reinterpret_cast<unsigned*>(a.final_out)[gi] = o;
       }
     }
+    if (a.trace && wave == 0 && lane == 0) a.trace[((size_t)cu * nph_total + ph) * 2 + 1] = (long long)wall_clock64();
     stream_x2 = (stream_x2 + (unsigned)count * ipx2 + 2u * SLOT - 1u) / (2u * SLOT) * (2u * SLOT);   // phases are padded to whole fills (loader)
   }
 }
@@ -395,7 +424,7 @@ int main(int argc, char** argv) {
     fn(); CK(hipStreamSynchronize(s));
     CK(hipEventRecord(e0, s)); for (int i = 0; i < iters; ++i) fn(); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-    printf("%-56s %8.1f us/pass  %6.2f us/layer  %5.2f TB/s\n", name, ms * 1e3, ms * 1e3 / nl, bytes / (ms * 1e-3) / 1e12);
+    printf("%-72s %8.1f us/pass  %6.2f us/layer  %5.2f TB/s\n", name, ms * 1e3, ms * 1e3 / nl, bytes / (ms * 1e-3) / 1e12);
     return ms;
   };
   // ---- A: graph of per-phase kernels (5 launches per layer, as the product)
@@ -432,12 +461,12 @@ int main(int argc, char** argv) {
   printf("engine: %zu B LDS per block, occupancy %d block/CU, grid %d\n", lds, occ, cus);
   if (occ < 1) { printf("engine does not fit\n"); return 1; }
   unsigned epoch = 1;
-  const int runs[][2] = {{2, 0}, {1, 0}, {3, 0}, {2, 1}, {2, 3}};      // (fills in flight, mode)
+  const int runs[][4] = {{2, 0, 3, 0}, {2, 0, 3, 1}, {2, 0, 1, 0}, {2, 0, 1, 1}, {3, 0, 1, 1}, {2, 1, 3, 0}, {2, 3, 3, 0}};      // (fills in flight, mode, sweeping waves, loader thinning)
   for (const auto& run : runs) {
     const int depth = run[0];
-    ea.depth = depth; ea.mode = run[1];
-    char nm[112]; snprintf(nm, sizeof nm, "C engine, %d fills in flight%s", depth,
-                           run[1] == 0 ? "" : run[1] == 1 ? " [no edges: streaming rate]" : " [no edges, no dot products: loader alone]");
+    ea.depth = depth; ea.mode = run[1]; ea.sweepers = run[2]; ea.thin = run[3];
+    char nm[128]; snprintf(nm, sizeof nm, "C engine, %d fills, %d sweeper%s, thinning %s%s", depth, run[2], run[2] == 1 ? "" : "s", run[3] ? "on" : "off",
+                           run[1] == 0 ? "" : run[1] == 1 ? " [no edges]" : " [no edges, no dots: loader alone]");
     auto go = [&] {
       ea.epoch0 = epoch;
       hipLaunchKernelGGL(k_publish_input, dim3(D / 2 / 256), dim3(256), 0, s, ea.vec[P_DOWN], x0, epoch);
@@ -451,6 +480,39 @@ int main(int argc, char** argv) {
     printf("   engine err code %u; final vector vs variant A: %d of %d elements differ (first values %04x %04x %04x vs %04x %04x %04x)\n",
            err, bad, D, got[0], got[1], got[2], ref[0], ref[1], ref[2]);
     if (err) { CK(hipMemset(ea.err, 0, 4)); }
+  }
+  // ---- where an edge's time goes: one traced launch (consumer wave 0 of every CU stamps "input ready" and "my last item published")
+  {
+    const int nph = nl * NPHASE;
+    long long* dtrace; CK(hipMalloc(&dtrace, (size_t)cus * nph * 2 * 8)); CK(hipMemset(dtrace, 0, (size_t)cus * nph * 2 * 8));
+    ea.depth = 2; ea.mode = 0; ea.sweepers = 3; ea.thin = 0; ea.trace = dtrace; ea.epoch0 = epoch;
+    hipLaunchKernelGGL(k_publish_input, dim3(D / 2 / 256), dim3(256), 0, s, ea.vec[P_DOWN], x0, epoch);
+    hipLaunchKernelGGL(k_engine, dim3(cus), dim3(256), lds, s, ea);
+    CK(hipStreamSynchronize(s));
+    std::vector<long long> tr((size_t)cus * nph * 2); CK(hipMemcpy(tr.data(), dtrace, tr.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[NPHASE] = {"qkv", "attn", "o", "gu", "down"};
+    printf("edge anatomy (one launch, wave 0 of each CU; us, 100 MHz wall clock): per phase, over CUs: ready = input vector in registers, done = own last item published\n");
+    long long t00 = tr[0]; for (int c = 0; c < cus; ++c) t00 = tr[(size_t)c * nph * 2] < t00 ? tr[(size_t)c * nph * 2] : t00;
+    double sum_edge = 0, sum_spread = 0, sum_body = 0; int n_edge = 0;
+    for (int ph = 0; ph < nph; ++ph) {
+      long long rmin = 1LL << 62, rmax = 0, dmin = 1LL << 62, dmax = 0; double ravg = 0, davg = 0;
+      for (int c = 0; c < cus; ++c) {
+        const long long r = tr[((size_t)c * nph + ph) * 2], d = tr[((size_t)c * nph + ph) * 2 + 1];
+        rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; ravg += r; davg += d;
+      }
+      ravg /= cus; davg /= cus;
+      if (ph >= NPHASE && ph < 2 * NPHASE)      // print layer 1 in full (layer 0 carries the cold start)
+        printf("  layer 1 %-5s ready min/avg/max %7.2f %7.2f %7.2f   done min/avg/max %7.2f %7.2f %7.2f   body(avg) %6.2f  done spread %5.2f\n", names[ph % NPHASE],
+               (rmin - t00) / 100.0, (ravg - t00) / 100.0, (rmax - t00) / 100.0, (dmin - t00) / 100.0, (davg - t00) / 100.0, (dmax - t00) / 100.0,
+               (davg - ravg) / 100.0, (dmax - dmin) / 100.0);
+      if (ph >= NPHASE) { sum_spread += (dmax - dmin) / 100.0; sum_body += (davg - ravg) / 100.0; }
+      if (ph + 1 < nph && ph >= NPHASE) {       // edge: slowest producer's publish -> average consumer has the vector
+        double nr = 0; for (int c = 0; c < cus; ++c) nr += tr[((size_t)c * nph + ph + 1) * 2]; nr /= cus;
+        sum_edge += (nr - dmax) / 100.0; ++n_edge;
+      }
+    }
+    printf("  layers 1..%d, per layer: sum of phase bodies (avg CU) %.1f us, sum over phases of the finish spread across CUs %.1f us, sum of edges (slowest publish -> avg ready) %.1f us\n",
+           nl - 1, sum_body / (nl - 1), sum_spread / (nl - 1), sum_edge / n_edge * NPHASE);
   }
   return 0;
 }
