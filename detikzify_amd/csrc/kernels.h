@@ -199,6 +199,10 @@ struct AttnArgs {
   float scale;
   int kv_group;  // query heads per K/V head (GQA): head h reads K/V head h / kv_group; 0 or 1 = one K/V head per query head
   int impl;   // 0 auto (MFMA flash kernel when hd is 72/128), 1 VALU kernel, 2 MFMA kernel
+  // several independent attention problems of the same shape in ONE launch (grid z): problem b reads / writes at + b * stride
+  // (elements).  The ViT batch: 8 images x 16 heads x 12 query blocks = 1536 blocks instead of 8 launches of 192 (the chip has 256 CUs)
+  int nbatch = 1;
+  long q_sb = 0, k_sb = 0, v_sb = 0, o_sb = 0;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

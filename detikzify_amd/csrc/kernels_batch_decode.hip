@@ -697,18 +697,23 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 #pragma unroll
   for (int g = 0; g < GQ; ++g) qv[g] = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + (h0 + g) * 128)[sub];
 
-  u32x4 kv[4], vv[4];
-  auto load_tile = [&](int j0) {
+  // Two register sets of K / V rows, ping-pong: while tile j is scored from one set, tile j + 1 is already in the other and tile
+  // j + 2 is requested as soon as its set is free — one to two tiles (8-16 KiB per wave) in flight instead of one.  (Round 2 copied
+  // the landed tile into a second set and then requested the next one: a block walked its context at one memory round trip per
+  // 64 keys, 16 round trips per block slot and layer.)  The keys are scored in the same order, so the result is bit-identical.
+  u32x4 kA[4], vA[4], kB[4], vB[4];
+  auto load_tile = [&](u32x4 (&kk)[4], u32x4 (&vv)[4], int j0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
       j = min(j, a.T_max - 1);
       const size_t off = (size_t)j * 128 + (j < slen ? sdelta : (size_t)0);
-      kv[i] = reinterpret_cast<const u32x4*>(kbase + off)[sub];
+      kk[i] = reinterpret_cast<const u32x4*>(kbase + off)[sub];
       vv[i] = reinterpret_cast<const u32x4*>(vbase + off)[sub];
     }
   };
-  if (start < n) load_tile(start);
+  if (start < n) load_tile(kA, vA, start);
+  if (start + ROWS < n) load_tile(kB, vB, start + ROWS);
   float m[GQ], l[GQ], o[GQ][8];
 #pragma unroll
   for (int g = 0; g < GQ; ++g) {
@@ -736,11 +741,7 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
       }
     }
   }
-  for (int j0 = start; j0 < n; j0 += ROWS) {
-    u32x4 kc[4], vc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { kc[i] = kv[i]; vc[i] = vv[i]; }
-    if (j0 + ROWS < n) load_tile(j0 + ROWS);
+  auto score_tile = [&](const u32x4 (&kc)[4], const u32x4 (&vc)[4], int j0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
@@ -765,6 +766,14 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
           m[g] = mn;
         }
       }
+    }
+  };
+  for (int j0 = start; j0 < n; j0 += 2 * ROWS) {
+    score_tile(kA, vA, j0);
+    if (j0 + 2 * ROWS < n) load_tile(kA, vA, j0 + 2 * ROWS);
+    if (j0 + ROWS < n) {
+      score_tile(kB, vB, j0 + ROWS);
+      if (j0 + 3 * ROWS < n) load_tile(kB, vB, j0 + 3 * ROWS);
     }
   }
 #pragma unroll

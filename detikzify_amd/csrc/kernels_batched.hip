@@ -706,6 +706,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   __shared__ uint32_t Vs[64 * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y;
+  { const long bz = blockIdx.z; a.Q += bz * a.q_sb; a.K += bz * a.k_sb; a.V += bz * a.v_sb; a.O += bz * a.o_sb; }   // batched problems
   const int hk = a.kv_group > 1 ? h / a.kv_group : h;   // GQA
   const int qi = blockIdx.x * 4 + wave;
   const bool qok = qi < a.Tq;
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int h = blockIdx.y;
+  { const long bz = blockIdx.z; a.Q += bz * a.q_sb; a.K += bz * a.k_sb; a.V += bz * a.v_sb; a.O += bz * a.o_sb; }   // batched problems
   const int hk = a.kv_group > 1 ? h / a.kv_group : h;   // GQA
   const int myq = blockIdx.x * 64 + wave * 16 + lq;
   const int qrow = myq < a.Tq ? myq : a.Tq - 1;
@@ -951,12 +953,12 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
   // which block / lane holds it)
   const bool mfma = can_mfma && a.impl != 1;
   if (mfma) {
-    dim3 grid((a.Tq + 63) / 64, a.H);
+    dim3 grid((a.Tq + 63) / 64, a.H, a.nbatch > 0 ? a.nbatch : 1);
     if (a.hd == 72) hipLaunchKernelGGL((k_attention_mfma<72>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_attention_mfma<128>), grid, dim3(256), 0, s, a);
     return;
   }
-  dim3 grid((a.Tq + 3) / 4, a.H);
+  dim3 grid((a.Tq + 3) / 4, a.H, a.nbatch > 0 ? a.nbatch : 1);
   if (a.hd == 72) hipLaunchKernelGGL((k_attention<72>), grid, dim3(256), 0, s, a);
   else if (a.hd == 128) hipLaunchKernelGGL((k_attention<128>), grid, dim3(256), 0, s, a);
   else if (a.hd == 64) hipLaunchKernelGGL((k_attention<64>), grid, dim3(256), 0, s, a);
