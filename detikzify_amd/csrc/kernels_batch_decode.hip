@@ -330,8 +330,8 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
     // from L2 per KiB of weights, which two tiles per block halve (at the price of 128 blocks)
     static int ks = 0;
     if (!ks) { const char* e = getenv("DTK_GB_RESID_KS"); ks = (e && atoi(e) == 8) ? 8 : 4; }
-    if (NT == 4 && !F8 && g_resid_split && ((a.N + 31) / 32) % 8 == 0)
-      hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 128, false, GB_WAVES, 2>), dim3(2 * ((a.N + 31) / 32)), dim3(GB_THREADS), 0, s, a);
+    if (NT == 4 && g_resid_split && ((a.N + 31) / 32) % 8 == 0)       // (fp8 too: two column tiles per block fit the register file)
+      hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 128, F8, GB_WAVES, 2>), dim3(2 * ((a.N + 31) / 32)), dim3(GB_THREADS), 0, s, a);
     else if (wide_resid) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 2, 0, F8, GB_WAVES, NT>), dim3((a.N + 31) / 32), dim3(GB_THREADS), 0, s, a);
     else if (resid_waves() == 16 && NT < 4 && !F8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, 16, NT>), dim3((a.N + 15) / 16), dim3(1024), 0, s, a);
     else if (ks == 8) hipLaunchKernelGGL((k_gemv_b<EPI_RESID, 1, 0, F8, GB_WAVES, NT, 8>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);

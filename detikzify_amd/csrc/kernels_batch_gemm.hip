@@ -676,45 +676,48 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkp(GemvBArgs a) {
     return;
   }
 
-  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
+  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice.  The weights sit in a register ring of TWO
+  // phases (16 k-steps, 16 KiB per wave, 128 KiB per CU in flight — k_gemv_bk's ring was one phase): phase p computes from one half
+  // while the other half already holds phase p + 1 and this half is refilled for phase p + 2 as its k-steps are used up.  o_proj
+  // (16 k-steps per slice) has its whole slice in flight before the first MFMA.  Same chains, same order: bit-identical partials.
   const int tn = rg * TPG + wave;
   const unsigned char* wrow = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16 + (size_t)s0 * 1024;
-  u32x4 wr[PH];
+  u32x4 wa[PH], wb[PH];
 #pragma unroll
-  for (int i = 0; i < PH; ++i) wr[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(i, Lc - 1) * 1024));
+  for (int i = 0; i < PH; ++i) wa[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(i, Lc - 1) * 1024));
+  if (nph > 1) {
+#pragma unroll
+    for (int i = 0; i < PH; ++i) wb[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(PH + i, Lc - 1) * 1024));
+  }
   f32x4 c[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  for (int p = 0; p + 1 < nph; ++p) {                            // steady phases: all 8 k-steps inside the chain
+  auto phase = [&](int p, u32x4 (&w)[PH], auto refill_tag) {
+    constexpr bool REFILL = decltype(refill_tag)::value;
     const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
       bf16x8_t xf[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[j]);
+      u32x4 wv = w[j];
+      if (p * PH + j >= Lc) wv = (u32x4){0u, 0u, 0u, 0u};          // k-steps past the end of the slice contribute nothing
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wv);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
-      wr[j] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min((p + 1) * PH + j, Lc - 1) * 1024));
+      if (REFILL) w[j] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min((p + 2) * PH + j, Lc - 1) * 1024));
     }
-    __syncthreads();
-  }
-  {                                                              // last phase: k-steps past the end contribute nothing
-    const int p = nph - 1;
-    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      bf16x8_t xf[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
-      u32x4 w = wr[j];
-      if (p * PH + j >= Lc) w = (u32x4){0u, 0u, 0u, 0u};
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
-    }
-  }
+    __syncthreads();   // the loader has parked the next phase; everybody is done reading this one
+  };
+  constexpr bx_flag<true> yes{};
+  constexpr bx_flag<false> no{};
+  int p = 0;
+  for (; p + 3 < nph; p += 2) { phase(p, wa, yes); phase(p + 1, wb, yes); }     // both phases have a phase two steps on
+  const int rest = nph - p;                                                      // 1, 2 or 3 phases left
+  if (rest == 3) { phase(p, wa, yes); phase(p + 1, wb, no); phase(p + 2, wa, no); }
+  else if (rest == 2) { phase(p, wa, no); phase(p + 1, wb, no); }
+  else phase(p, wa, no);
   // ---- the partial of (slice ks, tile tn): lane holds rows tn*16 + (lane>>4)*4 + 0..3 of slot nt*16 + (lane&15)
   float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
 #pragma unroll
