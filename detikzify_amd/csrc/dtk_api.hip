@@ -1675,7 +1675,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemm_impl")) {
-    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma) or 2 (k_gemm_glds where the shape has the tiles)");
+    if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma), 2 (k_gemm_glds where the shape has the tiles) or 3 (auto)");
     set_gemm_impl(value);
   }
   else if (!strcmp(name, "gemm_glds_min_tiles")) {

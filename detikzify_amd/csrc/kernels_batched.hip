@@ -408,7 +408,7 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
   return true;
 }
 
-static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring), 2 = k_gemm_glds for shapes with >= g_glds_min_tiles 128 x 128 tiles (else k_gemm_mfma); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
+static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring), 2 = k_gemm_glds for shapes with >= g_glds_min_tiles 128 x 128 tiles (else k_gemm_mfma), 3 = auto (default: 2 for M >= 1024, else 0); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
 void set_gemm_ring(int v) { g_gemm_ring = v; }
@@ -447,8 +447,11 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
     if (blocks(64, 64) < 512) tile = blocks(64, 32) >= 512 ? 4 : 5;
   }
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
-  if (g_gemm_impl < 0) { const char* e = getenv("DTK_GEMM_IMPL"); g_gemm_impl = e ? atoi(e) : 0; }
-  if (g_gemm_impl == 2 && !gemm_tile_override() && launch_gemm_glds(a, s)) return;     // 128 x 128 LDS-DMA kernel where the shape has the tiles for it
+  if (g_gemm_impl < 0) { const char* e = getenv("DTK_GEMM_IMPL"); g_gemm_impl = e ? atoi(e) : 3; }
+  // 3 = auto (default): k_gemm_glds for M >= 1024 (the batched ViT: same wall time as k_gemm_mfma, 319 instead of 711 MB fetched from
+  // the memory side per launch — profiles/r03_pmc_vit_batch8.csv — which is what a reward pass that runs BESIDE the HBM-bound decode
+  // steps should cost them), k_gemm_mfma below (prefill M = 243, one image M = 729: measured 14.4 vs 14.8 ms and 4.0 vs 4.6 ms)
+  if ((g_gemm_impl == 2 || (g_gemm_impl == 3 && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
     const int ring = g_gemm_ring;
 #define DMA_LAUNCH(BM_, BN_) do { if (ring == 2) launch_gemm_dma_t<BM_, BN_, 2>(a, s, grid(BM_, BN_)); else if (ring == 4) launch_gemm_dma_t<BM_, BN_, 4>(a, s, grid(BM_, BN_)); \

@@ -151,7 +151,7 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
             model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
             assert np.array_equal(out, outs[1]), (tile, ring)
     finally:
-        model.set_option("gemm_impl", 0); model.set_option("gemm_tile", 0); model.set_option("gemm_ring", 3)
+        model.set_option("gemm_impl", 3); model.set_option("gemm_tile", 0); model.set_option("gemm_ring", 3)
     # k_gemm_glds: 128 x 128 tiles, both operands by LDS-DMA in full 128-byte lines into an XOR-swizzled [row][chunk] image, two
     # LDS stages; K % 64 != 0 ends in a register-staged zero-filled tile (432, 304, 688, 4304 here); M, N tails clamp + mask
     try:
@@ -160,7 +160,7 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
         model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
         assert np.array_equal(out, outs[1]), "k_gemm_glds"
     finally:
-        model.set_option("gemm_impl", 0); model.set_option("gemm_glds_min_tiles", 160)
+        model.set_option("gemm_impl", 3); model.set_option("gemm_glds_min_tiles", 160)
     assert all(np.array_equal(outs[1], outs[t]) for t in (2, 3, 4, 5))
     frac = float((outs[1] != outs["naive"]).mean())
     assert frac < 2e-3     # fmaf chain vs MFMA tree inside a 32-wide k-step: rare 1-ulp flips only

@@ -31,4 +31,4 @@ for tile, name, impl in ap_variants:
             model.vit_encode(px[:B], want_pooled=True, want_feats=False)
         dt = (time.perf_counter() - t0) / n
         print(f"tile {name:8s} {B:2d} images per call: {1e3 * dt / B:6.2f} ms per image ({666.5e-3 * B / dt:6.0f} TFLOP/s)", flush=True)
-model.set_option("gemm_tile", 0); model.set_option("gemm_impl", 0)
+model.set_option("gemm_tile", 0); model.set_option("gemm_impl", 3)
