@@ -146,6 +146,7 @@ struct AttnDecBArgs {
   int pfx_splits;                      // key splits of the prefix kernel (its grid y)
   int tail_threads;                    // k_attn_tail_b block: 512 (default) | 256
   int gqa_fused;             // k_attn_tail_b: 1 = the query heads of a GQA group share one block (default), 0 = a block per query head
+  int nt_private = 0;        // k_attn_tail_b: non-temporal loads for key / value tiles beyond the shared prefix
   float* pfx_m; float* pfx_l; float* pfx_o;   // [slots][H][pfx_splits], ..., [slots][H][pfx_splits][128]: un-normalised prefix states
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);

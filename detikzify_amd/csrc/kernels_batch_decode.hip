@@ -702,7 +702,20 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   // the landed tile into a second set and then requested the next one: a block walked its context at one memory round trip per
   // 64 keys, 16 round trips per block slot and layer.)  The keys are scored in the same order, so the result is bit-identical.
   u32x4 kA[4], vA[4], kB[4], vB[4];
+  // a tile that lies wholly beyond the shared prefix holds PRIVATE rows: read once per step by this block alone, so they are loaded
+  // non-temporally (option "attn_nt", default on) and do not push the shared prefix rows and the x fragments out of the XCD's L2
+  const bool nt_ok = a.nt_private != 0;
   auto load_tile = [&](u32x4 (&kk)[4], u32x4 (&vv)[4], int j0) {
+    if (nt_ok && j0 >= slen) {      // block-uniform
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
+        j = min(j, a.T_max - 1);
+        kk[i] = ld_nt(reinterpret_cast<const u32x4*>(kbase + (size_t)j * 128) + sub);
+        vv[i] = ld_nt(reinterpret_cast<const u32x4*>(vbase + (size_t)j * 128) + sub);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int j = j0 + i * (ROWS / 4) + wave * 4 + grp;

@@ -936,8 +936,8 @@ __global__ __launch_bounds__(THREADS) void k_attn_decode_t(AttnDecArgs a) {
     for (int i = 0; i < 4; ++i) {
       int j = t * ROWS + i * (ROWS / 4) + wave * 4 + grp;
       j = min(j, a.T_max - 1);        // always a row of the cache; rows at or beyond the context are masked below
-      kv[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)j * 128)[sub];
-      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)j * 128)[sub];
+      kv[i] = ld_nt(reinterpret_cast<const u32x4*>(kbase + (size_t)j * 128) + sub);      // a K / V row is read once per token by one block:
+      vv[i] = ld_nt(reinterpret_cast<const u32x4*>(vbase + (size_t)j * 128) + sub);      // non-temporal, like the weights
     }
   };
   int t = sp;
