@@ -1692,6 +1692,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     set_resid_split(value != 0);
     drop_batch_graphs(c);
   }
+  else if (!strcmp(name, "gemv_bl")) {
+    if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..3 (bit 0: gate/up + lm_head, bit 1: qkv)");
+    set_gemv_bl(value);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "attn_nt")) { c->attn_nt = value != 0; drop_batch_graphs(c); }
   else if (!strcmp(name, "resid_kparts")) {     // batched N = d roles as k_gemv_bkp + k_resid_norm_b (64 slots, bf16 weights)
     c->resid_kparts = value != 0;

@@ -405,6 +405,192 @@ static int cu_count() {
   }
   return g_cu_count;
 }
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemv_bl — k_gemv_bx with the WEIGHTS decoupled from the compute waves: a loader wave streams both operands into LDS rings by
+// LDS-DMA and the compute waves only ever read LDS.
+//
+// What round 3's persistent-layer probe measured (profiles/r03_engine2_probe.txt): one LDS-DMA loader wave per CU that runs a few
+// fills ahead of v_dot2c consumers, ring + LDS flags instead of barriers, streams 6.4-6.5 TB/s — the batched MFMA GEMVs sit at
+// 3.5-4.9 TB/s.  They all stop the weight stream at synchronisation points: k_gemv_bx refills its register ring as it is consumed
+// and meets the x loader at a barrier every 8 k-steps, so a wave that waits issues nothing.  Here
+//   * ONE loader wave per block issues everything: per phase of 4 k-steps the 16 x fragments of the 64 slots (L2 hits) and the
+//     8 weight tiles of each unit (`nt`, HBM) — fragment-major tiles are 1 KiB contiguous = one `global_load_lds_dwordx4`, four
+//     consecutive k-steps = one M0 + four instruction offsets (the offset moves the LDS destination with the global source:
+//     tools/probe/glds_offset_probe.hip) — into rings of R = 3 phases, two phases in flight (counted vmcnt), no VGPR staging;
+//   * the compute waves (one unit = the two paired row tiles, over the FULL K, as in k_gemv_bx) poll an LDS word for "phase p has
+//     landed", read A and B fragments with conflict-free ds_read_b128, and publish "phase p consumed"; nobody meets at a barrier;
+//   * chains and epilogue exactly as k_gemv_bx: BIT-IDENTICAL to k_gemv_b / k_gemv_bx (tested).
+template <bool NONTEMPORAL>
+__device__ __forceinline__ void glds_run4(const void* g, unsigned lds_byte) {   // 4 consecutive 1 KiB pieces, global and LDS alike
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
+  if (NONTEMPORAL)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\tglobal_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, off offset:3072 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned bl_ld(unsigned off) {      // LDS control words by explicit ds_read / ds_write (a volatile access through
+  unsigned v;                                                   // a generic pointer compiles to FLAT + vmcnt(0): it would drain the DMA queue)
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+  return v;
+}
+__device__ __forceinline__ void bl_st(unsigned off, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory"); }
+__device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int EPI, int NC, int CHP4>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
+  constexpr int T = 2, NT = 4, PH = 4, R = 3;
+  constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
+  constexpr unsigned WPH = NC * T * PH * 1024u;                  // weight bytes of one phase (8 KiB per unit)
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr int PIECES = (NT + NC * T) * PH;                     // LDS-DMA instructions per phase
+  constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  __syncthreads();
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+
+  if (wave == NC) {
+    // ---- loader wave
+    const unsigned char* xsrc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
+    const unsigned char* wsrc[NC][T];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int g = blockIdx.x * NC + c, gc = g < groups ? g : groups - 1;      // a surplus unit streams valid memory and stores nothing
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
+        const int tn_max = ((a.N + 15) >> 4) - 1;
+        if (tn > tn_max) tn = tn_max;
+        wsrc[c][t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+      }
+    }
+    unsigned slot = 0;
+    for (int p = 0; p < NPH; ++p) {
+      if (p >= R) {                         // the slot still holds phase p - R: every compute wave must have released it
+        for (unsigned spins = 0; spins < SPIN; ++spins) {
+          unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+          for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          if (lo + R > (unsigned)p) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const size_t adv = (size_t)p * PH * 1024;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t) glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
+      if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)p);
+      }
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bl_st(OFF_FILLED, (unsigned)NPH);
+    return;
+  }
+
+  // ---- compute waves: one unit each over the full K, operands from LDS
+  const int g = blockIdx.x * NC + wave;
+  f32x4 tot[T][NT], c[T][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { tot[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  unsigned slot = 0;
+  for (int p = 0; p < NPH; ++p) {
+    for (unsigned spins = 0; spins < SPIN; ++spins) {
+      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned char* xb = smem + slot * XPH + lane * 16;
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * PH * 1024u + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
+      }
+    }
+    if ((p + 1) % CHP4 == 0) {              // a k_gemv_b wave slice is complete: slice sums are added in slice order
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { tot[t][nt] += c[t][nt]; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+    bl_drain();                             // every fragment read of this phase has returned
+    if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+  if (g >= groups) return;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    if (!a.bs->active[n]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
+    }
+  }
+}
+
+template <int EPI, int NC, int CHP4>
+static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
+  hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+}
+template <int EPI, int CHP4>
+static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
+  switch (units) {
+    case 1: case 2: launch_bl_one<EPI, 2, CHP4>(a, s); return true;
+    case 3: launch_bl_one<EPI, 3, CHP4>(a, s); return true;
+    case 4: launch_bl_one<EPI, 4, CHP4>(a, s); return true;
+    default: return false;
+  }
+}
+static int g_gemv_bl = -1;
+void set_gemv_bl(int v) { g_gemv_bl = v; }
+// variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block).  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,
+// K other than 2048 / 4096, more than 4 units per CU): the caller goes on to k_gemv_bx / k_gemv_b
+bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 0; }
+  if (g_gemv_bl <= 0 || a.W8 || a.nt < 3) return false;
+  if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
+  if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
+  if (a.K != 4096 && a.K != 2048) return false;
+  if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
+  if (epi == EPI_LOGITS && (a.N & 31)) return false;
+  const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
+                   : epi == EPI_SWIGLU ? gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH) : gg_groups<EPI_LOGITS, 2>(a.N, a.ff, a.H, a.KVH);
+  const int units = (groups + cu_count() - 1) / cu_count();
+#define BL(E) (a.K == 4096 ? launch_bl_units<E, 4>(units, a, s) : launch_bl_units<E, 2>(units, a, s))
+  if (epi == EPI_QKV) return BL(EPI_QKV);
+  if (epi == EPI_SWIGLU) return BL(EPI_SWIGLU);
+  return BL(EPI_LOGITS);
+#undef BL
+}
+
 template <int EPI, int UNITS, int CHP>
 static void launch_bx_one(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = 2 * 8 * 4 * 1024;

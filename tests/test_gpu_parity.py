@@ -1383,14 +1383,16 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         prompts = [torch.randint(3, cfg.vocab - 1, (6 + (i % 5),), generator=g) for i in range(64)]
         slots = list(range(64))
         runs = {}
-        # (gemv_bx, gemv_bk, resid_split, resid_kparts); resid_kparts = the N = d roles as k_gemv_bkp (K split over CUs, partials
-        # stored) + k_resid_norm_b (reduce + residual + the RMSNorm that follows): bf16 weights only, otherwise a no-op
-        for variant in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0), (0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 1, 0), (1, 0, 1, 0),
-                        (0, 0, 0, 1), (1, 0, 1, 1)):
+        # (gemv_bx, gemv_bk, resid_split, resid_kparts, gemv_bl); resid_kparts = the N = d roles as k_gemv_bkp (K split over CUs,
+        # partials stored) + k_resid_norm_b (reduce + residual + the RMSNorm that follows); gemv_bl = k_gemv_bl (both operands into LDS
+        # rings by a loader wave; bit 0 gate/up + lm_head, bit 1 qkv): both bf16 weights only, otherwise no-ops
+        for variant in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (4, 0, 0, 0, 0), (0, 1, 0, 0, 0), (1, 1, 0, 0, 0),
+                        (0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 1, 0), (1, 0, 1, 1, 0), (1, 0, 1, 1, 1), (1, 0, 1, 1, 2), (0, 0, 0, 0, 3)):
             model.set_option("gemv_bx", variant[0])
             model.set_option("gemv_bk", variant[1])
             model.set_option("resid_split", variant[2])     # N = d roles: two row tiles x 32 slots per block
             model.set_option("resid_kparts", variant[3])
+            model.set_option("gemv_bl", variant[4])
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1400,13 +1402,14 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                 toks.append(model.decode_batch_wait()[:64])
             runs[variant] = (toks, torch.stack([model.get_logits_slot(s_) for s_ in (0, 17, 40, 63)]))
         for variant in runs:
-            assert runs[variant][0] == runs[(0, 0, 0, 0)][0], (name, variant)
-            assert torch.equal(runs[variant][1], runs[(0, 0, 0, 0)][1]), (name, variant)
+            assert runs[variant][0] == runs[(0, 0, 0, 0, 0)][0], (name, variant)
+            assert torch.equal(runs[variant][1], runs[(0, 0, 0, 0, 0)][1]), (name, variant)
     finally:
         model.set_option("gemv_bx", 1)      # process-wide switches: back to the defaults
         model.set_option("gemv_bk", 0)
         model.set_option("resid_split", 1)
         model.set_option("resid_kparts", 1)
+        model.set_option("gemv_bl", 0)
         del model
         gc.collect()
 
