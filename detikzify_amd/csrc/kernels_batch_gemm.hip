@@ -910,6 +910,133 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkp(GemvBArgs a) {
   for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
 }
 
+// k_gemv_bkl — k_gemv_bkp with both operands through LDS rings filled by a loader wave (the k_gemv_bl treatment for the N = d
+// roles): block (row group, K slice) = TPG compute waves, one row tile each, + one loader wave that streams the slice's x
+// fragments (16 KiB per phase of 4 k-steps) and the TPG weight tiles (4 KiB each per phase) by LDS-DMA, two phases in flight, ring
+// of 3.  Same K slices, same MFMA chains, same partial layout as k_gemv_bkp: bit-identical.  A slice that is not a whole number
+// of phases (down: 43 k-steps) ends in a phase whose surplus k-steps are fetched clamped and not multiplied.
+__device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, bool nontemporal) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
+  if (nontemporal)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int TPG>
+__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
+  constexpr int NT = 4, PH = 4, R = 3;
+  constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr int PIECES = (NT + TPG) * PH;
+  constexpr unsigned SPIN = 1u << 22;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = (a.K + 31) >> 5;
+  const int per = (nsteps + 7) >> 3;
+  const int b = blockIdx.x, idx = b >> 3;
+  const int rgs_per_xcd = (int)(gridDim.x >> 6);                // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
+  const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
+  const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
+  const int Lc = s1 - s0;                                       // >= 1 (launcher)
+  const int nph = (Lc + PH - 1) / PH;
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  __syncthreads();
+
+  if (wave == TPG) {   // ---- loader wave
+    const unsigned char* xsrc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;   // tile rg*TPG + w at + w * nsteps KiB
+    unsigned slot = 0;
+    for (int p = 0; p < nph; ++p) {
+      if (p >= R) {
+        for (unsigned spins = 0; spins < SPIN; ++spins) {
+          unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+          for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          if (lo + R > (unsigned)p) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const size_t adv = (size_t)p * PH * 1024;
+      if ((p + 1) * PH <= Lc) {               // a whole phase inside the slice: runs of four consecutive pieces
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+#pragma unroll
+        for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
+      } else {                                // the ragged last phase: piece by piece, clamped to the slice's last k-step
+#pragma unroll
+        for (int j = 0; j < PH; ++j) {
+          const size_t kk = (size_t)min(p * PH + j, Lc - 1) * 1024;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) glds16_any(xsrc[nt] + kk, slot * XPH + (unsigned)(nt * PH + j) * 1024u, false);
+#pragma unroll
+          for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
+        }
+      }
+      if (p >= 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)p);
+      }
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bl_st(OFF_FILLED, (unsigned)nph);
+    return;
+  }
+
+  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
+  const int tn = rg * TPG + wave;
+  f32x4 c[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned slot = 0;
+  for (int p = 0; p < nph; ++p) {
+    for (unsigned spins = 0; spins < SPIN; ++spins) {
+      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned char* xb = smem + slot * XPH + lane * 16;
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * PH * 1024u + lane * 16;
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      if (p * PH + j < Lc) {                  // wave-uniform: k-steps past the end of the slice are not multiplied
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)j * 1024));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+          c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, c[nt], 0, 0, 0);
+        }
+      }
+    }
+    bl_drain();
+    if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+  float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
+}
+static int g_gemv_bkl = -1;
+void set_gemv_bkl(int v) { g_gemv_bkl = v; }
+static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
+  if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 0; }
+  if (g_gemv_bkl <= 0) return false;
+  if (((a.N + 15) >> 4) == 256) {
+    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;
+    static bool attr8 = false;
+    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    hipLaunchKernelGGL((k_gemv_bkl<8>), dim3(256), dim3(9 * 64), lds, s, a);
+  } else {
+    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 5 + 12;
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    hipLaunchKernelGGL((k_gemv_bkl<4>), dim3(256), dim3(5 * 64), lds, s, a);
+  }
+  return true;
+}
+
 // false = not covered (fp8 weights, fewer than 33 slots, a tile count that is not 32 row groups of 4 or 8 tiles, a K that
 // leaves one of the 8 slices empty, a width k_resid_norm_b does not handle): the caller uses k_gemv_b<RESID> + k_rmsnorm_b
 bool resid_kparts_covers(const GemvBArgs& a) {
@@ -921,6 +1048,7 @@ bool resid_kparts_covers(const GemvBArgs& a) {
   return D8 == 256 || D8 == 512 || D8 == 1024;
 }
 void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s) {
+  if (launch_gemv_bkl(a, s)) return;       // operands through LDS rings filled by a loader wave (option gemv_bkl)
   constexpr int lds = 2 * 8 * 4 * 1024;
   if (((a.N + 15) >> 4) == 256) {
     static bool attr8 = false;

@@ -1387,11 +1387,13 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         # partials stored) + k_resid_norm_b (reduce + residual + the RMSNorm that follows); gemv_bl = k_gemv_bl (both operands into LDS
         # rings by a loader wave; bit 0 gate/up + lm_head, bit 1 qkv): both bf16 weights only, otherwise no-ops
         for variant in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (4, 0, 0, 0, 0), (0, 1, 0, 0, 0), (1, 1, 0, 0, 0),
-                        (0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 1, 0), (1, 0, 1, 1, 0), (1, 0, 1, 1, 1), (1, 0, 1, 1, 2), (0, 0, 0, 0, 3)):
+                        (0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 1, 0), (1, 0, 1, 1, 0), (1, 0, 1, 1, 1), (1, 0, 1, 1, 2), (0, 0, 0, 0, 3),
+                        (1, 0, 1, 2, 1)):       # resid_kparts 2 = with k_gemv_bkl (LDS-ring operands) as the weight kernel
             model.set_option("gemv_bx", variant[0])
             model.set_option("gemv_bk", variant[1])
             model.set_option("resid_split", variant[2])     # N = d roles: two row tiles x 32 slots per block
-            model.set_option("resid_kparts", variant[3])
+            model.set_option("resid_kparts", 1 if variant[3] else 0)
+            model.set_option("gemv_bkl", 1 if variant[3] == 2 else 0)
             model.set_option("gemv_bl", variant[4])
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
@@ -1410,6 +1412,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("resid_split", 1)
         model.set_option("resid_kparts", 1)
         model.set_option("gemv_bl", 0)
+        model.set_option("gemv_bkl", 0)
         del model
         gc.collect()
 
