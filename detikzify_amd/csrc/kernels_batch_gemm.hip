@@ -574,7 +574,7 @@ void set_gemv_bl(int v) { g_gemv_bl = v; }
 // variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block).  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,
 // K other than 2048 / 4096, more than 4 units per CU): the caller goes on to k_gemv_bx / k_gemv_b
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 0; }
+  if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 1; }     // default: gate/up + lm_head (64-slot step 4.49 -> 4.35 ms); qkv has too few units per CU (4.64)
   if (g_gemv_bl <= 0 || a.W8 || a.nt < 3) return false;
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
   if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
 static int g_gemv_bkl = -1;
 void set_gemv_bkl(int v) { g_gemv_bkl = v; }
 static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
-  if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 0; }
+  if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
   if (((a.N + 15) >> 4) == 256) {
     constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;

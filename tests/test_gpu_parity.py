@@ -1411,8 +1411,8 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_bk", 0)
         model.set_option("resid_split", 1)
         model.set_option("resid_kparts", 1)
-        model.set_option("gemv_bl", 0)
-        model.set_option("gemv_bkl", 0)
+        model.set_option("gemv_bl", 1)
+        model.set_option("gemv_bkl", 1)
         del model
         gc.collect()
 
