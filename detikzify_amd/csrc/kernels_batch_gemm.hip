@@ -433,6 +433,12 @@ __device__ __forceinline__ void glds_run4(const void* g, unsigned lds_byte) {   
                  "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
+__device__ __forceinline__ void glds_run2_nt(const void* g, unsigned lds_byte) {   // two consecutive pieces (an fp8 pair-tile run of one phase)
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\tglobal_load_lds_dwordx4 %1, off offset:1024 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
 __device__ __forceinline__ unsigned bl_ld(unsigned off) {      // LDS control words by explicit ds_read / ds_write (a volatile access through
   unsigned v;                                                   // a generic pointer compiles to FLAT + vmcnt(0): it would drain the DMA queue)
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
@@ -441,13 +447,17 @@ __device__ __forceinline__ unsigned bl_ld(unsigned off) {      // LDS control wo
 __device__ __forceinline__ void bl_st(unsigned off, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory"); }
 __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int EPI, int NC, int CHP4>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+// F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps): half the DMA pieces and ring bytes, widened to
+// bf16 in registers and fed to the same MFMAs in the same k order, the per-row power-of-two scale on the finished sum — bit-identical
+// to the fp8 k_gemv_bx / k_gemv_b kernels
+template <int EPI, int NC, int CHP4, bool F8 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
 __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
   constexpr int T = 2, NT = 4, PH = 4, R = 3;
+  constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
-  constexpr unsigned WPH = NC * T * PH * 1024u;                  // weight bytes of one phase (8 KiB per unit)
+  constexpr unsigned WPH = NC * T * WT * 1024u;                  // weight bytes of one phase (8 KiB per unit; fp8: 4)
   constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
-  constexpr int PIECES = (NT + NC * T) * PH;                     // LDS-DMA instructions per phase
+  constexpr int PIECES = NT * PH + NC * T * WT;                  // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -470,7 +480,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
         int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
         const int tn_max = ((a.N + 15) >> 4) - 1;
         if (tn > tn_max) tn = tn_max;
-        wsrc[c][t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+        wsrc[c][t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                        : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
       }
     }
     unsigned slot = 0;
@@ -490,7 +501,10 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int t = 0; t < T; ++t) glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
+        for (int t = 0; t < T; ++t) {
+          if (F8) glds_run2_nt(wsrc[c][t] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)(c * T + t) * WT * 1024u);
+          else glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
+        }
       if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
         bl_st(OFF_FILLED, (unsigned)p);
@@ -516,7 +530,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
-    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * PH * 1024u + lane * 16;
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * WT * 1024u + lane * 16;
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
       bf16x8_t xf[NT];
@@ -524,7 +538,13 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+        bf16x8_t af;
+        if (F8) {
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
+          af = gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]);
+        } else {
+          af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
       }
@@ -546,7 +566,15 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     if (!a.bs->active[n]) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      if (F8) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
+          if (row >= a.N) row = a.N - 1;
+          v[t] *= a.wscale[row];                                // power of two: exact
+        }
+      }
       gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
     }
   }
@@ -554,11 +582,16 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
 
 template <int EPI, int NC, int CHP4>
 static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;        // (the fp8 kernel needs less; one size for both)
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -575,7 +608,7 @@ void set_gemv_bl(int v) { g_gemv_bl = v; }
 // K other than 2048 / 4096, more than 4 units per CU): the caller goes on to k_gemv_bx / k_gemv_b
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 1; }     // default: gate/up + lm_head (64-slot step 4.49 -> 4.35 ms); qkv has too few units per CU (4.64)
-  if (g_gemv_bl <= 0 || a.W8 || a.nt < 3) return false;
+  if (g_gemv_bl <= 0 || a.nt < 3) return false;
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
   if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
   if (a.K != 4096 && a.K != 2048) return false;
