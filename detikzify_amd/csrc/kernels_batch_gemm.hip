@@ -604,11 +604,12 @@ static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
 }
 static int g_gemv_bl = -1;
 void set_gemv_bl(int v) { g_gemv_bl = v; }
-// variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block).  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,
+// variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block), bit 2: also with fp8 weights.  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,
 // K other than 2048 / 4096, more than 4 units per CU): the caller goes on to k_gemv_bx / k_gemv_b
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 1; }     // default: gate/up + lm_head (64-slot step 4.49 -> 4.35 ms); qkv has too few units per CU (4.64)
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
+  if (a.W8 && !(g_gemv_bl & 4)) return false;     // fp8 weights: bit 2 (measured neutral against the fp8 k_gemv_bx: 4.01 vs 4.04 ms per 64-slot step)
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
   if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
   if (a.K != 4096 && a.K != 2048) return false;
