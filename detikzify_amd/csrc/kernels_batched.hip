@@ -449,7 +449,7 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(8 * ((((a.N + bn - 1) / bn) + 7) / 8) * ((a.M + bm - 1) / bm))); };
   if (g_gemm_impl < 0) { const char* e = getenv("DTK_GEMM_IMPL"); g_gemm_impl = e ? atoi(e) : 3; }
   // 3 = auto (default): k_gemm_glds for M >= 1024 (the batched ViT: same wall time as k_gemm_mfma, 319 instead of 711 MB fetched from
-  // the memory side per launch — profiles/r03_pmc_vit_batch8.csv — which is what a reward pass that runs BESIDE the HBM-bound decode
+  // the memory side per launch — profiles/r03_pmc_mfma.csv — which is what a reward pass that runs BESIDE the HBM-bound decode
   // steps should cost them), k_gemm_mfma below (prefill M = 243, one image M = 729: measured 14.4 vs 14.8 ms and 4.0 vs 4.6 ms)
   if ((g_gemm_impl == 2 || (g_gemm_impl == 3 && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
