@@ -450,14 +450,19 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps): half the DMA pieces and ring bytes, widened to
 // bf16 in registers and fed to the same MFMAs in the same k order, the per-row power-of-two scale on the finished sum — bit-identical
 // to the fp8 k_gemv_bx / k_gemv_b kernels
-template <int EPI, int NC, int CHP4, bool F8 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+// Q3 (QKV of an MHA model, NC = 2): the role has (H + KVH) * 4 RoPE pair units and KVH * 8 V row tiles that need no partner — 1.5 pair
+// units per CU for ds-7b, which no whole number of units per block balances (192 blocks of 2 units leave a quarter of the chip idle).
+// Here block b owns pair unit b of the q / k sections (wave 0) AND V row tile b (wave 1): 256 blocks x 3 row tiles, every CU busy.
+template <int EPI, int NC, int CHP4, bool F8 = false, bool Q3 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
 __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
+  static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
   constexpr int T = 2, NT = 4, PH = 4, R = 3;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
+  constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
-  constexpr unsigned WPH = NC * T * WT * 1024u;                  // weight bytes of one phase (8 KiB per unit; fp8: 4)
+  constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
   constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
-  constexpr int PIECES = NT * PH + NC * T * WT;                  // LDS-DMA instructions per phase
+  constexpr int PIECES = NT * PH + TILES * WT;                   // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -471,18 +476,20 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
-    const unsigned char* wsrc[NC][T];
+    const unsigned char* wsrc[TILES];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int g = blockIdx.x * NC + c, gc = g < groups ? g : groups - 1;      // a surplus unit streams valid memory and stores nothing
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
-        const int tn_max = ((a.N + 15) >> 4) - 1;
-        if (tn > tn_max) tn = tn_max;
-        wsrc[c][t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
-                        : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+    for (int j = 0; j < TILES; ++j) {
+      int tn;
+      if (Q3) {
+        tn = j < 2 ? gg_tile_row0<EPI, T>(a, blockIdx.x, j) >> 4 : (a.H + a.KVH) * 8 + (int)blockIdx.x;
+      } else {
+        const int g = blockIdx.x * NC + j / T, gc = g < groups ? g : groups - 1;    // a surplus unit streams valid memory and stores nothing
+        tn = gg_tile_row0<EPI, T>(a, gc, j % T) >> 4;
       }
+      const int tn_max = ((a.N + 15) >> 4) - 1;
+      if (tn > tn_max) tn = tn_max;
+      wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                   : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
     unsigned slot = 0;
     for (int p = 0; p < NPH; ++p) {
@@ -499,12 +506,10 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (F8) glds_run2_nt(wsrc[c][t] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)(c * T + t) * WT * 1024u);
-          else glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
-        }
+      for (int j = 0; j < TILES; ++j) {
+        if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
+        else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
+      }
       if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
         bl_st(OFF_FILLED, (unsigned)p);
@@ -517,7 +522,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
   }
 
   // ---- compute waves: one unit each over the full K, operands from LDS
-  const int g = blockIdx.x * NC + wave;
+  const int g = Q3 ? (int)blockIdx.x : blockIdx.x * NC + wave;
+  const int myT = (Q3 && wave == 1) ? 1 : T;                  // Q3: wave 1 owns the single V row tile (ring tile 2)
   f32x4 tot[T][NT], c[T][NT];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -538,6 +544,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+        if (Q3 && t >= myT) continue;
         bf16x8_t af;
         if (F8) {
           const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
@@ -560,6 +567,22 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     slot = slot + 1 == R ? 0 : slot + 1;
   }
   if (g >= groups) return;
+  if (Q3 && wave == 1) {                    // the V row tile of this block: rows (H + KVH) * 128 + 16 b .. + 15 = dims (b & 7) * 16 .. of V head b >> 3
+    const int b = blockIdx.x, head = b >> 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + (lane & 15);
+      if (!a.bs->active[n]) continue;
+      bf16_t* dst = a.vcache + (size_t)n * a.kv_slot_stride + ((size_t)head * a.T_max + a.st[n].pos) * 128 + (b & 7) * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = tot[0][nt][r];
+        if (F8) v *= a.wscale[(a.H + a.KVH) * 128 + b * 16 + (lane >> 4) * 4 + r];
+        dst[r] = f2bf(rbf(v));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = nt * 16 + (lane & 15);
@@ -578,6 +601,21 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
     }
   }
+}
+
+// QKV of an MHA model as 3 row tiles per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
+template <int CHP4>
+static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (3 * 4 * 1024) + 4 * 3 + 12;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int blocks = (a.H + a.KVH) * 4;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, true>), dim3(blocks), dim3(3 * 64), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, true>), dim3(blocks), dim3(3 * 64), lds, s, a);
 }
 
 template <int EPI, int NC, int CHP4>
@@ -611,8 +649,15 @@ bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
   if (a.W8 && !(g_gemv_bl & 4)) return false;     // fp8 weights: bit 2 (measured neutral against the fp8 k_gemv_bx: 4.01 vs 4.04 ms per 64-slot step)
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
-  if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
+  if (epi == EPI_QKV ? !(g_gemv_bl & (2 | 8 | 16)) : !(g_gemv_bl & 1)) return false;
   if (a.K != 4096 && a.K != 2048) return false;
+  if (epi == EPI_QKV && (g_gemv_bl & (8 | 16))) {      // bit 3: a pair unit + a V row tile per block for MHA models whose q / k pair count fills the chip; bit 4: for any MHA model (tests)
+    if (a.H == a.KVH && a.N == (a.H + 2 * a.KVH) * 128 && ((g_gemv_bl & 16) || (a.H + a.KVH) * 4 * 4 >= cu_count() * 3)) {
+      if (a.K == 4096) launch_bl_q3<4>(a, s); else launch_bl_q3<2>(a, s);
+      return true;
+    }
+    if (!(g_gemv_bl & 2)) return false;
+  }
   if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
   if (epi == EPI_LOGITS && (a.N & 31)) return false;
   const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)

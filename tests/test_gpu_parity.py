@@ -1388,7 +1388,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         # rings by a loader wave; bit 0 gate/up + lm_head, bit 1 qkv, bit 2 fp8 weights too); resid_kparts is bf16 only (a no-op with fp8)
         for variant in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (4, 0, 0, 0, 0), (0, 1, 0, 0, 0), (1, 1, 0, 0, 0),
                         (0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 1, 0), (1, 0, 1, 1, 0), (1, 0, 1, 1, 5), (1, 0, 1, 1, 6), (0, 0, 0, 0, 7),
-                        (1, 0, 1, 2, 5)):       # resid_kparts 2 = with k_gemv_bkl (LDS-ring operands) as the weight kernel
+                        (1, 0, 1, 2, 5), (1, 0, 1, 2, 1 + 4 + 16)):       # resid_kparts 2 = with k_gemv_bkl (LDS-ring operands) as the weight kernel; gemv_bl bit 4 = qkv as a RoPE pair unit + a V row tile per block
             model.set_option("gemv_bx", variant[0])
             model.set_option("gemv_bk", variant[1])
             model.set_option("resid_split", variant[2])     # N = d roles: two row tiles x 32 slots per block
