@@ -1002,9 +1002,12 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-template <int TPG>
-__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
-  constexpr int NT = 4, PH = 4, R = 3;
+// CW compute waves own TPG / CW row tiles each: with two tiles per wave an x fragment read from LDS feeds two A fragments (LDS reads per
+// phase 160 -> 96 KiB at TPG = 8) for twice the MFMAs per wave.
+template <int TPG, int CW = TPG>
+__global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
+  constexpr int NT = 4, PH = 4, R = 3, TPW = TPG / CW;
+  static_assert(TPW * CW == TPG, "row tiles divide over the compute waves");
   constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
   constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
   constexpr int PIECES = (NT + TPG) * PH;
@@ -1019,10 +1022,10 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
   const int Lc = s1 - s0;                                       // >= 1 (launcher)
   const int nph = (Lc + PH - 1) / PH;
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (CW + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
 
-  if (wave == TPG) {   // ---- loader wave
+  if (wave == CW) {   // ---- loader wave
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
         for (unsigned spins = 0; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
 #pragma unroll
-          for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          for (int c = 1; c < CW; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
           if (lo + R > (unsigned)p) break;
           __builtin_amdgcn_s_sleep(1);
         }
@@ -1065,11 +1068,13 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
     return;
   }
 
-  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
-  const int tn = rg * TPG + wave;
-  f32x4 c[NT];
+  // ---- compute waves: wave w owns row tiles rg * TPG + w * TPW .. + TPW - 1 over this block's K slice
+  const int tn = rg * TPG + wave * TPW;
+  f32x4 c[TPW][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   unsigned slot = 0;
   for (int p = 0; p < nph; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
@@ -1077,15 +1082,18 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
-    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * PH * 1024u + lane * 16;
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)(wave * TPW) * PH * 1024u + lane * 16;
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
       if (p * PH + j < Lc) {                  // wave-uniform: k-steps past the end of the slice are not multiplied
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)j * 1024));
+        bf16x8_t af[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) af[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
-          c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, c[nt], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], xf, c[t][nt], 0, 0, 0);
         }
       }
     }
@@ -1095,23 +1103,36 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   }
   float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N + t * 16) = c[t][nt];
 }
 static int g_gemv_bkl = -1;
 void set_gemv_bkl(int v) { g_gemv_bkl = v; }
 static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
+  const bool two = g_gemv_bkl == 2;          // 2: two row tiles per compute wave
   if (((a.N + 15) >> 4) == 256) {
     constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;
     static bool attr8 = false;
-    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
-    hipLaunchKernelGGL((k_gemv_bkl<8>), dim3(256), dim3(9 * 64), lds, s, a);
+    if (!attr8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr8 = true;
+    }
+    if (two) hipLaunchKernelGGL((k_gemv_bkl<8, 4>), dim3(256), dim3(5 * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_gemv_bkl<8, 8>), dim3(256), dim3(9 * 64), lds, s, a);
   } else {
     constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 5 + 12;
     static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
-    hipLaunchKernelGGL((k_gemv_bkl<4>), dim3(256), dim3(5 * 64), lds, s, a);
+    if (!attr4) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr4 = true;
+    }
+    if (two) hipLaunchKernelGGL((k_gemv_bkl<4, 2>), dim3(256), dim3(3 * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_gemv_bkl<4, 4>), dim3(256), dim3(5 * 64), lds, s, a);
   }
   return true;
 }

@@ -4,6 +4,7 @@ kernel (RMSNorm + gate/up GEMV + SiLU*mul) from the rocprofv3 --pmc FETCH_SIZE s
 the sha256 of the kernel source they were measured on.  bench.py reports the figure only while that hash matches.
 
     python tools/make_dominant_kernel_json.py profiles/r02_kernel_stats.csv profiles/r02_pmc_fetch.csv detikzify-ds-7b"""
+import os
 import csv
 import hashlib
 import json
@@ -25,7 +26,7 @@ for row in csv.DictReader(open(stats_csv)):
 for row in csv.DictReader(open(pmc_csv)):
     if row["counter"] == "FETCH_SIZE" and row["kernel"].startswith(PREFIX):
         out["hbm_read_bytes_per_launch"] = float(row["hbm_read_bytes_per_launch_x2"])
-        out["traffic_source"] = f"{pmc_csv} (rocprofv3 --pmc FETCH_SIZE in its own pass, x 1024 B, x2 gfx950 correction: guides/MI355X_MICROARCH.md §HBM)"
+        out["traffic_source"] = f"profiles/{os.path.basename(pmc_csv)} (rocprofv3 --pmc FETCH_SIZE in its own pass, x 1024 B, x2 gfx950 correction: guides/MI355X_MICROARCH.md §HBM)"
         break
 missing = [k for k in ("rocprofv3_avg_us", "hbm_read_bytes_per_launch") if k not in out]
 if missing:
