@@ -453,26 +453,31 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // Q3 (QKV of an MHA model, NC = 2): the role has (H + KVH) * 4 RoPE pair units and KVH * 8 V row tiles that need no partner — 1.5 pair
 // units per CU for ds-7b, which no whole number of units per block balances (192 blocks of 2 units leave a quarter of the chip idle).
 // Here block b owns pair unit b of the q / k sections (wave 0) AND V row tile b (wave 1): 256 blocks x 3 row tiles, every CU busy.
-template <int EPI, int NC, int CHP4, bool F8 = false, bool Q3 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
-__global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
+// LW loader waves: a wave's vector-memory counter holds 63 outstanding instructions = 63 KiB of LDS-DMA pieces, and at ~2 us of latency
+// under load that caps ONE loader at ~30-39 GB/s per CU whatever the ring depth (profiles/r03f_step_time_q3_bkl2.txt: every role took
+// ~1 us per phase regardless of the bytes in it).  With LW = 2 the loaders take alternate phases, each with its own counter and its own
+// "landed" word; R = ring depth in phases.
+template <int EPI, int NC, int CHP4, bool F8 = false, bool Q3 = false, int LW = 1, int R = 3>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
   static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
-  constexpr int T = 2, NT = 4, PH = 4, R = 3;
+  constexpr int T = 2, NT = 4, PH = 4;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
   constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
   constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4 * LW;
   constexpr int PIECES = NT * PH + TILES * WT;                   // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + LW); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
 
-  if (wave == NC) {
-    // ---- loader wave
+  if (wave >= NC) {
+    // ---- loader wave l: phases l, l + LW, ...
+    const int l = wave - NC;
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
@@ -491,8 +496,9 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
                    : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
-    unsigned slot = 0;
-    for (int p = 0; p < NPH; ++p) {
+    unsigned slot = (unsigned)l % R;
+    int own = 0;                            // own phases issued so far
+    for (int p = l; p < NPH; p += LW, ++own) {
       if (p >= R) {                         // the slot still holds phase p - R: every compute wave must have released it
         for (unsigned spins = 0; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
@@ -503,21 +509,29 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
         }
       }
       const size_t adv = (size_t)p * PH * 1024;
+      const int skip = p >= R * LW ? (a.probe & 3) : 0;          // timing experiments: leave an operand's DMA out once the ring is primed
+      if (!(skip & 1)) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+      }
+      if (!(skip & 2)) {
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) {
-        if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
-        else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
+        for (int j = 0; j < TILES; ++j) {
+          if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
+          else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
+        }
       }
-      if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        bl_st(OFF_FILLED, (unsigned)p);
+      if (own >= 1) {                       // this wave's previous phase has landed when only this phase's loads are outstanding
+        if (skip == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        else if (skip == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TILES * WT) : "memory");
+        else if (skip == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NT * PH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
       }
-      slot = slot + 1 == R ? 0 : slot + 1;
+      slot = (slot + LW) % R;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bl_st(OFF_FILLED, (unsigned)NPH);
+    bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
     return;
   }
 
@@ -532,28 +546,37 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
   unsigned slot = 0;
   for (int p = 0; p < NPH; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      if (bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW)) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
     const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * WT * 1024u + lane * 16;
+    if (!(a.probe & 4)) {
+      // every fragment read of the phase goes out before the first MFMA (one wave per SIMD: nothing else hides the LDS latency; the
+      // k-step-at-a-time form took 0.95 us per phase, as long as the DMA of the phase itself — profiles/r03h_loader_kernel_probe.txt)
+      u32x4 xr[PH][NT], wr[T][F8 ? WT : PH];
 #pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      bf16x8_t xf[NT];
+      for (int j = 0; j < PH; ++j) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+        for (int nt = 0; nt < NT; ++nt) xr[j][nt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024);
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if (Q3 && t >= myT) continue;
-        bf16x8_t af;
-        if (F8) {
-          const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
-          af = gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]);
-        } else {
-          af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+        for (int t = 0; t < T; ++t) {
+          if (Q3 && t >= myT) continue;
+          if (F8) { if (!(j & 1)) wr[t][j / 2] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024); }
+          else wr[t][j] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024);
         }
+      }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
+      for (int j = 0; j < PH; ++j) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (Q3 && t >= myT) continue;
+          bf16x8_t af;
+          if (F8) af = gg_f8x8_to_bf16x8(wr[t][j / 2][2 * (j & 1)], wr[t][j / 2][2 * (j & 1) + 1]);
+          else af = __builtin_bit_cast(bf16x8_t, wr[t][j]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, xr[j][nt]), c[t][nt], 0, 0, 0);
+        }
       }
     }
     if ((p + 1) % CHP4 == 0) {              // a k_gemv_b wave slice is complete: slice sums are added in slice order
@@ -566,7 +589,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
-  if (g >= groups) return;
+  if (g >= groups || (a.probe & 8)) return;
   if (Q3 && wave == 1) {                    // the V row tile of this block: rows (H + KVH) * 128 + 16 b .. + 15 = dims (b & 7) * 16 .. of V head b >> 3
     const int b = blockIdx.x, head = b >> 3;
 #pragma unroll
@@ -604,32 +627,52 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
 }
 
 // QKV of an MHA model as 3 row tiles per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
-template <int CHP4>
-static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (3 * 4 * 1024) + 4 * 3 + 12;
+static int g_gemv_probe = 0;
+void set_gemv_probe(int v) { g_gemv_probe = v; }
+static int g_gemv_loaders = -1;                 // loader waves per block of k_gemv_bl / k_gemv_bkl (1 or 2)
+void set_gemv_loaders(int v) { g_gemv_loaders = v; }
+static int gemv_loaders() {
+  if (g_gemv_loaders < 0) { const char* e = getenv("DTK_GEMV_LOADERS"); g_gemv_loaders = e ? atoi(e) : 1; }
+  return g_gemv_loaders >= 2 ? 2 : 1;
+}
+template <int CHP4, int LW, int R>
+static void launch_bl_q3_lw(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW) + 12;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int blocks = (a.H + a.KVH) * 4;
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, true>), dim3(blocks), dim3(3 * 64), lds, s, a);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, true>), dim3(blocks), dim3(3 * 64), lds, s, a);
+  GemvBArgs ap = a; ap.probe = g_gemv_probe;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, true, LW, R>), dim3(blocks), dim3((2 + LW) * 64), lds, s, ap);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, true, LW, R>), dim3(blocks), dim3((2 + LW) * 64), lds, s, ap);
+}
+template <int CHP4>
+static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
+  if (gemv_loaders() == 2) launch_bl_q3_lw<CHP4, 2, 5>(a, s);      // 28 KiB phases: a ring of 5, four phases in flight over the two loaders
+  else launch_bl_q3_lw<CHP4, 1, 3>(a, s);
 }
 
-template <int EPI, int NC, int CHP4>
-static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;        // (the fp8 kernel needs less; one size for both)
+template <int EPI, int NC, int CHP4, int LW>
+static void launch_bl_one_lw(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + LW) + 12;        // (the fp8 kernel needs less; one size for both)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, false, LW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true, false, LW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  GemvBArgs ap = a; ap.probe = g_gemv_probe;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true, false, LW, 3>), dim3((groups + NC - 1) / NC), dim3((NC + LW) * 64), lds, s, ap);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false, false, LW, 3>), dim3((groups + NC - 1) / NC), dim3((NC + LW) * 64), lds, s, ap);
+}
+template <int EPI, int NC, int CHP4>
+static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
+  if (gemv_loaders() == 2) launch_bl_one_lw<EPI, NC, CHP4, 2>(a, s);
+  else launch_bl_one_lw<EPI, NC, CHP4, 1>(a, s);
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -1004,12 +1047,12 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
 }
 // CW compute waves own TPG / CW row tiles each: with two tiles per wave an x fragment read from LDS feeds two A fragments (LDS reads per
 // phase 160 -> 96 KiB at TPG = 8) for twice the MFMAs per wave.
-template <int TPG, int CW = TPG>
-__global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
+template <int TPG, int CW = TPG, int LW = 1>      // LW loader waves taking alternate phases (see k_gemv_bl)
+__global__ __launch_bounds__((CW + LW) * 64) void k_gemv_bkl(GemvBArgs a) {
   constexpr int NT = 4, PH = 4, R = 3, TPW = TPG / CW;
   static_assert(TPW * CW == TPG, "row tiles divide over the compute waves");
   constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4 * LW;
   constexpr int PIECES = (NT + TPG) * PH;
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1022,16 +1065,18 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
   const int Lc = s1 - s0;                                       // >= 1 (launcher)
   const int nph = (Lc + PH - 1) / PH;
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (CW + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (CW + LW); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
 
-  if (wave == CW) {   // ---- loader wave
+  if (wave >= CW) {   // ---- loader wave l: phases l, l + LW, ...
+    const int l = wave - CW;
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;   // tile rg*TPG + w at + w * nsteps KiB
-    unsigned slot = 0;
-    for (int p = 0; p < nph; ++p) {
+    unsigned slot = (unsigned)l % R;
+    int own = 0;
+    for (int p = l; p < nph; p += LW, ++own) {
       if (p >= R) {
         for (unsigned spins = 0; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
@@ -1042,11 +1087,16 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
         }
       }
       const size_t adv = (size_t)p * PH * 1024;
+      const int skip = p >= R * LW ? (a.probe & 3) : 0;          // timing experiments (whole phases only)
       if ((p + 1) * PH <= Lc) {               // a whole phase inside the slice: runs of four consecutive pieces
+        if (!(skip & 1)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+          for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+        }
+        if (!(skip & 2)) {
 #pragma unroll
-        for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
+          for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
+        }
       } else {                                // the ragged last phase: piece by piece, clamped to the slice's last k-step
 #pragma unroll
         for (int j = 0; j < PH; ++j) {
@@ -1057,14 +1107,17 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
           for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
         }
       }
-      if (p >= 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        bl_st(OFF_FILLED, (unsigned)p);
+      if (own >= 1) {
+        if (skip == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        else if (skip == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TPG * PH) : "memory");
+        else if (skip == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NT * PH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
       }
-      slot = slot + 1 == R ? 0 : slot + 1;
+      slot = (slot + LW) % R;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bl_st(OFF_FILLED, (unsigned)nph);
+    bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
     return;
   }
 
@@ -1078,22 +1131,30 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   unsigned slot = 0;
   for (int p = 0; p < nph; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      if (bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW)) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
     const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)(wave * TPW) * PH * 1024u + lane * 16;
+    if (!(a.probe & 4)) {
+      // all fragment reads of the phase before its first MFMA (see k_gemv_bl); k-steps past the end of the slice (wave-uniform) are
+      // read — the loader fetched them clamped — and not multiplied
+      u32x4 xr[PH][NT], wr[TPW][PH];
 #pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      if (p * PH + j < Lc) {                  // wave-uniform: k-steps past the end of the slice are not multiplied
-        bf16x8_t af[TPW];
+      for (int j = 0; j < PH; ++j) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) af[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+        for (int t = 0; t < TPW; ++t) wr[t][j] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+        for (int nt = 0; nt < NT; ++nt) xr[j][nt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024);
+      }
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], xf, c[t][nt], 0, 0, 0);
+      for (int j = 0; j < PH; ++j) {
+        if (p * PH + j < Lc) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+              c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[t][j]), __builtin_bit_cast(bf16x8_t, xr[j][nt]), c[t][nt], 0, 0, 0);
         }
       }
     }
@@ -1101,6 +1162,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
     if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
+  if (a.probe & 8) return;
   float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
@@ -1113,27 +1175,25 @@ static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
   const bool two = g_gemv_bkl == 2;          // 2: two row tiles per compute wave
+  const bool lw2 = gemv_loaders() == 2;
+#define BKL_ATTR(TPG_, CW_, LW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, CW_, LW_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+  GemvBArgs ap = a; ap.probe = g_gemv_probe;
+#define BKL_GO(TPG_, CW_, LW_) hipLaunchKernelGGL((k_gemv_bkl<TPG_, CW_, LW_>), dim3(256), dim3((CW_ + LW_) * 64), lds, s, ap)
   if (((a.N + 15) >> 4) == 256) {
-    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;
+    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 10 + 12;
     static bool attr8 = false;
-    if (!attr8) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr8 = true;
-    }
-    if (two) hipLaunchKernelGGL((k_gemv_bkl<8, 4>), dim3(256), dim3(5 * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_gemv_bkl<8, 8>), dim3(256), dim3(9 * 64), lds, s, a);
+    if (!attr8) { BKL_ATTR(8, 8, 1); BKL_ATTR(8, 4, 1); BKL_ATTR(8, 8, 2); BKL_ATTR(8, 4, 2); attr8 = true; }
+    if (two) { if (lw2) BKL_GO(8, 4, 2); else BKL_GO(8, 4, 1); }
+    else { if (lw2) BKL_GO(8, 8, 2); else BKL_GO(8, 8, 1); }
   } else {
-    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 5 + 12;
+    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 6 + 12;
     static bool attr4 = false;
-    if (!attr4) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr4 = true;
-    }
-    if (two) hipLaunchKernelGGL((k_gemv_bkl<4, 2>), dim3(256), dim3(3 * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_gemv_bkl<4, 4>), dim3(256), dim3(5 * 64), lds, s, a);
+    if (!attr4) { BKL_ATTR(4, 4, 1); BKL_ATTR(4, 2, 1); BKL_ATTR(4, 4, 2); BKL_ATTR(4, 2, 2); attr4 = true; }
+    if (two) { if (lw2) BKL_GO(4, 2, 2); else BKL_GO(4, 2, 1); }
+    else { if (lw2) BKL_GO(4, 4, 2); else BKL_GO(4, 4, 1); }
   }
+#undef BKL_ATTR
+#undef BKL_GO
   return true;
 }
 
