@@ -106,7 +106,6 @@ struct GemvBArgs {
   const float* wscale;
   int nt;                              // 16-slot column tiles: 1 (<= 16 slots), 2 (<= 32) or 4 (<= 64)
   float* kpart; unsigned* kctr;        // k_gemv_bk: K-split partials [8][N / 16][4][256] fp32, one arrival counter per row tile (zero between launches)
-  int probe;                           // k_gemv_bl / k_gemv_bkl timing experiments (WRONG RESULTS): 1 no x DMA after the ring is primed, 2 no weight DMA, 4 no LDS reads / MFMA, 8 no epilogue / stores
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
@@ -115,8 +114,6 @@ void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: k_gemv_bx with both operands streamed into LDS rings by a loader wave (LDS-DMA); false = not covered / off
 void set_gemv_bl(int v);       // bit 0: gate/up + lm_head, bit 1: qkv
-void set_gemv_probe(int v);    // GemvBArgs::probe for every k_gemv_bl / k_gemv_bkl launch (0 = off)
-void set_gemv_loaders(int v);  // loader waves per block of k_gemv_bl / k_gemv_bkl: 1 or 2 (alternate phases; a wave holds at most 63 LDS-DMA pieces in flight)
 void set_gemv_bkl(int v);      // 1: the resid_kparts weight kernel with LDS-DMA operand rings (k_gemv_bkl) instead of k_gemv_bkp
 bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: N = d roles at 64 slots, K split over 8 CUs per row group; false = not covered
 void set_gemv_bk(int v);       // 0: off, 1: on

@@ -450,55 +450,42 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps): half the DMA pieces and ring bytes, widened to
 // bf16 in registers and fed to the same MFMAs in the same k order, the per-row power-of-two scale on the finished sum — bit-identical
 // to the fp8 k_gemv_bx / k_gemv_b kernels
-// Q3 (QKV of an MHA model, NC = 2): the role has (H + KVH) * 4 RoPE pair units and KVH * 8 V row tiles that need no partner — 1.5 pair
-// units per CU for ds-7b, which no whole number of units per block balances (192 blocks of 2 units leave a quarter of the chip idle).
-// Here block b owns pair unit b of the q / k sections (wave 0) AND V row tile b (wave 1): 256 blocks x 3 row tiles, every CU busy.
-// LW loader waves: a wave's vector-memory counter holds 63 outstanding instructions = 63 KiB of LDS-DMA pieces, and at ~2 us of latency
-// under load that caps ONE loader at ~30-39 GB/s per CU whatever the ring depth (profiles/r03f_step_time_q3_bkl2.txt: every role took
-// ~1 us per phase regardless of the bytes in it).  With LW = 2 the loaders take alternate phases, each with its own counter and its own
-// "landed" word; R = ring depth in phases.
-template <int EPI, int NC, int CHP4, bool F8 = false, bool Q3 = false, int LW = 1, int R = 3>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
-__global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
-  static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
-  constexpr int T = 2, NT = 4, PH = 4;
+template <int EPI, int NC, int CHP4, bool F8 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
+  constexpr int T = 2, NT = 4, PH = 4, R = 3;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
-  constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
-  constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4 * LW;
-  constexpr int PIECES = NT * PH + TILES * WT;                   // LDS-DMA instructions per phase
+  constexpr unsigned WPH = NC * T * WT * 1024u;                  // weight bytes of one phase (8 KiB per unit; fp8: 4)
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr int PIECES = NT * PH + NC * T * WT;                  // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + LW); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
 
-  if (wave >= NC) {
-    // ---- loader wave l: phases l, l + LW, ...
-    const int l = wave - NC;
+  if (wave == NC) {
+    // ---- loader wave
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
-    const unsigned char* wsrc[TILES];
+    const unsigned char* wsrc[NC][T];
 #pragma unroll
-    for (int j = 0; j < TILES; ++j) {
-      int tn;
-      if (Q3) {
-        tn = j < 2 ? gg_tile_row0<EPI, T>(a, blockIdx.x, j) >> 4 : (a.H + a.KVH) * 8 + (int)blockIdx.x;
-      } else {
-        const int g = blockIdx.x * NC + j / T, gc = g < groups ? g : groups - 1;    // a surplus unit streams valid memory and stores nothing
-        tn = gg_tile_row0<EPI, T>(a, gc, j % T) >> 4;
+    for (int c = 0; c < NC; ++c) {
+      const int g = blockIdx.x * NC + c, gc = g < groups ? g : groups - 1;      // a surplus unit streams valid memory and stores nothing
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
+        const int tn_max = ((a.N + 15) >> 4) - 1;
+        if (tn > tn_max) tn = tn_max;
+        wsrc[c][t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                        : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
       }
-      const int tn_max = ((a.N + 15) >> 4) - 1;
-      if (tn > tn_max) tn = tn_max;
-      wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
-                   : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
-    unsigned slot = (unsigned)l % R;
-    int own = 0;                            // own phases issued so far
-    for (int p = l; p < NPH; p += LW, ++own) {
+    unsigned slot = 0;
+    for (int p = 0; p < NPH; ++p) {
       if (p >= R) {                         // the slot still holds phase p - R: every compute wave must have released it
         for (unsigned spins = 0; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
@@ -509,35 +496,28 @@ __global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
         }
       }
       const size_t adv = (size_t)p * PH * 1024;
-      const int skip = p >= R * LW ? (a.probe & 3) : 0;          // timing experiments: leave an operand's DMA out once the ring is primed
-      if (!(skip & 1)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
-      }
-      if (!(skip & 2)) {
+      for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
 #pragma unroll
-        for (int j = 0; j < TILES; ++j) {
-          if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
-          else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (F8) glds_run2_nt(wsrc[c][t] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)(c * T + t) * WT * 1024u);
+          else glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
         }
+      if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)p);
       }
-      if (own >= 1) {                       // this wave's previous phase has landed when only this phase's loads are outstanding
-        if (skip == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        else if (skip == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TILES * WT) : "memory");
-        else if (skip == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NT * PH) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
-      }
-      slot = (slot + LW) % R;
+      slot = slot + 1 == R ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
+    bl_st(OFF_FILLED, (unsigned)NPH);
     return;
   }
 
   // ---- compute waves: one unit each over the full K, operands from LDS
-  const int g = Q3 ? (int)blockIdx.x : blockIdx.x * NC + wave;
-  const int myT = (Q3 && wave == 1) ? 1 : T;                  // Q3: wave 1 owns the single V row tile (ring tile 2)
+  const int g = blockIdx.x * NC + wave;
   f32x4 tot[T][NT], c[T][NT];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -546,37 +526,27 @@ __global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
   unsigned slot = 0;
   for (int p = 0; p < NPH; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW)) break;
+      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
     const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * WT * 1024u + lane * 16;
-    if (!(a.probe & 4)) {
-      // every fragment read of the phase goes out before the first MFMA (one wave per SIMD: nothing else hides the LDS latency; the
-      // k-step-at-a-time form took 0.95 us per phase, as long as the DMA of the phase itself — profiles/r03h_loader_kernel_probe.txt)
-      u32x4 xr[PH][NT], wr[T][F8 ? WT : PH];
 #pragma unroll
-      for (int j = 0; j < PH; ++j) {
+    for (int j = 0; j < PH; ++j) {
+      bf16x8_t xf[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xr[j][nt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024);
+      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (Q3 && t >= myT) continue;
-          if (F8) { if (!(j & 1)) wr[t][j / 2] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024); }
-          else wr[t][j] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024);
+      for (int t = 0; t < T; ++t) {
+        bf16x8_t af;
+        if (F8) {
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
+          af = gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]);
+        } else {
+          af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
         }
-      }
 #pragma unroll
-      for (int j = 0; j < PH; ++j) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (Q3 && t >= myT) continue;
-          bf16x8_t af;
-          if (F8) af = gg_f8x8_to_bf16x8(wr[t][j / 2][2 * (j & 1)], wr[t][j / 2][2 * (j & 1) + 1]);
-          else af = __builtin_bit_cast(bf16x8_t, wr[t][j]);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, xr[j][nt]), c[t][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
       }
     }
     if ((p + 1) % CHP4 == 0) {              // a k_gemv_b wave slice is complete: slice sums are added in slice order
@@ -589,23 +559,7 @@ __global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
     if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
-  if (g >= groups || (a.probe & 8)) return;
-  if (Q3 && wave == 1) {                    // the V row tile of this block: rows (H + KVH) * 128 + 16 b .. + 15 = dims (b & 7) * 16 .. of V head b >> 3
-    const int b = blockIdx.x, head = b >> 3;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + (lane & 15);
-      if (!a.bs->active[n]) continue;
-      bf16_t* dst = a.vcache + (size_t)n * a.kv_slot_stride + ((size_t)head * a.T_max + a.st[n].pos) * 128 + (b & 7) * 16 + (lane >> 4) * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = tot[0][nt][r];
-        if (F8) v *= a.wscale[(a.H + a.KVH) * 128 + b * 16 + (lane >> 4) * 4 + r];
-        dst[r] = f2bf(rbf(v));
-      }
-    }
-    return;
-  }
+  if (g >= groups) return;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = nt * 16 + (lane & 15);
@@ -626,53 +580,18 @@ __global__ __launch_bounds__((NC + LW) * 64) void k_gemv_bl(GemvBArgs a) {
   }
 }
 
-// QKV of an MHA model as 3 row tiles per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
-static int g_gemv_probe = 0;
-void set_gemv_probe(int v) { g_gemv_probe = v; }
-static int g_gemv_loaders = -1;                 // loader waves per block of k_gemv_bl / k_gemv_bkl (1 or 2)
-void set_gemv_loaders(int v) { g_gemv_loaders = v; }
-static int gemv_loaders() {
-  if (g_gemv_loaders < 0) { const char* e = getenv("DTK_GEMV_LOADERS"); g_gemv_loaders = e ? atoi(e) : 1; }
-  return g_gemv_loaders >= 2 ? 2 : 1;
-}
-template <int CHP4, int LW, int R>
-static void launch_bl_q3_lw(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW) + 12;
+template <int EPI, int NC, int CHP4>
+static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;        // (the fp8 kernel needs less; one size for both)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  const int blocks = (a.H + a.KVH) * 4;
-  GemvBArgs ap = a; ap.probe = g_gemv_probe;
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, true, LW, R>), dim3(blocks), dim3((2 + LW) * 64), lds, s, ap);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, true, LW, R>), dim3(blocks), dim3((2 + LW) * 64), lds, s, ap);
-}
-template <int CHP4>
-static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
-  if (gemv_loaders() == 2) launch_bl_q3_lw<CHP4, 2, 5>(a, s);      // 28 KiB phases: a ring of 5, four phases in flight over the two loaders
-  else launch_bl_q3_lw<CHP4, 1, 3>(a, s);
-}
-
-template <int EPI, int NC, int CHP4, int LW>
-static void launch_bl_one_lw(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + LW) + 12;        // (the fp8 kernel needs less; one size for both)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, false, LW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true, false, LW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  GemvBArgs ap = a; ap.probe = g_gemv_probe;
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true, false, LW, 3>), dim3((groups + NC - 1) / NC), dim3((NC + LW) * 64), lds, s, ap);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false, false, LW, 3>), dim3((groups + NC - 1) / NC), dim3((NC + LW) * 64), lds, s, ap);
-}
-template <int EPI, int NC, int CHP4>
-static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
-  if (gemv_loaders() == 2) launch_bl_one_lw<EPI, NC, CHP4, 2>(a, s);
-  else launch_bl_one_lw<EPI, NC, CHP4, 1>(a, s);
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -692,15 +611,8 @@ bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
   if (a.W8 && !(g_gemv_bl & 4)) return false;     // fp8 weights: bit 2 (measured neutral against the fp8 k_gemv_bx: 4.01 vs 4.04 ms per 64-slot step)
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
-  if (epi == EPI_QKV ? !(g_gemv_bl & (2 | 8 | 16)) : !(g_gemv_bl & 1)) return false;
+  if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
   if (a.K != 4096 && a.K != 2048) return false;
-  if (epi == EPI_QKV && (g_gemv_bl & (8 | 16))) {      // bit 3: a pair unit + a V row tile per block for MHA models whose q / k pair count fills the chip; bit 4: for any MHA model (tests)
-    if (a.H == a.KVH && a.N == (a.H + 2 * a.KVH) * 128 && ((g_gemv_bl & 16) || (a.H + a.KVH) * 4 * 4 >= cu_count() * 3)) {
-      if (a.K == 4096) launch_bl_q3<4>(a, s); else launch_bl_q3<2>(a, s);
-      return true;
-    }
-    if (!(g_gemv_bl & 2)) return false;
-  }
   if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
   if (epi == EPI_LOGITS && (a.N & 31)) return false;
   const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
@@ -1045,14 +957,11 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-// CW compute waves own TPG / CW row tiles each: with two tiles per wave an x fragment read from LDS feeds two A fragments (LDS reads per
-// phase 160 -> 96 KiB at TPG = 8) for twice the MFMAs per wave.
-template <int TPG, int CW = TPG, int LW = 1>      // LW loader waves taking alternate phases (see k_gemv_bl)
-__global__ __launch_bounds__((CW + LW) * 64) void k_gemv_bkl(GemvBArgs a) {
-  constexpr int NT = 4, PH = 4, R = 3, TPW = TPG / CW;
-  static_assert(TPW * CW == TPG, "row tiles divide over the compute waves");
+template <int TPG>
+__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
+  constexpr int NT = 4, PH = 4, R = 3;
   constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4 * LW;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
   constexpr int PIECES = (NT + TPG) * PH;
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1065,38 +974,31 @@ __global__ __launch_bounds__((CW + LW) * 64) void k_gemv_bkl(GemvBArgs a) {
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
   const int Lc = s1 - s0;                                       // >= 1 (launcher)
   const int nph = (Lc + PH - 1) / PH;
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (CW + LW); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
 
-  if (wave >= CW) {   // ---- loader wave l: phases l, l + LW, ...
-    const int l = wave - CW;
+  if (wave == TPG) {   // ---- loader wave
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;   // tile rg*TPG + w at + w * nsteps KiB
-    unsigned slot = (unsigned)l % R;
-    int own = 0;
-    for (int p = l; p < nph; p += LW, ++own) {
+    unsigned slot = 0;
+    for (int p = 0; p < nph; ++p) {
       if (p >= R) {
         for (unsigned spins = 0; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
 #pragma unroll
-          for (int c = 1; c < CW; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
           if (lo + R > (unsigned)p) break;
           __builtin_amdgcn_s_sleep(1);
         }
       }
       const size_t adv = (size_t)p * PH * 1024;
-      const int skip = p >= R * LW ? (a.probe & 3) : 0;          // timing experiments (whole phases only)
       if ((p + 1) * PH <= Lc) {               // a whole phase inside the slice: runs of four consecutive pieces
-        if (!(skip & 1)) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
-        }
-        if (!(skip & 2)) {
+        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
 #pragma unroll
-          for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
-        }
+        for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
       } else {                                // the ragged last phase: piece by piece, clamped to the slice's last k-step
 #pragma unroll
         for (int j = 0; j < PH; ++j) {
@@ -1107,54 +1009,38 @@ __global__ __launch_bounds__((CW + LW) * 64) void k_gemv_bkl(GemvBArgs a) {
           for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
         }
       }
-      if (own >= 1) {
-        if (skip == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        else if (skip == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TPG * PH) : "memory");
-        else if (skip == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NT * PH) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
+      if (p >= 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)p);
       }
-      slot = (slot + LW) % R;
+      slot = slot + 1 == R ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
+    bl_st(OFF_FILLED, (unsigned)nph);
     return;
   }
 
-  // ---- compute waves: wave w owns row tiles rg * TPG + w * TPW .. + TPW - 1 over this block's K slice
-  const int tn = rg * TPG + wave * TPW;
-  f32x4 c[TPW][NT];
+  // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
+  const int tn = rg * TPG + wave;
+  f32x4 c[NT];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   unsigned slot = 0;
   for (int p = 0; p < nph; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW)) break;
+      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
-    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)(wave * TPW) * PH * 1024u + lane * 16;
-    if (!(a.probe & 4)) {
-      // all fragment reads of the phase before its first MFMA (see k_gemv_bl); k-steps past the end of the slice (wave-uniform) are
-      // read — the loader fetched them clamped — and not multiplied
-      u32x4 xr[PH][NT], wr[TPW][PH];
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * PH * 1024u + lane * 16;
 #pragma unroll
-      for (int j = 0; j < PH; ++j) {
+    for (int j = 0; j < PH; ++j) {
+      if (p * PH + j < Lc) {                  // wave-uniform: k-steps past the end of the slice are not multiplied
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)j * 1024));
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) wr[t][j] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xr[j][nt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024);
-      }
-#pragma unroll
-      for (int j = 0; j < PH; ++j) {
-        if (p * PH + j < Lc) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-              c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[t][j]), __builtin_bit_cast(bf16x8_t, xr[j][nt]), c[t][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+          c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, c[nt], 0, 0, 0);
         }
       }
     }
@@ -1162,38 +1048,26 @@ __global__ __launch_bounds__((CW + LW) * 64) void k_gemv_bkl(GemvBArgs a) {
     if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
-  if (a.probe & 8) return;
   float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N + t * 16) = c[t][nt];
+  for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
 }
 static int g_gemv_bkl = -1;
 void set_gemv_bkl(int v) { g_gemv_bkl = v; }
 static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
-  const bool two = g_gemv_bkl == 2;          // 2: two row tiles per compute wave
-  const bool lw2 = gemv_loaders() == 2;
-#define BKL_ATTR(TPG_, CW_, LW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, CW_, LW_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-  GemvBArgs ap = a; ap.probe = g_gemv_probe;
-#define BKL_GO(TPG_, CW_, LW_) hipLaunchKernelGGL((k_gemv_bkl<TPG_, CW_, LW_>), dim3(256), dim3((CW_ + LW_) * 64), lds, s, ap)
   if (((a.N + 15) >> 4) == 256) {
-    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 10 + 12;
+    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;
     static bool attr8 = false;
-    if (!attr8) { BKL_ATTR(8, 8, 1); BKL_ATTR(8, 4, 1); BKL_ATTR(8, 8, 2); BKL_ATTR(8, 4, 2); attr8 = true; }
-    if (two) { if (lw2) BKL_GO(8, 4, 2); else BKL_GO(8, 4, 1); }
-    else { if (lw2) BKL_GO(8, 8, 2); else BKL_GO(8, 8, 1); }
+    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    hipLaunchKernelGGL((k_gemv_bkl<8>), dim3(256), dim3(9 * 64), lds, s, a);
   } else {
-    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 6 + 12;
+    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 5 + 12;
     static bool attr4 = false;
-    if (!attr4) { BKL_ATTR(4, 4, 1); BKL_ATTR(4, 2, 1); BKL_ATTR(4, 4, 2); BKL_ATTR(4, 2, 2); attr4 = true; }
-    if (two) { if (lw2) BKL_GO(4, 2, 2); else BKL_GO(4, 2, 1); }
-    else { if (lw2) BKL_GO(4, 4, 2); else BKL_GO(4, 4, 1); }
+    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    hipLaunchKernelGGL((k_gemv_bkl<4>), dim3(256), dim3(5 * 64), lds, s, a);
   }
-#undef BKL_ATTR
-#undef BKL_GO
   return true;
 }
 

@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ran at commit 689b07b, whose kernels_batch_gemm.hip has the experimental options; reverted afterwards — results: profiles/r03_loader_kernel_experiments.txt)
 # round 3, lease F: qkv as a RoPE pair unit + a V row tile per block (gemv_bl bit 3), k_gemv_bkl with two row tiles per compute wave
 # (gemv_bkl 2): identity tests, 64-slot step time per variant, per-kernel times of the best
 set -uo pipefail

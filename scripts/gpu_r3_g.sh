@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ran at commit 689b07b, whose kernels_batch_gemm.hip has the experimental options; reverted afterwards — results: profiles/r03_loader_kernel_experiments.txt)
 # round 3, lease G: TWO loader waves per block (alternate phases; one wave's vmcnt holds 63 pieces = 63 KiB in flight): identity tests,
 # 64-slot step time per variant, per-kernel times
 set -uo pipefail

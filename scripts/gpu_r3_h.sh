@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ran at commit 689b07b, whose kernels_batch_gemm.hip has the experimental options; reverted afterwards — results: profiles/r03_loader_kernel_experiments.txt)
 # round 3, lease H: where the loader-wave kernels' time goes — the 64-slot step with one operand's DMA / the MFMAs / the epilogue left
 # out (gemv_probe bits; wrong results), per-kernel times under rocprofv3
 set -uo pipefail

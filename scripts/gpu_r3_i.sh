@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ran at commit 689b07b, whose kernels_batch_gemm.hip has the experimental options; reverted afterwards — results: profiles/r03_loader_kernel_experiments.txt)
 # round 3, lease I: the loader-wave kernels with all LDS fragment reads of a phase issued before its MFMAs: identity tests, then
 # per-kernel times of the 64-slot step for (loaders, qkv form, probe) combinations
 set -uo pipefail
