@@ -450,61 +450,77 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps): half the DMA pieces and ring bytes, widened to
 // bf16 in registers and fed to the same MFMAs in the same k order, the per-row power-of-two scale on the finished sum — bit-identical
 // to the fp8 k_gemv_bx / k_gemv_b kernels
-template <int EPI, int NC, int CHP4, bool F8 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
-__global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
+// XW: the x fragments do NOT go through the LDS-DMA queue.  Leaving parts out showed what bounds the kernel (DESIGN §3.1b,
+// profiles/r03_loader_kernel_experiments.txt): every LDS-DMA piece costs the CU ~25-32 ns whichever wave issues it, so a phase of
+// 16 x + 24 weight pieces takes ~1 us — and 16 of the 40 were x from L2.  With XW an extra wave brings x in with ordinary 16-byte
+// loads (one phase ahead, in registers) and stores it to the ring with ds_write_b128; the DMA queue carries weights only.
+// Q3 (QKV of an MHA model, NC = 2): the role has (H + KVH) * 4 RoPE pair units and KVH * 8 V row tiles that need no partner — 1.5
+// pair units per CU for ds-7b, which no whole number of units per block balances.  Block b owns pair unit b of the q / k sections
+// (wave 0) AND V row tile b (wave 1): 256 blocks x 3 row tiles, every CU busy.
+// launch bound 2: a budget of 256 VGPRs keeps the MFMA accumulators in VGPRs; with 512 (one wave per SIMD) the compiler puts
+// them in AGPRs and copies all 32 to and fro every phase for the chain adds.
+template <int EPI, int NC, int CHP4, bool F8 = false, bool XW = false, bool Q3 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBArgs a) {
+  static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
   constexpr int T = 2, NT = 4, PH = 4, R = 3;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
+  constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
-  constexpr unsigned WPH = NC * T * WT * 1024u;                  // weight bytes of one phase (8 KiB per unit; fp8: 4)
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
-  constexpr int PIECES = NT * PH + NC * T * WT;                  // LDS-DMA instructions per phase
+  constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 8;
+  constexpr int PIECES = (XW ? 0 : NT * PH) + TILES * WT;        // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 2); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
-  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+  const int groups = Q3 ? (a.H + a.KVH) * 4 : gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+
+  auto wait_slot_free = [&](int p) {        // the ring slot of phase p still holds phase p - R: every compute wave must have released it
+    if (p < R) return;
+    for (unsigned spins = 0; spins < SPIN; ++spins) {
+      unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+      for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+      if (lo + R > (unsigned)p) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
 
   if (wave == NC) {
-    // ---- loader wave
+    // ---- loader wave (LDS-DMA)
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
-    const unsigned char* wsrc[NC][T];
+    const unsigned char* wsrc[TILES];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int g = blockIdx.x * NC + c, gc = g < groups ? g : groups - 1;      // a surplus unit streams valid memory and stores nothing
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
-        const int tn_max = ((a.N + 15) >> 4) - 1;
-        if (tn > tn_max) tn = tn_max;
-        wsrc[c][t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
-                        : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+    for (int j = 0; j < TILES; ++j) {
+      int tn;
+      if (Q3) {
+        tn = j < 2 ? gg_tile_row0<EPI, T>(a, blockIdx.x, j) >> 4 : (a.H + a.KVH) * 8 + (int)blockIdx.x;
+      } else {
+        const int g = blockIdx.x * NC + j / T, gc = g < groups ? g : groups - 1;    // a surplus unit streams valid memory and stores nothing
+        tn = gg_tile_row0<EPI, T>(a, gc, j % T) >> 4;
       }
+      const int tn_max = ((a.N + 15) >> 4) - 1;
+      if (tn > tn_max) tn = tn_max;
+      wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                   : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
     unsigned slot = 0;
     for (int p = 0; p < NPH; ++p) {
-      if (p >= R) {                         // the slot still holds phase p - R: every compute wave must have released it
-        for (unsigned spins = 0; spins < SPIN; ++spins) {
-          unsigned lo = bl_ld(OFF_DONE);
-#pragma unroll
-          for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
-          if (lo + R > (unsigned)p) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
+      wait_slot_free(p);
       const size_t adv = (size_t)p * PH * 1024;
+      if (!XW) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+      }
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (F8) glds_run2_nt(wsrc[c][t] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)(c * T + t) * WT * 1024u);
-          else glds_run4<true>(wsrc[c][t] + adv, OFF_W + slot * WPH + (unsigned)(c * T + t) * PH * 1024u);
-        }
+      for (int j = 0; j < TILES; ++j) {
+        if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
+        else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
+      }
       if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
         bl_st(OFF_FILLED, (unsigned)p);
@@ -516,8 +532,39 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     return;
   }
 
+  if (XW && wave == NC + 1) {
+    // ---- x wave: phase p + 1 is loaded into registers while phase p is stored to its ring slot
+    const unsigned char* xsrc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
+    u32x4 bufA[NT * PH], bufB[NT * PH];
+    auto fetch = [&](u32x4 (&buf)[NT * PH], int p) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < PH; ++j) buf[nt * PH + j] = *reinterpret_cast<const u32x4*>(xsrc[nt] + ((size_t)p * PH + j) * 1024);
+    };
+    auto put = [&](const u32x4 (&buf)[NT * PH], int p) {
+      wait_slot_free(p);
+      unsigned char* dst = smem + (unsigned)(p % R) * XPH + lane * 16;
+#pragma unroll
+      for (int i = 0; i < NT * PH; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 1024) = buf[i];
+      bl_drain();
+      bl_st(OFF_FILLED_X, (unsigned)p + 1u);
+    };
+    fetch(bufA, 0);
+    for (int p = 0; p < NPH; p += 2) {      // NPH is even (K = 2048 / 4096)
+      fetch(bufB, p + 1);
+      put(bufA, p);
+      if (p + 2 < NPH) fetch(bufA, p + 2);
+      put(bufB, p + 1);
+    }
+    return;
+  }
+
   // ---- compute waves: one unit each over the full K, operands from LDS
-  const int g = blockIdx.x * NC + wave;
+  const int g = Q3 ? (int)blockIdx.x : blockIdx.x * NC + wave;
+  const int myT = (Q3 && wave == 1) ? 1 : T;                  // Q3: wave 1 owns the single V row tile (ring tile 2)
   f32x4 tot[T][NT], c[T][NT];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -526,7 +573,9 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
   unsigned slot = 0;
   for (int p = 0; p < NPH; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      bool ok = bl_ld(OFF_FILLED) > (unsigned)p;
+      if (XW) ok = ok && bl_ld(OFF_FILLED_X) > (unsigned)p;
+      if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
@@ -538,6 +587,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
       for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+        if (Q3 && t >= myT) continue;
         bf16x8_t af;
         if (F8) {
           const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
@@ -560,6 +610,22 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
     slot = slot + 1 == R ? 0 : slot + 1;
   }
   if (g >= groups) return;
+  if (Q3 && wave == 1) {                    // the V row tile of this block: rows (H + KVH) * 128 + 16 b .. + 15 = dims (b & 7) * 16 .. of V head b >> 3
+    const int b = blockIdx.x, head = b >> 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + (lane & 15);
+      if (!a.bs->active[n]) continue;
+      bf16_t* dst = a.vcache + (size_t)n * a.kv_slot_stride + ((size_t)head * a.T_max + a.st[n].pos) * 128 + (b & 7) * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = tot[0][nt][r];
+        if (F8) v *= a.wscale[(a.H + a.KVH) * 128 + b * 16 + (lane >> 4) * 4 + r];
+        dst[r] = f2bf(rbf(v));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = nt * 16 + (lane & 15);
@@ -580,18 +646,48 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_bl(GemvBArgs a) {
   }
 }
 
-template <int EPI, int NC, int CHP4>
-static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 1) + 12;        // (the fp8 kernel needs less; one size for both)
+static int g_gemv_xw = -1;                      // x fragments by an extra wave's ordinary loads + ds_write instead of LDS-DMA pieces (k_gemv_bl, k_gemv_bkl)
+void set_gemv_xw(int v) { g_gemv_xw = v; }
+static bool gemv_xw() {
+  if (g_gemv_xw < 0) { const char* e = getenv("DTK_GEMV_XW"); g_gemv_xw = e ? atoi(e) : 0; }
+  return g_gemv_xw > 0;
+}
+template <int EPI, int NC, int CHP4, bool XW>
+static void launch_bl_one_xw(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 2) + 12;        // (the fp8 kernel needs less; one size for both)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  constexpr int threads = (NC + (XW ? 2 : 1)) * 64;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true, XW>), dim3((groups + NC - 1) / NC), dim3(threads), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false, XW>), dim3((groups + NC - 1) / NC), dim3(threads), lds, s, a);
+}
+template <int EPI, int NC, int CHP4>
+static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
+  if (gemv_xw()) launch_bl_one_xw<EPI, NC, CHP4, true>(a, s); else launch_bl_one_xw<EPI, NC, CHP4, false>(a, s);
+}
+// QKV of an MHA model as a pair unit + a V row tile per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
+template <int CHP4, bool XW>
+static void launch_bl_q3_xw(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (3 * 4 * 1024) + 4 * 4 + 12;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int blocks = (a.H + a.KVH) * 4;
+  constexpr int threads = (2 + (XW ? 2 : 1)) * 64;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true>), dim3(blocks), dim3(threads), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true>), dim3(blocks), dim3(threads), lds, s, a);
+}
+template <int CHP4>
+static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
+  if (gemv_xw()) launch_bl_q3_xw<CHP4, true>(a, s); else launch_bl_q3_xw<CHP4, false>(a, s);
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -611,8 +707,15 @@ bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
   if (a.W8 && !(g_gemv_bl & 4)) return false;     // fp8 weights: bit 2 (measured neutral against the fp8 k_gemv_bx: 4.01 vs 4.04 ms per 64-slot step)
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
-  if (epi == EPI_QKV ? !(g_gemv_bl & 2) : !(g_gemv_bl & 1)) return false;
+  if (epi == EPI_QKV ? !(g_gemv_bl & (2 | 8 | 16)) : !(g_gemv_bl & 1)) return false;
   if (a.K != 4096 && a.K != 2048) return false;
+  if (epi == EPI_QKV && (g_gemv_bl & (8 | 16))) {      // bit 3: a pair unit + a V row tile per block for MHA models whose q / k pair count fills the chip; bit 4: for any MHA model (tests)
+    if (a.H == a.KVH && a.N == (a.H + 2 * a.KVH) * 128 && ((g_gemv_bl & 16) || (a.H + a.KVH) * 4 * 4 >= cu_count() * 3)) {
+      if (a.K == 4096) launch_bl_q3<4>(a, s); else launch_bl_q3<2>(a, s);
+      return true;
+    }
+    if (!(g_gemv_bl & 2)) return false;
+  }
   if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
   if (epi == EPI_LOGITS && (a.N & 31)) return false;
   const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
@@ -957,12 +1060,12 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-template <int TPG>
-__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
+template <int TPG, bool XW = false>       // XW: x by an extra wave's ordinary loads + ds_write_b128 (see k_gemv_bl)
+__global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArgs a) {
   constexpr int NT = 4, PH = 4, R = 3;
   constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_DONE = OFF_FILLED + 4;
-  constexpr int PIECES = (NT + TPG) * PH;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 8;
+  constexpr int PIECES = ((XW ? 0 : NT) + TPG) * PH;
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -974,8 +1077,18 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
   const int Lc = s1 - s0;                                       // >= 1 (launcher)
   const int nph = (Lc + PH - 1) / PH;
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 2); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
+  auto wait_slot_free = [&](int p) {
+    if (p < R) return;
+    for (unsigned spins = 0; spins < SPIN; ++spins) {
+      unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+      for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+      if (lo + R > (unsigned)p) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
 
   if (wave == TPG) {   // ---- loader wave
     const unsigned char* xsrc[NT];
@@ -984,27 +1097,23 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;   // tile rg*TPG + w at + w * nsteps KiB
     unsigned slot = 0;
     for (int p = 0; p < nph; ++p) {
-      if (p >= R) {
-        for (unsigned spins = 0; spins < SPIN; ++spins) {
-          unsigned lo = bl_ld(OFF_DONE);
-#pragma unroll
-          for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
-          if (lo + R > (unsigned)p) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
+      wait_slot_free(p);
       const size_t adv = (size_t)p * PH * 1024;
       if ((p + 1) * PH <= Lc) {               // a whole phase inside the slice: runs of four consecutive pieces
+        if (!XW) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+          for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+        }
 #pragma unroll
         for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
       } else {                                // the ragged last phase: piece by piece, clamped to the slice's last k-step
 #pragma unroll
         for (int j = 0; j < PH; ++j) {
           const size_t kk = (size_t)min(p * PH + j, Lc - 1) * 1024;
+          if (!XW) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) glds16_any(xsrc[nt] + kk, slot * XPH + (unsigned)(nt * PH + j) * 1024u, false);
+            for (int nt = 0; nt < NT; ++nt) glds16_any(xsrc[nt] + kk, slot * XPH + (unsigned)(nt * PH + j) * 1024u, false);
+          }
 #pragma unroll
           for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
         }
@@ -1020,6 +1129,35 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
     return;
   }
 
+  if (XW && wave == TPG + 1) {   // ---- x wave: phase p + 1 in registers while phase p is stored to its ring slot
+    const unsigned char* xsrc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
+    u32x4 bufA[NT * PH], bufB[NT * PH];
+    auto fetch = [&](u32x4 (&buf)[NT * PH], int p) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < PH; ++j) buf[nt * PH + j] = *reinterpret_cast<const u32x4*>(xsrc[nt] + (size_t)min(p * PH + j, Lc - 1) * 1024);
+    };
+    auto put = [&](const u32x4 (&buf)[NT * PH], int p) {
+      wait_slot_free(p);
+      unsigned char* dst = smem + (unsigned)(p % R) * XPH + lane * 16;
+#pragma unroll
+      for (int i = 0; i < NT * PH; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 1024) = buf[i];
+      bl_drain();
+      bl_st(OFF_FILLED_X, (unsigned)p + 1u);
+    };
+    fetch(bufA, 0);
+    for (int p = 0; p < nph; p += 2) {
+      if (p + 1 < nph) fetch(bufB, p + 1);
+      put(bufA, p);
+      if (p + 2 < nph) fetch(bufA, p + 2);
+      if (p + 1 < nph) put(bufB, p + 1);
+    }
+    return;
+  }
+
   // ---- compute waves: wave w owns row tile rg * TPG + w over this block's K slice
   const int tn = rg * TPG + wave;
   f32x4 c[NT];
@@ -1028,7 +1166,9 @@ __global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bkl(GemvBArgs a) {
   unsigned slot = 0;
   for (int p = 0; p < nph; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+      bool ok = bl_ld(OFF_FILLED) > (unsigned)p;
+      if (XW) ok = ok && bl_ld(OFF_FILLED_X) > (unsigned)p;
+      if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
     const unsigned char* xb = smem + slot * XPH + lane * 16;
@@ -1057,17 +1197,22 @@ void set_gemv_bkl(int v) { g_gemv_bkl = v; }
 static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
+  const bool xw = gemv_xw();
+#define BKL_ATTR(TPG_, XW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
   if (((a.N + 15) >> 4) == 256) {
-    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 9 + 12;
+    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 10 + 12;
     static bool attr8 = false;
-    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
-    hipLaunchKernelGGL((k_gemv_bkl<8>), dim3(256), dim3(9 * 64), lds, s, a);
+    if (!attr8) { BKL_ATTR(8, false); BKL_ATTR(8, true); attr8 = true; }
+    if (xw) hipLaunchKernelGGL((k_gemv_bkl<8, true>), dim3(256), dim3(10 * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_gemv_bkl<8, false>), dim3(256), dim3(9 * 64), lds, s, a);
   } else {
-    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 5 + 12;
+    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 6 + 12;
     static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
-    hipLaunchKernelGGL((k_gemv_bkl<4>), dim3(256), dim3(5 * 64), lds, s, a);
+    if (!attr4) { BKL_ATTR(4, false); BKL_ATTR(4, true); attr4 = true; }
+    if (xw) hipLaunchKernelGGL((k_gemv_bkl<4, true>), dim3(256), dim3(6 * 64), lds, s, a);
+    else hipLaunchKernelGGL((k_gemv_bkl<4, false>), dim3(256), dim3(5 * 64), lds, s, a);
   }
+#undef BKL_ATTR
   return true;
 }
 
