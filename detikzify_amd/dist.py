@@ -149,11 +149,11 @@ def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys"
     is allowed to use; returns the CPU list, or None when nothing was changed (unknown topology, DTK_NO_PIN=1)."""
     if os.environ.get("DTK_NO_PIN") or not torch.cuda.is_available():
         return None
-    i = torch.cuda.current_device() if device_index is None else device_index
-    props = torch.cuda.get_device_properties(i)
     try:
+        i = torch.cuda.current_device() if device_index is None else device_index
+        props = torch.cuda.get_device_properties(i)
         bdf = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}.0"
-    except (AttributeError, TypeError, ValueError):
+    except (AttributeError, TypeError, ValueError, RuntimeError, AssertionError):
         return None
     cpus = gpu_numa_cpus(bdf, sysfs)
     if not cpus:
@@ -161,7 +161,10 @@ def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys"
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
     if not allowed:
         return None
-    os.sched_setaffinity(0, allowed)
+    try:
+        os.sched_setaffinity(0, allowed)
+    except OSError:             # a container that forbids it: placement is advice, never a reason to fail the run
+        return None
     return allowed
 
 
