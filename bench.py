@@ -477,7 +477,7 @@ def main():
                                  "slots: b * 8 TB/s / (W + b*K*n_new/2 + images*K*prefix) — the weights once per step, every slot's own "
                                  "keys at the mean depth of a from-the-root rollout, the image prefix once per image"}
 
-        def search(the_model, the_proc, images, trees_per_image, expansions, ragged=False, pipe_kw=None, Wk=None):
+        def search(the_model, the_proc, images, trees_per_image, expansions, ragged=False, pipe_kw=None, Wk=None, slots=None):
             """This rank's share of a root-parallel search: len(images) * trees_per_image trees as ONE batched decode (one tree:
             the unmodified sequential search), then the path's single exchange — (score, code) records to rank 0 — timed on its
             own.  Every rank calls this (the gather is a collective) even with no image of its own."""
@@ -492,7 +492,7 @@ def main():
             t_begin = time.perf_counter()
             local = [[] for _ in images]
             if n_trees:
-                for k, score, doc in simulate_parallel_images(pipe, images, trees_per_image, expansions,
+                for k, score, doc in simulate_parallel_images(pipe, images, trees_per_image, expansions, slots=slots,
                                                               seeds=[ddist.tree_seed(1000, t) for t in range(n_trees)]):
                     local[k].append([float(score), doc.code])
             t_search = time.perf_counter() - t_begin
@@ -555,19 +555,22 @@ def main():
                 from detikzify_amd.infer.tikz import SleepingSyntheticTikzDocument
                 os.environ["DTK_SYNTH_COMPILE_SECONDS"] = str(S)
                 entry = {}
-                for n_t in (1, trees) if trees > 1 else (1,):
-                    for pooled in (False, True):
-                        pool = CompilePool(workers=min(64, max(1, n_t)), document_class=SleepingSyntheticTikzDocument) if pooled else None
+                # the last variant runs TWICE as many trees as there are decode slots (pool on): a tree that waits for its compile
+                # holds no slot, so the other half decodes meanwhile — what hides a reward of seconds when one batch of trees cannot
+                for n_t, over in ((1, False), (trees, False), (2 * trees, True)) if trees > 1 else ((1, False),):
+                    for pooled in ((True,) if over else (False, True)):
+                        pool = CompilePool(workers=min(128, max(1, n_t)), document_class=SleepingSyntheticTikzDocument) if pooled else None
                         try:
                             if pool is not None:
                                 pool.warm()
                             doc_cls = pooled_document_class(pool) if pooled else SleepingSyntheticTikzDocument
-                            r = search(model, proc, [img0], n_t, 2, ragged=True, pipe_kw=dict(document_class=doc_cls), Wk=(W, Kb))
+                            r = search(model, proc, [img0], n_t, 2, ragged=True, pipe_kw=dict(document_class=doc_cls), Wk=None if over else (W, Kb),
+                                       slots=trees if over else None)
                         finally:
                             if pool is not None:
                                 pool.close()
                         busy = (r.get("engine") or {}).get("wait_s")
-                        entry[f"{n_t}_trees_pool_{'on' if pooled else 'off'}"] = {
+                        entry[f"{n_t}_trees_over_{trees}_slots_pool_on" if over else f"{n_t}_trees_pool_{'on' if pooled else 'off'}"] = {
                             k: r.get(k) for k in ("rollouts", "rollouts_per_sec", "seconds", "decode_steps_per_gpu", "tokens_generated_per_gpu",
                                                   "frac_of_roofline")} | {"engine_wait_s": busy}
                 mcts.setdefault("reward_latency", {})[f"{S:g}s"] = entry

@@ -477,17 +477,19 @@ class BatchEngine:
 
 
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
-                      seeds: Optional[List[int]] = None, resume_in_place: bool = True, **gen_kwargs) -> Iterator[Tuple[float, Any]]:
+                      seeds: Optional[List[int]] = None, resume_in_place: bool = True, slots: Optional[int] = None,
+                      **gen_kwargs) -> Iterator[Tuple[float, Any]]:
     """Root-parallel MCTS on one GPU: `trees` independent DetikzifyGenerator searches (tree t draws its sampling seeds
     from a torch generator seeded seeds[t], default seed_base + t) decoded as one batch.  Yields (score, document)
-    pairs in completion order.  trees == 1 is the unmodified sequential search."""
+    pairs in completion order.  trees == 1 is the unmodified sequential search.  `slots` < trees: the trees take turns in that
+    many decode slots — a tree holds a slot only while it generates, so the others decode while it waits for its reward."""
     for _, score, doc in simulate_parallel_images(pipeline, [image], trees, expansions_per_tree, seed_base, seeds=seeds,
-                                                  resume_in_place=resume_in_place, **gen_kwargs):
+                                                  resume_in_place=resume_in_place, slots=slots, **gen_kwargs):
         yield score, doc
 
 
 def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_per_tree: int, seed_base: int = 1000,
-                             seeds: Optional[List[int]] = None, resume_in_place: bool = True,
+                             seeds: Optional[List[int]] = None, resume_in_place: bool = True, slots: Optional[int] = None,
                              **gen_kwargs) -> Iterator[Tuple[int, float, Any]]:
     """Several images in flight on one GPU (BASELINE config 5: 8 images x 4 rollouts): len(images) * trees_per_image
     independent searches decoded as one batch; the engine encodes every image once and forks its KV prefix into the
@@ -502,7 +504,10 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
     if seeds is None:
         seeds = [seed_base + t for t in range(trees)]
     assert len(seeds) == trees, "one seed per tree"
-    engine = BatchEngine(pipeline.model, max_batch=trees, gather=trees, resume_in_place=resume_in_place) if trees > 1 else None
+    # more trees than decode slots (the model's, or `slots`): a join waits for a slot to come free (BatchEngine.sequence), i.e. for
+    # another tree to finish its rollout and go off to its reward — with rewards that take seconds that keeps the batch full
+    engine = (BatchEngine(pipeline.model, max_batch=min(trees, slots) if slots else trees, gather=trees, resume_in_place=resume_in_place)
+              if trees > 1 else None)
     out: "queue.Queue" = queue.Queue()
     trace_path = os.environ.get("DTK_TRACE_MCTS")
     trace: Optional[List[Tuple[float, int, str]]] = [(time.perf_counter(), -1, "start")] if trace_path else None

@@ -90,8 +90,8 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert d["mcts_config4_rollouts_per_sec"] == c4["fixed_length"]["rollouts_per_sec"]
     assert d["mcts_config5_rollouts_per_sec"] == c5["fixed_length"]["rollouts_per_sec"]
     rl = m["reward_latency"]["0.05s"]                                                      # f3: reward latency x pool on / off x 1 / N trees
-    assert set(rl) == {"1_trees_pool_off", "1_trees_pool_on", "4_trees_pool_off", "4_trees_pool_on"}
-    assert all(v["rollouts"] == (2 if k.startswith("1_") else 8) and v["rollouts_per_sec"] > 0 for k, v in rl.items())
+    assert set(rl) == {"1_trees_pool_off", "1_trees_pool_on", "4_trees_pool_off", "4_trees_pool_on", "8_trees_over_4_slots_pool_on"}
+    assert all(v["rollouts"] == {"1": 2, "4": 8, "8": 16}[k.split("_")[0]] and v["rollouts_per_sec"] > 0 for k, v in rl.items())   # 8 trees take turns in 4 slots
 
 
 def test_bench_skip_batched_and_no_batch(monkeypatch, capsys):

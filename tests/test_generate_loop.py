@@ -315,6 +315,29 @@ def test_parallel_trees_share_one_metric_but_never_a_score():
     assert len(seq) == 4 and len(list(gen.simulate(expansions=2))) == 2
 
 
+def test_more_trees_than_decode_slots_take_turns():
+    """8 trees over 3 decode slots (simulate_parallel(slots=3)): a tree holds a slot only while it generates and gives it up for
+    its reward, so the trees take turns; every rollout of every tree arrives, never more than 3 sequences decode at once, and a
+    tree's rollouts are the ones the same seed produces with a slot per tree (sampling is a function of the tree's own seed
+    stream and its own prompt, not of the slot or of who else is in the batch)."""
+    proc = fake_processor(VOCAB, NIMG)
+    image = sketch_image(9, 96)
+
+    def run(slots):
+        dev = ScriptedDevice(slots=10)
+        pipe = DetikzifyPipeline(dev, proc, metric="fast", document_class=SyntheticTikzDocument, max_length=NIMG + 40, compile_timeout=None)
+        peak = [0]
+        launch = dev.decode_batch_launch
+        dev.decode_batch_launch = lambda active: (peak.__setitem__(0, max(peak[0], len(active))), launch(active))[1]
+        res = sorted((doc.code, score) for score, doc in simulate_parallel(pipe, image, trees=8, expansions_per_tree=3, slots=slots))
+        return res, peak[0], dev.last_batch_stats
+
+    crowded, peak, st = run(3)
+    roomy, peak_all, _ = run(None)
+    assert len(crowded) == 24 and peak <= 3 < peak_all <= 8 and st["joins"] >= 8
+    assert crowded == roomy
+
+
 def test_returning_sequences_resume_in_the_slot_that_holds_their_prompt():
     """A sequence whose prompt is a path inside an earlier sequence of the same image (an MCTS tree returning to a node of its
     previous rollout) finds the free slot whose cache still holds that path and continues there: no fork, no tail prefill; the
