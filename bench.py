@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--mcts-trees", type=int, default=-1, help="trees per GPU of the parallel MCTS phase (-1 = as many as --batch, 0 = skip)")
     ap.add_argument("--mcts-expansions", type=int, default=2, help="rollouts per tree in the parallel MCTS phase")
     ap.add_argument("--mcts-seq-expansions", type=int, default=3, help="rollouts of the sequential (one tree per GPU) search, 0 = skip")
+    ap.add_argument("--mcts-oversubscribe", type=float, default=1.5, help="mcts.parallel_oversubscribed: this many times --mcts-trees trees "
+                    "taking turns in the --mcts-trees decode slots (<= 1: skip)")
     ap.add_argument("--no-config4", action="store_true", help="skip mcts.config4 (BASELINE configs[3]: 16 rollouts of one image over the ranks)")
     ap.add_argument("--no-config5", action="store_true", help="skip mcts.config5 (BASELINE configs[4]: cl-7b fp8, 8 images x 32 rollouts over the ranks)")
     ap.add_argument("--config5-model", default="detikzify-cl-7b")
@@ -520,7 +522,8 @@ def main():
                 out["scores_min_max"] = [min(scores), max(scores)] if scores else None
                 if Wk is not None and tokens and n_trees > 1:
                     Wm, Km = Wk
-                    roof = n_trees * HBM_PEAK_GBS * 1e9 / (Wm + n_trees * Km * n_new / 2.0 + len(images) * Km * T0)
+                    nb = min(n_trees, slots) if slots else n_trees          # decode slots in use
+                    roof = nb * HBM_PEAK_GBS * 1e9 / (Wm + nb * Km * n_new / 2.0 + len(images) * Km * T0)
                     out.update(tokens_per_sec_this_gpu=tokens / t_search, roofline_tokens_per_sec_per_gpu=roof,
                                frac_of_roofline=tokens / t_search / roof)
             return out
@@ -537,6 +540,13 @@ def main():
                 mcts["sequential"] = r
             if trees > 1:
                 mcts["parallel"] = search(model, proc, [img0], trees, args.mcts_expansions, Wk=(W, Kb))
+                if args.mcts_oversubscribe > 1:
+                    # more trees than decode slots: a tree holds a slot only while it generates, so the reward waves of one part of the
+                    # trees are covered by the decoding of the others (with fixed-length rollouts every tree of a batch reaches its
+                    # reward on the same step — the 64-tree run above idles there)
+                    mcts["parallel_oversubscribed"] = search(model, proc, [img0], int(trees * args.mcts_oversubscribe), args.mcts_expansions,
+                                                             Wk=(W, Kb), slots=trees)
+                    mcts["parallel_oversubscribed"]["decode_slots"] = trees
             if want_c4:
                 # BASELINE configs[3]: "ds-7b, MCTS refine (16 rollouts, LaTeX-compile reward) sharded across 8 MI355X" — 16 rollouts of ONE
                 # image in total: rank r grows shard_expansions(16, N)[r] trees of one expansion each as one batch (N=1: 16 trees,
@@ -608,6 +618,7 @@ def main():
         result["mcts"] = mcts
         result["mcts_rollouts_per_sec"] = (mcts.get("parallel") or {}).get("rollouts_per_sec")
         result["mcts_rollouts_per_sec_sequential"] = (mcts.get("sequential") or {}).get("rollouts_per_sec")
+        result["mcts_rollouts_per_sec_oversubscribed"] = (mcts.get("parallel_oversubscribed") or {}).get("rollouts_per_sec")
         result["mcts_config4_rollouts_per_sec"] = ((mcts.get("config4") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
         result["mcts_config5_rollouts_per_sec"] = ((mcts.get("config5") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
 

@@ -75,6 +75,9 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert m["parallel"]["rollouts"] == 8 and m["parallel"]["trees_per_gpu"] == 4
     assert m["sequential"]["rollouts"] == 3 and m["sequential"]["trees_per_gpu"] == 1      # one tree: the unmodified search
     assert d["mcts_rollouts_per_sec"] == m["parallel"]["rollouts_per_sec"] > 0
+    over = m["parallel_oversubscribed"]                 # 6 trees taking turns in 4 decode slots
+    assert over["rollouts"] == 12 and over["trees_per_gpu"] == 6 and over["decode_slots"] == 4 and over["rollouts_per_sec"] > 0
+    assert d["mcts_rollouts_per_sec_oversubscribed"] == over["rollouts_per_sec"]
     assert d["mcts_rollouts_per_sec_sequential"] == m["sequential"]["rollouts_per_sec"] > 0
     assert d["ranks"] == [d["ranks"][0]] and d["ranks"][0]["world"] == 1
     # BASELINE configs[3] and [4] as stated: 16 rollouts of one image; N images x (trees x expansions) rollouts
