@@ -459,21 +459,26 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // (wave 0) AND V row tile b (wave 1): 256 blocks x 3 row tiles, every CU busy.
 // launch bound 2: a budget of 256 VGPRs keeps the MFMA accumulators in VGPRs; with 512 (one wave per SIMD) the compiler puts
 // them in AGPRs and copies all 32 to and fro every phase for the chain adds.
-template <int EPI, int NC, int CHP4, bool F8 = false, bool XW = false, bool Q3 = false>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
-__global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBArgs a) {
+// LW loader waves take alternate phases, R = ring depth in phases.  A loader issues phase p and then waits for its previous phase to
+// land before it looks at the next slot, so ONE loader with a ring of 3 keeps two phases in flight and the kernel runs at one phase
+// per (memory latency / 2) whatever the phase holds — ~1 us under a saturated stream, for 28 KiB (Q3) as for 40 (gate/up).  More
+// phases in flight need a deeper ring (LDS: R x phase bytes) and, because a wave's vmcnt counts at most 63 outstanding pieces, a
+// second loader.
+template <int EPI, int NC, int CHP4, bool F8 = false, bool XW = false, bool Q3 = false, int LW = 1, int R = 3>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(GemvBArgs a) {
   static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
-  constexpr int T = 2, NT = 4, PH = 4, R = 3;
+  constexpr int T = 2, NT = 4, PH = 4;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
   constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
   constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 8;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4 * LW, OFF_DONE = OFF_FILLED_X + 4;
   constexpr int PIECES = (XW ? 0 : NT * PH) + TILES * WT;        // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 2); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + LW + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   const int groups = Q3 ? (a.H + a.KVH) * 4 : gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
 
@@ -488,8 +493,9 @@ __global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBAr
     }
   };
 
-  if (wave == NC) {
-    // ---- loader wave (LDS-DMA)
+  if (wave >= NC && wave < NC + LW) {
+    // ---- loader wave l (LDS-DMA): phases l, l + LW, ...
+    const int l = wave - NC;
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
@@ -508,8 +514,9 @@ __global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBAr
       wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
                    : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
-    unsigned slot = 0;
-    for (int p = 0; p < NPH; ++p) {
+    unsigned slot = (unsigned)l % R;
+    int own = 0;                            // own phases issued so far
+    for (int p = l; p < NPH; p += LW, ++own) {
       wait_slot_free(p);
       const size_t adv = (size_t)p * PH * 1024;
       if (!XW) {
@@ -521,18 +528,18 @@ __global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBAr
         if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, OFF_W + slot * WPH + (unsigned)j * WT * 1024u);
         else glds_run4<true>(wsrc[j] + adv, OFF_W + slot * WPH + (unsigned)j * PH * 1024u);
       }
-      if (p >= 1) {                         // two phases in flight: phase p - 1 has landed when only this phase's loads are outstanding
+      if (own >= 1) {                       // this wave's previous phase has landed when only this phase's loads are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        bl_st(OFF_FILLED, (unsigned)p);
+        bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
       }
-      slot = slot + 1 == R ? 0 : slot + 1;
+      slot = (slot + LW) % R;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bl_st(OFF_FILLED, (unsigned)NPH);
+    bl_st(OFF_FILLED + 4u * (unsigned)l, (unsigned)own);
     return;
   }
 
-  if (XW && wave == NC + 1) {
+  if (XW && wave == NC + LW) {
     // ---- x wave: phase p + 1 is loaded into registers while phase p is stored to its ring slot
     const unsigned char* xsrc[NT];
 #pragma unroll
@@ -573,7 +580,7 @@ __global__ __launch_bounds__((NC + (XW ? 2 : 1)) * 64, 2) void k_gemv_bl(GemvBAr
   unsigned slot = 0;
   for (int p = 0; p < NPH; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
-      bool ok = bl_ld(OFF_FILLED) > (unsigned)p;
+      bool ok = bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW);
       if (XW) ok = ok && bl_ld(OFF_FILLED_X) > (unsigned)p;
       if (ok) break;
       __builtin_amdgcn_s_sleep(1);
@@ -671,23 +678,31 @@ static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
   if (gemv_xw()) launch_bl_one_xw<EPI, NC, CHP4, true>(a, s); else launch_bl_one_xw<EPI, NC, CHP4, false>(a, s);
 }
 // QKV of an MHA model as a pair unit + a V row tile per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
-template <int CHP4, bool XW>
+static int g_gemv_loaders = -1;                 // loader waves of the Q3 kernel: 1 (ring of 3 phases) or 2 (ring of 5: four 28 KiB phases in flight)
+void set_gemv_loaders(int v) { g_gemv_loaders = v; }
+static int gemv_loaders() {
+  if (g_gemv_loaders < 0) { const char* e = getenv("DTK_GEMV_LOADERS"); g_gemv_loaders = e ? atoi(e) : 1; }
+  return g_gemv_loaders >= 2 ? 2 : 1;
+}
+template <int CHP4, bool XW, int LW, int R>
 static void launch_bl_q3_xw(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (3 * 4 * 1024) + 4 * 4 + 12;
+  constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW + 1) + 12;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int blocks = (a.H + a.KVH) * 4;
-  constexpr int threads = (2 + (XW ? 2 : 1)) * 64;
-  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true>), dim3(blocks), dim3(threads), lds, s, a);
-  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true>), dim3(blocks), dim3(threads), lds, s, a);
+  constexpr int threads = (2 + LW + (XW ? 1 : 0)) * 64;
+  if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true, LW, R>), dim3(blocks), dim3(threads), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), dim3(blocks), dim3(threads), lds, s, a);
 }
 template <int CHP4>
 static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
-  if (gemv_xw()) launch_bl_q3_xw<CHP4, true>(a, s); else launch_bl_q3_xw<CHP4, false>(a, s);
+  const bool two = gemv_loaders() == 2;
+  if (gemv_xw()) { if (two) launch_bl_q3_xw<CHP4, true, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, true, 1, 3>(a, s); }
+  else { if (two) launch_bl_q3_xw<CHP4, false, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, false, 1, 3>(a, s); }
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {

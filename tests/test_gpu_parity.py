@@ -1389,8 +1389,9 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         for variant in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (4, 0, 0, 0, 0), (0, 1, 0, 0, 0), (1, 1, 0, 0, 0),
                         (0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 1, 0), (1, 0, 1, 1, 0), (1, 0, 1, 1, 5), (1, 0, 1, 1, 6), (0, 0, 0, 0, 7),
                         (1, 0, 1, 2, 5),        # resid_kparts 2 = with k_gemv_bkl (LDS-ring operands) as the weight kernel
-                        (1, 0, 1, 2, 5, 1), (1, 0, 1, 2, 1 + 4 + 16, 0), (1, 0, 1, 2, 1 + 4 + 16, 1), (0, 0, 0, 2, 7, 1)):   # 6th entry: gemv_xw (x by an
-                        # extra wave's ordinary loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block
+                        (1, 0, 1, 2, 5, 1), (1, 0, 1, 2, 1 + 4 + 16, 0), (1, 0, 1, 2, 1 + 4 + 16, 1), (0, 0, 0, 2, 7, 1),
+                        (1, 0, 1, 2, 1 + 4 + 16, 0, 2), (1, 0, 1, 2, 1 + 4 + 16, 1, 2)):   # 6th entry: gemv_xw (x by an extra wave's ordinary
+                        # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
             model.set_option("gemv_bx", variant[0])
             model.set_option("gemv_bk", variant[1])
             model.set_option("resid_split", variant[2])     # N = d roles: two row tiles x 32 slots per block
@@ -1398,6 +1399,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
             model.set_option("gemv_bkl", 1 if variant[3] == 2 else 0)
             model.set_option("gemv_bl", variant[4])
             model.set_option("gemv_xw", variant[5] if len(variant) > 5 else 0)
+            model.set_option("gemv_loaders", variant[6] if len(variant) > 6 else 1)
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1417,6 +1419,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_bl", 1)
         model.set_option("gemv_bkl", 1)
         model.set_option("gemv_xw", 0)
+        model.set_option("gemv_loaders", 1)
         del model
         gc.collect()
 
