@@ -464,21 +464,21 @@ __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)"
 // per (memory latency / 2) whatever the phase holds — ~1 us under a saturated stream, for 28 KiB (Q3) as for 40 (gate/up).  More
 // phases in flight need a deeper ring (LDS: R x phase bytes) and, because a wave's vmcnt counts at most 63 outstanding pieces, a
 // second loader.
-template <int EPI, int NC, int CHP4, bool F8 = false, bool XW = false, bool Q3 = false, int LW = 1, int R = 3>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
-__global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(GemvBArgs a) {
+template <int EPI, int NC, int CHP4, bool F8 = false, int XW = 0, bool Q3 = false, int LW = 1, int R = 3>     // NC compute waves (units) per block; CHP4 = phases per chain (a k_gemv_b wave slice = 4 * CHP4 k-steps)
+__global__ __launch_bounds__((NC + LW + XW) * 64, 2) void k_gemv_bl(GemvBArgs a) {   // XW = 0 / 1 / 2 x waves (2: alternate phases, i.e. two phases of lead each)
   static_assert(!Q3 || (EPI == EPI_QKV && NC == 2), "Q3 is the QKV role with a pair wave and a V wave");
   constexpr int T = 2, NT = 4, PH = 4;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
   constexpr int TILES = Q3 ? 3 : NC * T;                         // weight row tiles per block
   constexpr unsigned XPH = PH * NT * 1024u;                      // x bytes of one phase (16 KiB)
   constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase (4 KiB per row tile; fp8: 2)
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4 * LW, OFF_DONE = OFF_FILLED_X + 4;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4 * LW, OFF_DONE = OFF_FILLED_X + 8;
   constexpr int PIECES = (XW ? 0 : NT * PH) + TILES * WT;        // LDS-DMA instructions per phase
   constexpr unsigned SPIN = 1u << 22;                            // bounded waits: a protocol error must not hang the chip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS object (LDS address 0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + LW + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + LW + 2); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   const int groups = Q3 ? (a.H + a.KVH) * 4 : gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
 
@@ -539,8 +539,9 @@ __global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(Ge
     return;
   }
 
-  if (XW && wave == NC + LW) {
-    // ---- x wave: phase p + 1 is loaded into registers while phase p is stored to its ring slot
+  if (XW && wave >= NC + LW) {
+    // ---- x wave xi: phases xi, xi + XW, ...; its next phase is loaded into registers while the current one is stored to the ring
+    const int xi = wave - (NC + LW);
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
@@ -551,20 +552,21 @@ __global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(Ge
 #pragma unroll
         for (int j = 0; j < PH; ++j) buf[nt * PH + j] = *reinterpret_cast<const u32x4*>(xsrc[nt] + ((size_t)p * PH + j) * 1024);
     };
-    auto put = [&](const u32x4 (&buf)[NT * PH], int p) {
+    auto put = [&](const u32x4 (&buf)[NT * PH], int p, int own) {
       wait_slot_free(p);
       unsigned char* dst = smem + (unsigned)(p % R) * XPH + lane * 16;
 #pragma unroll
       for (int i = 0; i < NT * PH; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 1024) = buf[i];
       bl_drain();
-      bl_st(OFF_FILLED_X, (unsigned)p + 1u);
+      bl_st(OFF_FILLED_X + 4u * (unsigned)xi, (unsigned)own);
     };
-    fetch(bufA, 0);
-    for (int p = 0; p < NPH; p += 2) {      // NPH is even (K = 2048 / 4096)
-      fetch(bufB, p + 1);
-      put(bufA, p);
-      if (p + 2 < NPH) fetch(bufA, p + 2);
-      put(bufB, p + 1);
+    constexpr int XS = XW > 0 ? XW : 1;
+    if (xi < NPH) fetch(bufA, xi);
+    for (int p = xi, own = 0; p < NPH; p += 2 * XS, own += 2) {
+      if (p + XS < NPH) fetch(bufB, p + XS);
+      put(bufA, p, own + 1);
+      if (p + 2 * XS < NPH) fetch(bufA, p + 2 * XS);
+      if (p + XS < NPH) put(bufB, p + XS, own + 2);
     }
     return;
   }
@@ -581,7 +583,7 @@ __global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(Ge
   for (int p = 0; p < NPH; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
       bool ok = bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW);
-      if (XW) ok = ok && bl_ld(OFF_FILLED_X) > (unsigned)p;
+      if (XW) ok = ok && bl_ld(OFF_FILLED_X + 4u * (unsigned)(p % (XW > 0 ? XW : 1))) > (unsigned)(p / (XW > 0 ? XW : 1));
       if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -655,13 +657,13 @@ __global__ __launch_bounds__((NC + LW + (XW ? 1 : 0)) * 64, 2) void k_gemv_bl(Ge
 
 static int g_gemv_xw = -1;                      // x fragments by an extra wave's ordinary loads + ds_write instead of LDS-DMA pieces (k_gemv_bl, k_gemv_bkl)
 void set_gemv_xw(int v) { g_gemv_xw = v; }
-static bool gemv_xw() {
+static int gemv_xw() {                           // 0: x by LDS-DMA, 1 / 2: that many x waves
   if (g_gemv_xw < 0) { const char* e = getenv("DTK_GEMV_XW"); g_gemv_xw = e ? atoi(e) : 0; }
-  return g_gemv_xw > 0;
+  return g_gemv_xw > 2 ? 2 : g_gemv_xw;
 }
-template <int EPI, int NC, int CHP4, bool XW>
+template <int EPI, int NC, int CHP4, int XW>
 static void launch_bl_one_xw(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 2) + 12;        // (the fp8 kernel needs less; one size for both)
+  constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 3) + 12;        // (the fp8 kernel needs less; one size for both)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -669,13 +671,17 @@ static void launch_bl_one_xw(const GemvBArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  constexpr int threads = (NC + (XW ? 2 : 1)) * 64;
+  constexpr int threads = (NC + 1 + XW) * 64;
   if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, true, XW>), dim3((groups + NC - 1) / NC), dim3(threads), lds, s, a);
   else hipLaunchKernelGGL((k_gemv_bl<EPI, NC, CHP4, false, XW>), dim3((groups + NC - 1) / NC), dim3(threads), lds, s, a);
 }
 template <int EPI, int NC, int CHP4>
 static void launch_bl_one(const GemvBArgs& a, hipStream_t s) {
-  if (gemv_xw()) launch_bl_one_xw<EPI, NC, CHP4, true>(a, s); else launch_bl_one_xw<EPI, NC, CHP4, false>(a, s);
+  switch (gemv_xw()) {
+    case 1: launch_bl_one_xw<EPI, NC, CHP4, 1>(a, s); break;
+    case 2: launch_bl_one_xw<EPI, NC, CHP4, 2>(a, s); break;
+    default: launch_bl_one_xw<EPI, NC, CHP4, 0>(a, s);
+  }
 }
 // QKV of an MHA model as a pair unit + a V row tile per block (Q3 above).  Covers H == KVH, K = 2048 / 4096.
 static int g_gemv_loaders = -1;                 // loader waves of the Q3 kernel: 1 (ring of 3 phases) or 2 (ring of 5: four 28 KiB phases in flight)
@@ -684,9 +690,9 @@ static int gemv_loaders() {
   if (g_gemv_loaders < 0) { const char* e = getenv("DTK_GEMV_LOADERS"); g_gemv_loaders = e ? atoi(e) : 1; }
   return g_gemv_loaders >= 2 ? 2 : 1;
 }
-template <int CHP4, bool XW, int LW, int R>
+template <int CHP4, int XW, int LW, int R>
 static void launch_bl_q3_xw(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW + 1) + 12;
+  constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW + 2) + 12;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -694,15 +700,18 @@ static void launch_bl_q3_xw(const GemvBArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int blocks = (a.H + a.KVH) * 4;
-  constexpr int threads = (2 + LW + (XW ? 1 : 0)) * 64;
+  constexpr int threads = (2 + LW + XW) * 64;
   if (a.W8) hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true, LW, R>), dim3(blocks), dim3(threads), lds, s, a);
   else hipLaunchKernelGGL((k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), dim3(blocks), dim3(threads), lds, s, a);
 }
 template <int CHP4>
 static void launch_bl_q3(const GemvBArgs& a, hipStream_t s) {
   const bool two = gemv_loaders() == 2;
-  if (gemv_xw()) { if (two) launch_bl_q3_xw<CHP4, true, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, true, 1, 3>(a, s); }
-  else { if (two) launch_bl_q3_xw<CHP4, false, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, false, 1, 3>(a, s); }
+  switch (gemv_xw()) {
+    case 1: if (two) launch_bl_q3_xw<CHP4, 1, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, 1, 1, 3>(a, s); break;
+    case 2: if (two) launch_bl_q3_xw<CHP4, 2, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, 2, 1, 3>(a, s); break;
+    default: if (two) launch_bl_q3_xw<CHP4, 0, 2, 5>(a, s); else launch_bl_q3_xw<CHP4, 0, 1, 3>(a, s);
+  }
 }
 template <int EPI, int CHP4>
 static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
@@ -1075,11 +1084,11 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-template <int TPG, bool XW = false>       // XW: x by an extra wave's ordinary loads + ds_write_b128 (see k_gemv_bl)
-__global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArgs a) {
+template <int TPG, int XW = 0>       // XW x waves: x by ordinary loads + ds_write_b128 (see k_gemv_bl)
+__global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
   constexpr int NT = 4, PH = 4, R = 3;
   constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
-  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 8;
+  constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 12;
   constexpr int PIECES = ((XW ? 0 : NT) + TPG) * PH;
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArg
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
   const int Lc = s1 - s0;                                       // >= 1 (launcher)
   const int nph = (Lc + PH - 1) / PH;
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 2); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 3); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   auto wait_slot_free = [&](int p) {
     if (p < R) return;
@@ -1144,7 +1153,8 @@ __global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArg
     return;
   }
 
-  if (XW && wave == TPG + 1) {   // ---- x wave: phase p + 1 in registers while phase p is stored to its ring slot
+  if (XW && wave > TPG) {   // ---- x wave xi: phases xi, xi + XW, ...; the next own phase in registers while the current one is stored
+    const int xi = wave - (TPG + 1);
     const unsigned char* xsrc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
@@ -1155,20 +1165,21 @@ __global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArg
 #pragma unroll
         for (int j = 0; j < PH; ++j) buf[nt * PH + j] = *reinterpret_cast<const u32x4*>(xsrc[nt] + (size_t)min(p * PH + j, Lc - 1) * 1024);
     };
-    auto put = [&](const u32x4 (&buf)[NT * PH], int p) {
+    auto put = [&](const u32x4 (&buf)[NT * PH], int p, int own) {
       wait_slot_free(p);
       unsigned char* dst = smem + (unsigned)(p % R) * XPH + lane * 16;
 #pragma unroll
       for (int i = 0; i < NT * PH; ++i) *reinterpret_cast<u32x4*>(dst + (size_t)i * 1024) = buf[i];
       bl_drain();
-      bl_st(OFF_FILLED_X, (unsigned)p + 1u);
+      bl_st(OFF_FILLED_X + 4u * (unsigned)xi, (unsigned)own);
     };
-    fetch(bufA, 0);
-    for (int p = 0; p < nph; p += 2) {
-      if (p + 1 < nph) fetch(bufB, p + 1);
-      put(bufA, p);
-      if (p + 2 < nph) fetch(bufA, p + 2);
-      if (p + 1 < nph) put(bufB, p + 1);
+    constexpr int XS = XW > 0 ? XW : 1;
+    if (xi < nph) fetch(bufA, xi);
+    for (int p = xi, own = 0; p < nph; p += 2 * XS, own += 2) {
+      if (p + XS < nph) fetch(bufB, p + XS);
+      put(bufA, p, own + 1);
+      if (p + 2 * XS < nph) fetch(bufA, p + 2 * XS);
+      if (p + XS < nph) put(bufB, p + XS, own + 2);
     }
     return;
   }
@@ -1182,7 +1193,7 @@ __global__ __launch_bounds__((TPG + (XW ? 2 : 1)) * 64) void k_gemv_bkl(GemvBArg
   for (int p = 0; p < nph; ++p) {
     for (unsigned spins = 0; spins < SPIN; ++spins) {
       bool ok = bl_ld(OFF_FILLED) > (unsigned)p;
-      if (XW) ok = ok && bl_ld(OFF_FILLED_X) > (unsigned)p;
+      if (XW) ok = ok && bl_ld(OFF_FILLED_X + 4u * (unsigned)(p % (XW > 0 ? XW : 1))) > (unsigned)(p / (XW > 0 ? XW : 1));
       if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
@@ -1212,21 +1223,21 @@ void set_gemv_bkl(int v) { g_gemv_bkl = v; }
 static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
-  const bool xw = gemv_xw();
+  const int xw = gemv_xw();
 #define BKL_ATTR(TPG_, XW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+#define BKL_GO(TPG_, XW_) hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a)
   if (((a.N + 15) >> 4) == 256) {
-    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 10 + 12;
+    constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 11 + 12;
     static bool attr8 = false;
-    if (!attr8) { BKL_ATTR(8, false); BKL_ATTR(8, true); attr8 = true; }
-    if (xw) hipLaunchKernelGGL((k_gemv_bkl<8, true>), dim3(256), dim3(10 * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_gemv_bkl<8, false>), dim3(256), dim3(9 * 64), lds, s, a);
+    if (!attr8) { BKL_ATTR(8, 0); BKL_ATTR(8, 1); BKL_ATTR(8, 2); attr8 = true; }
+    if (xw == 2) BKL_GO(8, 2); else if (xw == 1) BKL_GO(8, 1); else BKL_GO(8, 0);
   } else {
-    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 6 + 12;
+    constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 7 + 12;
     static bool attr4 = false;
-    if (!attr4) { BKL_ATTR(4, false); BKL_ATTR(4, true); attr4 = true; }
-    if (xw) hipLaunchKernelGGL((k_gemv_bkl<4, true>), dim3(256), dim3(6 * 64), lds, s, a);
-    else hipLaunchKernelGGL((k_gemv_bkl<4, false>), dim3(256), dim3(5 * 64), lds, s, a);
+    if (!attr4) { BKL_ATTR(4, 0); BKL_ATTR(4, 1); BKL_ATTR(4, 2); attr4 = true; }
+    if (xw == 2) BKL_GO(4, 2); else if (xw == 1) BKL_GO(4, 1); else BKL_GO(4, 0);
   }
+#undef BKL_GO
 #undef BKL_ATTR
   return true;
 }
