@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import os
 import queue
+import random
 import threading
 import time
 from collections import OrderedDict
@@ -519,7 +520,8 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
             gen = torch.Generator().manual_seed(int(seeds[t]))
             draws = iter(lambda: int(torch.randint(0, 2 ** 62, (), generator=gen).item()), None)
             g = generators[t] = pipeline._generator(imgs[t // trees_per_image], None, False, metric=pipeline.metric,
-                                                    processed=encs[t // trees_per_image], **gen_kwargs)
+                                                    processed=encs[t // trees_per_image], rng=random.Random(int(seeds[t])),
+                                                    **gen_kwargs)      # (tie-breaks of the search from the tree's own stream too)
             base_generate = g.generate
 
             def generate(input_ids, **kw):      # per-tree RNG stream; a cancelled search starts no further rollout

@@ -140,7 +140,7 @@ class DetikzifyGenerator:
     def __init__(self, model, processor, image: Optional[Image.Image], text: Optional[str] = None,
                  metric=None, compile_timeout: Optional[int] = 60, mcts_timeout: Optional[int] = None,
                  streamer=None, control: Optional[ExplicitAbort] = None, exploration: float = 0.6,
-                 strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, processed=None, **gen_kwargs):
+                 strict: bool = False, document_class: Type[TikzDocument] = TikzDocument, processed=None, rng=None, **gen_kwargs):
         assert processed is None or text is None, "a shared processor output is for image-only prompts"
         self.model, self.processor = model, processor
         self.image, self.text, self.metric = image, text, metric
@@ -155,7 +155,8 @@ class DetikzifyGenerator:
         self.failed_rollouts: Dict[NodeState, List[WideNode]] = {}      # position -> the chain that failed from there on
         self.solution: deque = deque(maxlen=1)                          # the last expansion's (score, document)
         prompt = processed if processed is not None else processor(images=image, text=text, return_tensors="pt")
-        self.montecarlo = MonteCarlo(root_node=self._node(prompt.input_ids.to(model.device).squeeze(), 0))
+        # rng: this tree's own random.Random for the search's tie-breaks (parallel trees); None = the module-level stream, as the reference
+        self.montecarlo = MonteCarlo(root_node=self._node(prompt.input_ids.to(model.device).squeeze(), 0), rng=rng)
         self.montecarlo.child_finder = self.child_finder
         # equal token sequences decode to the SAME document object and equal renderings score once (the search revisits
         # positions; a TikzDocument compiles lazily and keeps its result)

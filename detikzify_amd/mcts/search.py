@@ -72,15 +72,21 @@ class Node:
                 best, best_score = [child], s
             elif s == best_score:
                 best.append(child)
-        return random.choice(best)
+        return (getattr(root_node, "rng", None) or random).choice(best)       # the search's own stream when it has one (MonteCarlo(rng=...))
 
     def is_scorable(self) -> bool:
         return bool(self.visits) or self.policy_value is not None
 
 
 class MonteCarlo:
-    def __init__(self, root_node: Node, mins_timeout: Optional[float] = None):
+    def __init__(self, root_node: Node, mins_timeout: Optional[float] = None, rng=None):
+        """`rng`: a `random.Random` of this search's own (not in the reference, whose ties break on the process-wide `random`
+        module — the default here too).  Searches that run side by side in threads draw from ONE module-level stream in whatever
+        order the scheduler gives them; with a stream per search a fixed-seed parallel search no longer depends on thread timing."""
         self.root_node = root_node
+        self.rng = rng or random
+        if rng is not None:
+            root_node.rng = rng
         self.solution = None
         self.child_finder: Optional[Callable[[Node, "MonteCarlo"], None]] = None
         self.node_evaluator: Callable[[Node, "MonteCarlo"], Optional[float]] = lambda child, mc: None
@@ -91,10 +97,10 @@ class MonteCarlo:
     # -- choices at the root ---------------------------------------------------------------------
     def make_choice(self) -> Node:
         top = max(child.visits for child in self.root_node.children)
-        return random.choice([c for c in self.root_node.children if c.visits == top])
+        return self.rng.choice([c for c in self.root_node.children if c.visits == top])
 
     def make_exploratory_choice(self) -> Optional[Node]:
-        threshold, acc = random.uniform(0, 1), 0.0
+        threshold, acc = self.rng.uniform(0, 1), 0.0
         for child in self.root_node.children:
             p = child.visits / self.root_node.visits
             if acc + p >= threshold:
@@ -135,7 +141,7 @@ class MonteCarlo:
 
     def random_rollout(self, node: Node):
         self.child_finder(node, self)
-        child = random.choice(node.children)
+        child = self.rng.choice(node.children)
         node.children = []
         node.add_child(child)
         value = self.node_evaluator(child, self)

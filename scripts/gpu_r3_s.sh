@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ran at commit ef278c3, which has k_gemv_br; removed afterwards — results: profiles/r03_loader_kernel_experiments.txt)
 # round 3, lease S: k_gemv_br (weights through registers with a hand-counted 4-phase ring, x through a 6-phase LDS-DMA ring):
 # identity tests, per-kernel times of the 64-slot step
 set -uo pipefail

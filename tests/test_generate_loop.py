@@ -317,9 +317,9 @@ def test_parallel_trees_share_one_metric_but_never_a_score():
 
 def test_more_trees_than_decode_slots_take_turns():
     """8 trees over 3 decode slots (simulate_parallel(slots=3)): a tree holds a slot only while it generates and gives it up for
-    its reward, so the trees take turns; every rollout of every tree arrives, never more than 3 sequences decode at once, and a
-    tree's rollouts are the ones the same seed produces with a slot per tree (sampling is a function of the tree's own seed
-    stream and its own prompt, not of the slot or of who else is in the batch)."""
+    its reward, so the trees take turns; every rollout of every tree arrives, never more than 3 sequences decode at once, and —
+    every tree drawing its sampling seeds AND the tie-breaks of its search from its own stream (MonteCarlo(rng=...)) — the
+    rollouts are the ones a slot per tree produces, run after run, whatever the thread timing."""
     proc = fake_processor(VOCAB, NIMG)
     image = sketch_image(9, 96)
 
@@ -334,8 +334,8 @@ def test_more_trees_than_decode_slots_take_turns():
 
     crowded, peak, st = run(3)
     roomy, peak_all, _ = run(None)
-    assert len(crowded) == 24 and peak <= 3 < peak_all <= 8 and st["joins"] >= 8
-    assert crowded == roomy
+    assert len(crowded) == len(roomy) == 24 and peak <= 3 < peak_all <= 8 and st["joins"] >= 8
+    assert crowded == roomy == run(None)[0] == run(5)[0]          # a fixed-seed parallel search is reproducible
 
 
 def test_returning_sequences_resume_in_the_slot_that_holds_their_prompt():
