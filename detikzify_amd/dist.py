@@ -176,7 +176,7 @@ def merge_rollouts(per_rank: Sequence[Sequence[Sequence[Any]]]) -> List[List[Any
             if (score, code) not in seen:
                 seen.add((score, code))
                 out.append([score, code])
-    return sorted(out, key=lambda sc: sc[0])
+    return sorted(out, key=lambda sc: (sc[0], sc[1]))       # equal scores in code order, not in arrival order (thread timing)
 
 
 def root_parallel_search(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,

@@ -54,6 +54,8 @@ def _worker(rank, world, port, outdir):
     pipe = DetikzifyPipeline(ScriptedDevice(slots=4), proc, metric="fast", document_class=SyntheticTikzDocument,
                              max_length=NIMG + 40, compile_timeout=None)
     best = dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2, all_ranks=True)
+    # fixed seeds (1000 + rank + world * tree) and a tie-break stream per tree: the same merged records on every run
+    assert dd.root_parallel_search(pipe, sketch_image(2, 64), trees=3, expansions_per_tree=2, all_ranks=True) == best
     images = [sketch_image(10 + i, 64) for i in range(5)]
     codes = dd.sharded_sample(pipe, images, all_ranks=True, do_sample=False)
     per_image = dd.root_parallel_search_images(pipe, images[:3], trees_per_image=2, expansions_per_tree=2, all_ranks=True)
