@@ -1696,7 +1696,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
   else if (!strcmp(name, "gemv_bl")) {
-    if (value < 0 || value > 31) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..31 (bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair + V tile per block where that fills the chip, bit 4: for any MHA model)");
+    if (value < 0 || value > 63) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..63 (bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair + V tile per block where that fills the chip, bit 4: for any MHA model, bit 5: fp8 weights through registers (k_gemv_br, K = 4096))");
     set_gemv_bl(value);
     drop_batch_graphs(c);
   }

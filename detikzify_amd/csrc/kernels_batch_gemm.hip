@@ -722,13 +722,208 @@ static bool launch_bl_units(int units, const GemvBArgs& a, hipStream_t s) {
     default: return false;
   }
 }
+// weight loads the compiler does not count (its waitcnt pass merges the ring's loads of earlier loop iterations into "wait for
+// nearly everything": vmcnt(7) where 30 loads may stay outstanding) — issued and waited for by hand
+__device__ __forceinline__ void br_load_nt(u32x4& dst, const void* src) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(src) : "memory"); }
+template <int N>
+__device__ __forceinline__ void br_wait(u32x4& a0, u32x4& a1) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a0), "+v"(a1) : "n"(N)); }   // ties the two tiles to the wait
+// k_gemv_br — k_gemv_bl with the WEIGHTS back in registers.  What bounds k_gemv_bl is the rate at which one CU's LDS-DMA path lands
+// bytes (~25 GB/s from HBM: DESIGN §3.1b); the register path has no such cap.  Here
+//   * the loader wave streams the x fragments only (16 KiB per phase of 4 k-steps, L2 hits) into a ring of R = 6 phases, three
+//     phases in flight (counted vmcnt), paced by the compute waves' DONE words as in k_gemv_bl;
+//   * every compute wave (one unit = two paired row tiles over the full K) loads its OWN weight tiles with non-temporal 16-byte
+//     loads into a register ring of WD = 4 phases (32 KiB in flight per wave) and refills a ring slot right after the MFMAs that
+//     consumed it; nobody meets at a barrier, so a wave that waits for x keeps its weight loads in flight;
+//   * chains and epilogue exactly as k_gemv_bl / k_gemv_bx: BIT-IDENTICAL to k_gemv_b (tested).
+// SHIPPED FOR fp8 WEIGHTS AT K = 4096 ONLY: with bf16 weights it is slower than k_gemv_bl (gate/up 35.4 vs 32.6 us), and the K = 2048
+// instantiations (CHP4 = 2) need 254 VGPRs + 68 bytes of scratch — a spilled ring register is stored before its hand-issued load has
+// landed, which is how the first version faulted on ds-1.3b.  The launcher admits fp8, K = 4096 (170 VGPRs, no scratch).
+template <int EPI, int NC, int CHP4, bool F8 = false>
+__global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
+  constexpr int T = 2, NT = 4, PH = 4, R = 6, WD = 4, XD = 3;
+  constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
+  constexpr unsigned XPH = PH * NT * 1024u;
+  constexpr unsigned OFF_FILLED = R * XPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr int XP = NT * PH;                                    // LDS-DMA pieces per phase
+  constexpr unsigned SPIN = 1u << 22;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4 (NPH = 16 or 32)
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  __syncthreads();
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+
+  if (wave == NC) {
+    // ---- loader wave: x only
+    const unsigned char* xsrc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)nt * nsteps * 512 + lane * 8) * 2;
+    unsigned slot = 0;
+    for (int p = 0; p < NPH; ++p) {
+      if (p >= R) {
+        for (unsigned spins = 0; spins < SPIN; ++spins) {
+          unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+          for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          if (lo + R > (unsigned)p) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const size_t adv = (size_t)p * PH * 1024;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
+      if (p >= XD - 1) {                    // XD phases in flight: phase p - (XD - 1) has landed when only the last XD - 1 phases are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((XD - 1) * XP) : "memory");
+        bl_st(OFF_FILLED, (unsigned)(p - (XD - 2)));
+      }
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bl_st(OFF_FILLED, (unsigned)NPH);
+    return;
+  }
+
+  // ---- compute waves
+  const int g = blockIdx.x * NC + wave, gc = g < groups ? g : groups - 1;     // a surplus wave streams valid memory and stores nothing
+  const unsigned char* wrow[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
+    const int tn_max = ((a.N + 15) >> 4) - 1;
+    if (tn > tn_max) tn = tn_max;
+    wrow[t] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                 : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+  }
+  u32x4 wr[WD][T][WT];
+#pragma unroll
+  for (int b = 0; b < WD; ++b)
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int t = 0; t < T; ++t) br_load_nt(wr[b][t][i], wrow[t] + (size_t)(b * WT + i) * 1024);      // issue order: phase, tile, row tile
+  f32x4 tot[T][NT], c[T][NT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { tot[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  unsigned slot = 0;
+  auto group = [&](int p0, auto refill_tag) {       // WD phases on ring slots 0 .. WD - 1; REFILL: each used-up tile is reloaded for phase p + WD
+    constexpr bool REFILL = decltype(refill_tag)::value;
+#pragma unroll
+    for (int b = 0; b < WD; ++b) {
+      const int p = p0 + b;
+      for (unsigned spins = 0; spins < SPIN; ++spins) {
+        if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned char* xb = smem + slot * XPH + lane * 16;
+#pragma unroll
+      for (int j = 0; j < PH; ++j) {
+        bf16x8_t xf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
+        // loads issued after tile i of this phase: the rest of the phase, the WD - 1 later phases, and this phase's refills so far —
+        // T * ((WT - 1 - i) + (WD - 1) * WT + i) = T * (WD * WT - 1) with refills; without, the later phases are b + 1 .. WD - 1 only
+        if (!F8 || !(j & 1)) {
+          constexpr int dummy = 0; (void)dummy;
+          const int i = F8 ? j / 2 : j;
+          if (REFILL) br_wait<T * (WD * WT - 1)>(wr[b][0][i], wr[b][1][i]);
+          else {
+            switch ((WD - 1 - b) * WT + (WT - 1 - i)) {        // compile-time after unrolling (b, j are unrolled indices)
+#define BRW(N) case N: br_wait<T * N>(wr[b][0][i], wr[b][1][i]); break;
+              BRW(0) BRW(1) BRW(2) BRW(3) BRW(4) BRW(5) BRW(6) BRW(7) BRW(8) BRW(9) BRW(10) BRW(11) BRW(12) BRW(13) BRW(14) BRW(15)
+#undef BRW
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          bf16x8_t af;
+          if (F8) { const u32x4 wv = wr[b][t][j / 2]; af = gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]); }
+          else af = __builtin_bit_cast(bf16x8_t, wr[b][t][j]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) c[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[t][nt], 0, 0, 0);
+        }
+        if (REFILL && (!F8 || (j & 1))) {   // the tile just used up
+          const int i = F8 ? j / 2 : j;
+#pragma unroll
+          for (int t = 0; t < T; ++t) br_load_nt(wr[b][t][i], wrow[t] + (size_t)((p + WD) * WT + i) * 1024);
+        }
+      }
+      if ((p + 1) % CHP4 == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { tot[t][nt] += c[t][nt]; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      }
+      bl_drain();
+      if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+  };
+  constexpr bx_flag<true> yes{};
+  constexpr bx_flag<false> no{};
+  for (int p0 = 0; p0 + WD < NPH; p0 += WD) group(p0, yes);      // NPH is a multiple of WD = 4
+  group(NPH - WD, no);
+  if (g >= groups) return;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    if (!a.bs->active[n]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
+      if (F8) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
+          if (row >= a.N) row = a.N - 1;
+          v[t] *= a.wscale[row];                                // power of two: exact
+        }
+      }
+      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
+    }
+  }
+}
+template <int EPI, int NC, int CHP4>
+static void launch_br_one(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 6 * (4 * 4 * 1024) + 4 * (NC + 1) + 12;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
+  if (a.W8) hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  else hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+}
+template <int EPI, int CHP4>
+static bool launch_br_units(int units, const GemvBArgs& a, hipStream_t s) {
+  switch (units) {
+    case 1: case 2: launch_br_one<EPI, 2, CHP4>(a, s); return true;
+    case 3: launch_br_one<EPI, 3, CHP4>(a, s); return true;
+    case 4: launch_br_one<EPI, 4, CHP4>(a, s); return true;
+    default: return false;
+  }
+}
 static int g_gemv_bl = -1;
 void set_gemv_bl(int v) { g_gemv_bl = v; }
 // variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block), bit 2: also with fp8 weights.  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,
 // K other than 2048 / 4096, more than 4 units per CU): the caller goes on to k_gemv_bx / k_gemv_b
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 1; }     // default: gate/up + lm_head (64-slot step 4.49 -> 4.35 ms); qkv has too few units per CU (4.64)
+  if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 33; }    // default: bit 0 = gate/up + lm_head (64-slot step 4.49 -> 4.35 ms; qkv has too few units per CU: 4.64), bit 5 = k_gemv_br for fp8 weights
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
+  if (a.W8 && (g_gemv_bl & 32) && a.K == 4096 && (epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LOGITS)
+      && !(epi == EPI_SWIGLU && (a.ff & 15)) && !(epi == EPI_LOGITS && (a.N & 31))) {
+    // fp8 weights through registers (k_gemv_br): gate/up 28.9 -> 25.5 us, qkv 28.1 -> 24.8 (profiles/r03_loader_kernel_experiments.txt)
+    const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
+                     : epi == EPI_SWIGLU ? gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH) : gg_groups<EPI_LOGITS, 2>(a.N, a.ff, a.H, a.KVH);
+    const int units = (groups + cu_count() - 1) / cu_count();
+    if (epi == EPI_QKV) { if (launch_br_units<EPI_QKV, 4>(units, a, s)) return true; }
+    else if (epi == EPI_SWIGLU) { if (launch_br_units<EPI_SWIGLU, 4>(units, a, s)) return true; }
+    else if (launch_br_units<EPI_LOGITS, 4>(units, a, s)) return true;
+  }
   if (a.W8 && !(g_gemv_bl & 4)) return false;     // fp8 weights: bit 2 (measured neutral against the fp8 k_gemv_bx: 4.01 vs 4.04 ms per 64-slot step)
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
   if (epi == EPI_QKV ? !(g_gemv_bl & (2 | 8 | 16)) : !(g_gemv_bl & 1)) return false;

@@ -228,7 +228,7 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * head, 1 = per K/V head, 2 = per pair of query heads), "share_prefix_reads", "resid_split" (o_proj / down: two row tiles x half of
  * the slots per block), "resid_kparts" (o_proj / down at 49..64 slots: K-slice partials stored, reduced by the RMSNorm kernel that
  * follows), "gemv_bkl" (that kernel with LDS-DMA operand rings), "gemv_bl" (bit 0: loader-wave kernel for gate/up + lm_head, bit 1:
- * qkv by pair units, bit 2: fp8 weights too, bit 3 / 4: qkv as a RoPE pair unit + a V row tile per block), "gemv_xw" (x fragments
+ * qkv by pair units, bit 2: fp8 weights too, bit 3 / 4: qkv as a RoPE pair unit + a V row tile per block, bit 5: fp8 weights at K = 4096 through registers), "gemv_xw" (x fragments
  * by an extra wave's ordinary loads instead of LDS-DMA), "attn_nt" (non-temporal K / V loads).  Prefill / ViT: "attn_impl" (0 auto,
  * 1 VALU, 2 MFMA flash), "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages"
  * (1..4), "gemm_impl" (0 register-staged, 1 LDS-DMA fragment order, 2 128x128 LDS-DMA row order, 3 auto), "gemm_ring" (2..4),

@@ -1391,7 +1391,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                         (1, 0, 1, 2, 5),        # resid_kparts 2 = with k_gemv_bkl (LDS-ring operands) as the weight kernel
                         (1, 0, 1, 2, 5, 1), (1, 0, 1, 2, 1 + 4 + 16, 0), (1, 0, 1, 2, 1 + 4 + 16, 1), (0, 0, 0, 2, 7, 1),
                         (1, 0, 1, 2, 1 + 4 + 16, 0, 2), (1, 0, 1, 2, 1 + 4 + 16, 1, 2), (1, 0, 1, 2, 5, 2), (1, 0, 1, 2, 1 + 2 + 4, 2),
-                        (1, 0, 1, 2, 1 + 4 + 16, 2, 2)):   # 6th entry: gemv_xw (x by an extra wave's ordinary
+                        (1, 0, 1, 2, 1 + 4 + 16, 2, 2), (1, 0, 1, 2, 1 + 32), (0, 0, 0, 0, 32 + 1)):     # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
                         # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
             model.set_option("gemv_bx", variant[0])
             model.set_option("gemv_bk", variant[1])
@@ -1417,7 +1417,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_bk", 0)
         model.set_option("resid_split", 1)
         model.set_option("resid_kparts", 1)
-        model.set_option("gemv_bl", 1)
+        model.set_option("gemv_bl", 33)
         model.set_option("gemv_bkl", 1)
         model.set_option("gemv_xw", 0)
         model.set_option("gemv_loaders", 1)
