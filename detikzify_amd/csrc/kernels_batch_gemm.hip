@@ -885,25 +885,33 @@ __global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
     }
   }
 }
+// false = this instantiation must not run: its weight loads are issued by hand, so a register the compiler SPILLS would be stored
+// before its load has landed (how the K = 2048 instantiations faulted).  The code object says whether it spills: any private
+// (scratch) bytes per thread disqualify the kernel, and the caller falls back to k_gemv_bx / k_gemv_b.
 template <int EPI, int NC, int CHP4>
-static void launch_br_one(const GemvBArgs& a, hipStream_t s) {
+static bool launch_br_one(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = 6 * (4 * 4 * 1024) + 4 * (NC + 1) + 12;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static int usable_by_format[2] = {-1, -1};
+  int& usable = usable_by_format[a.W8 ? 1 : 0];
+  if (usable < 0) {
+    const void* fn = a.W8 ? reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, true>) : reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, false>);
+    hipFuncAttributes fa;
+    const bool ok = hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.localSizeBytes == 0
+                    && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    usable = ok ? 1 : 0;
   }
+  if (!usable) return false;
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
   if (a.W8) hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
   else hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  return true;
 }
 template <int EPI, int CHP4>
 static bool launch_br_units(int units, const GemvBArgs& a, hipStream_t s) {
   switch (units) {
-    case 1: case 2: launch_br_one<EPI, 2, CHP4>(a, s); return true;
-    case 3: launch_br_one<EPI, 3, CHP4>(a, s); return true;
-    case 4: launch_br_one<EPI, 4, CHP4>(a, s); return true;
+    case 1: case 2: return launch_br_one<EPI, 2, CHP4>(a, s);
+    case 3: return launch_br_one<EPI, 3, CHP4>(a, s);
+    case 4: return launch_br_one<EPI, 4, CHP4>(a, s);
     default: return false;
   }
 }
