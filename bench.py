@@ -75,6 +75,9 @@ def parse():
                     "taking turns in the --mcts-trees decode slots (<= 1: skip)")
     ap.add_argument("--no-config4", action="store_true", help="skip mcts.config4 (BASELINE configs[3]: 16 rollouts of one image over the ranks)")
     ap.add_argument("--no-config5", action="store_true", help="skip mcts.config5 (BASELINE configs[4]: cl-7b fp8, 8 images x 32 rollouts over the ranks)")
+    ap.add_argument("--no-rank-shapes", action="store_true", help="skip mcts.config4.rank_shape / mcts.config5.rank_shape: what ONE rank of an "
+                                                                   "N = 2 / 4 / 8 job decodes (16/N trees; 8/N images), run on this GPU at N = 1, and "
+                                                                   "the whole-job rate that predicts (the path has no data-path collective)")
     ap.add_argument("--config5-model", default="detikzify-cl-7b")
     ap.add_argument("--config5-images", type=int, default=8)
     ap.add_argument("--config5-trees", type=int, default=8, help="trees per image (x --config5-expansions = 32 rollouts per image)")
@@ -555,6 +558,36 @@ def main():
                 c4 = {"shape": "16 rollouts of one image over all ranks, root-parallel: 16/N trees x 1 expansion per rank",
                       "fixed_length": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, Wk=(W, Kb)),
                       "ragged": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, ragged=True, Wk=(W, Kb))}
+                if world == 1 and not args.no_rank_shapes:
+                    # What rank 0 of an N-GPU job would decode, run here on ONE GPU: 16/N trees of one expansion (N = 4 / 8: 4 / 2
+                    # trees in a 5-slot context = the multi-vector kernels; N = 2: 8 trees = one MFMA column tile).  Every rank of
+                    # such a job has the same shape and the path has no data-path collective (one gather of strings at the end), so
+                    # N x this rank's rate is what the N-GPU job should deliver; SCALE_rNN.json then only has to confirm it.
+                    shapes, small, m_, p_ = {}, None, None, None
+                    try:
+                        for N in (2, 4, 8):
+                            per = ddist.shard_expansions(16, N)[0]
+                            if per <= 4 and small is None:
+                                t_l = time.perf_counter()
+                                small = dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=5, weight_format=args.weight_format)
+                                shapes["small_context_load_seconds"] = round(time.perf_counter() - t_l, 1)
+                            m_, p_ = small if per <= 4 else (model, proc)
+                            per = per if per <= 4 else min(per, args.batch)
+                            r = search(m_, p_, [img0], per, 1, Wk=(W, Kb))
+                            rate = r.get("rollouts_per_sec")
+                            shapes[f"N{N}"] = {"trees_per_rank": per, "context_slots": m_.num_slots(),
+                                               "step_kernels_cover_slots": m_.stats().get("last_batch_step_slots"),
+                                               "rollouts_per_sec_one_rank": rate, "predicted_rollouts_per_sec_at_N": None if rate is None else N * rate,
+                                               "predicted_scaling_vs_N1": None if not (rate and c4["fixed_length"].get("rollouts_per_sec")) else
+                                               N * rate / c4["fixed_length"]["rollouts_per_sec"],
+                                               "seconds": r["seconds"], "decode_steps": r["decode_steps_per_gpu"], "frac_of_roofline": r.get("frac_of_roofline"),
+                                               "ms_per_decode_step": (1e3 * (r.get("engine") or {}).get("wait_s", 0.0) / r["decode_steps_per_gpu"]) if r.get("decode_steps_per_gpu") else None}
+                    finally:
+                        if small is not None:
+                            del small, m_, p_
+                            import gc
+                            gc.collect()
+                    c4["rank_shape"] = shapes
                 mcts["config4"] = c4
             for S in args.reward_latency:
                 # f3: what a reward that costs what LaTeX costs does to rollouts/s.  The renderer sleeps S seconds per document
@@ -608,6 +641,22 @@ def main():
                 try:
                     for key, ragged in (("fixed_length", False), ("ragged", True)):
                         c5[key] = search(m5, p5, [imgs5[i] for i in mine5], args.config5_trees, args.config5_expansions, ragged=ragged, Wk=Wk5)
+                    if world == 1 and not args.no_rank_shapes:
+                        # one rank's share at N = 2 / 4 / 8: 8/N images x the same trees (32 / 16 / 8 decode slots: two / one MFMA
+                        # column tiles — the kernels a step runs follow its highest active slot, so the 72-slot context runs
+                        # exactly what an N-GPU rank's smaller context would)
+                        shapes5 = {}
+                        for N in (2, 4, 8):
+                            imgs_n = ddist.chunk(list(range(len(imgs5))), N)[0]
+                            r = search(m5, p5, [imgs5[i] for i in imgs_n], args.config5_trees, args.config5_expansions, Wk=Wk5)
+                            rate = r.get("rollouts_per_sec")
+                            shapes5[f"N{N}"] = {"images_per_rank": len(imgs_n), "trees_per_rank": len(imgs_n) * args.config5_trees,
+                                                "step_kernels_cover_slots": m5.stats().get("last_batch_step_slots"),
+                                                "rollouts_per_sec_one_rank": rate, "predicted_rollouts_per_sec_at_N": None if rate is None else N * rate,
+                                                "predicted_scaling_vs_N1": None if not (rate and c5["fixed_length"].get("rollouts_per_sec")) else
+                                                N * rate / c5["fixed_length"]["rollouts_per_sec"],
+                                                "seconds": r["seconds"], "frac_of_roofline": r.get("frac_of_roofline")}
+                        c5["rank_shape"] = shapes5
                 finally:
                     del m5
                     import gc
@@ -621,6 +670,10 @@ def main():
         result["mcts_rollouts_per_sec_oversubscribed"] = (mcts.get("parallel_oversubscribed") or {}).get("rollouts_per_sec")
         result["mcts_config4_rollouts_per_sec"] = ((mcts.get("config4") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
         result["mcts_config5_rollouts_per_sec"] = ((mcts.get("config5") or {}).get("fixed_length") or {}).get("rollouts_per_sec")
+        for key in ("config4", "config5"):      # {N: predicted whole-job rollouts/s} from the one-rank shapes measured above
+            rs = (mcts.get(key) or {}).get("rank_shape") or {}
+            if rs:
+                result[f"mcts_{key}_predicted_rollouts_per_sec"] = {k: v.get("predicted_rollouts_per_sec_at_N") for k, v in rs.items() if isinstance(v, dict)}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: probe pass (plain launches, HIP events around the kernel)

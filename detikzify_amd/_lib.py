@@ -8,7 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
-DTK_ABI_VERSION = 3          # include/dtk.h DTK_ABI_VERSION
+DTK_ABI_VERSION = 4          # include/dtk.h DTK_ABI_VERSION
 DTK_VIT_BATCH = 8            # include/dtk.h: images per pass of dtk_vit_encode
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
@@ -48,6 +48,7 @@ class DtkStats(C.Structure):
         ("last_prefill_ms", C.c_double), ("last_vit_ms", C.c_double),
         ("probe_kernel_ms_sum", C.c_double), ("probe_kernel_launches", C.c_uint64),
         ("probe_kernel_bytes", C.c_uint64), ("probe_event_pair_ms", C.c_double),
+        ("last_batch_step_slots", C.c_uint32), ("device_errors", C.c_uint32),
     ]
 
 
@@ -77,6 +78,7 @@ SYMBOLS = {
     "dtk_synchronize": (C.c_int, [_P]),
     "dtk_get_stats": (C.c_int, [_P, C.POINTER(DtkStats)]),
     "dtk_num_slots": (C.c_int, [_P]),
+    "dtk_max_decode_slots": (C.c_int, [_P]),
     "dtk_prefill_slot": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64, C.c_int, _P]),
     "dtk_set_sampling_slot": (C.c_int, [_P, C.c_int, C.POINTER(DtkSampling)]),
     "dtk_decode_batch_launch": (C.c_int, [_P, C.POINTER(C.c_int32)]),
@@ -92,6 +94,7 @@ SYMBOLS = {
     "dtk_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "dtk_op_gemv_mv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "dtk_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "dtk_op_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int64), _P]),

@@ -153,10 +153,18 @@ struct dtk_ctx {
   hipEvent_t bstep_done[DTK_MAX_INFLIGHT] = {};
   // one captured step per column-tile count (1, 2, 4 tiles of 16 slots): a step only pays for the tiles up to its highest
   // active slot (32 trees on a 65-slot context run the 2-tile kernels)
-  bool bgraph_ready[3] = {false, false, false};
-  hipGraph_t bgraph[3] = {nullptr, nullptr, nullptr};
-  hipGraphExec_t bgraph_exec[3] = {nullptr, nullptr, nullptr};
+  // (+ three more for the multi-vector step of a context with <= 5 slots: 1, 2 or 4 vectors)
+  bool bgraph_ready[6] = {false, false, false, false, false, false};
+  hipGraph_t bgraph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t bgraph_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int nt_step = 1;                   // tile count of the step being launched / captured
+  // Contexts with at most 5 slots (<= 4 decoding + a prefix slot: BASELINE config 4's 2 / 4 trees per rank at N = 8 / 4) decode
+  // with the multi-vector kernels (kernels_decode_mv.hip): the single-sequence GEMVs carrying 1, 2 or 4 x vectors instead of a
+  // 16-column MFMA tile.  The kernel family is a property of the CONTEXT (slot count at dtk_create, dtk_set_option "mv_slots"),
+  // never of the active set, so a sequence's logits do not depend on which other slots happen to decode with it.
+  int mv_slots = 4;                  // contexts with nb <= mv_slots + 1 use the family (0 = never)
+  int mv_step = 0;                   // vectors of the step being launched / captured (0 = an MFMA step)
+  int mv_tail_threads = 512;         // block of k_attn_tail_b in a multi-vector step (few blocks: more rows per round trip)
   dtk_sampling sampling{};
   SampleMB* smb = nullptr;           // multi-block sampler scratch (single sequence) / per slot
   SampleMB* smb_b = nullptr;
@@ -663,6 +671,58 @@ void batch_step_launches(dtk_ctx* c) {
   launch_gemv_b(EPI_LOGITS, g, s);
 }
 
+static inline bool mv_family(const dtk_ctx* c) { return c->mv_slots > 0 && c->nb > 0 && c->nb <= c->mv_slots + 1 && c->nb <= 5; }
+// slots that may take part in a decode step: 0..3 of a multi-vector context, else the context's column tiles
+static inline int max_decode_slots(const dtk_ctx* c) {
+  const int lim = mv_family(c) ? 4 : 16 * c->nt;
+  return c->nb < lim ? c->nb : lim;
+}
+
+// launches of one multi-vector decode step (c->mv_step = 1, 2 or 4 vectors = slots 0..mv_step-1): five kernels per layer
+void batch_step_launches_mv(dtk_ctx* c) {
+  hipStream_t s = c->stream;
+  const int d = c->d, ff = c->ff, NB = c->mv_step;
+  SampleArgs sa;
+  sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
+  sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = NB; sa.mb = c->smb_b;
+  if (c->mb_batch) launch_sample_mb(sa, s); else launch_sample_b(sa, s);
+  const float scale = 1.0f / sqrtf(128.f);
+  const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
+  GemvMvArgs g{};
+  g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.eps = c->cfg.rms_eps;
+  g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride;
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    bf16_t* kc = c->kvb + (size_t)l * kv_layer;
+    bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
+    // 1. input_layernorm + q/k/v + RoPE + KV append at every slot's own position
+    g.W = w.wqkv; g.W8 = w.q_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X = c->xb; g.ldx = d; g.norm_w = w.ln1;
+    g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    launch_gemv_mv(PRO_RMSNORM, EPI_QKV, NB, g, s);
+    // 2. attention: one block per (head, slot), output in fragment order
+    AttnDecBArgs ad;
+    ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = NB;
+    ad.scale = scale;
+    ad.impl = c->attn_b_impl; ad.use_prefix = 0; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->mv_tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
+    ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
+    launch_attn_decode_b(ad, s);
+    // 3. o_proj + residual
+    g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.Y = c->xb; g.ldy = d;
+    launch_gemv_mv(PRO_COPY, EPI_RESID, NB, g, s);
+    // 4. post_attention_layernorm + gate/up + SiLU * mul
+    g.W = w.wgu; g.W8 = w.q_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X = c->xb; g.ldx = d; g.norm_w = w.ln2; g.Y = c->actb; g.ldy = ff;
+    launch_gemv_mv(PRO_RMSNORM, EPI_SWIGLU, NB, g, s);
+    // 5. down + residual
+    g.W = w.wdown; g.W8 = w.q_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X = c->actb; g.Y = c->xb; g.ldy = d;
+    launch_gemv_mv(PRO_COPY, EPI_RESID, NB, g, s);
+  }
+  g.W = c->lm_head; g.W8 = c->q_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xb; g.ldx = d; g.norm_w = c->final_norm;
+  g.logits = c->logits_b;
+  launch_gemv_mv(PRO_RMSNORM, EPI_LOGITS, NB, g, s);
+}
+
 // fp8 mode: quantise the decoder Linear weights (per-row power-of-two scale) and overwrite the bf16 masters
 // with the de-quantised values, so every consumer (prefill GEMM, tiled copy, read-back, oracle) sees the
 // same effective weights as the fp8 decode kernels
@@ -708,20 +768,21 @@ void ensure_tiled_weights(dtk_ctx* c) {
 }
 
 static inline int nt_index(int nt) { return nt >= 3 ? 2 : nt - 1; }
+static inline int step_graph_index(const dtk_ctx* c) { return c->mv_step ? 3 + (c->mv_step >= 4 ? 2 : c->mv_step - 1) : nt_index(c->nt_step); }
 
 void drop_batch_graphs(dtk_ctx* c) {
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 6; ++i) {
     if (c->bgraph_exec[i]) { (void)hipGraphExecDestroy(c->bgraph_exec[i]); c->bgraph_exec[i] = nullptr; }
     if (c->bgraph[i]) { (void)hipGraphDestroy(c->bgraph[i]); c->bgraph[i] = nullptr; }
     c->bgraph_ready[i] = false;
   }
 }
 
-int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step
-  const int gi = nt_index(c->nt_step);
+int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step / c->mv_step
+  const int gi = step_graph_index(c);
   if (c->bgraph_ready[gi]) return DTK_OK;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  batch_step_launches(c);
+  if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
   HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph[gi]));
@@ -1269,6 +1330,7 @@ int dtk_set_sampling_slot(dtk_ctx* c, int slot, const dtk_sampling* sp) {
 }
 
 int dtk_num_slots(const dtk_ctx* c) { return c ? c->nb : 0; }
+int dtk_max_decode_slots(const dtk_ctx* c) { return (c && c->nb > 0) ? max_decode_slots(c) : 0; }
 
 // One batched decode step for the slots with active[slot] != 0 (every one must have been prefilled).
 int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
@@ -1278,7 +1340,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   int n_active = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) {
     if (!active[j]) continue;
-    if (j >= c->nb || j >= 16 * c->nt) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    if (j >= max_decode_slots(c)) return fail(c, DTK_ERR_ARG, "slot %d cannot decode: slots 0..%d of this %d-slot context do", j, max_decode_slots(c) - 1, c->nb);
     const SeqHost& sh = c->bseq[(size_t)j];
     if (!sh.have_logits) return fail(c, DTK_ERR_STATE, "slot %d: decode before prefill", j);
     if (sh.host_next_pos >= c->Tmax) return fail(c, DTK_ERR_RANGE, "slot %d: context length %d reached max_positions", j, sh.host_next_pos);
@@ -1316,16 +1378,18 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   int hi = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) if (active[j]) hi = j;
   c->nt_step = hi < 16 ? 1 : (hi < 32 ? 2 : 4);      // column tiles this step needs (per-column results do not depend on it)
+  c->mv_step = mv_family(c) ? (hi < 1 ? 1 : (hi < 2 ? 2 : 4)) : 0;   // vectors of a multi-vector step (per-slot results do not depend on it)
   HIPCHK(c, hipMemcpyAsync(c->bs_dev, hb, sizeof(BatchState), hipMemcpyHostToDevice, c->stream));
   if (c->use_graph) {
     int rc = ensure_batch_graph(c);
     if (rc) return rc;
-    HIPCHK(c, hipGraphLaunch(c->bgraph_exec[nt_index(c->nt_step)], c->stream));
+    HIPCHK(c, hipGraphLaunch(c->bgraph_exec[step_graph_index(c)], c->stream));
   } else {
-    batch_step_launches(c);
+    if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
     HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
+  c->stats.last_batch_step_slots = (uint32_t)(c->mv_step ? c->mv_step : 16 * c->nt_step);
   c->blaunched++;
   c->stats.decode_steps++;
   for (int j = 0; j < DTK_MAX_BATCH; ++j)
@@ -1701,6 +1765,24 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "attn_nt")) { c->attn_nt = value != 0; drop_batch_graphs(c); }
+  else if (!strcmp(name, "mv_slots")) {     // contexts with at most value + 1 slots decode with the multi-vector kernels (0 = never)
+    if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "mv_slots must be 0..4");
+    if (c->blaunched != c->bwaited) return fail(c, DTK_ERR_STATE, "mv_slots: a batch step is in flight");
+    c->mv_slots = value;
+    drop_batch_graphs(c);
+  }
+  else if (!strcmp(name, "mv_tail_threads")) {
+    if (value != 256 && value != 512 && value != 1024) return fail(c, DTK_ERR_ARG, "mv_tail_threads must be 256, 512 or 1024");
+    c->mv_tail_threads = value;
+    drop_batch_graphs(c);
+  }
+  else if (!strncmp(name, "mv_shape_", 9)) {   // block shape of one multi-vector role: qkv | o | gu | down | lm_head; 0..3, -1 = measured default
+    const char* r = name + 9;
+    const int role = !strcmp(r, "qkv") ? EPI_QKV : !strcmp(r, "o") ? 5 : !strcmp(r, "gu") ? EPI_SWIGLU : !strcmp(r, "down") ? EPI_RESID : !strcmp(r, "lm_head") ? EPI_LOGITS : -1;
+    if (role < 0 || value < -1 || value > 3) return fail(c, DTK_ERR_ARG, "mv_shape_{qkv,o,gu,down,lm_head} must be -1..3");
+    set_gemv_mv_shape(role, value);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "resid_kparts")) {     // batched N = d roles as k_gemv_bkp + k_resid_norm_b (64 slots, bf16 weights)
     c->resid_kparts = value != 0;
     drop_batch_graphs(c);
@@ -1820,6 +1902,29 @@ int dtk_op_gemv(dtk_ctx* c, const uint16_t* W, const uint16_t* x, const uint16_t
   HIPCHK(c, hipMemcpyAsync(y, dy, (size_t)N * 2, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  return DTK_OK;
+}
+
+// nb (1, 2 or 4) input vectors through k_gemv_mv: y[b] = W . x[b] (mode 0) or W . rmsnorm(x[b], norm_w) (mode 1); per vector
+// the result must equal dtk_op_gemv's bit for bit (same lane / chunk order, same wave reduction, same block size)
+int dtk_op_gemv_mv(dtk_ctx* c, const uint16_t* W, const uint16_t* X, const uint16_t* norm_w, int N, int K, int mode, float eps, int nb, uint16_t* Y) {
+  if (!c || !W || !X || !Y || N < 1 || K < 8 || (K & 7) || (nb != 1 && nb != 2 && nb != 4) || (mode == 1 && !norm_w))
+    return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mv: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  OPBUF(bf16_t, dW, (size_t)N * K);
+  OPBUF(bf16_t, dX, (size_t)nb * K);
+  OPBUF(bf16_t, dG, (size_t)K);
+  OPBUF(bf16_t, dY, (size_t)nb * N);
+  HIPCHK(c, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dX, X, (size_t)nb * K * 2, hipMemcpyHostToDevice, c->stream));
+  if (norm_w) HIPCHK(c, hipMemcpyAsync(dG, norm_w, (size_t)K * 2, hipMemcpyHostToDevice, c->stream));
+  GemvMvArgs g{};
+  g.W = dW; g.N = N; g.K = K; g.X = dX; g.ldx = K; g.x_rowmajor = 1; g.norm_w = dG; g.eps = eps; g.Y = dY; g.ldy = N; g.d = K; g.ff = N;
+  launch_gemv_mv(mode == 1 ? PRO_RMSNORM : PRO_COPY, EPI_STORE, nb, g, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(Y, dY, (size_t)nb * N * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return DTK_OK;
 }
 

@@ -156,6 +156,30 @@ struct AttnDecBArgs {
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- batched decode with <= 4 slots (kernels_decode_mv.hip)
+// k_gemv_mv = k_gemv carrying NB <= 4 input vectors (slots 0..NB-1): row-major weights read once, per slot the arithmetic of
+// the single-sequence kernel.
+struct GemvMvArgs {
+  const bf16_t* W;       // [N][K] row-major (the single-sequence copy)
+  const uint8_t* W8;     // fp8 rows + wscale[N], or null
+  const float* wscale;
+  int N; int K;
+  const bf16_t* X;       // PRO_RMSNORM: residual streams [slot][ldx]; PRO_COPY: fragment order (xtile_off) unless x_rowmajor
+  int ldx;
+  int x_rowmajor;        // PRO_COPY input is [slot][ldx] (op-level tests)
+  const bf16_t* norm_w; float eps;
+  bf16_t* Y; int ldy;    // RESID: residual streams [slot][ldy] in place; SWIGLU: activation, fragment order; STORE: [slot][ldy]
+  float* logits;         // LOGITS: [slot][N]
+  bf16_t* q_out;         // QKV: [slot][d]
+  bf16_t* kcache; bf16_t* vcache; size_t kv_slot_stride;   // this layer's caches of slot 0
+  const bf16_t* rope_cos; const bf16_t* rope_sin;
+  const DecState* st;    // [slots]
+  const BatchState* bs;  // active flags, or null = every slot
+  int T_max; int d; int ff; int H; int KVH;
+};
+void launch_gemv_mv(int pro, int epi, int nb, const GemvMvArgs& a, hipStream_t s);   // nb = 1, 2 or 4 vectors
+void set_gemv_mv_shape(int role, int shape);   // role = epilogue id (5 = o_proj alone); shape 0..3, -1 = measured default
+
 // ---------------------------------------------------------------- batched (prefill / ViT) kernels
 #define GEMM_BIAS 1
 #define GEMM_GELU_ERF 2

@@ -866,6 +866,7 @@ void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
     if (a.tail_threads == 64) hipLaunchKernelGGL(k_attn_tail_b<64>, dim3(a.H, a.nslots), dim3(64), 0, s, a);
     else if (a.tail_threads == 128) hipLaunchKernelGGL(k_attn_tail_b<128>, dim3(a.H, a.nslots), dim3(128), 0, s, a);
     else if (a.tail_threads == 256) hipLaunchKernelGGL(k_attn_tail_b<256>, dim3(a.H, a.nslots), dim3(256), 0, s, a);
+    else if (a.tail_threads == 1024) hipLaunchKernelGGL(k_attn_tail_b<1024>, dim3(a.H, a.nslots), dim3(1024), 0, s, a);   // multi-vector step: 256 keys per tile
     else hipLaunchKernelGGL(k_attn_tail_b<512>, dim3(a.H, a.nslots), dim3(512), 0, s, a);
     return;
   }

@@ -65,10 +65,12 @@ class BatchEngine:
         if n <= 0:
             raise ValueError("model was loaded without batch slots (load(..., batch_slots=N))")
         self.model = model
-        maxdec = 64 if n > 33 else (32 if n > 17 else 16)   # one / two / four 16-slot MFMA column tiles (include/dtk.h)
-        dec = min(n, maxdec)
+        # slots that can take part in a step (include/dtk.h): 4 of a context with <= 5 slots (multi-vector kernels), else one /
+        # two / four 16-slot MFMA column tiles
+        probe = getattr(model, "max_decode_slots", None)
+        dec = int(probe()) if callable(probe) else min(n, 64 if n > 33 else (32 if n > 17 else 16))
         self.share_prefix = share_prefix and n >= 2
-        self.capacity = min(dec, max_batch) if max_batch else (dec if n > maxdec else dec - 1)
+        self.capacity = min(dec, max_batch) if max_batch else (dec if n > dec else dec - 1)
         # Slots the decode batch does not need are the prefix cache (the highest indices: a step only runs the column
         # tiles up to its highest ACTIVE slot): each holds the KV of one image prefix ([image_token]*n + pixels), least
         # recently used first out; sequences fork it (bit-identical KV) and only prefill what follows.  With

@@ -367,6 +367,11 @@ class DetikzifyForCausalLM:
     def num_slots(self) -> int:
         return int(self.lib.dtk_num_slots(self._ctx))
 
+    def max_decode_slots(self) -> int:
+        """slots 0..n-1 that may take part in a decode step: 4 (contexts with <= 5 slots: multi-vector kernels), 16, 32 or 64
+        (one, two, four MFMA column tiles), never more than num_slots()"""
+        return int(self.lib.dtk_max_decode_slots(self._ctx))
+
     def decode_batch_launch(self, active_slots: Iterable[int]):
         arr = (C.c_int32 * _lib.DTK_MAX_BATCH)()
         for j in active_slots:

@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define DTK_ABI_VERSION 3   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64 */
+#define DTK_ABI_VERSION 4   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
+                             * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels) */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -106,6 +107,10 @@ typedef struct dtk_stats {
   uint64_t probe_kernel_bytes;      /* algorithmic bytes of one such launch           */
   double   probe_event_pair_ms;     /* elapsed time of an EMPTY hipEventRecord pair on the stream (the fixed cost inside every
                                      * probe interval; calibrated when probe mode is switched on)            */
+  uint32_t last_batch_step_slots;   /* slots the kernels of the last dtk_decode_batch_launch computed: 1 | 2 | 4 (multi-vector
+                                     * kernels) or 16 | 32 | 64 (one, two, four MFMA column tiles)            */
+  uint32_t device_errors;           /* sticky: in-kernel protocol timeouts seen so far (a ring hand-off that expired); any
+                                     * non-zero value makes dtk_decode_batch_wait fail                          */
 } dtk_stats;
 
 int  dtk_abi_version(void);
@@ -184,7 +189,9 @@ int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
 /* Batched decode for independent rollouts of one GPU: dtk_config.reserved[0] = number
  * of slots (<= DTK_MAX_SLOTS), each with its own KV cache, sampling state and logits.  One
  * dtk_decode_batch_* step = one _sample iteration for every active slot with ONE pass over the weights
- * (bytes/step = W + sum_b K*t_b).  Up to 17 slots: slots 0..15 decode (one 16-column MFMA tile); 18..33 slots:
+ * (bytes/step = W + sum_b K*t_b).  Up to 5 slots: slots 0..3 decode with the multi-vector kernels (the single-sequence GEMVs
+ * carrying 1, 2 or 4 input vectors: BASELINE config 4 leaves 2 / 4 trees per rank at N = 8 / 4, reference examples/eval.py:80-83);
+ * 6..17 slots: slots 0..15 decode (one 16-column MFMA tile); 18..33 slots:
  * slots 0..31 decode (two tiles); 34..72 slots: slots 0..63 decode (four tiles); slots beyond the decoding ones can only be
  * prefilled / forked from (prefix cache: one per image in flight — BASELINE config 5 runs 8 images on one GPU).
  * The `active` / `tokens_out` arrays always have DTK_MAX_BATCH entries.
@@ -192,6 +199,8 @@ int  dtk_get_stats(dtk_ctx* ctx, dtk_stats* out);
 #define DTK_MAX_BATCH 64
 #define DTK_MAX_SLOTS (DTK_MAX_BATCH + 8)
 int  dtk_num_slots(const dtk_ctx* ctx);
+/* how many slots (0 .. n-1) may take part in a decode step: 4, 16, 32 or 64, at most dtk_num_slots */
+int  dtk_max_decode_slots(const dtk_ctx* ctx);
 int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const float* pixels,
                       uint64_t image_key, int flags, float* logits_last_out);
 int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
@@ -229,7 +238,10 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * the slots per block), "resid_kparts" (o_proj / down at 49..64 slots: K-slice partials stored, reduced by the RMSNorm kernel that
  * follows), "gemv_bkl" (that kernel with LDS-DMA operand rings), "gemv_bl" (bit 0: loader-wave kernel for gate/up + lm_head, bit 1:
  * qkv by pair units, bit 2: fp8 weights too, bit 3 / 4: qkv as a RoPE pair unit + a V row tile per block, bit 5: fp8 weights at K = 4096 through registers), "gemv_xw" (x fragments
- * by an extra wave's ordinary loads instead of LDS-DMA), "attn_nt" (non-temporal K / V loads).  Prefill / ViT: "attn_impl" (0 auto,
+ * by an extra wave's ordinary loads instead of LDS-DMA), "attn_nt" (non-temporal K / V loads), "mv_slots" (0..4: contexts with at most
+ * that many + 1 slots decode with the multi-vector kernels; 0 = the MFMA kernels for every context), "mv_tail_threads" (256 | 512 |
+ * 1024: attention block of that step), "mv_shape_qkv|o|gu|down|lm_head" (-1 = measured default, 0 = the single-sequence block
+ * shape, 1..3 = persistent with 8 / 4 / 16 waves).  Prefill / ViT: "attn_impl" (0 auto,
  * 1 VALU, 2 MFMA flash), "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages"
  * (1..4), "gemm_impl" (0 register-staged, 1 LDS-DMA fragment order, 2 128x128 LDS-DMA row order, 3 auto), "gemm_ring" (2..4),
  * "gemm_glds_min_tiles".  DESIGN.md 3.4 has the defaults and what each switch measured.
@@ -252,6 +264,10 @@ int  dtk_op_gemm(dtk_ctx* ctx, const uint16_t* A, const uint16_t* W, const uint1
 /* mode 0: y = W.x ; mode 1: y = W.rmsnorm(x, norm_w) ; fp32 result of the bf16-rounded output */
 int  dtk_op_gemv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* x, const uint16_t* norm_w,
                  int N, int K, int mode, float eps, uint16_t* y);
+/* the multi-vector GEMV of the <= 4-slot step on nb (1, 2, 4) row-major vectors X[nb][K] -> Y[nb][N]; per vector bit-identical
+ * to dtk_op_gemv */
+int  dtk_op_gemv_mv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* X, const uint16_t* norm_w,
+                    int N, int K, int mode, float eps, int nb, uint16_t* Y);
 /* softmax(Q K^T * scale [+ causal mask with q_offset]) V, heads-major [H][T][hd] bf16 */
 int  dtk_op_attention(dtk_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* V,
                       int H, int Tq, int Tk, int hd, int causal, int q_offset, uint16_t* O);

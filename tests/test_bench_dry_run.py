@@ -92,6 +92,17 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert c4["ragged"]["tokens_generated_per_gpu"] < c4["fixed_length"]["tokens_generated_per_gpu"]     # rollouts of different lengths
     assert d["mcts_config4_rollouts_per_sec"] == c4["fixed_length"]["rollouts_per_sec"]
     assert d["mcts_config5_rollouts_per_sec"] == c5["fixed_length"]["rollouts_per_sec"]
+    # the one-rank shapes of an N = 2 / 4 / 8 job and the whole-job rate they predict
+    rs4, rs5 = c4["rank_shape"], c5["rank_shape"]
+    assert [rs4[f"N{n}"]["trees_per_rank"] for n in (2, 4, 8)] == [8, 4, 2] and rs4["N4"]["context_slots"] == rs4["N8"]["context_slots"] == 5
+    assert [rs5[f"N{n}"]["images_per_rank"] for n in (2, 4, 8)] == [2, 1, 1]                # 3 images: chunk(3, N)[0]
+    for rs in (rs4, rs5):
+        for n in (2, 4, 8):
+            e = rs[f"N{n}"]
+            assert e["rollouts_per_sec_one_rank"] > 0 and e["predicted_rollouts_per_sec_at_N"] == pytest.approx(n * e["rollouts_per_sec_one_rank"])
+            assert e["predicted_scaling_vs_N1"] > 0
+    assert d["mcts_config4_predicted_rollouts_per_sec"] == {f"N{n}": rs4[f"N{n}"]["predicted_rollouts_per_sec_at_N"] for n in (2, 4, 8)}
+    assert set(d["mcts_config5_predicted_rollouts_per_sec"]) == {"N2", "N4", "N8"}
     rl = m["reward_latency"]["0.05s"]                                                      # f3: reward latency x pool on / off x 1 / N trees
     assert set(rl) == {"1_trees_pool_off", "1_trees_pool_on", "4_trees_pool_off", "4_trees_pool_on", "8_trees_over_4_slots_pool_on"}
     assert all(v["rollouts"] == {"1": 2, "4": 8, "8": 16}[k.split("_")[0]] and v["rollouts_per_sec"] > 0 for k, v in rl.items())   # 8 trees take turns in 4 slots

@@ -38,6 +38,10 @@ class _Lib:
     def dtk_context_len_slot(self, ctx, s):
         return len(self.dev.ctx[s])
 
+    def dtk_max_decode_slots(self, ctx):       # the rule of include/dtk.h: <= 5 slots -> 0..3 decode; else 16 / 32 / 64 column slots
+        n = self.dev.slots
+        return min(n, 4 if n <= 5 else (64 if n > 33 else (32 if n > 17 else 16)))
+
 
 class _Vision:
     """pooled 'features' = 4x4 average pool of the pixels; the sleep releases the GIL like the ctypes call does"""

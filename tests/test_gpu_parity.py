@@ -755,6 +755,9 @@ def tiny_batched():
     from detikzify_amd.model import load
     model, proc = load("detikzify-tiny", synthetic=1234, batch_slots=5)
     model.set_option("prefix_mfma", 0)
+    # five slots that all decode on the 16-column MFMA kernels: the tests below pin THAT family at toy size (the multi-vector
+    # family a context of <= 5 slots takes by default has its own module, tests/test_gpu_parity_mv.py)
+    model.set_option("mv_slots", 0)
     return model, proc
 
 
@@ -1069,6 +1072,7 @@ def test_fp8_weights_parity_and_quantisation_error():
     shift caused by quantisation itself is reported."""
     from detikzify_amd.model import load
     m8, proc = load("detikzify-tiny", synthetic=1234, weight_format="fp8", batch_slots=2)
+    m8.set_option("mv_slots", 0)           # the MFMA family (the multi-vector fp8 kernels: tests/test_gpu_parity_mv.py)
     m16, _ = load("detikzify-tiny", synthetic=1234)
     name = "model.layers.1.mlp.gate_proj.weight"
     w8, w16 = m8.read_tensor(name).float().view(TINY.ffn, TINY.hidden), m16.read_tensor(name).float().view(TINY.ffn, TINY.hidden)
@@ -1113,6 +1117,7 @@ def test_fp8_weights_parity_and_quantisation_error():
     # the fp8 batched kernels (fp8 pair tiles widened to bf16 in registers, same MFMA k order, exact 2^e row scale)
     # are BIT-identical to the bf16 batched kernels run on the de-quantised weights
     mref, _ = load("detikzify-tiny", synthetic=1234, batch_slots=2)
+    mref.set_option("mv_slots", 0)
     for name in m8.tensor_names():
         if not name.startswith("rope."):
             mref.load_tensor(name, m8.read_tensor(name).view(-1))
@@ -1169,6 +1174,7 @@ def tiny_v2():
     from detikzify_amd.model import load
     model, proc = load("detikzify-tiny-v2", synthetic=4321, batch_slots=5)
     model.set_option("prefix_mfma", 0)      # bit-identity of the per-slot path (see tiny_batched)
+    model.set_option("mv_slots", 0)         # the MFMA family, all five slots decode (see tiny_batched)
     return model, proc
 
 

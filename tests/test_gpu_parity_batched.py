@@ -56,19 +56,19 @@ def oracle_restore(o, snap):
     o.llm.k, o.llm.v, o.llm.pos = list(snap[0]), list(snap[1]), snap[2]
 
 
-@pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-cl-7b", "fp8")])
-def test_batched_headline_matches_cpu_oracle(name, weight_format):
-    """The 64-slot batched decode step exactly as `bench.py`'s rollouts/sec phases run it — full depth, 65 slots allocated
-    (64 decoding + the prefix-cache slot), every default (k_gemv_bx for gate/up and lm_head, resid_split for o_proj / down,
-    k_attn_tail_b<256>, forked slots reading the shared image prefix from the source slot) — against the CPU oracle.
-    The image prefix is prefilled once into slot 64 and forked into slots 0..63; 8 SAMPLED steps with per-slot seeds make
-    the 64 contexts diverge, then 8 GREEDY steps.  For slots {0, 17, 40, 63} (one per 16-slot MFMA column tile) every step's
-    logits are compared with the oracle teacher-forced on the device's tokens (fp32 envelope on slot 40, bf16-policy
-    distance on all four); every sampled token of all 64 slots must equal the oracle sampler's draw from the device's
-    logits; greedy tokens of the four slots follow the near-tie rule."""
+def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, max_positions=512, private_tail=0, tail_watch=()):
+    """One context of `batch_slots` slots: the image prefix is prefilled once into the last slot and forked into every decoding
+    slot; then `phases` = [(active slots, sampled steps, greedy steps, slots the step's kernels must cover)] run one after the
+    other — which kernels a step runs is decided by its highest active slot (MFMA family: 1 / 2 / 4 column tiles of 16) or by the
+    number of vectors (multi-vector family: 1 / 2 / 4), asserted per step through dtk_stats.last_batch_step_slots.  Every
+    sampled token of every active slot must equal the oracle sampler's draw from the device's logits; for the `watch` slots
+    every step's logits are compared with the CPU oracle teacher-forced on the device's tokens (bf16-policy distance on all,
+    fp32 envelope on `watch32`), greedy tokens by the near-tie rule.  `private_tail` > 0: all slots then sample that many more
+    tokens (device only), the oracle re-reads the whole sequence of the `tail_watch` slots in one pass and 4 greedy steps are
+    compared there: attention over hundreds of PRIVATE keys per slot that the decode kernels themselves appended."""
     from detikzify_amd.model import load
     t_start = time.perf_counter()
-    model, proc = load(name, synthetic=1234, max_positions=512, weight_format=weight_format, batch_slots=65)
+    model, proc = load(name, synthetic=1234, max_positions=max_positions, weight_format=weight_format, batch_slots=batch_slots)
     try:
         cfg = model.config.oracle_dict()
         w = weights_from_device(model, cfg)
@@ -76,39 +76,50 @@ def test_batched_headline_matches_cpu_oracle(name, weight_format):
         ids, px = enc.input_ids[0], enc.pixel_values
         n_img = ids.numel()
         img_tok, eos = cfg["image_token_id"], 2
-        NS, SRC, N_SAMPLED, N_GREEDY = 64, 64, 8, 8
-        watch, watch32 = (0, 17, 40, 63), (40,)
-        assert model.num_slots() >= 65
-
+        SRC = batch_slots - 1
+        NS = min(SRC, model.max_decode_slots())
+        seed_of = lambda s: 4242 + s
         model.set_sampling(do_sample=False, slot=SRC)
         dev_prefill = model.prefill(ids, px, slot=SRC, return_logits=True)
         for s in range(NS):
-            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=4242 + s, bad_ids=[img_tok],
-                               begin_suppress_ids=[eos], slot=s)
+            model.set_sampling(do_sample=False, bad_ids=[img_tok], begin_suppress_ids=[eos], slot=s)
             model.kv_fork(SRC, s, n_img)          # whole-prefix fork: KV rows and the next-token logits
-        assert torch.equal(model.get_logits_slot(63), dev_prefill)
+        assert torch.equal(model.get_logits_slot(NS - 1), dev_prefill)
 
-        toks = [[] for _ in range(NS)]
-        logit_log = {s: [] for s in watch}        # logits AFTER step i of slot s
-        prev = [dev_prefill] * NS
-        draws_checked = 0
-        for i in range(N_SAMPLED + N_GREEDY):
-            if i == N_SAMPLED:
-                for s in range(NS):               # draw counter restarts: begin-suppress applies to this step again
-                    model.set_sampling(do_sample=False, bad_ids=[img_tok], begin_suppress_ids=[eos], slot=s)
-            model.decode_batch_launch(range(NS))
-            out = model.decode_batch_wait()
-            for s in range(NS):
-                toks[s].append(out[s])
-                if i < N_SAMPLED:
-                    rt, _ = sampling.draw(prev[s], 0.8, 0, 0.95, 4242 + s, i, [img_tok], [eos], i == 0)
-                    assert out[s] == rt, f"slot {s} sampled draw {i}: device {out[s]}, oracle draw from the device's logits {rt}"
-                    draws_checked += 1
-            prev = [model.get_logits_slot(s) for s in range(NS)]
-            for s in watch:
-                logit_log[s].append(prev[s])
-            assert all(model.context_len_slot(s) == n_img + i + 1 for s in watch)
-        assert len({tuple(t[:N_SAMPLED]) for t in toks}) > NS // 2, "the per-slot seeds did not make the contexts diverge"
+        log = {s: [] for s in range(NS)}          # per slot: (sampled?, first step after set_sampling?, token)
+        logit_log = {s: [] for s in watch}        # logits AFTER each step of a watched slot
+        prev = {s: dev_prefill for s in range(NS)}
+        draws_checked, kinds = 0, []
+        for active, n_sampled, n_greedy, kind in phases:
+            active = list(active)
+            assert max(active) < NS
+            for sampled, n in ((True, n_sampled), (False, n_greedy)):
+                if not n:
+                    continue
+                for s in active:                  # (the draw counter restarts: begin-suppress applies to the next step again)
+                    if sampled:
+                        model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=seed_of(s), bad_ids=[img_tok],
+                                           begin_suppress_ids=[eos], slot=s)
+                    else:
+                        model.set_sampling(do_sample=False, bad_ids=[img_tok], begin_suppress_ids=[eos], slot=s)
+                for i in range(n):
+                    model.decode_batch_launch(active)
+                    out = model.decode_batch_wait()
+                    got_kind = model.stats()["last_batch_step_slots"]
+                    assert got_kind == kind, f"{len(active)} active slots up to {max(active)}: the step ran the {got_kind}-slot kernels, expected {kind}"
+                    for s in active:
+                        if sampled:
+                            rt, _ = sampling.draw(prev[s], 0.8, 0, 0.95, seed_of(s), i, [img_tok], [eos], i == 0)
+                            assert out[s] == rt, f"slot {s} sampled draw {i} ({kind}-slot kernels): device {out[s]}, oracle draw from the device's logits {rt}"
+                            draws_checked += 1
+                        log[s].append((sampled, i == 0, out[s]))
+                        prev[s] = model.get_logits_slot(s)
+                        if s in logit_log:
+                            logit_log[s].append(prev[s])
+                kinds.append(kind)
+        assert all(model.context_len_slot(s) == n_img + len(log[s]) for s in watch)
+        if NS >= 8:
+            assert len({tuple(t for _, _, t in log[s][:4]) for s in range(NS)}) > NS // 2, "the per-slot seeds did not make the contexts diverge"
 
         o16 = DetikzifyOracle(cfg, w, precision="bf16")
         ref = o16.prefill(ids, px[0])
@@ -119,16 +130,16 @@ def test_batched_headline_matches_cpu_oracle(name, weight_format):
         e_dev, e_orc = rel_l2(dev_prefill, truth), rel_l2(ref, truth)
         assert e_dev < 1.5 * e_orc + 2e-3
 
-        worst_ratio, worst_r16, near_ties, near_tie_steps, identical, gaps = 0.0, 0.0, 0, 0, 0, []
+        worst_ratio, worst_r16, near_ties, near_tie_steps, identical, n_greedy_total, gaps = 0.0, 0.0, 0, 0, 0, 0, []
         for s in watch:
             oracle_restore(o16, snap16)
             if s in watch32:
                 oracle_restore(o32, snap32)
             logits = ref
-            for i, t in enumerate(toks[s]):
-                if i >= N_SAMPLED:
-                    first = i == N_SAMPLED
-                    gaps.append(top2_gap_ulps(logits, [img_tok], [eos], first))
+            for i, (sampled, first, t) in enumerate(log[s]):
+                gaps.append(top2_gap_ulps(logits, [img_tok], [eos], first))
+                if not sampled:
+                    n_greedy_total += 1
                     near_tie_steps += gaps[-1] <= 2.0 + 1e-3
                     top2 = torch.topk(sampling.mask_scores(logits, [img_tok], [eos], first), 2)[1].tolist()
                     if top2[0] == t:
@@ -136,8 +147,6 @@ def test_batched_headline_matches_cpu_oracle(name, weight_format):
                     else:       # a flip: only at a near-tie, and only to the oracle's runner-up
                         assert gaps[-1] <= 2.0 + 1e-3 and t == top2[1], (s, i, t, top2, gaps[-1])
                         near_ties += 1
-                else:
-                    gaps.append(top2_gap_ulps(logits, [img_tok], [eos], i == 0))
                 logits = o16.step(t)
                 r16 = rel_l2(logit_log[s][i], logits)
                 worst_r16 = max(worst_r16, r16)
@@ -147,26 +156,109 @@ def test_batched_headline_matches_cpu_oracle(name, weight_format):
                     d, o = rel_l2(logit_log[s][i], t32), rel_l2(logits, t32)
                     worst_ratio = max(worst_ratio, d / (1.5 * o + 2e-3))
                     assert d < 1.5 * o + 2e-3, (s, i, d, o)
-        n_greedy_total = N_GREEDY * len(watch)
-        # uniform synthetic rows put the oracle's own top-2 within 2 bf16 ulps in ~30 % of the steps (histogram below); two correct
-        # bf16 pipelines order such a pair either way, so the budget is counted against the NEAR-TIE steps, not against all steps
-        # (the peaked weight set below has no near-ties and demands 16 of 16)
-        budget = max(1, (3 * near_tie_steps + 3) // 4)
+        # uniform synthetic rows put the oracle's own top-2 within 2 bf16 ulps in ~25 % of the steps (histogram below); two correct
+        # bf16 pipelines order such a pair either way, so flips are counted against the NEAR-TIE steps — at most every second one
+        # (was three of four) — and must go to the oracle's runner-up (asserted above).  Whether the flips lean one
+        # way is measured over 256 steps by test_greedy_margins_are_not_biased_against_the_oracle.
+        budget = max(1, (near_tie_steps + 1) // 2)
         assert near_ties <= budget, f"{near_ties} flips in {near_tie_steps} near-tie steps of {n_greedy_total} greedy steps: too many"
-        print(f"batched {name}{' fp8' if weight_format == 'fp8' else ''}, 64 slots x {N_SAMPLED + N_GREEDY} steps: prefill logits vs fp32: "
-              f"device {e_dev:.2e} oracle {e_orc:.2e}; slots {watch}: step logits dev-vs-bf16-oracle worst {worst_r16:.2e}, worst "
+        tail_report = ""
+        if private_tail:
+            everyone = list(range(NS))
+            for s in everyone:
+                model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=seed_of(s) + 1000, bad_ids=[img_tok, eos], slot=s)
+            seqs = {s: [t for _, _, t in log[s]] for s in tail_watch}
+            model.decode_batch_launch(everyone)
+            for i in range(private_tail):          # one step in flight, like the engine drives it
+                if i + 1 < private_tail:
+                    model.decode_batch_launch(everyone)
+                out = model.decode_batch_wait()
+                for s in tail_watch:
+                    seqs[s].append(out[s])
+            for s in everyone:
+                model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=s)
+            tail_logits = {s: [model.get_logits_slot(s)] for s in tail_watch}
+            tail_toks = {s: [] for s in tail_watch}
+            for _ in range(4):
+                model.decode_batch_launch(everyone)
+                out = model.decode_batch_wait()
+                for s in tail_watch:
+                    tail_toks[s].append(out[s])
+                    tail_logits[s].append(model.get_logits_slot(s))
+            t_worst, t_same = 0.0, 0
+            for s in tail_watch:
+                full = torch.cat([ids, torch.tensor(seqs[s], dtype=torch.long)])
+                assert model.context_len_slot(s) == full.numel() + 4 and full.numel() - n_img >= private_tail
+                a16, a32 = DetikzifyOracle(cfg, w, precision="bf16"), DetikzifyOracle(cfg, w, precision="fp32")
+                lg16, lg32 = a16.prefill(full, px[0]), a32.prefill(full, px[0])
+                for i in range(5):
+                    d, o = rel_l2(tail_logits[s][i], lg32), rel_l2(lg16, lg32)
+                    t_worst = max(t_worst, d / (1.5 * o + 2e-3))
+                    assert d < 1.5 * o + 2e-3, (s, i, d, o)
+                    if i == 4:
+                        break
+                    t = tail_toks[s][i]
+                    rt = sampling.greedy(lg16, [img_tok], [], False)
+                    if rt != t:
+                        assert top2_gap_ulps(lg16, [img_tok], [], False) <= 2.0 + 1e-3, (s, i, t, rt)
+                    else:
+                        t_same += 1
+                    lg16, lg32 = a16.step(t), a32.step(t)
+            tail_report = (f"; after {private_tail} more sampled tokens per slot (contexts {n_img + len(log[tail_watch[0]]) + private_tail}, all but {n_img} keys private): "
+                           f"slots {tuple(tail_watch)} 5 logit checks worst ratio to the envelope {t_worst:.2f}, {t_same}/{4 * len(tail_watch)} greedy tokens identical")
+        print(f"batched {name}{' fp8' if weight_format == 'fp8' else ''}, {batch_slots} slots, step kinds {kinds}: prefill logits vs fp32: "
+              f"device {e_dev:.2e} oracle {e_orc:.2e}; slots {tuple(watch)}: step logits dev-vs-bf16-oracle worst {worst_r16:.2e}, worst "
               f"ratio to the fp32 envelope {worst_ratio:.2f}; greedy {identical}/{n_greedy_total} identical ({near_ties} flips to the runner-up in {near_tie_steps} near-tie steps); "
-              f"{draws_checked} sampled draws exact (64 slots x {N_SAMPLED}); oracle top-2 gap histogram (bf16 ulps of the top logit, "
-              f"{len(gaps)} steps): {histogram(gaps)}; {time.perf_counter() - t_start:.0f} s")
+              f"{draws_checked} sampled draws exact; oracle top-2 gap histogram (bf16 ulps of the top logit, "
+              f"{len(gaps)} steps): {histogram(gaps)}{tail_report}; {time.perf_counter() - t_start:.0f} s")
     finally:
         del model
         gc.collect()
 
 
+R64, R32, R16 = range(64), range(32), range(16)
+
+
+@pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-cl-7b", "fp8")])
+def test_batched_headline_matches_cpu_oracle(name, weight_format):
+    """The batched decode step exactly as `bench.py`'s rollouts/sec phases run it — full depth, 65 slots allocated (64 decoding
+    + the prefix-cache slot), every default — against the CPU oracle, at EVERY column-tile count: 64 active slots (4 tiles:
+    k_gemv_bl / k_gemv_bkl / k_resid_norm_b, the 64-slot kernels), then 32 (2 tiles: k_gemv_b<.., NT = 2>, the shape of BASELINE
+    config 5 at N = 8: 1 image x 32 rollouts per rank, reference examples/eval.py:80-83), then 16 (1 tile: config 4 at N = 1 and
+    config 5's ragged tail).  A step's kernels depend only on its highest active slot (csrc/dtk_api.hip: nt_step), asserted per
+    step; slots 0 and 9 are followed through all three shapes.  ds-7b continues with 500 sampled tokens per slot and compares
+    4 more steps there (>= 500 private keys per slot: k_attn_tail_b's steady state)."""
+    ds = name == "detikzify-ds-7b"
+    _phases_vs_oracle(name, weight_format, 65,
+                      phases=[(R64, 4, 4, 64), (R32, 2, 2, 32), (R16, 2, 2, 16)],
+                      watch=(0, 9, 17, 40, 63), watch32=(9,), max_positions=1024 if ds else 512,
+                      private_tail=500 if ds else 0, tail_watch=(40,) if ds else ())
+
+
+@pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-cl-7b", "fp8")])
+def test_few_slot_contexts_match_cpu_oracle(name, weight_format):
+    """Contexts of at most 5 slots decode with the multi-vector kernels (csrc/kernels_decode_mv.hip: the single-sequence GEMVs
+    carrying 1 / 2 / 4 vectors) — the per-rank shape of BASELINE config 4 at N = 4 / 8 (4 / 2 trees per rank).  Full depth against
+    the CPU oracle: 4 vectors, then 2, then 1 (slot 0 is followed through all three)."""
+    _phases_vs_oracle(name, weight_format, 5,
+                      phases=[(range(4), 3, 3, 4), (range(2), 2, 2, 2), (range(1), 1, 2, 1)],
+                      watch=(0, 1, 3), watch32=(0,))
+
+
+def test_v2_8b_batched_matches_cpu_oracle():
+    """The repo's default family (reference detikzify/model/modeling_detikzify.py:119-271: LLaMA-3.1-8B decoder, GQA 32 / 8,
+    128 256-token vocabulary) at 64 slots, full depth: the GQA-fused attention blocks and the multi-block sampler (7 kernels x
+    64 slots) against the CPU oracle — every sampled draw of every slot exact."""
+    _phases_vs_oracle("detikzify-v2-8b", "bf16", 65, phases=[(R64, 3, 3, 64)], watch=(0, 40), watch32=(40,))
+
+
+N_LONG = 8       # decode steps per long-context checkpoint (round 3: 3)
+
+
 def test_long_context_steps_match_cpu_oracle():
     """ds-7b decode steps at contexts ~700 (where bench.py's 512-token rollouts end) and ~1900 (the API allows 2048) against
     the CPU oracle: the prompt is the image prefix + seeded text tokens; the oracle prefills it ONCE (KV kept across the two
-    checkpoints), the device prefills to the checkpoint and decodes 3 greedy steps there (the attention kernel walks 700 /
+    checkpoints), the device prefills to the checkpoint and decodes 8 greedy steps there (the attention kernel walks 700 /
     1900 keys of KV the prefill GEMMs wrote).  Same logits envelope as the short-context tests, tokens by the near-tie rule."""
     from detikzify_amd.model import load
     t_start = time.perf_counter()
@@ -199,7 +291,7 @@ def test_long_context_steps_match_cpu_oracle():
             e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
             assert e_dev < 1.5 * e_orc + 2e-3, (T, e_dev, e_orc)
             logits, worst, ties = ref, 0.0, 0
-            for i in range(3):
+            for i in range(N_LONG):
                 model.decode_launch()
                 t = model.decode_wait()
                 rt = sampling.greedy(logits, [img_tok], [], False)
@@ -211,26 +303,29 @@ def test_long_context_steps_match_cpu_oracle():
                 d, o = rel_l2(lg, t32), rel_l2(logits, t32)
                 worst = max(worst, d / (1.5 * o + 2e-3))
                 assert d < 1.5 * o + 2e-3, (T, i, d, o)
-            assert model.context_len() == T + 3
-            report.append(f"context {T}: prefill logits vs fp32: device {e_dev:.2e} oracle {e_orc:.2e}; 3 decode steps worst ratio to the "
-                          f"envelope {worst:.2f}, {3 - ties}/3 tokens identical")
+            assert model.context_len() == T + N_LONG
+            report.append(f"context {T}: prefill logits vs fp32: device {e_dev:.2e} oracle {e_orc:.2e}; {N_LONG} decode steps worst ratio to the "
+                          f"envelope {worst:.2f}, {N_LONG - ties}/{N_LONG} tokens identical")
         print("ds-7b long-context decode vs CPU oracle: " + "; ".join(report) + f"; {time.perf_counter() - t_start:.0f} s")
     finally:
         del model
         gc.collect()
 
 
-PEAKED_SEED, PEAKED_BETA = 0, 2.0      # chosen by tools/peaked_seed_search.py on the CPU oracle (every top-2 gap >= MIN_PEAKED_GAP ulps)
-MIN_PEAKED_GAP = 4.0
+PEAKED_SEED, PEAKED_BETA = 0, 2.0      # the weight set (tests/helpers.py::peaked_lm_head); the SEQUENCES below come from fixed sampling seeds
+PEAKED_PREFIX, PEAKED_CONTEXTS = 48, 64
 
 
 def test_peaked_logits_weight_set_is_token_identical():
-    """A second synthetic weight set whose logits are PEAKED (tests/helpers.py::peaked_lm_head: lm_head rows scaled by
-    log-normal powers of two, exact in bf16): the uniform set gives 32 k equal-variance logits, i.e. a top-2 gap below one
-    bf16 ulp of the top logit in ~10 % of the steps, and the near-tie rule of the other tests then forgives a mismatch.  Here
-    the oracle's own top-2 gap is >= 4 ulps at every one of the 16 steps (asserted), so there is nothing to forgive:
-    ds-7b, full depth, 16 of 16 greedy tokens must be identical — on the single-sequence decode graph AND in a 64-slot
-    batched step (slot 37, its 63 neighbours decoding other contexts)."""
+    """A second synthetic weight set whose logits are PEAKED (lm_head rows scaled by log-normal powers of two, exact in bf16): the
+    uniform set gives 32 k equal-variance logits — a top-2 gap below 2 bf16 ulps in ~25 % of the steps — and the near-tie rule of
+    the other tests then forgives a mismatch.  Round 3 compared 16 GREEDY tokens here and the greedy sequence fell into a
+    two-token cycle after 5 steps (6 distinct contexts), on a seed searched for until no near-tie occurred.  Now the device
+    SAMPLES its continuation (T 0.8, top-p 0.95, fixed seeds 11 / 12 / 13, nothing searched): 48 tokens of run-in, then 64 further
+    positions — 64 distinct contexts per sequence — at each of which the argmax of the device's processed logits must equal the
+    argmax of the CPU oracle's logits for the SAME token sequence (one batched oracle pass per sequence).  ds-7b at full depth;
+    three sequences on the single-sequence graph, one more in slot 37 of a 64-slot batched step.  Contexts where the oracle's own
+    top-2 gap is below 2 ulps are reported and excluded; at least 90 % must remain."""
     from detikzify_amd.model import load
     from tests.helpers import peaked_lm_head
     t_start = time.perf_counter()
@@ -242,39 +337,113 @@ def test_peaked_logits_weight_set_is_token_identical():
         w = weights_from_device(model, cfg)
         enc = proc(images=sketch_image(0, 224), return_tensors="pt")
         ids, px = enc.input_ids[0], enc.pixel_values
-        n_img, img_tok, eos, N = ids.numel(), cfg["image_token_id"], 2, 16
-        # single sequence
-        model.set_sampling(do_sample=False, bad_ids=[img_tok], begin_suppress_ids=[eos])
-        model.prefill(ids, px)
-        single = []
-        for _ in range(N):
-            model.decode_launch()
-            single.append(model.decode_wait())
-        # 64-slot batch: slot 37 greedy, the others sampling their own continuations
+        n_img, img_tok, N = ids.numel(), cfg["image_token_id"], PEAKED_PREFIX + PEAKED_CONTEXTS
+        runs = []           # (label, tokens, the device's logits BEFORE each token was drawn)
+        for seed in (11, 12, 13):
+            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=seed, bad_ids=[img_tok])
+            lg = [model.prefill(ids, px, return_logits=True)]
+            toks = []
+            for _ in range(N):
+                model.decode_launch()
+                toks.append(model.decode_wait())
+                lg.append(model.get_logits())
+            runs.append((f"single, seed {seed}", toks, lg))
         model.set_sampling(do_sample=False, slot=64)
         model.prefill(ids, px, slot=64)
-        for s in range(64):
-            if s == 37:
-                model.set_sampling(do_sample=False, bad_ids=[img_tok], begin_suppress_ids=[eos], slot=s)
-            else:
-                model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=99 + s, bad_ids=[img_tok], begin_suppress_ids=[eos], slot=s)
-            model.kv_fork(64, s, n_img)
-        batched = []
+        for s_ in range(64):
+            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=99 + s_, bad_ids=[img_tok], slot=s_)
+            model.kv_fork(64, s_, n_img)
+        toks, lg = [], [model.get_logits_slot(37)]
         for _ in range(N):
             model.decode_batch_launch(range(64))
-            batched.append(model.decode_batch_wait()[37])
+            toks.append(model.decode_batch_wait()[37])
+            lg.append(model.get_logits_slot(37))
+        runs.append(("slot 37 of 64", toks, lg))
+
         o16 = DetikzifyOracle(cfg, w, precision="bf16")
-        logits, gaps, ref = o16.prefill(ids, px[0]), [], []
-        for i in range(N):
-            gaps.append(top2_gap_ulps(logits, [img_tok], [eos], i == 0))
-            ref.append(sampling.greedy(logits, [img_tok], [eos], i == 0))
-            logits = o16.step(ref[-1])
-        print(f"peaked weight set (lm_head rows x 2^round({PEAKED_BETA} z), seed {PEAKED_SEED}): oracle top-2 gaps in bf16 ulps "
-              f"{' '.join(f'{g:.0f}' for g in gaps)} (histogram {histogram(gaps)}); greedy tokens single {sum(a == b for a, b in zip(single, ref))}/{N}, "
-              f"batched slot 37 {sum(a == b for a, b in zip(batched, ref))}/{N} identical; {time.perf_counter() - t_start:.0f} s")
-        assert min(gaps) >= MIN_PEAKED_GAP, f"the weight set is not peaked enough on this host's oracle: min gap {min(gaps):.2f} ulps"
-        assert single == ref, (single, ref)
-        assert batched == ref, (batched, ref)
+        ref0 = o16.prefill(ids, px[0])
+        snap = oracle_snapshot(o16)
+        report, all_gaps = [], []
+        for label, toks, lg in runs:
+            oracle_restore(o16, snap)
+            h = o16.llm.forward(o16.llm.embed(torch.tensor(toks, dtype=torch.long)))
+            same = judged = 0
+            assert len(set(map(tuple, (toks[:k] for k in range(PEAKED_PREFIX, N))))) == PEAKED_CONTEXTS      # distinct contexts
+            for k in range(PEAKED_PREFIX, N):        # position k: context = image + toks[:k]; oracle logits from the state after toks[k-1]
+                ref = o16.llm.logits(h[k - 1]) if k > 0 else ref0
+                gap = top2_gap_ulps(ref, [img_tok], [], False)
+                all_gaps.append(gap)
+                if gap < 2.0:
+                    continue
+                judged += 1
+                a_dev = sampling.greedy(lg[k], [img_tok], [], False)
+                a_orc = sampling.greedy(ref, [img_tok], [], False)
+                assert a_dev == a_orc, (label, k, a_dev, a_orc, gap)
+                same += 1
+            assert judged >= 0.9 * PEAKED_CONTEXTS, (label, judged)
+            assert len(set(toks[PEAKED_PREFIX:])) > 8, (label, "degenerate continuation")
+            report.append(f"{label}: {same}/{judged} argmax identical ({PEAKED_CONTEXTS - judged} contexts below 2 ulps excluded, {len(set(toks[PEAKED_PREFIX:]))} distinct tokens)")
+        print(f"peaked weight set (lm_head rows x 2^round({PEAKED_BETA} z)), sampled teacher sequences of {PEAKED_PREFIX} + {PEAKED_CONTEXTS} tokens: "
+              + "; ".join(report) + f"; oracle top-2 gap histogram ({len(all_gaps)} contexts): {histogram(all_gaps)}; {time.perf_counter() - t_start:.0f} s")
+    finally:
+        del model
+        gc.collect()
+
+
+def test_greedy_margins_are_not_biased_against_the_oracle():
+    """Is the device's rounding one-sided?  ds-7b width at 4 layers (a cheap oracle), 64-slot batched step, 4 watched slots x 64
+    sampled steps = 256 distinct contexts.  At every step the oracle's top-2 pair (a, b) is looked up in the device's logits of the
+    same context: margin_dev = dev[a] - dev[b] against margin_orc = orc[a] - orc[b] > 0.  Two correct bf16 pipelines scatter
+    around each other, so the sign of (margin_dev - margin_orc) must be balanced (|n+ - n-| <= 4 sqrt(n): a pipeline that
+    truncated where the reference rounds, or dropped a rounding point, would push every margin the same way), and the argmax
+    may differ only where margin_orc is within 2 bf16 ulps — at most half of those."""
+    from detikzify_amd.model.config import preset
+    from detikzify_amd.model.modeling import DetikzifyForCausalLM
+    t_start = time.perf_counter()
+    cfg_dev = preset("detikzify-ds-7b")
+    cfg_dev.layers, cfg_dev.max_positions, cfg_dev.batch_slots = 4, 256, 65
+    model = DetikzifyForCausalLM(cfg_dev, 0)
+    try:
+        model.fill_synthetic(4321)
+        cfg = model.config.oracle_dict()
+        w = {k: v for k, v in weights_from_device(model, cfg).items() if not k.startswith("vision_model.")}
+        img_tok = cfg["image_token_id"]
+        g = torch.Generator().manual_seed(3)
+        ids = torch.randint(3, cfg["vocab"] - 1, (48,), generator=g)
+        ids = ids[ids != img_tok]
+        watch, STEPS = (0, 21, 42, 63), 64
+        model.set_sampling(do_sample=False, slot=64)
+        dev0 = model.prefill(ids, None, slot=64, return_logits=True)
+        for s_ in range(64):
+            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=700 + s_, bad_ids=[img_tok], slot=s_)
+            model.kv_fork(64, s_, ids.numel())
+        oracles = {s_: DetikzifyOracle(cfg, w, precision="bf16") for s_ in watch}
+        orc = {s_: o.prefill(ids, None) for s_, o in oracles.items()}
+        dev = {s_: dev0 for s_ in watch}
+        plus = minus = equal = flips = near = 0
+        for _ in range(STEPS):
+            for s_ in watch:       # compare the logits both sides hold for the CURRENT context, then advance
+                masked = sampling.mask_scores(orc[s_], [img_tok], [], False)
+                top = torch.topk(masked, 2)
+                a, b = top[1].tolist()
+                m_orc = float(top[0][0] - top[0][1])
+                m_dev = float(dev[s_][a] - dev[s_][b])
+                gap = m_orc / (float(top[0][0].abs()) * ULP + 1e-30)
+                near += gap <= 2.0 + 1e-3
+                if m_dev < 0 or (m_dev == 0 and b < a):
+                    assert gap <= 2.0 + 1e-3, (s_, a, b, m_orc, m_dev)
+                    flips += 1
+                plus, minus, equal = plus + (m_dev > m_orc), minus + (m_dev < m_orc), equal + (m_dev == m_orc)
+            model.decode_batch_launch(range(64))
+            out = model.decode_batch_wait()
+            for s_ in watch:
+                orc[s_] = oracles[s_].step(out[s_])
+                dev[s_] = model.get_logits_slot(s_)
+        n = plus + minus
+        print(f"margin sign test, ds-7b width x 4 layers, 64-slot step, {len(watch) * STEPS} contexts: device margin above the oracle's {plus}, below {minus}, "
+              f"equal {equal}; {flips} argmax flips in {near} near-tie contexts; {time.perf_counter() - t_start:.0f} s")
+        assert n >= 128 and abs(plus - minus) <= 4.0 * n ** 0.5, (plus, minus)
+        assert flips <= max(1, (near + 1) // 2), (flips, near)
     finally:
         del model
         gc.collect()
