@@ -464,7 +464,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
       }
       c->t_lm_head = P.take<bf16_t>(tiled_elems(V, d));
     }
-    c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH);
+    c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH + 1);   // + the sticky device error word (TOKB_ERR)
   }
   c->scratch_bytes = (size_t)64 << 20;
   c->scratch = P.take<unsigned char>(c->scratch_bytes);
@@ -559,6 +559,12 @@ void project_image(dtk_ctx* c) {
 }
 
 // launches of one decoded token (captured into the graph, or issued directly)
+// tokb_dev / tokb_host: the token ring of the batched step + one word the LDS-ring kernels count expired hand-off waits in (it
+// travels to the host with every step's tokens; dtk_decode_batch_wait fails once it is non-zero)
+#define TOKB_ERR ((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH)
+#define TOKB_WORDS (TOKB_ERR + 1)
+static inline unsigned* batch_err_word(const dtk_ctx* c) { return reinterpret_cast<unsigned*>(c->tokb_dev + TOKB_ERR); }
+
 void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
   hipStream_t s = c->stream;
   SampleArgs sa;
@@ -632,7 +638,7 @@ void batch_step_launches(dtk_ctx* c) {
     bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
     GemvBArgs g{};
     g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt_step;
-    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride; g.kpart = c->kpart; g.kctr = c->kctr;
+    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride; g.kpart = c->kpart; g.kctr = c->kctr; g.err = batch_err_word(c);
     // resid_kparts (64 slots): an N = d role is k_gemv_bkp (K split over CUs, fp32 partials stored) and the RMSNorm that follows it
     // is k_resid_norm_b, which first adds the partials + the residual — so the norm of layer l > 0 has already been produced by
     // layer l - 1's down projection, and the final norm by the last layer's
@@ -667,7 +673,7 @@ void batch_step_launches(dtk_ctx* c) {
   if (!kparts) launch_rmsnorm_b(c->xb, d, c->final_norm, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, 16 * c->nt_step, s);
   GemvBArgs g{};
   g.bs = c->bs_dev; g.st = c->st_b; g.W = c->t_lm_head; g.W8 = c->t8_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X = c->xnb; g.ldx = d; g.logits = c->logits_b;
-  g.d = d; g.ff = ff; g.nt = c->nt_step;
+  g.d = d; g.ff = ff; g.nt = c->nt_step; g.err = batch_err_word(c);
   launch_gemv_b(EPI_LOGITS, g, s);
 }
 
@@ -783,7 +789,7 @@ int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step / c->mv_step
   if (c->bgraph_ready[gi]) return DTK_OK;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
-  HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH,
+  HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph[gi]));
   HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec[gi], c->bgraph[gi], nullptr, nullptr, 0));
@@ -940,7 +946,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   for (int i = 0; i < DTK_MAX_INFLIGHT; ++i) CCHK(hipEventCreateWithFlags(&c->step_done[i], hipEventDisableTiming));
   if (c->nb > 0) {
     CCHK(hipHostMalloc((void**)&c->bs_host, sizeof(BatchState) * DTK_MAX_INFLIGHT, hipHostMallocDefault));
-    CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipHostMallocDefault));
+    CCHK(hipHostMalloc((void**)&c->tokb_host, sizeof(int64_t) * TOKB_WORDS, hipHostMallocDefault));
     CCHK(hipHostMalloc((void**)&c->st_stage, sizeof(DecState) * (DTK_MAX_SLOTS), hipHostMallocDefault));
     CCHK(hipHostMalloc((void**)&c->sp_stage, sizeof(SamplingDev) * (DTK_MAX_SLOTS), hipHostMallocDefault));
     CCHK(hipHostMalloc((void**)&c->draw_stage, sizeof(uint32_t) * (DTK_MAX_SLOTS), hipHostMallocDefault));
@@ -1386,7 +1392,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     HIPCHK(c, hipGraphLaunch(c->bgraph_exec[step_graph_index(c)], c->stream));
   } else {
     if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
-    HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * DTK_MAX_INFLIGHT * DTK_MAX_BATCH, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
   c->stats.last_batch_step_slots = (uint32_t)(c->mv_step ? c->mv_step : 16 * c->nt_step);
@@ -1405,6 +1411,12 @@ int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
   const uint64_t k = c->bwaited;
   const int ring = (int)(k % DTK_MAX_INFLIGHT);
   HIPCHK(c, hipEventSynchronize(c->bstep_done[ring]));
+  const uint32_t dev_err = (uint32_t)((volatile int64_t*)c->tokb_host)[TOKB_ERR];
+  if (dev_err) {      // sticky: the tokens of this and every later step cannot be trusted
+    c->stats.device_errors = dev_err;
+    c->bwaited++;
+    return fail(c, DTK_ERR_HIP, "%u in-kernel hand-off waits expired (LDS-ring GEMVs): the step's results are invalid; re-create the context", dev_err);
+  }
   const BatchState* hb = c->bs_host + ring;
   // how many steps were launched after step k for each slot (their cached ids are still -1)
   for (int j = 0; j < DTK_MAX_BATCH; ++j) {
@@ -1757,10 +1769,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bkl")) { set_gemv_bkl(value != 0); drop_batch_graphs(c); }
+  else if (!strcmp(name, "gemv_br_wd")) { if (value != 4 && value != 8) return fail(c, DTK_ERR_ARG, "gemv_br_wd must be 4 or 8"); set_gemv_br_wd(value); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
   else if (!strcmp(name, "gemv_bl")) {
-    if (value < 0 || value > 63) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..63 (bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair + V tile per block where that fills the chip, bit 4: for any MHA model, bit 5: fp8 weights through registers (k_gemv_br, K = 4096))");
+    if (value < 0 || value > 127) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..127 (bit 6: bf16 qkv through k_gemv_br; bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair + V tile per block where that fills the chip, bit 4: for any MHA model, bit 5: fp8 weights through registers (k_gemv_br, K = 4096))");
     set_gemv_bl(value);
     drop_batch_graphs(c);
   }

@@ -446,6 +446,9 @@ __device__ __forceinline__ unsigned bl_ld(unsigned off) {      // LDS control wo
 }
 __device__ __forceinline__ void bl_st(unsigned off, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory"); }
 __device__ __forceinline__ void bl_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a bounded hand-off wait ran out (preemption, a debugger, a protocol bug): the kernel goes on with whatever the ring holds, so the
+// step's tokens are garbage — counted in a device word the step's D2H copy carries, and dtk_decode_batch_wait fails on it
+__device__ __forceinline__ void bl_timeout(unsigned* err) { if (err) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // F8: the weights come from the fp8 pair-tiled copy (1 KiB = 16 rows x 64 k = two k-steps): half the DMA pieces and ring bytes, widened to
 // bf16 in registers and fed to the same MFMAs in the same k order, the per-row power-of-two scale on the finished sum — bit-identical
@@ -484,13 +487,15 @@ __global__ __launch_bounds__((NC + LW + XW) * 64, 2) void k_gemv_bl(GemvBArgs a)
 
   auto wait_slot_free = [&](int p) {        // the ring slot of phase p still holds phase p - R: every compute wave must have released it
     if (p < R) return;
-    for (unsigned spins = 0; spins < SPIN; ++spins) {
+    unsigned spins = 0;
+    for (; spins < SPIN; ++spins) {
       unsigned lo = bl_ld(OFF_DONE);
 #pragma unroll
       for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
       if (lo + R > (unsigned)p) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    if (spins == SPIN) bl_timeout(a.err);
   };
 
   if (wave >= NC && wave < NC + LW) {
@@ -581,12 +586,14 @@ __global__ __launch_bounds__((NC + LW + XW) * 64, 2) void k_gemv_bl(GemvBArgs a)
     for (int nt = 0; nt < NT; ++nt) { tot[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   unsigned slot = 0;
   for (int p = 0; p < NPH; ++p) {
-    for (unsigned spins = 0; spins < SPIN; ++spins) {
+    unsigned spins = 0;
+    for (; spins < SPIN; ++spins) {
       bool ok = bl_ld(OFF_FILLED + 4u * (unsigned)(p % LW)) > (unsigned)(p / LW);
       if (XW) ok = ok && bl_ld(OFF_FILLED_X + 4u * (unsigned)(p % (XW > 0 ? XW : 1))) > (unsigned)(p / (XW > 0 ? XW : 1));
       if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    if (spins == SPIN) bl_timeout(a.err);
     const unsigned char* xb = smem + slot * XPH + lane * 16;
     const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * T * WT * 1024u + lane * 16;
 #pragma unroll
@@ -738,9 +745,13 @@ __device__ __forceinline__ void br_wait(u32x4& a0, u32x4& a1) { asm volatile("s_
 // SHIPPED FOR fp8 WEIGHTS AT K = 4096 ONLY: with bf16 weights it is slower than k_gemv_bl (gate/up 35.4 vs 32.6 us), and the K = 2048
 // instantiations (CHP4 = 2) need 254 VGPRs + 68 bytes of scratch — a spilled ring register is stored before its hand-issued load has
 // landed, which is how the first version faulted on ds-1.3b.  The launcher admits fp8, K = 4096 (170 VGPRs, no scratch).
-template <int EPI, int NC, int CHP4, bool F8 = false>
-__global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
-  constexpr int T = 2, NT = 4, PH = 4, R = 6, WD = 4, XD = 3;
+// WD = phases of the register ring.  A phase of fp8 weights is half the bytes of a bf16 phase, so WD = 4 leaves an fp8 wave with
+// 16 KiB in flight (48 KiB per CU with three compute waves: measured 3.5 TB/s on gate/up, half the bytes of the bf16 kernel in 3/4
+// of its time — profiles/r04_batch64_fp8_kernel_stats.csv); WD = 8 restores the 32 KiB per wave of the bf16 form.
+template <int EPI, int NC, int CHP4, bool F8 = false, int WD = 4>
+__global__ __launch_bounds__((NC + 1) * 64, WD == 8 ? 1 : 2) void k_gemv_br(GemvBArgs a) {   // (the 96 KiB x ring admits one block per CU anyway; WD = 8 needs > 256 registers)
+  constexpr int T = 2, NT = 4, PH = 4, R = 6, XD = 3;
+  static_assert(WD == 4 || WD == 8, "ring depth");
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight tiles per row tile and phase
   constexpr unsigned XPH = PH * NT * 1024u;
   constexpr unsigned OFF_FILLED = R * XPH, OFF_DONE = OFF_FILLED + 4;
@@ -761,13 +772,15 @@ __global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
     unsigned slot = 0;
     for (int p = 0; p < NPH; ++p) {
       if (p >= R) {
-        for (unsigned spins = 0; spins < SPIN; ++spins) {
+        unsigned spins = 0;
+        for (; spins < SPIN; ++spins) {
           unsigned lo = bl_ld(OFF_DONE);
 #pragma unroll
           for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
           if (lo + R > (unsigned)p) break;
           __builtin_amdgcn_s_sleep(1);
         }
+        if (spins == SPIN) bl_timeout(a.err);
       }
       const size_t adv = (size_t)p * PH * 1024;
 #pragma unroll
@@ -812,10 +825,12 @@ __global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
 #pragma unroll
     for (int b = 0; b < WD; ++b) {
       const int p = p0 + b;
-      for (unsigned spins = 0; spins < SPIN; ++spins) {
+      unsigned spins = 0;
+      for (; spins < SPIN; ++spins) {
         if (bl_ld(OFF_FILLED) > (unsigned)p) break;
         __builtin_amdgcn_s_sleep(1);
       }
+      if (spins == SPIN) bl_timeout(a.err);
       const unsigned char* xb = smem + slot * XPH + lane * 16;
 #pragma unroll
       for (int j = 0; j < PH; ++j) {
@@ -863,7 +878,7 @@ __global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
   };
   constexpr bx_flag<true> yes{};
   constexpr bx_flag<false> no{};
-  for (int p0 = 0; p0 + WD < NPH; p0 += WD) group(p0, yes);      // NPH is a multiple of WD = 4
+  for (int p0 = 0; p0 + WD < NPH; p0 += WD) group(p0, yes);      // NPH (16 or 32) is a multiple of WD
   group(NPH - WD, no);
   if (g >= groups) return;
 #pragma unroll
@@ -888,22 +903,33 @@ __global__ __launch_bounds__((NC + 1) * 64, 2) void k_gemv_br(GemvBArgs a) {
 // false = this instantiation must not run: its weight loads are issued by hand, so a register the compiler SPILLS would be stored
 // before its load has landed (how the K = 2048 instantiations faulted).  The code object says whether it spills: any private
 // (scratch) bytes per thread disqualify the kernel, and the caller falls back to k_gemv_bx / k_gemv_b.
-template <int EPI, int NC, int CHP4>
-static bool launch_br_one(const GemvBArgs& a, hipStream_t s) {
-  constexpr int lds = 6 * (4 * 4 * 1024) + 4 * (NC + 1) + 12;
-  static int usable_by_format[2] = {-1, -1};
-  int& usable = usable_by_format[a.W8 ? 1 : 0];
+static int g_br_wd = 8;          // fp8 ring depth: 8 (default where the instantiation has no scratch) | 4
+void set_gemv_br_wd(int v) { g_br_wd = v == 4 ? 4 : 8; }
+template <int EPI, int NC, int CHP4, bool F8, int WD>
+static bool br_usable(int lds) {
+  static int usable = -1;
   if (usable < 0) {
-    const void* fn = a.W8 ? reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, true>) : reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, false>);
+    const void* fn = reinterpret_cast<const void*>(&k_gemv_br<EPI, NC, CHP4, F8, WD>);
     hipFuncAttributes fa;
     const bool ok = hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.localSizeBytes == 0
                     && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     usable = ok ? 1 : 0;
   }
-  if (!usable) return false;
+  return usable == 1;
+}
+template <int EPI, int NC, int CHP4>
+static bool launch_br_one(const GemvBArgs& a, hipStream_t s) {
+  constexpr int lds = 6 * (4 * 4 * 1024) + 4 * (NC + 1) + 12;
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
-  if (a.W8) hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, true>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
-  else hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, false>), dim3((groups + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
+  const dim3 grid((groups + NC - 1) / NC), block((NC + 1) * 64);
+  if (a.W8) {
+    if (NC <= 3) if (g_br_wd == 8 && br_usable<EPI, (NC <= 3 ? NC : 3), CHP4, true, 8>(lds)) { hipLaunchKernelGGL((k_gemv_br<EPI, (NC <= 3 ? NC : 3), CHP4, true, 8>), grid, block, lds, s, a); return true; }   // (5 waves of > 256 registers do not fit: NC = 4 keeps WD = 4)
+    if (!br_usable<EPI, NC, CHP4, true, 4>(lds)) return false;
+    hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, true, 4>), grid, block, lds, s, a);
+    return true;
+  }
+  if (!br_usable<EPI, NC, CHP4, false, 4>(lds)) return false;
+  hipLaunchKernelGGL((k_gemv_br<EPI, NC, CHP4, false, 4>), grid, block, lds, s, a);
   return true;
 }
 template <int EPI, int CHP4>
@@ -922,7 +948,8 @@ void set_gemv_bl(int v) { g_gemv_bl = v; }
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bl < 0) { const char* e = getenv("DTK_GEMV_BL"); g_gemv_bl = e ? atoi(e) : 33; }    // default: bit 0 = gate/up + lm_head (64-slot step 4.49 -> 4.35 ms; qkv has too few units per CU: 4.64), bit 5 = k_gemv_br for fp8 weights
   if (g_gemv_bl <= 0 || a.nt < 3) return false;
-  if (a.W8 && (g_gemv_bl & 32) && a.K == 4096 && (epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LOGITS)
+  // bit 6 (experiment): bf16 qkv through k_gemv_br too — its 1.5 units per CU leave k_gemv_bl one loader wave for two streams
+  if (((a.W8 && (g_gemv_bl & 32)) || (!a.W8 && (g_gemv_bl & 64) && epi == EPI_QKV)) && a.K == 4096 && (epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LOGITS)
       && !(epi == EPI_SWIGLU && (a.ff & 15)) && !(epi == EPI_LOGITS && (a.N & 31))) {
     // fp8 weights through registers (k_gemv_br): gate/up 28.9 -> 25.5 us, qkv 28.1 -> 24.8 (profiles/r03_loader_kernel_experiments.txt)
     const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
@@ -1287,12 +1314,17 @@ __device__ __forceinline__ void glds16_any(const void* gsrc, unsigned lds_byte, 
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
-template <int TPG, int XW = 0>       // XW x waves: x by ordinary loads + ds_write_b128 (see k_gemv_bl)
+// F8: the weights are the fp8 pair tiles (1 KiB = 16 rows x two k-steps): half the bytes per phase, widened to bf16 in registers
+// and fed to the same MFMA chain; the per-row 2^e scale multiplies the partial (exact), so the 8 partials + the residual that
+// k_resid_norm_b adds are bit for bit what k_gemv_b<RESID, fp8> reduces through LDS.  A K slice that starts at an odd k-step
+// (down: 43 k-steps per slice) fetches the pair tile it shares with its left neighbour and skips that neighbour's k-step.
+template <int TPG, int XW = 0, bool F8 = false>       // XW x waves: x by ordinary loads + ds_write_b128 (see k_gemv_bl)
 __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
   constexpr int NT = 4, PH = 4, R = 3;
-  constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * PH * 1024u;
+  constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight pieces per row tile and phase
+  constexpr unsigned XPH = PH * NT * 1024u, WPH = TPG * WT * 1024u;
   constexpr unsigned OFF_W = R * XPH, OFF_FILLED = OFF_W + R * WPH, OFF_FILLED_X = OFF_FILLED + 4, OFF_DONE = OFF_FILLED + 12;
-  constexpr int PIECES = ((XW ? 0 : NT) + TPG) * PH;
+  constexpr int PIECES = (XW ? 0 : NT) * PH + TPG * WT;
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1302,26 +1334,33 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
   const int rgs_per_xcd = (int)(gridDim.x >> 6);                // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
   const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
   const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
-  const int Lc = s1 - s0;                                       // >= 1 (launcher)
+  const int e0 = F8 ? (s0 & ~1) : s0;                           // first k-step FETCHED (fp8 pair tiles start at even k-steps)
+  const int Lc = s1 - e0;                                       // >= 1 (launcher); k-steps e0 .. e0 + skip - 1 belong to the left neighbour
+  const int skip = s0 - e0;
   const int nph = (Lc + PH - 1) / PH;
   if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (TPG + 3); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
   __syncthreads();
   auto wait_slot_free = [&](int p) {
     if (p < R) return;
-    for (unsigned spins = 0; spins < SPIN; ++spins) {
+    unsigned spins = 0;
+    for (; spins < SPIN; ++spins) {
       unsigned lo = bl_ld(OFF_DONE);
 #pragma unroll
       for (int c = 1; c < TPG; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
       if (lo + R > (unsigned)p) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    if (spins == SPIN) bl_timeout(a.err);
   };
 
   if (wave == TPG) {   // ---- loader wave
     const unsigned char* xsrc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;   // tile rg*TPG + w at + w * nsteps KiB
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + e0) * 512 + lane * 8) * 2;
+    const int upr = F8 ? (nsteps + 1) >> 1 : nsteps;            // 1 KiB pieces per row tile (fp8: pair tiles)
+    const unsigned char* wbase = F8 ? a.W8 + (((size_t)rg * TPG * upr + (e0 >> 1)) * 64 + lane) * 16       // tile rg*TPG + w at + w * upr KiB
+                                    : reinterpret_cast<const unsigned char*>(a.W) + (((size_t)rg * TPG * nsteps + s0) * 64 + lane) * 16;
+    const int last_u = F8 ? ((s1 - 1) >> 1) - (e0 >> 1) : Lc - 1;   // last piece of the slice, relative to wbase
     unsigned slot = 0;
     for (int p = 0; p < nph; ++p) {
       wait_slot_free(p);
@@ -1331,8 +1370,16 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) glds_run4<false>(xsrc[nt] + adv, slot * XPH + (unsigned)nt * PH * 1024u);
         }
+        if (F8) {
 #pragma unroll
-        for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
+          for (int w = 0; w < TPG; ++w)
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+              glds16_any(wbase + ((size_t)w * upr + (size_t)(p * WT + i)) * 1024, OFF_W + slot * WPH + (unsigned)(w * WT + i) * 1024u, true);
+        } else {
+#pragma unroll
+          for (int w = 0; w < TPG; ++w) glds_run4<true>(wbase + (size_t)w * nsteps * 1024 + adv, OFF_W + slot * WPH + (unsigned)w * PH * 1024u);
+        }
       } else {                                // the ragged last phase: piece by piece, clamped to the slice's last k-step
 #pragma unroll
         for (int j = 0; j < PH; ++j) {
@@ -1341,8 +1388,17 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) glds16_any(xsrc[nt] + kk, slot * XPH + (unsigned)(nt * PH + j) * 1024u, false);
           }
+          if (!F8) {
 #pragma unroll
-          for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
+            for (int w = 0; w < TPG; ++w) glds16_any(wbase + (size_t)w * nsteps * 1024 + kk, OFF_W + slot * WPH + (unsigned)(w * PH + j) * 1024u, true);
+          }
+        }
+        if (F8) {
+#pragma unroll
+          for (int w = 0; w < TPG; ++w)
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+              glds16_any(wbase + ((size_t)w * upr + (size_t)min(p * WT + i, last_u)) * 1024, OFF_W + slot * WPH + (unsigned)(w * WT + i) * 1024u, true);
         }
       }
       if (p >= 1) {
@@ -1360,7 +1416,7 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
     const int xi = wave - (TPG + 1);
     const unsigned char* xsrc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + s0) * 512 + lane * 8) * 2;
+    for (int nt = 0; nt < NT; ++nt) xsrc[nt] = reinterpret_cast<const unsigned char*>(a.X) + (((size_t)nt * nsteps + e0) * 512 + lane * 8) * 2;
     u32x4 bufA[NT * PH], bufB[NT * PH];
     auto fetch = [&](u32x4 (&buf)[NT * PH], int p) {
 #pragma unroll
@@ -1394,18 +1450,22 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
   for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   unsigned slot = 0;
   for (int p = 0; p < nph; ++p) {
-    for (unsigned spins = 0; spins < SPIN; ++spins) {
+    unsigned spins = 0;
+    for (; spins < SPIN; ++spins) {
       bool ok = bl_ld(OFF_FILLED) > (unsigned)p;
       if (XW) ok = ok && bl_ld(OFF_FILLED_X + 4u * (unsigned)(p % (XW > 0 ? XW : 1))) > (unsigned)(p / (XW > 0 ? XW : 1));
       if (ok) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    if (spins == SPIN) bl_timeout(a.err);
     const unsigned char* xb = smem + slot * XPH + lane * 16;
-    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * PH * 1024u + lane * 16;
+    const unsigned char* wb = smem + OFF_W + slot * WPH + (unsigned)wave * WT * 1024u + lane * 16;
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
-      if (p * PH + j < Lc) {                  // wave-uniform: k-steps past the end of the slice are not multiplied
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)j * 1024));
+      if (p * PH + j < Lc && p * PH + j >= skip) {     // wave-uniform: k-steps outside the slice are not multiplied
+        bf16x8_t af;
+        if (F8) { const u32x4 wv = *reinterpret_cast<const u32x4*>(wb + (size_t)(j >> 1) * 1024); af = gg_f8x8_to_bf16x8(wv[2 * (j & 1)], wv[2 * (j & 1) + 1]); }
+        else af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)j * 1024));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
@@ -1417,6 +1477,11 @@ __global__ __launch_bounds__((TPG + 1 + XW) * 64) void k_gemv_bkl(GemvBArgs a) {
     if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
     slot = slot + 1 == R ? 0 : slot + 1;
   }
+  if (F8) {                                                      // per-row power-of-two scale: exact on the partial
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.wscale + tn * 16 + (lane >> 4) * 4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) c[nt] *= sc;
+  }
   float* out = a.kpart + ((size_t)ks * 64 + (lane & 15)) * a.N + tn * 16 + (lane >> 4) * 4;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + (size_t)nt * 16 * a.N) = c[nt];
@@ -1427,8 +1492,10 @@ static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
   const int xw = gemv_xw();
-#define BKL_ATTR(TPG_, XW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-#define BKL_GO(TPG_, XW_) hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a)
+#define BKL_ATTR(TPG_, XW_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+                                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); } while (0)
+#define BKL_GO(TPG_, XW_) do { if (a.W8) hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_, true>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a); \
+                               else hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_, false>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a); } while (0)
   if (((a.N + 15) >> 4) == 256) {
     constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 11 + 12;
     static bool attr8 = false;
@@ -1445,10 +1512,15 @@ static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   return true;
 }
 
-// false = not covered (fp8 weights, fewer than 33 slots, a tile count that is not 32 row groups of 4 or 8 tiles, a K that
+// false = not covered (fewer than 33 slots, a tile count that is not 32 row groups of 4 or 8 tiles, a K that
 // leaves one of the 8 slices empty, a width k_resid_norm_b does not handle): the caller uses k_gemv_b<RESID> + k_rmsnorm_b
+static bool gemv_bkl_on() {
+  if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }
+  return g_gemv_bkl > 0;
+}
 bool resid_kparts_covers(const GemvBArgs& a) {
-  if (a.W8 || a.nt < 3 || !a.kpart) return false;
+  if (a.nt < 3 || !a.kpart) return false;
+  if (a.W8 && !gemv_bkl_on()) return false;      // fp8 weights: only the LDS-ring kernel reads the pair tiles
   const int ntiles = (a.N + 15) >> 4, nsteps = (a.K + 31) >> 5, per = (nsteps + 7) >> 3;
   if ((a.N & 15) || (a.K & 31) || 7 * per >= nsteps) return false;
   if (ntiles != 256 && ntiles != 128) return false;

@@ -46,5 +46,53 @@ def test_kernels_with_hand_issued_loads_do_not_spill(tmp_path):
     assert len(br) >= 9 and len(kernels) > 100, (len(br), len(kernels))         # 3 roles x 3 block shapes x {bf16, fp8}
     for name, meta in br.items():
         assert meta.get("private_segment_fixed_size") == 0 and meta.get("vgpr_spill_count") == 0, (name, meta)
-        assert meta["vgpr_count"] <= 256, (name, meta)
+        deep = name.endswith("ELb1ELi8EEv9GemvBArgs")          # fp8, register ring of 8 phases: one wave per SIMD, up to 512 unified registers
+        assert meta["vgpr_count"] <= (512 if deep else 256), (name, meta)
+    assert any(k.endswith("ELb1ELi8EEv9GemvBArgs") for k in br), "the fp8 ring-of-8 instantiations are the shipped fp8 kernels"
     assert not any("k_gemv_brILi" in k and re.search(r"k_gemv_brILi\dELi\dELi2E", k) for k in kernels), "the K = 2048 instantiations spill: not to be built"
+
+
+def test_hand_load_checker_sees_a_register_read_before_its_wait():
+    """tools/check_hand_loads.py on hand-made instruction streams: a ring register read (or copied to an AGPR, or stored) before the
+    wait that retires its load is reported; the same stream with the wait in place, a loop whose back edge carries a pending load
+    into a reader, and a wait that leaves exactly the newer loads outstanding are judged correctly."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_hand_loads as ch
+
+    def run(lines):
+        return ch.check_kernel("k", [(4 * i, mn, ops) for i, (mn, ops) in enumerate(lines)])[0]
+    load = lambda r, a: ("global_load_dwordx4", f"v[{r}:{r + 3}], v[{a}:{a + 1}], off nt")
+    assert run([load(0, 100), ("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v9, v1"), ("s_endpgm", "")]) == []
+    assert len(run([load(0, 100), ("v_mov_b32_e32", "v9, v1"), ("s_waitcnt", "vmcnt(0)"), ("s_endpgm", "")])) == 1
+    assert len(run([load(0, 100), ("v_accvgpr_write_b32", "a7, v3"), ("s_endpgm", "")])) == 1
+    assert len(run([load(0, 100), ("scratch_store_dword", "off, v2, s0"), ("s_endpgm", "")])) == 1
+    # two loads, vmcnt(1) retires the older one only
+    two = [load(0, 100), load(4, 100), ("s_waitcnt", "vmcnt(1)")]
+    assert run(two + [("v_add_u32_e32", "v9, v0, v9"), ("s_endpgm", "")]) == []
+    assert len(run(two + [("v_add_u32_e32", "v9, v4, v9"), ("s_endpgm", "")])) == 1
+    # a compiler-issued load (no nt) takes a counter slot but protects nothing: an extra operation only makes a hand count wait
+    # for more; a count that is one too HIGH retires nothing
+    assert run([load(0, 100), ("global_load_dword", "v20, v[100:101], off"), ("s_waitcnt", "vmcnt(1)"), ("v_mov_b32_e32", "v9, v0"), ("s_endpgm", "")]) == []
+    assert len(run([load(0, 100), load(4, 100), ("s_waitcnt", "vmcnt(2)"), ("v_mov_b32_e32", "v9, v0"), ("s_endpgm", "")])) == 1
+    # loop: the load at the bottom is still pending when the back edge returns to the reader at the top
+    loop = [("v_mov_b32_e32", "v9, v0"), load(0, 100), ("s_cbranch_scc1", "65533"), ("s_waitcnt", "vmcnt(0)"), ("s_endpgm", "")]
+    assert {v[0] for v in run(loop)} == {0, 4}       # the reader, and the re-issue into a register whose previous load is still in flight
+
+
+@pytest.mark.skipif(not (LLVM / "clang-offload-bundler").exists(), reason="needs the ROCm LLVM tools")
+def test_no_instruction_touches_a_hand_loaded_register_before_its_wait(tmp_path):
+    """k_gemv_br's correctness rests on where the compiler puts its own moves relative to the hand-issued
+    loads and waits.  This walks the shipped code object: every k_gemv_br instantiation, every path, 0 violations."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_hand_loads as ch
+    obj = ROOT / "build" / "kernels_batch_gemm.o"
+    if not obj.exists():
+        subprocess.run(["bash", str(ROOT / "build.sh")], check=True, capture_output=True, cwd=str(ROOT))
+    kernels = ch.kernels_of(ch.disassemble(obj, tmp_path), "k_gemv_br")
+    assert len(kernels) >= 9
+    for name, insts in kernels.items():
+        violations, stats = ch.check_kernel(name, insts)
+        assert stats["hand_loads"] >= 32 and stats["vmcnt_waits"] >= 32, (name, stats)
+        assert not violations, (name, violations[:4])
