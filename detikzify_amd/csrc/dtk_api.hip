@@ -1433,6 +1433,65 @@ int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
   return DTK_OK;
 }
 
+// Several batched steps per host call: the per-token launch / wait / dispatch loop of 64 sequences in Python
+// cost ~3 ms per step next to a 6 ms GPU step (profiles/r03_host_emulation.txt).  This runs up to max_steps steps for ONE active
+// set, always with the next step in flight while the last one's tokens are inspected, and returns as soon as a step produced a
+// reason for the host to look: a slot emitted one of `stop_ids` (EOS), a slot used up its `budget` (tokens it may still emit:
+// max_length / max_positions), `*interrupt` became non-zero (a sequence wants to join or leave), or max_steps were collected.
+// A step that is in flight on entry (dtk_decode_batch_launch, or left behind by the previous run) must have the same active set;
+// it is collected as this run's first step.  On return *inflight_out says whether one more step — same active set — is in flight:
+// a finished sequence discards its token of that step, exactly as with the launch / wait pair.
+int dtk_decode_batch_run(dtk_ctx* c, const int32_t* active, int max_steps, const int32_t* budget, const int64_t* stop_ids, int n_stop,
+                         const volatile int32_t* interrupt, int64_t* tokens_out, int32_t* steps_out, int32_t* inflight_out) {
+  if (!c || !active || !tokens_out || !steps_out || max_steps < 1 || n_stop < 0 || (n_stop > 0 && !stop_ids))
+    return fail(c, DTK_ERR_ARG, "dtk_decode_batch_run: bad argument");
+  *steps_out = 0;
+  if (inflight_out) *inflight_out = 0;
+  if (c->blaunched - c->bwaited > 1) return fail(c, DTK_ERR_STATE, "dtk_decode_batch_run: more than one step in flight");
+  if (c->blaunched > c->bwaited) {          // the step in flight becomes step 0 of this run
+    const BatchState* hb = c->bs_host + ((c->blaunched - 1) % DTK_MAX_INFLIGHT);
+    for (int j = 0; j < DTK_MAX_BATCH; ++j)
+      if ((hb->active[j] != 0) != (active[j] != 0)) return fail(c, DTK_ERR_STATE, "dtk_decode_batch_run: the step in flight has another active set (slot %d)", j);
+  }
+  int remaining[DTK_MAX_BATCH];
+  int min_budget = 1 << 30;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) {
+    remaining[j] = 1 << 30;
+    if (!active[j]) continue;
+    if (j >= c->nb) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    int b = budget ? budget[j] : (1 << 30);
+    const int room = c->Tmax - (c->bseq[(size_t)j].host_next_pos - (int)(c->blaunched - c->bwaited));   // tokens the cache still takes, before the step in flight
+    if (room < b) b = room;
+    if (b < 1) return fail(c, DTK_ERR_RANGE, "slot %d: no budget left (context %d of %d)", j, c->bseq[(size_t)j].host_next_pos, c->Tmax);
+    remaining[j] = b;
+    if (b < min_budget) min_budget = b;
+  }
+  int launched = (int)(c->blaunched - c->bwaited), collected = 0;
+  bool done = false;
+  while (!done) {
+    // keep one step ahead — unless that step would take some slot past its budget
+    while (launched < collected + 2 && launched < max_steps && launched < min_budget) {
+      const int rc = dtk_decode_batch_launch(c, active);
+      if (rc) return rc;
+      ++launched;
+    }
+    if (collected >= launched) break;
+    int64_t* out = tokens_out + (size_t)collected * DTK_MAX_BATCH;
+    const int rc = dtk_decode_batch_wait(c, out);
+    if (rc) return rc;
+    ++collected;
+    for (int j = 0; j < DTK_MAX_BATCH && !done; ++j) {
+      if (!active[j]) continue;
+      if (collected >= remaining[j]) done = true;
+      for (int k = 0; k < n_stop; ++k) if (out[j] == stop_ids[k]) done = true;
+    }
+    if (collected >= max_steps || (interrupt && *interrupt)) done = true;
+  }
+  *steps_out = collected;
+  if (inflight_out) *inflight_out = launched > collected ? 1 : 0;
+  return DTK_OK;
+}
+
 // Copy the KV of the first n_tokens positions of slot src into slot dst (SURVEY §8 f1 / the proposed
 // dtk_kv_fork): rollouts that share a prefix (always: the 243 image tokens) reuse its KV bit for bit instead
 // of re-running ViT + prefill.  dst then needs a dtk_prefill_slot(..., DTK_PREFILL_REUSE_PREFIX) of the full

@@ -93,6 +93,21 @@ class TokenStreamer(_QueueStreamer):
         if token_id in self.flush_on:
             self._flush()
 
+    def put_tokens(self, token_ids):
+        """several generated tokens at once, in order (the engine's multi-step runs hand a sequence the tokens of a whole run):
+        the consumer sees exactly what one put_token per id would have produced"""
+        if self.flush_on is None:
+            for token_id in token_ids:
+                self.queue.put(token_id, timeout=self.timeout)
+            return
+        start, flush_on = 0, self.flush_on
+        for i, token_id in enumerate(token_ids):
+            if token_id in flush_on:
+                self._out.extend(token_ids[start:i + 1])
+                self._flush()
+                start = i + 1
+        self._out.extend(token_ids[start:])
+
     def _flush(self):
         if self._out:
             burst, self._out = self._out, []
