@@ -6,7 +6,7 @@ SRC=detikzify_amd/csrc
 OUT=detikzify_amd/lib
 mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-variable"
 pids=()
 for f in kernels_decode kernels_decode_mv kernels_batch_decode kernels_batch_gemm kernels_batched kernels_sample_mb dtk_api; do
   if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ $SRC/common.h -nt build/$f.o ] || [ $SRC/kernels.h -nt build/$f.o ] || [ $SRC/gemv_inl.h -nt build/$f.o ] || [ include/dtk.h -nt build/$f.o ]; then

@@ -832,6 +832,8 @@ void compute_rope_tables(const dtk_config& cfg, std::vector<uint16_t>& cosv, std
 }  // namespace
 
 // ============================================================================ C ABI
+// the library is built with -fvisibility=hidden: the C ABI of include/dtk.h is all it exports
+#pragma GCC visibility push(default)
 extern "C" {
 
 int dtk_abi_version(void) { return DTK_ABI_VERSION; }
@@ -1469,8 +1471,9 @@ int dtk_decode_batch_run(dtk_ctx* c, const int32_t* active, int max_steps, const
   int launched = (int)(c->blaunched - c->bwaited), collected = 0;
   bool done = false;
   while (!done) {
-    // keep one step ahead — unless that step would take some slot past its budget
-    while (launched < collected + 2 && launched < max_steps && launched < min_budget) {
+    // keep one step ahead — also of the LAST collected step (the host dispatches the run's tokens under it, as the per-step loop
+    // does) — unless that step would take some slot past its budget
+    while (launched < collected + 2 && launched <= max_steps && launched < min_budget) {
       const int rc = dtk_decode_batch_launch(c, active);
       if (rc) return rc;
       ++launched;
@@ -2062,3 +2065,4 @@ int dtk_op_sample(dtk_ctx* c, const float* logits, int V, int step, int64_t* tok
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -746,8 +746,8 @@ __device__ __forceinline__ void br_wait(u32x4& a0, u32x4& a1) { asm volatile("s_
 // instantiations (CHP4 = 2) need 254 VGPRs + 68 bytes of scratch — a spilled ring register is stored before its hand-issued load has
 // landed, which is how the first version faulted on ds-1.3b.  The launcher admits fp8, K = 4096 (170 VGPRs, no scratch).
 // WD = phases of the register ring.  A phase of fp8 weights is half the bytes of a bf16 phase, so WD = 4 leaves an fp8 wave with
-// 16 KiB in flight (48 KiB per CU with three compute waves: measured 3.5 TB/s on gate/up, half the bytes of the bf16 kernel in 3/4
-// of its time — profiles/r04_batch64_fp8_kernel_stats.csv); WD = 8 restores the 32 KiB per wave of the bf16 form.
+// 16 KiB in flight (48 KiB per CU with three compute waves: 3.5 TB/s on gate/up, half the bytes of the bf16 kernel in 3/4 of its
+// time); WD = 8 restores the 32 KiB per wave of the bf16 form — and measured slower (launcher note below): kept as an experiment.
 template <int EPI, int NC, int CHP4, bool F8 = false, int WD = 4>
 __global__ __launch_bounds__((NC + 1) * 64, WD == 8 ? 1 : 2) void k_gemv_br(GemvBArgs a) {   // (the 96 KiB x ring admits one block per CU anyway; WD = 8 needs > 256 registers)
   constexpr int T = 2, NT = 4, PH = 4, R = 6, XD = 3;
@@ -903,8 +903,11 @@ __global__ __launch_bounds__((NC + 1) * 64, WD == 8 ? 1 : 2) void k_gemv_br(Gemv
 // false = this instantiation must not run: its weight loads are issued by hand, so a register the compiler SPILLS would be stored
 // before its load has landed (how the K = 2048 instantiations faulted).  The code object says whether it spills: any private
 // (scratch) bytes per thread disqualify the kernel, and the caller falls back to k_gemv_bx / k_gemv_b.
-static int g_br_wd = 8;          // fp8 ring depth: 8 (default where the instantiation has no scratch) | 4
-void set_gemv_br_wd(int v) { g_br_wd = v == 4 ? 4 : 8; }
+// fp8 ring depth: 4 (default) | 8.  Measured (profiles/r04_batch64_fp8_wd8_kernel_stats.csv): the deeper ring is SLOWER — gate/up
+// 30.1 vs 25.7 us, qkv 31.1 vs 24.6 — what bounds these kernels is not the bytes in flight but the compute waves' own instruction
+// stream (one wave per SIMD: SQ_ACTIVE_INST + SQ_WAIT_INST = 3/4 of a compute wave's cycles, profiles/r04_batch64_fp8_pmc_sq.csv)
+static int g_br_wd = 4;
+void set_gemv_br_wd(int v) { g_br_wd = v == 8 ? 8 : 4; }
 template <int EPI, int NC, int CHP4, bool F8, int WD>
 static bool br_usable(int lds) {
   static int usable = -1;

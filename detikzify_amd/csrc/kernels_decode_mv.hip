@@ -415,12 +415,16 @@ static int g_mv_shape[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // indexed like l
 void set_gemv_mv_shape(int role, int shape) { if (role >= 0 && role < 8) g_mv_shape[role] = shape; }
 
 static int mv_default_shape(int epi, bool o_proj, int nb, int K) {
-  (void)o_proj;
   if (nb <= 1) return 0;                                   // one vector: the single-sequence shapes
   const size_t x_bytes = (size_t)nb * K * 2;
   if (x_bytes > 64 * 1024) return 3;                       // 88 KB of x: one block per CU is all that fits
-  if (epi == EPI_RESID) return nb >= 4 ? 1 : 0;
-  return nb >= 4 ? 1 : 0;
+  // measured, ds-7b, ms per step (profiles/r04_tune_mv_ds7b.txt; every shape gives the same bits):
+  //   2 vectors: shape 0 wins every role (2.867-2.869) except down, where one 16-wave block per CU does (2.841)
+  //   4 vectors: qkv 3.268 / 3.194 / 3.233 / 3.204 -> 1; o_proj 3.186 / 3.193 / 3.224 / 3.178 -> 3; gate/up 3.227 / 3.190 /
+  //              3.183 / 3.115 -> 3; lm_head 3.207 / 3.191 / 3.190 / 3.186 -> 3
+  if (nb == 2) return (epi == EPI_RESID && !o_proj) ? 3 : 0;
+  if (epi == EPI_QKV) return 1;
+  return 3;
 }
 
 // fp8 rows hold 16 weights per 16-byte chunk (two x chunks each): half the chunks per stage keep the same K span in flight;

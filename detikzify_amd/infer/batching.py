@@ -125,7 +125,7 @@ class BatchEngine:
         # leave: `_interrupt`), or the run is used up — instead of one launch / wait / dispatch round trip per token for up to 64
         # sequences (round 3: ~3 ms of Python per 6 ms step).  DTK_ENGINE_RUN_STEPS=1 restores the per-step loop.
         import ctypes
-        self.run_steps = max(1, int(os.environ.get("DTK_ENGINE_RUN_STEPS", "32"))) if callable(getattr(model, "decode_batch_run", None)) else 1
+        self.run_steps = max(1, int(os.environ.get("DTK_ENGINE_RUN_STEPS", "8"))) if callable(getattr(model, "decode_batch_run", None)) else 1
         self._interrupt = ctypes.c_int32(0)
         self.runs = 0
         model.batch_engine = self

@@ -137,9 +137,12 @@ class CompilePool:
 
     def imap(self, codes: Iterable[str], timeout: Optional[int] = 60) -> Iterator[CompiledFigure]:
         """all documents in flight at once, results in input order (multiprocessing.Pool.imap, refine.py:176)"""
+        codes = list(codes)
         futures = [self.submit(code, timeout) for code in codes]
-        for f in futures:
+        for code, f in zip(codes, futures):
             fig = self.result(f)
+            if fig is None:         # lost with a dying sibling: once more on the restarted pool
+                fig = self.result(self.submit(code, timeout))
             yield fig if fig is not None else CompiledFigure(-1, "compile worker died", None, None)
 
     def close(self):
@@ -165,7 +168,13 @@ def pooled_document_class(pool: CompilePool) -> Type[TikzDocument]:
 
         def _compile(self) -> Output:
             fig = pool.result(self.prefetch()._future)
-            if fig is None:         # the worker died under this job (or under a sibling): a failed compile, not a failed search
+            if fig is None:
+                # a worker died and concurrent.futures failed EVERY pending job of that executor — most of them innocent siblings
+                # whose document would otherwise be cached as a failed compile (reward -1 for good: ADVICE r3).  The pool has been
+                # restarted: run this document once more; only a second loss is reported as a failed compile.
+                self._future = pool.submit(self.code, self.timeout)
+                fig = pool.result(self._future)
+            if fig is None:         # the worker died under this very job twice: a failed compile, not a failed search
                 return Output()
             return Output(pdf=_PooledPdf(fig) if fig.png is not None else None, status=fig.status, log=fig.log)
 

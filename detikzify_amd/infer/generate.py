@@ -293,7 +293,14 @@ class DetikzifyGenerator:
     def _graft_before_error(self, anchor: WideNode, chain: List[WideNode], cap: int, error_line: int) -> WideNode:
         """positions in front of the first located error join the tree (at most `cap`: those with index < cap); the chain
         from the first position beyond the error line is remembered as a failing continuation of that position.  A position
-        whose last line IS the error line is neither (the line may still be incomplete)."""
+        whose last line IS the error line is neither (the line may still be incomplete).
+
+        Deliberately bug-for-bug: the reference has one more branch here — `num_lines == errorln and ends_with_eol` memoises the
+        failing tail from the error line itself (detikzify/infer/generate.py:331-336) — but it looks the line ending up with
+        `self.newlineinfo.get(<0-d tensor>)`, tensors hash by identity, so the lookup always misses and the branch is never
+        taken.  This port keeps what the reference DOES (and what tests/golden/generator_trace.json records), not what it
+        intends; if upstream fixes the lookup, add `or (link.num_lines == error_line and <last token ends with a newline>)` to
+        the first test below and regenerate the golden trace."""
         for i, link in enumerate(chain):
             if link.num_lines > error_line:
                 self.failed_rollouts[link.state] = chain[i:]

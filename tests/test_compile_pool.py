@@ -21,7 +21,9 @@ assert "-file-line-error" in sys.argv and "-interaction=nonstopmode" in sys.argv
 code = open(tex).read()
 lines = code.split("\n")
 print(f"Latexmk: fake run of {engine}\n({tex}")
-if "HANG" in code:                      # a run that never ends and has a child of its own (TeX spawns helpers)
+once = os.path.join(os.environ["FAKE_TEX_STATE"], "hung.once")
+if "HANG" in code and not ("HANG_ONCE" in code and os.path.exists(once)):   # a run that never ends and has a child of its own (TeX spawns helpers)
+    open(once, "w").write("x")
     child = subprocess.Popen(["sleep", "600"])
     open(os.path.join(os.environ["FAKE_TEX_STATE"], "grandchild.pid"), "w").write(str(child.pid))
     time.sleep(600)
@@ -192,26 +194,47 @@ def test_parallel_trees_compile_in_the_pool_while_the_others_decode(tex_box):
         assert len(seq) == 2
 
 
+def _wait_for(path, what):
+    for _ in range(100):
+        if path.exists():
+            return
+        time.sleep(0.1)
+    raise AssertionError(what)
+
+
 def test_a_dying_worker_fails_one_compile_not_the_search(tex_box):
-    """a worker killed under a TeX run (OOM killer) breaks concurrent.futures' executor for good: the pool replaces it, the
-    lost job reads as a failed compile (status -1, nothing to rasterise) and the jobs after it compile normally"""
+    """a worker killed under a TeX run (OOM killer) breaks concurrent.futures' executor for good: the pool replaces it and the
+    lost job is run ONCE more on the new executor (the executor fails every pending job, innocent siblings included,
+    and a cached failed compile is a reward of -1 for good); a job that keeps killing its worker reads as a failed compile
+    (status -1, nothing to rasterise) and the jobs after it compile normally"""
     import signal
     from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
-    with CompilePool(workers=1) as pool:
-        assert pool.warm() == 1
-        Pooled = pooled_document_class(pool)
-        victim = Pooled(GOOD + "% HANG\n", timeout=30).prefetch()
-        pidfile = tex_box / "grandchild.pid"
-        for _ in range(100):
-            if pidfile.exists():
-                break
-            time.sleep(0.1)
-        assert pidfile.exists(), "the fake TeX run never started"
+    pidfile = tex_box / "grandchild.pid"
+
+    def kill_worker_and_tex(pool):
+        _wait_for(pidfile, "the fake TeX run never started")
         worker = next(iter(pool._pool._processes))           # the one worker process
         os.kill(worker, signal.SIGKILL)
         os.kill(int(pidfile.read_text()), signal.SIGKILL)
-        assert victim.status == -1 and not victim.is_rasterizable
+        pidfile.unlink()
+
+    with CompilePool(workers=1) as pool:
+        assert pool.warm() == 1
+        Pooled = pooled_document_class(pool)
+        victim = Pooled(GOOD + "% HANG_ONCE\n", timeout=30).prefetch()       # hangs the first time only: an OOM kill, not a bad document
+        sibling = Pooled(GOOD + "% sibling\n").prefetch()                    # queued behind it on the same executor
+        kill_worker_and_tex(pool)
+        assert victim.status == 0 and victim.is_rasterizable                 # the retry on the restarted pool compiled it
+        assert sibling.status == 0 and sibling.is_rasterizable               # ... and the innocent sibling is not a failed compile
         assert pool.restarts == 1
+        deadly = Pooled(GOOD + "% HANG\n", timeout=30).prefetch()            # this one takes its worker down every time
+        kill_worker_and_tex(pool)
+        import threading
+        second = threading.Thread(target=kill_worker_and_tex, args=(pool,))  # the retry hangs again: kill that worker too
+        second.start()
+        assert deadly.status == -1 and not deadly.is_rasterizable
+        second.join(timeout=30)
+        assert pool.restarts == 3
         after = Pooled(GOOD)
         assert after.status == 0 and after.is_rasterizable
         figs = list(pool.imap([GOOD, BROKEN]))

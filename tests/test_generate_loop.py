@@ -174,7 +174,7 @@ class ScriptedDevice(DetikzifyForCausalLM):
         launched, collected, out, done = inflight, 0, [], False
         self.runs = getattr(self, "runs", 0) + 1
         while not done:
-            while launched < collected + 2 and launched < max_steps and launched < min(remaining.values()):
+            while launched < collected + 2 and launched <= max_steps and launched < min(remaining.values()):
                 self.decode_batch_launch(slots)
                 launched += 1
             if collected >= launched:

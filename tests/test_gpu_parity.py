@@ -1399,7 +1399,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                         (1, 0, 1, 2, 5, 1), (1, 0, 1, 2, 1 + 4 + 16, 0), (1, 0, 1, 2, 1 + 4 + 16, 1), (0, 0, 0, 2, 7, 1),
                         (1, 0, 1, 2, 1 + 4 + 16, 0, 2), (1, 0, 1, 2, 1 + 4 + 16, 1, 2), (1, 0, 1, 2, 5, 2), (1, 0, 1, 2, 1 + 2 + 4, 2),
                         (1, 0, 1, 2, 1 + 4 + 16, 2, 2), (1, 0, 1, 2, 1 + 32), (0, 0, 0, 0, 32 + 1),
-                        (1, 0, 1, 2, 1 + 32, 0, 1, 4), (0, 0, 0, 0, 32 + 1, 0, 1, 4),       # 8th entry: fp8 register ring of 4 phases (default 8: round 4)
+                        (1, 0, 1, 2, 1 + 32, 0, 1, 8), (0, 0, 0, 0, 32 + 1, 0, 1, 8),       # 8th entry: fp8 register ring of 8 phases (round 4 experiment; default 4)
                         (1, 0, 1, 2, 1 + 64), (1, 0, 1, 0, 1 + 64)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
                         # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
             model.set_option("gemv_bx", variant[0])
@@ -1410,7 +1410,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
             model.set_option("gemv_bl", variant[4])
             model.set_option("gemv_xw", variant[5] if len(variant) > 5 else 0)
             model.set_option("gemv_loaders", variant[6] if len(variant) > 6 else 1)
-            model.set_option("gemv_br_wd", variant[7] if len(variant) > 7 else 8)
+            model.set_option("gemv_br_wd", variant[7] if len(variant) > 7 else 4)
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1431,7 +1431,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_bkl", 1)
         model.set_option("gemv_xw", 0)
         model.set_option("gemv_loaders", 1)
-        model.set_option("gemv_br_wd", 8)
+        model.set_option("gemv_br_wd", 4)
         del model
         gc.collect()
 

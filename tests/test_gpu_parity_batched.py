@@ -10,8 +10,8 @@ configuration is the one detikzify/infer/generate.py:218-227 passes to HF `gener
 Tolerances (stated where used):
   * logits of a step: the device may be no further from the fp32 oracle than 1.5 x the bf16-policy oracle is, + 2e-3
     (two correct bf16 pipelines random-walk apart with depth; DESIGN.md §5);
-  * greedy tokens: identical, except where the oracle's own top-2 gap is within 2 bf16 ulps of the top logit (near-tie),
-    at most n // 8 of those;
+  * greedy tokens: identical, except where the oracle's own top-2 gap is within 2 bf16 ulps of the top logit (near-tie) AND the
+    device's token is one the oracle scores within 2 ulps of its best; at most every second near-tie step may flip;
   * sampled tokens: EXACTLY the oracle sampler's counter-based draw from the device's logits of that step (integer work);
   * the peaked-logits weight set: 16 of 16 greedy tokens identical, no near-tie rule.
 """
@@ -141,11 +141,15 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                 if not sampled:
                     n_greedy_total += 1
                     near_tie_steps += gaps[-1] <= 2.0 + 1e-3
-                    top2 = torch.topk(sampling.mask_scores(logits, [img_tok], [eos], first), 2)[1].tolist()
-                    if top2[0] == t:
-                        identical += 1
-                    else:       # a flip: only at a near-tie, and only to the oracle's runner-up
-                        assert gaps[-1] <= 2.0 + 1e-3 and t == top2[1], (s, i, t, top2, gaps[-1])
+                    masked = sampling.mask_scores(logits, [img_tok], [eos], first)
+                    best = float(masked.max())
+                    if float(masked[t]) == best and t == int(torch.nonzero(masked == best)[0]):
+                        identical += 1      # the oracle's argmax (lowest index among exactly equal maxima, like torch.argmax and the device)
+                    else:
+                        # a flip: only at a near-tie, and only to a token the ORACLE itself scores within 2 bf16 ulps of its best (the
+                        # runner-up, or — bf16 logits tie exactly now and then — any of several tokens at that distance)
+                        behind = (best - float(masked[t])) / (abs(best) * ULP + 1e-30)
+                        assert gaps[-1] <= 2.0 + 1e-3 and behind <= 2.0 + 1e-3, (s, i, t, torch.topk(masked, 3), gaps[-1], behind)
                         near_ties += 1
                 logits = o16.step(t)
                 r16 = rel_l2(logit_log[s][i], logits)
