@@ -1814,8 +1814,12 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemm_impl")) {
-    if (value < 0 || value > 3) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma), 2 (k_gemm_glds where the shape has the tiles) or 3 (auto)");
+    if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma), 2 (k_gemm_glds where the shape has the tiles), 3 (auto) or 4 (k_gemm_g3: 8 waves, 3 LDS stages)");
     set_gemm_impl(value);
+  }
+  else if (!strcmp(name, "gemm_g3_min_blocks")) {
+    if (value < 1) return fail(c, DTK_ERR_ARG, "gemm_g3_min_blocks must be >= 1");
+    set_gemm_g3_min_blocks(value);
   }
   else if (!strcmp(name, "gemm_glds_min_tiles")) {
     if (value < 1) return fail(c, DTK_ERR_ARG, "gemm_glds_min_tiles must be >= 1");

@@ -200,8 +200,9 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
 void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4
 void set_gemm_tile(int v);   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32
-void set_gemm_impl(int v);   // 0 = k_gemm_mfma (operands staged through registers), 1 = k_gemm_dma (LDS-DMA ring, fragment-major LDS)
+void set_gemm_impl(int v);   // 0 = k_gemm_mfma (operands staged through registers), 1 = k_gemm_dma (LDS-DMA ring, fragment-major LDS), 2 = k_gemm_glds, 3 = auto, 4 = k_gemm_g3 (8 waves, 3 LDS stages)
 void set_gemm_ring(int v);   // LDS stages of k_gemm_dma: 2..4
+void set_gemm_g3_min_blocks(int v);     // gemm_impl 4: 256 x 128 blocks a shape needs to take k_gemm_g3 (default 128)
 void set_gemm_glds_min_tiles(int v);   // gemm_impl 2: 128 x 128 tiles a shape needs to take k_gemm_glds
 void launch_gemm_naive(const GemmArgs& a, hipStream_t s);
 

@@ -408,6 +408,168 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_gemm_g3 — 8 waves, 256 x 128 (or 128 x 256) block tile, THREE LDS stages filled by LDS-DMA two k-tiles ahead.
+//
+// Why k_gemm_glds sits at ~300 TFLOP/s on the batched ViT (M = 5832, K = 1152): a 128 x 128 x 64 k-tile is 32 KiB of operands
+// for 2.1 MFLOP (65 FLOP per byte into the CU), two blocks per CU keep ONE fill each in flight = 64 KiB per CU, and an L2 ->
+// LDS round trip under load is 2-3 us: 64 KiB / 2.5 us = 26 GB/s per CU = 1.7 TFLOP/s per CU = 430 TFLOP/s before epilogues and
+// tile quantisation (measured: 21 GB/s per CU, 341 TFLOP/s on the qkv GEMM).  The operand stream is latency-bound by its
+// in-flight depth, not the matrix cores (MFMA-busy 20 %, profiles/r03_pmc_mfma.csv).  This kernel changes both terms:
+//   * 256 x 128 tile, BK = 64: 48 KiB per k-tile for 4.2 MFLOP = 87 FLOP per byte (1.33 x);
+//   * 3 stages x 48 KiB = 144 KiB of LDS, one block per CU, TWO fills (96 KiB) in flight (1.5 x): counted `s_waitcnt vmcnt(6)`
+//     (a wave's six 1 KiB pieces of the NEXT tile may stay outstanding) + a raw `s_barrier` — `__syncthreads()` would drain the
+//     fills (guides/cdna_hip_programming.md §5, glds table: "3 LDS buffers, counted vmcnt(N), raw s_barrier");
+//   * 8 waves = 2 per SIMD, each a 64 x 64 sub-tile (16 fragment reads per 32 MFMAs and k-tile): one wave's ds_reads and
+//     waits hide under the other's MFMAs;
+//   * the MFMA runs TRANSPOSED (A operand = W rows, B operand = activation rows), so a lane ends up with 4 consecutive output
+//     columns of one row: the epilogue stores 8 bytes per lane instead of four scattered 2-byte values.
+// LDS image, swizzle and fill map are k_gemm_glds's ([row][8 x 16 B], chunk ^ ((row >> 1) & 7), applied on the SOURCE address).
+// Same k order per output element as every other GEMM here (32-wide k-steps in order from zero).
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
+  constexpr int BK = 64, NST = 3, WAVES = 8;
+  constexpr unsigned OPA = BM * BK * 2, OPW = BN * BK * 2, STB = OPA + OPW;   // 48 KiB per stage
+  constexpr int PIECES = (int)(STB / 1024), PPW = PIECES / WAVES;              // 48 pieces of 1 KiB, 6 per wave
+  constexpr int WN = BN / 64;                                                   // waves along n (the grid of 64 x 64 wave tiles is (BM/64) x (BN/64) = 8)
+  static_assert((BM / 64) * (BN / 64) == WAVES && PIECES % WAVES == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];          // the kernel's only LDS object: LDS address 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int MB = (a.M + BM - 1) / BM, NB = (a.N + BN - 1) / BN;
+  const int b = blockIdx.x;
+  const int nt = (b & 7) + 8 * ((b >> 3) / MB), mb = (b >> 3) % MB;            // XCD-aware map (see k_gemm_mfma)
+  if (nt >= NB) return;
+  const int m0 = mb * BM, n0 = nt * BN;
+  const int K = a.K;
+
+  // fill map: piece p covers 8 tile rows of one operand (A: pieces 0 .. BM/8-1, then W); lane l fills LDS chunk (row l >> 3,
+  // position l & 7) from source chunk (l & 7) ^ swz(row)
+  const bf16_t* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave * PPW + i;
+    const bool isA = p < BM / 8;
+    const int row = (isA ? p : p - BM / 8) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (isA) { int am = m0 + row; if (am >= a.M) am = a.M - 1; src[i] = a.A + (size_t)am * a.lda + chunk * 8; }
+    else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; src[i] = a.W + (size_t)wn * a.ldw + chunk * 8; }
+  }
+  auto fill = [&](int t) {
+    const unsigned base = (unsigned)(t % NST) * STB + (unsigned)wave * (unsigned)PPW * 1024u;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16_row(src[i] + (size_t)t * BK, base + (unsigned)i * 1024u);
+  };
+
+  f32x4 acc[4][4];      // acc[i][j]: m tile i, n tile j; register r = column n + r of row m (transposed MFMA)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ra = (unsigned)(wr * 64 + i * 16 + (lane & 15)), rb = (unsigned)(wc * 64 + i * 16 + (lane & 15));
+    aoff[i] = ra * 128u; boff[i] = OPA + rb * 128u;
+  }
+  const unsigned swz = (unsigned)(((lane & 15) >> 1) & 7);
+  const unsigned q0 = (unsigned)(lane >> 4);
+  auto compute = [&](int stage) {
+    const unsigned char* st = gsm + (unsigned)stage * STB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned coff = (((unsigned)ks * 4u + q0) ^ swz) * 16u;
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i] + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + boff[j] + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]: rows = W rows, columns = activation rows
+    }
+  };
+
+  const int nk = K / BK;
+  if (nk > 0) fill(0);
+  if (nk > 1) fill(1);
+  for (int t = 0; t < nk; ++t) {
+    // this wave's pieces of k-tile t have landed when only the next tile's PPW pieces may still be outstanding; then everybody's
+    // have, and everybody is past compute(t - 1), whose stage the fill below overwrites.  One asm: no LDS access crosses it.
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 < nk) fill(t + 2);
+    compute(t % NST);
+  }
+  if (K % BK) {                                    // ragged tail: register-staged, zero-filled, same image (swizzle included)
+    const int stage = nk % NST, k0 = nk * BK;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // nothing in flight; stage last read by compute(nk - 3)
+    unsigned char* st = gsm + (unsigned)stage * STB;
+    for (int c = tid; c < (BM + BN) * 8; c += 512) {
+      const bool isA = c < BM * 8;
+      const int cc = isA ? c : c - BM * 8, row = cc >> 3, pos = cc & 7;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      const int k = k0 + chunk * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k < K) {
+        if (isA) { int am = m0 + row; if (am >= a.M) am = a.M - 1; v = *reinterpret_cast<const u32x4*>(a.A + (size_t)am * a.lda + k); }
+        else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; v = *reinterpret_cast<const u32x4*>(a.W + (size_t)wn * a.ldw + k); }
+      }
+      *reinterpret_cast<u32x4*>(st + (isA ? 0u : OPA) + (unsigned)row * 128u + (unsigned)pos * 16u) = v;
+    }
+    __syncthreads();
+    compute(stage);
+  }
+  // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n
+  const bool vec = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      if (m >= a.M || n >= a.N) continue;
+      bf16_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (n + r < a.N) ? f2bf(gemm_epilogue(acc[i][j][r], m, n + r, a)) : (bf16_t)0;
+      bf16_t* dst = a.C + (size_t)m * a.ldc + n;
+      if (vec && n + 3 < a.N) {
+        u32x2 pk = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+        *reinterpret_cast<u32x2*>(dst) = pk;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < a.N) dst[r] = o[r];
+      }
+    }
+  }
+}
+static int g_g3_min_blocks = 128;     // blocks a shape must give k_gemm_g3 (one per CU): below that the smaller tiles fill the chip better
+void set_gemm_g3_min_blocks(int v) { g_g3_min_blocks = v; }
+template <int BM, int BN>
+static void launch_gemm_g3_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (BM + BN) * 64 * 2;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm_g3<BM, BN>), dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(512), lds, s, a);
+}
+static bool launch_gemm_g3(const GemmArgs& a, hipStream_t s) {
+  if ((a.lda % 8) || (a.ldw % 8) || a.K < 128 || (a.K % 8)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
+  int cus = 256;
+  { static int n = 0; if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; } cus = n; }
+  // orientation: the one that needs fewer rounds of one block per CU; ties go to the tall tile (activations are the larger operand)
+  auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  const long tall = blocks(256, 128), wide = blocks(128, 256);
+  const long rt = (tall + cus - 1) / cus, rw = (wide + cus - 1) / cus;
+  const bool use_wide = rw < rt || (rw == rt && wide < tall && a.M < 256);
+  if ((use_wide ? wide : tall) < g_g3_min_blocks) return false;
+  if (use_wide) launch_gemm_g3_t<128, 256>(a, s); else launch_gemm_g3_t<256, 128>(a, s);
+  return true;
+}
+
 static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring), 2 = k_gemm_glds for shapes with >= g_glds_min_tiles 128 x 128 tiles (else k_gemm_mfma), 3 = auto (default: 2 for M >= 1024, else 0); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
@@ -451,7 +613,8 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   // 3 = auto (default): k_gemm_glds for M >= 1024 (the batched ViT: same wall time as k_gemm_mfma, 319 instead of 711 MB fetched from
   // the memory side per launch — profiles/r03_pmc_mfma.csv — which is what a reward pass that runs BESIDE the HBM-bound decode
   // steps should cost them), k_gemm_mfma below (prefill M = 243, one image M = 729: measured 14.4 vs 14.8 ms and 4.0 vs 4.6 ms)
-  if ((g_gemm_impl == 2 || (g_gemm_impl == 3 && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
+  if (g_gemm_impl == 4 && !gemm_tile_override() && launch_gemm_g3(a, s)) return;      // 4 = k_gemm_g3 wherever the shape gives it a block per two CUs
+  if ((g_gemm_impl == 2 || ((g_gemm_impl == 3 || g_gemm_impl == 4) && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
     const int ring = g_gemm_ring;
 #define DMA_LAUNCH(BM_, BN_) do { if (ring == 2) launch_gemm_dma_t<BM_, BN_, 2>(a, s, grid(BM_, BN_)); else if (ring == 4) launch_gemm_dma_t<BM_, BN_, 4>(a, s, grid(BM_, BN_)); \

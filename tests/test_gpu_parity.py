@@ -166,6 +166,33 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
     assert frac < 2e-3     # fmaf chain vs MFMA tree inside a 32-wide k-step: rare 1-ulp flips only
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(300, 200, 592, 1), (256, 128, 128, 0), (1000, 520, 1152, 3), (513, 260, 4304, 5), (729, 1152, 1152, 7),
+                                         (243, 384, 4096, 0), (70, 1000, 336, 1)])
+def test_op_gemm_three_stage_kernel_is_bit_identical(tiny, M, N, K, flags):
+    """k_gemm_g3 (8 waves, 256 x 128 / 128 x 256 tiles, three LDS stages filled two k-tiles ahead, transposed MFMA with 8-byte
+    stores: option gemm_impl = 4) against k_gemm_mfma on the same operands: the k order per output element is the same, so the
+    bf16 outputs must be equal bit for bit — ragged M / N edges, K tails that are not a multiple of 64, every epilogue."""
+    model, _ = tiny
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = rb(torch.randn(M, K, generator=g)); W = rb(torch.randn(N, K, generator=g) * 0.05)
+    b = rb(torch.randn(N, generator=g) * 0.1); R = rb(torch.randn(M, N, generator=g))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    Ab, Wb, bb, Rb = bf16_bits(A), bf16_bits(W), bf16_bits(b), bf16_bits(R)
+    outs = {}
+    try:
+        model.set_option("gemm_g3_min_blocks", 1)
+        for impl in (0, 4):
+            model.set_option("gemm_impl", impl)
+            out = np.empty((M, N), dtype=np.uint16)
+            model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
+            outs[impl] = out
+    finally:
+        model.set_option("gemm_impl", 3)
+        model.set_option("gemm_g3_min_blocks", 128)
+    diff = int((outs[0] != outs[4]).sum())
+    assert diff == 0, f"{diff} of {M * N} elements differ"
+
+
 @pytest.mark.parametrize("N,K,mode", [(512, 256, 0), (256, 688, 0), (100, 2048, 1), (37, 4096, 1), (2048, 5504, 0)])
 def test_op_gemv(tiny, N, K, mode):
     model, _ = tiny

@@ -21,7 +21,7 @@ if args.only:
 alone = [model.vit_encode(px[i:i + 1], want_pooled=True) for i in range(3)]
 f8, p8 = model.vit_encode(px[:8], want_pooled=True)
 print("batched == alone (features, pooled):", all(torch.equal(f8[i], alone[i][0][0]) for i in range(3)), all(torch.equal(p8[i], alone[i][1][0]) for i in range(3)))
-ap_variants = ((0, "auto", 0), (1, "64x64", 0), (2, "128x64", 0), (3, "128x128", 0), (0, "glds128", 2))   # (gemm_tile, name, gemm_impl)
+ap_variants = ((0, "auto", 3), (1, "64x64", 0), (0, "glds128", 2), (0, "g3", 4))   # (gemm_tile, name, gemm_impl)
 for tile, name, impl in ap_variants:
     model.set_option("gemm_tile", tile); model.set_option("gemm_impl", impl)
     for B in (1, 2, 4, 8, 16):

@@ -47,7 +47,11 @@ __host__ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __host__ __device__ __forceinline__ float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-constexpr int D = 4096, FF = 11008;
+#ifndef PROBE_D            // -DPROBE_D=2048 -DPROBE_FF=5504: the ds-1.3b layer (8 / 8 / 8 / 8 / 22 KB edges, 101 MB of weights) — VERDICT r3 item 4
+#define PROBE_D 4096
+#define PROBE_FF 11008
+#endif
+constexpr int D = PROBE_D, FF = PROBE_FF;
 constexpr int NPHASE = 5;                       // qkv, attn, o, gu, down
 enum { P_QKV = 0, P_ATTN = 1, P_O = 2, P_GU = 3, P_DOWN = 4 };
 constexpr float SCALE = 1.0f;
