@@ -1797,6 +1797,16 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   if (!c || !name) return DTK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+#ifdef DTK_EXPERIMENTS
+  constexpr bool kExperiments = true;
+#else
+  constexpr bool kExperiments = false;
+#endif
+  // kernels that lost their measurements are only built with DTK_EXPERIMENTS=1 ./build.sh: "experiments" (any value) tells a test
+  // whether they are there; selecting one in a default build is an error, not a silent fall-back
+  if (!strcmp(name, "experiments")) return kExperiments ? DTK_OK : fail(c, DTK_ERR_ARG, "built without DTK_EXPERIMENTS");
+  if (!kExperiments && ((!strcmp(name, "gemm_b") && value != 0) || (!strcmp(name, "gemv_bk") && value != 0) || (!strcmp(name, "gemm_impl") && value == 1)))
+    return fail(c, DTK_ERR_ARG, "option %s = %d selects a kernel that is only built with DTK_EXPERIMENTS=1 ./build.sh", name, value);
   if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
   else if (!strcmp(name, "gemm_tile")) {   // MFMA GEMM block tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (process-wide)
     if (value < 0 || value > 5) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..5");

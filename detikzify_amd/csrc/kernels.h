@@ -187,6 +187,8 @@ void set_gemv_mv_shape(int role, int shape);   // role = epilogue id (5 = o_proj
 #define GEMM_GELU_ERF 2
 #define GEMM_GELU_TANH 4
 #define GEMM_RESIDUAL 8
+#define GEMM_PROBE_NOFILL 65536    // k_gemm_g3 timing experiments (DTK_G3_PROBE): leave parts of the kernel out
+#define GEMM_PROBE_NOMFMA 131072
 struct GemmArgs {
   const bf16_t* A; int lda;      // [M][K]
   const bf16_t* W; int ldw;      // [N][K]

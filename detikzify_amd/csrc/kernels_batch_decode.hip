@@ -266,11 +266,15 @@ void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGL
   const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
 #define GBM(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV>), g, b, 0, s, a)
 #define GBM2(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV, 2>), g, b, 0, s, a)   // 2 k-steps per stage
+#ifdef DTK_EXPERIMENTS      // the timing-experiment instantiations (tools/probe_batch.py): 16 modes x 3 tile counts of a 0.5 MB kernel each
 #define GBMS(NTV) switch (mode) { case 1: GBM(1, NTV); break; case 2: GBM(2, NTV); break; case 3: GBM(3, NTV); break; case 4: GBM(4, NTV); break; \
                                   case 5: GBM(5, NTV); break; case 6: GBM(6, NTV); break; case 7: GBM(7, NTV); break; \
                                   case 8: GBM(8, NTV); break; case 16: GBM2(16, NTV); break; case 24: GBM2(24, NTV); break; case 17: GBM(16, NTV); break; \
                                   case 32: GBM(32, NTV); break; case 40: GBM(40, NTV); break; case 48: GBM2(48, NTV); break; case 56: GBM2(56, NTV); break; \
                                   case 64: GBM(64, NTV); break; default: GBM(0, NTV); }
+#else
+#define GBMS(NTV) GBM(0, NTV);
+#endif
   if (a.W8) {
     if (a.nt >= 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
     else if (a.nt == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);

@@ -89,6 +89,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+#ifdef DTK_EXPERIMENTS      // k_gemm_b: measured not faster than k_gemv_b / k_gemv_bl at any slot count; built with DTK_EXPERIMENTS=1 ./build.sh only
 // T tiles per wave, KQ splits of K x RP row groups per block, NT column tiles of 16 slots, SK k-steps per stage, both streams
 // XA stages ahead.  Iteration t issues stage u = t + XA of both streams — weights first, then the x fragments — and computes
 // stage t; the prologue is iterations -XA .. -1.
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(KQ * RP * 64) void k_gemm_b(GemvBArgs a) {
     if (gg < groups && a.bs->active[n]) gg_epilogue<EPI, T>(a, gg, n, m, v);
   }
 }
+
+#endif  // DTK_EXPERIMENTS (k_gemm_b)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_gemv_bx — the rows >> d roles (qkv, gate/up, lm_head) at 49..64 slots with the x operand read ONCE PER CU.
@@ -1030,6 +1033,7 @@ bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
 #undef BX
 }
 
+#ifdef DTK_EXPERIMENTS      // k_gemv_bk: the in-kernel exchange of its K split lost to k_gemv_bkp / k_gemv_bkl + k_resid_norm_b (partials stored, reduced by the norm kernel)
 // ------------------------------------------------------------------------------------------------------------------------
 // k_gemv_bk — the N = d roles (o_proj, down: 256 row tiles) at 49..64 slots: K split over the CUs of a row group.
 //
@@ -1195,6 +1199,9 @@ bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
   }
   return false;
 }
+#else
+bool launch_gemv_bk(int, int, const GemvBArgs&, hipStream_t) { return false; }
+#endif  // DTK_EXPERIMENTS (k_gemv_bk)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_gemv_bkp + k_resid_norm_b — the N = d roles at 33..64 slots as TWO launches: K split over the CUs of a row group, the
@@ -1608,6 +1615,7 @@ void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w,
   else hipLaunchKernelGGL((k_resid_norm_b<4>), dim3(nslots), dim3(1024), 0, s, part, X, ldx, w, Y, D, eps, bs);
 }
 
+#ifdef DTK_EXPERIMENTS
 template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
 static void launch_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
@@ -1675,3 +1683,7 @@ bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
   if (a.nt == 2) return launch_nt<2>(epi, shape, a, s);
   return launch_nt<1>(epi, shape, a, s);
 }
+#else   // the LDS-staged batched GEMM is an experiment: not built, "gemm_b" stays 0
+void launch_gemm_b_mode(int, int mode, const GemvBArgs& a, hipStream_t s) { launch_gemv_b_mode(mode, a, s); }
+bool launch_gemm_b(int, int, const GemvBArgs&, hipStream_t) { return false; }
+#endif  // DTK_EXPERIMENTS

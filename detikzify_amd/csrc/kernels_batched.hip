@@ -30,6 +30,55 @@ __device__ __forceinline__ float gemm_epilogue(float acc, int m, int n, const Ge
   return v;
 }
 
+// the same epilogue with its memory operands already in registers.  Round 4 found the GEMMs' epilogues — not their main loops —
+// to be half of a ViT launch (k_gemm_g3 with neither fills nor MFMAs: 68.7 of 132 us, profiles/r04_vit8_g3_*_kernel_stats.csv):
+// every output element loaded its bias / residual value right before use inside a branchy loop, i.e. 16-64 dependent memory
+// round trips per lane.  The kernels now issue every epilogue load first (clamped addresses, no branch), then compute, then store.
+__device__ __forceinline__ float gemm_epilogue_pre(float acc, float bias, float res, int flags) {
+  float v = acc;
+  if (flags & GEMM_BIAS) v += bias;
+  v = rbf(v);  // the Linear's bf16 output tensor
+  if (flags & GEMM_GELU_ERF) v = rbf(gelu_erf(v));
+  else if (flags & GEMM_GELU_TANH) v = rbf(gelu_tanh(v));
+  if (flags & GEMM_RESIDUAL) v = rbf(res + v);
+  return v;
+}
+// epilogue of the kernels whose lanes hold the standard C/D layout of TM x TN 16 x 16 tiles (col = lane & 15, row = (lane >> 4) * 4 + reg)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_store_tiles(const GemmArgs& a, const f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane) {
+  const int flags = a.flags;
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(nbase + j * 16 + (lane & 15), a.N - 1);
+    bv[j] = (flags & GEMM_BIAS) ? bf2f(a.bias[n]) : 0.f;
+  }
+  float rv[TM][TN][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rv[i][j][r] = 0.f;
+        if (flags & GEMM_RESIDUAL) {
+          const int m = min(mbase + i * 16 + (lane >> 4) * 4 + r, a.M - 1), n = min(nbase + j * 16 + (lane & 15), a.N - 1);
+          rv[i][j][r] = bf2f(a.residual[(size_t)m * a.ldr + n]);
+        }
+      }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mbase + i * 16 + (lane >> 4) * 4 + r;
+        const int n = nbase + j * 16 + (lane & 15);
+        const bf16_t o = f2bf(gemm_epilogue_pre(acc[i][j][r], bv[j], rv[i][j][r], flags));
+        if (m < a.M && n < a.N) a.C[(size_t)m * a.ldc + n] = o;
+      }
+}
+
 // TBM x TBN block tile, 4 waves in a 2 x 2 grid, each wave (TBM/2) x (TBN/2) = TM x TN MFMA tiles: per 32-wide k-step a
 // wave reads TM + TN fragments from LDS for TM*TN MFMAs.  64x64 (2+2 reads per 4 MFMAs) is LDS-read-bound; 128x64 and
 // 128x128 (4+4 per 16) are not, but need M*N large enough to fill 256 CUs: launch_gemm_mfma picks per shape.  The k order
@@ -130,18 +179,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmArgs a) {
       }
     }
   }
-  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * (TBM / 2) + i * 16 + (lane >> 4) * 4 + r;
-        const int n = n0 + wc * (TBN / 2) + j * 16 + (lane & 15);
-        if (m < a.M && n < a.N)
-          a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
-      }
+  gemm_store_tiles<TM, TN>(a, acc, m0 + wr * (TBM / 2), n0 + wc * (TBN / 2), lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -160,6 +198,7 @@ __device__ __forceinline__ void gemm_glds16(const void* gsrc, unsigned lds_byte)
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+#ifdef DTK_EXPERIMENTS      // k_gemm_dma: no faster than k_gemm_mfma (round 2); superseded by k_gemm_glds / k_gemm_g3
 template <int TBM, int TBN, int RING>
 __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs a) {
   constexpr int TM = TBM / 32, TN = TBN / 32;        // MFMA tiles per wave (2 x 2 wave grid)
@@ -268,6 +307,8 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs a) {
           a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
       }
 }
+
+#endif  // DTK_EXPERIMENTS (k_gemm_dma)
 
 // ------------------------------------------------------------------------------------------
 // k_gemm_glds: the GEMM for shapes with enough tiles to fill the chip at 128 x 128 (batched ViT M = images x 729, long prompts, the
@@ -381,18 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmArgs a) {
     __syncthreads();
     compute(stage);
   }
-  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
-        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
-        if (m < a.M && n < a.N)
-          a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
-      }
+  gemm_store_tiles<4, 4>(a, acc, m0 + wr * 64, n0 + wc * 64, lane);
 }
 static int g_glds_min_tiles = 160;   // 128 x 128 tiles a shape must have for k_gemm_glds (gemm_impl 2 / 3); below that the small-tile kernel fills the chip better
 void set_gemm_glds_min_tiles(int v) { g_glds_min_tiles = v; }
@@ -500,8 +530,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     // have, and everybody is past compute(t - 1), whose stage the fill below overwrites.  One asm: no LDS access crosses it.
     if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + 2 < nk) fill(t + 2);
-    compute(t % NST);
+    if (t + 2 < nk && !(a.flags & GEMM_PROBE_NOFILL)) fill(t + 2);
+    if (!(a.flags & GEMM_PROBE_NOMFMA)) compute(t % NST);
   }
   if (K % BK) {                                    // ragged tail: register-staged, zero-filled, same image (swizzle included)
     const int stage = nk % NST, k0 = nk * BK;
@@ -522,25 +552,61 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     __syncthreads();
     compute(stage);
   }
-  // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n
+  // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n.
+  // All bias / residual loads first (8 bytes each, clamped), then the arithmetic, then 8-byte stores.
+  const int flags = a.flags;
   const bool vec = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
+  const bool nvec = (a.N & 3) == 0;      // n is a multiple of 4: a lane's 4 columns are all inside or all outside the matrix
+  const bool rvec = nvec && (flags & GEMM_RESIDUAL) && (a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.residual) & 7) == 0;
+  const bool bvec = nvec && (flags & GEMM_BIAS) && (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0;
+  float bv[4][4], rv[4][4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+    if (bvec) {
+      const u32x2 p2 = *reinterpret_cast<const u32x2*>(a.bias + min(n, a.N - 4));
+      bv[j][0] = pk_lo(p2[0]); bv[j][1] = pk_hi(p2[0]); bv[j][2] = pk_lo(p2[1]); bv[j][3] = pk_hi(p2[1]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (flags & GEMM_BIAS) ? bf2f(a.bias[min(n + r, a.N - 1)]) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + wr * 64 + i * 16 + (lane & 15), a.M - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      if (rvec) {
+        const u32x2 p2 = *reinterpret_cast<const u32x2*>(a.residual + (size_t)m * a.ldr + min(n, a.N - 4));
+        rv[i][j][0] = pk_lo(p2[0]); rv[i][j][1] = pk_hi(p2[0]); rv[i][j][2] = pk_lo(p2[1]); rv[i][j][3] = pk_hi(p2[1]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[i][j][r] = (flags & GEMM_RESIDUAL) ? bf2f(a.residual[(size_t)m * a.ldr + min(n + r, a.N - 1)]) : 0.f;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-      if (m >= a.M || n >= a.N) continue;
-      bf16_t o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (n + r < a.N) ? f2bf(gemm_epilogue(acc[i][j][r], m, n + r, a)) : (bf16_t)0;
+      const uint32_t o0 = f2bf(gemm_epilogue_pre(acc[i][j][0], bv[j][0], rv[i][j][0], flags));
+      const uint32_t o1 = f2bf(gemm_epilogue_pre(acc[i][j][1], bv[j][1], rv[i][j][1], flags));
+      const uint32_t o2 = f2bf(gemm_epilogue_pre(acc[i][j][2], bv[j][2], rv[i][j][2], flags));
+      const uint32_t o3 = f2bf(gemm_epilogue_pre(acc[i][j][3], bv[j][3], rv[i][j][3], flags));
       bf16_t* dst = a.C + (size_t)m * a.ldc + n;
-      if (vec && n + 3 < a.N) {
-        u32x2 pk = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
-        *reinterpret_cast<u32x2*>(dst) = pk;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < a.N) dst[r] = o[r];
+      if (m < a.M && n < a.N) {
+        if (vec && n + 3 < a.N) {
+          const u32x2 pk = {o0 | (o1 << 16), o2 | (o3 << 16)};
+          *reinterpret_cast<u32x2*>(dst) = pk;
+        } else {
+          dst[0] = (bf16_t)o0;
+          if (n + 1 < a.N) dst[1] = (bf16_t)o1;
+          if (n + 2 < a.N) dst[2] = (bf16_t)o2;
+          if (n + 3 < a.N) dst[3] = (bf16_t)o3;
+        }
       }
     }
   }
@@ -566,7 +632,12 @@ static bool launch_gemm_g3(const GemmArgs& a, hipStream_t s) {
   const long rt = (tall + cus - 1) / cus, rw = (wide + cus - 1) / cus;
   const bool use_wide = rw < rt || (rw == rt && wide < tall && a.M < 256);
   if ((use_wide ? wide : tall) < g_g3_min_blocks) return false;
-  if (use_wide) launch_gemm_g3_t<128, 256>(a, s); else launch_gemm_g3_t<256, 128>(a, s);
+  static int probe = -1;          // DTK_G3_PROBE: 1 = no fills after the first two k-tiles, 2 = no MFMAs (timing experiments: wrong results)
+  if (probe < 0) { const char* e = getenv("DTK_G3_PROBE"); probe = e ? atoi(e) : 0; }
+  GemmArgs b = a;
+  if (probe & 1) b.flags |= GEMM_PROBE_NOFILL;
+  if (probe & 2) b.flags |= GEMM_PROBE_NOMFMA;
+  if (use_wide) launch_gemm_g3_t<128, 256>(b, s); else launch_gemm_g3_t<256, 128>(b, s);
   return true;
 }
 
@@ -574,6 +645,7 @@ static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
 void set_gemm_ring(int v) { g_gemm_ring = v; }
+#ifdef DTK_EXPERIMENTS
 template <int BM, int BN, int RING>
 static void launch_gemm_dma_t(const GemmArgs& a, hipStream_t s, dim3 grid) {
   constexpr size_t lds = (size_t)RING * ((BM / 16) * 2 + (BN / 16) * 2) * 1024;
@@ -584,6 +656,7 @@ static void launch_gemm_dma_t(const GemmArgs& a, hipStream_t s, dim3 grid) {
   }
   hipLaunchKernelGGL((k_gemm_dma<BM, BN, RING>), grid, dim3(256), lds, s, a);
 }
+#endif
 
 static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
 void set_gemm_stages(int v) { g_gemm_stages = v; }
@@ -615,6 +688,7 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   // steps should cost them), k_gemm_mfma below (prefill M = 243, one image M = 729: measured 14.4 vs 14.8 ms and 4.0 vs 4.6 ms)
   if (g_gemm_impl == 4 && !gemm_tile_override() && launch_gemm_g3(a, s)) return;      // 4 = k_gemm_g3 wherever the shape gives it a block per two CUs
   if ((g_gemm_impl == 2 || ((g_gemm_impl == 3 || g_gemm_impl == 4) && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
+#ifdef DTK_EXPERIMENTS
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
     const int ring = g_gemm_ring;
 #define DMA_LAUNCH(BM_, BN_) do { if (ring == 2) launch_gemm_dma_t<BM_, BN_, 2>(a, s, grid(BM_, BN_)); else if (ring == 4) launch_gemm_dma_t<BM_, BN_, 4>(a, s, grid(BM_, BN_)); \
@@ -626,6 +700,7 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
 #undef DMA_LAUNCH
     return;
   }
+#endif
   if (g_gemm_stages < 0) { const char* e = getenv("DTK_GEMM_STAGES"); g_gemm_stages = e ? atoi(e) : 3; }
   const int D = g_gemm_stages;
 #define GEMM_LAUNCH(BM_, BN_)                                                                                         \

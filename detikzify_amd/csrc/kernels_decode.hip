@@ -1354,15 +1354,20 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
   const float zmax = s_max;
 
   if (sampling) {
-    uint32_t q[SF_PER];   // floor(exp(z - zmax) * 2^31) <= 2^31
+    // integer mass floor(exp(z - zmax) * 2^31) <= 2^31 of logit k.  Recomputed from the key wherever it is needed (the key is an
+    // invertible image of the logit, so the value is the same every time): holding 32 masses next to 32 keys put the kernel 33
+    // VGPRs + 201 SGPRs over the 128-register budget of a 1024-thread block (profiles/r03_kernel_resources.txt: 136 B of scratch)
 #pragma unroll
     for (int k = 0; k < SF_PER; ++k) {
       const bool in = i0 + k < V;
-      const float zz = z[k];
-      q[k] = in ? (uint32_t)((double)expf(zz - zmax) * 2147483648.0) : 0u;
-      z[k] = __uint_as_float(in ? fkey(zz) : 0u);   // the slot now holds the order-preserving key
+      z[k] = __uint_as_float(in ? fkey(z[k]) : 0u);   // the slot now holds the order-preserving key
     }
 #define key(k) __float_as_uint(z[k])
+    auto mass_of = [&](uint32_t kb) -> uint32_t {     // only called for k with i0 + k < V
+      const float zz = (kb & 0x80000000u) ? __uint_as_float(kb & 0x7fffffffu) : __uint_as_float(~kb);
+      return (uint32_t)((double)expf(zz - zmax) * 2147483648.0);
+    };
+#define q_(k) mass_of(key(k))
     // radix descent helper state: run-length aggregated histogram update
     uint32_t thr_k = 0;
     if (sp->top_k > 0 && sp->top_k < V) {
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
     }
     unsigned long long loc = 0;
 #pragma unroll
-    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr_k) loc += q[k];
+    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr_k) loc += q_(k);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) loc += __shfl_xor(loc, off, 64);
     if (lane == 0) s_q[wave] = loc;
@@ -1430,7 +1435,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
             if (cc) { atomicAdd(&h_mass[cur], cm); atomicAdd(&h_cnt[cur], cc); }
             cur = bin; cc = 0; cm = 0;
           }
-          ++cc; cm += q[k];
+          ++cc; cm += q_(k);
         }
         if (cc) { atomicAdd(&h_mass[cur], cm); atomicAdd(&h_cnt[cur], cc); }
         __syncthreads();
@@ -1444,7 +1449,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
     // kept mass + inverse-CDF draw in index order (thread t's range is contiguous: a plain block scan)
     unsigned long long mine = 0;
 #pragma unroll
-    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr) mine += q[k];
+    for (int k = 0; k < SF_PER; ++k) if (i0 + k < V && key(k) >= thr) mine += q_(k);
     scan[tid] = mine;
     __syncthreads();
     for (int off = 1; off < SAMPLE_THREADS; off <<= 1) {
@@ -1464,15 +1469,16 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
 #pragma unroll
       for (int k = 0; k < SF_PER; ++k) {
         if (!done && i0 + k < V && key(k) >= thr) {
-          if (target < run + q[k]) { s_token = i0 + k; done = true; }
-          run += q[k];
+          const unsigned long long qk = q_(k);
+          if (target < run + qk) { s_token = i0 + k; done = true; }
+          run += qk;
         }
       }
     }
     if (a.probs_out) {
 #pragma unroll
       for (int k = 0; k < SF_PER; ++k)
-        if (i0 + k < V) a.probs_out[i0 + k] = (key(k) >= thr) ? (float)((double)q[k] / (double)kept) : 0.f;
+        if (i0 + k < V) a.probs_out[i0 + k] = (key(k) >= thr) ? (float)((double)q_(k) / (double)kept) : 0.f;
     }
     __syncthreads();
   } else if (a.probs_out) {
@@ -1500,6 +1506,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(SampleArgs a) {
   }
 }
 #undef key
+#undef q_
 
 static bool sample_fast_ok(const SampleArgs& a) {
   static int force_generic = -1;

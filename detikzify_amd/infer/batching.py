@@ -120,12 +120,17 @@ class BatchEngine:
         # trickle in one pipeline flush at a time); gives up after gather_timeout seconds
         self.gather_left = min(int(gather), self.capacity)
         self.gather_deadline = time.perf_counter() + gather_timeout
-        # Multi-step runs (dtk_decode_batch_run): while every active sequence is a push sequence the driver hands the device up to
-        # `run_steps` steps per native call and wakes only when a sequence ends (EOS / length), somebody wants the context (join,
-        # leave: `_interrupt`), or the run is used up — instead of one launch / wait / dispatch round trip per token for up to 64
-        # sequences (round 3: ~3 ms of Python per 6 ms step).  DTK_ENGINE_RUN_STEPS=1 restores the per-step loop.
+        # Multi-step runs (dtk_decode_batch_run): while every active sequence is a push sequence the driver can hand the device up to
+        # `run_steps` steps per native call and wake only when a sequence ends (EOS / length), somebody wants the context (join,
+        # leave: `_interrupt`), or the run is used up — instead of one launch / wait / dispatch round trip per token.  OPT-IN
+        # (DTK_ENGINE_RUN_STEPS=8): measured on the MI355X it LOSES to the per-step loop — 64 trees x 2 expansions, stub reward: 18.7
+        # rollouts/s per step, 17.0 with runs of 8, 16.5 with runs of 32 (profiles/r04_engine_run_steps.json) — the per-step loop
+        # already hides its Python under the GPU's next step (2 host-bound steps of 1032), while a run hands the GIL to the 64
+        # rollout / reward threads for tens of milliseconds and the driver then queues for it behind them.  What it does buy is host
+        # CPU: the driver thread spends its time in native code (tools/host_emulation.py).  The C entry point is there for native
+        # callers either way.
         import ctypes
-        self.run_steps = max(1, int(os.environ.get("DTK_ENGINE_RUN_STEPS", "8"))) if callable(getattr(model, "decode_batch_run", None)) else 1
+        self.run_steps = max(1, int(os.environ.get("DTK_ENGINE_RUN_STEPS", "1"))) if callable(getattr(model, "decode_batch_run", None)) else 1
         self._interrupt = ctypes.c_int32(0)
         self.runs = 0
         model.batch_engine = self

@@ -22,16 +22,27 @@ def _kernel_metadata(obj: Path, tmp: Path):
     subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
                     f"--output={co}", "--unbundle"], check=True, capture_output=True)
     notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
-    kernels, cur = {}, None
+    # a kernel is one YAML map item with alphabetically ordered keys (.agpr_count opens it, .name sits in the middle): collect the item,
+    # file it under its name when the next one starts
+    kernels, item = {}, None
+    wanted = ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count", "agpr_count")
+
+    def close(item):
+        name = item.get("name") if item else None
+        if name and name.startswith("_Z") and not name.endswith(".kd"):
+            kernels[name] = {k: int(v) for k, v in item.items() if k in wanted}
+
     for line in notes.splitlines():
-        m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)\s*$", line)
+        m = re.match(r"\s*(-?)\s*\.(\w+):\s*(\S+)\s*$", line)
         if not m:
             continue
-        key, val = m.groups()
-        if key == "name" and val.startswith("_Z") and not val.endswith(".kd"):
-            cur = kernels.setdefault(val, {})
-        elif cur is not None and key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count", "agpr_count"):
-            cur[key] = int(val)
+        dash, key, val = m.groups()
+        if dash and key in ("agpr_count", "args"):
+            close(item)
+            item = {}
+        if item is not None and key not in item:
+            item[key] = val
+    close(item)
     return kernels
 
 

@@ -275,7 +275,7 @@ def test_generate_protocol_streamer_criteria_and_length_budget():
         dev.generate(input_ids=ids[None], pixel_values=px)
 
 
-@pytest.mark.parametrize("run_steps", [32, 3, 1])
+@pytest.mark.parametrize("run_steps", [32, 8, 3, 1])
 def test_sequences_in_engine_slots_decode_exactly_as_alone(run_steps, monkeypatch):
     """run_steps: device steps per native call of the driving thread (dtk_decode_batch_run; 1 = one launch / wait pair per token,
     the round-3 loop): the sequences are the same ids either way, and a run of 32 needs far fewer native calls than steps"""

@@ -19,16 +19,26 @@ def kernels_of(obj: Path, tmp: Path):
     subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
                     f"--output={co}", "--unbundle"], check=True, capture_output=True)
     notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
-    out, cur = {}, None
+    # the metadata lists every kernel as one YAML map item ("  - .agpr_count: ..." opens it) with its keys in alphabetical order, so
+    # .agpr_count and .group_segment_fixed_size come BEFORE .name: collect an item's keys first, file them under its name at the end
+    out, item = {}, None
+
+    def close(item):
+        name = item.get("name") if item else None
+        if name and name.startswith("_Z") and not name.endswith(".kd"):
+            out[name] = {k: int(v) for k, v in item.items() if k in KEYS}
+
     for line in notes.splitlines():
-        m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)\s*$", line)
+        m = re.match(r"(\s*)(-?)\s*\.(\w+):\s*(\S+)\s*$", line)
         if not m:
             continue
-        key, val = m.groups()
-        if key == "name" and val.startswith("_Z") and not val.endswith(".kd"):
-            cur = out.setdefault(val, {})
-        elif cur is not None and key in KEYS:
-            cur[key] = int(val)
+        indent, dash, key, val = m.groups()
+        if dash and key in ("agpr_count", "args"):      # first key of a kernel's map
+            close(item)
+            item = {}
+        if item is not None and key not in item:
+            item[key] = val
+    close(item)
     return out
 
 

@@ -1,5 +1,7 @@
 """Differential timing of the batched gate/up GEMV (dtk_bench_gemv role 5): what the kernel costs without its x-fragment
-loads (mode bit 1), without its MFMAs (bit 2), without its cross-wave reduction + epilogue (bit 4), at 16 / 32 / 64 slots."""
+loads (mode bit 1), without its MFMAs (bit 2), without its cross-wave reduction + epilogue (bit 4), at 16 / 32 / 64 slots.
+(Some of the variants timed here — k_gemm_b, k_gemv_bk, k_gemm_dma, the experiment modes of k_gemv_b — are only built with
+DTK_EXPERIMENTS=1 ./build.sh; a default build reports "built without DTK_EXPERIMENTS" for them.)"""
 import ctypes as C, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))

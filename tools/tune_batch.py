@@ -4,7 +4,9 @@ ms per step at a short tail (context = image prefix + a few tokens) and at a lon
 tokens behind the shared prefix), graph replay.
 
     python tools/tune_batch.py --model detikzify-ds-7b --batch 64 --out gpurun_out/tune_batch_ds7b.json
-"""
+
+(Some of the variants timed here — k_gemm_b, k_gemv_bk, k_gemm_dma, the experiment modes of k_gemv_b — are only built with
+DTK_EXPERIMENTS=1 ./build.sh; a default build reports "built without DTK_EXPERIMENTS" for them.)"""
 import argparse
 import json
 import sys

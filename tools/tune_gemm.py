@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """ViT and prefill time (device events, dtk_get_stats) under every GEMM implementation / tile / ring setting, one model load.
-    python tools/tune_gemm.py --model detikzify-ds-7b"""
+    python tools/tune_gemm.py --model detikzify-ds-7b
+(Some of the variants timed here — k_gemm_b, k_gemv_bk, k_gemm_dma, the experiment modes of k_gemv_b — are only built with
+DTK_EXPERIMENTS=1 ./build.sh; a default build reports "built without DTK_EXPERIMENTS" for them.)"""
 import argparse
 import sys
 from pathlib import Path
