@@ -79,6 +79,90 @@ __device__ __forceinline__ void gg_epilogue(const GemvBArgs& a, int g, int n, in
   }
 }
 
+// The epilogue of one unit (T = 2 paired row tiles x 64 slots) from the accumulators of a wave of k_gemv_bx / k_gemv_bl / k_gemv_br:
+// lane holds rows (lane >> 4) * 4 + r, column (slot) nt * 16 + (lane & 15) of each tile.  Everything the epilogue READS — the
+// slots' active flags and positions, the fp8 row scales, the RoPE table entries of 16 (slot, row) pairs — is issued up front:
+// written as a loop of `if (!active) continue; pos = ...; cos = table[pos]...` it was up to a dozen dependent L2 round trips at
+// the end of every wave (round 4: the same mistake that made the GEMM epilogues half of a ViT launch).  Same arithmetic, same
+// rounding points as gg_epilogue.
+template <int EPI, int T, bool F8>
+__device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const f32x4 (&tot)[T][4], int lane) {
+  static_assert(T == 2, "paired row tiles");
+  constexpr int NT = 4;
+  const int m0 = (lane >> 4) * 4;
+  int act[NT], pos[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    act[nt] = a.bs->active[n];
+    pos[nt] = (EPI == EPI_QKV) ? a.st[n].pos : 0;
+  }
+  float sc[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[t][r] = 1.f;
+      if (F8) {
+        int row = gg_tile_row0<EPI, T>(a, g, t) + m0 + r;
+        if (row >= a.N) row = a.N - 1;
+        sc[t][r] = a.wscale[row];                                 // power of two: exact
+      }
+    }
+  if (EPI == EPI_QKV) {
+    const int hb = g >> 2;
+    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
+    float cs[NT][4], sn[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cs[nt][r] = 1.f; sn[nt][r] = 0.f;
+        if (sec != 2) {      // (an inactive slot's stale position is clamped: its table entry is read and dropped)
+          const int p = min(max(pos[nt], 0), a.T_max - 1), i = (g & 3) * 16 + m0 + r;
+          cs[nt][r] = bf2f(a.rope_cos[(size_t)p * 64 + i]);
+          sn[nt][r] = bf2f(a.rope_sin[(size_t)p * 64 + i]);
+        }
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + (lane & 15);
+      if (!act[nt]) continue;
+      const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = (g & 3) * 16 + m0 + r;
+        const float x1 = rbf(tot[0][nt][r] * sc[0][r]), x2 = rbf(tot[1][nt][r] * sc[1][r]);
+        if (sec == 2) {
+          bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128;
+          dst[i] = f2bf(x1);
+          dst[i + 64] = f2bf(x2);
+        } else {
+          const float c = cs[nt][r], sv = sn[nt][r];
+          const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * sv));
+          const float o2 = rbf(rbf(x2 * c) + rbf(x1 * sv));
+          bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                                   : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128);
+          dst[i] = f2bf(o1);
+          dst[i + 64] = f2bf(o2);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + (lane & 15);
+    if (!act[nt]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v[T] = {tot[0][nt][r] * sc[0][r], tot[1][nt][r] * sc[1][r]};
+      gg_epilogue<EPI, T>(a, g, n, m0 + r, v);                    // SwiGLU / logits: stores only
+    }
+  }
+}
+
 // One 1 KiB fragment, global -> LDS, no VGPR: lane l's 16 bytes land at lds_byte + 16 l (guides/cdna_hip_programming.md §5.7:
 // M0 carries the wave-uniform LDS address and is restored; the load is invisible to the compiler's vmcnt bookkeeping).
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
@@ -379,24 +463,7 @@ __global__ __launch_bounds__((UNITS + 1) * 64) void k_gemv_bx(GemvBArgs a) {
   close_chain();
   if (g >= groups) return;
   // C/D layout: lane holds rows (lane >> 4) * 4 + r, column (slot) nt * 16 + (lane & 15) of each tile
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    if (!a.bs->active[n]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
-      if (F8) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
-          if (row >= a.N) row = a.N - 1;
-          v[t] *= a.wscale[row];                                // power of two: exact
-        }
-      }
-      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
-    }
-  }
+  gg_finish_unit<EPI, T, F8>(a, g, tot, lane);
 }
 
 static int g_cu_count = 0;
@@ -645,24 +712,7 @@ __global__ __launch_bounds__((NC + LW + XW) * 64, 2) void k_gemv_bl(GemvBArgs a)
     }
     return;
   }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    if (!a.bs->active[n]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
-      if (F8) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
-          if (row >= a.N) row = a.N - 1;
-          v[t] *= a.wscale[row];                                // power of two: exact
-        }
-      }
-      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
-    }
-  }
+  gg_finish_unit<EPI, T, F8>(a, g, tot, lane);
 }
 
 static int g_gemv_xw = -1;                      // x fragments by an extra wave's ordinary loads + ds_write instead of LDS-DMA pieces (k_gemv_bl, k_gemv_bkl)
@@ -884,24 +934,7 @@ __global__ __launch_bounds__((NC + 1) * 64, WD == 8 ? 1 : 2) void k_gemv_br(Gemv
   for (int p0 = 0; p0 + WD < NPH; p0 += WD) group(p0, yes);      // NPH (16 or 32) is a multiple of WD
   group(NPH - WD, no);
   if (g >= groups) return;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    if (!a.bs->active[n]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v[T] = {tot[0][nt][r], tot[1][nt][r]};
-      if (F8) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          int row = gg_tile_row0<EPI, T>(a, g, t) + (lane >> 4) * 4 + r;
-          if (row >= a.N) row = a.N - 1;
-          v[t] *= a.wscale[row];                                // power of two: exact
-        }
-      }
-      gg_epilogue<EPI, T>(a, g, n, (lane >> 4) * 4 + r, v);
-    }
-  }
+  gg_finish_unit<EPI, T, F8>(a, g, tot, lane);
 }
 // false = this instantiation must not run: its weight loads are issued by hand, so a register the compiler SPILLS would be stored
 // before its load has landed (how the K = 2048 instantiations faulted).  The code object says whether it spills: any private

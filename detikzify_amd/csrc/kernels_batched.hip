@@ -686,7 +686,10 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   // 3 = auto (default): k_gemm_glds for M >= 1024 (the batched ViT: same wall time as k_gemm_mfma, 319 instead of 711 MB fetched from
   // the memory side per launch — profiles/r03_pmc_mfma.csv — which is what a reward pass that runs BESIDE the HBM-bound decode
   // steps should cost them), k_gemm_mfma below (prefill M = 243, one image M = 729: measured 14.4 vs 14.8 ms and 4.0 vs 4.6 ms)
-  if (g_gemm_impl == 4 && !gemm_tile_override() && launch_gemm_g3(a, s)) return;      // 4 = k_gemm_g3 wherever the shape gives it a block per two CUs
+  // 3 = auto, 4 (kept as a name for the same choice): k_gemm_g3 wherever the shape gives it a block per two CUs — the batched ViT
+  // (8 images: 2.25 -> 1.91 ms per image, profiles/r04_bench_vit_epilogue.txt) and the prefill's gate/up GEMM (14.4 -> 13.6 ms for
+  // ViT + projector + prefill) — then k_gemm_glds for M >= 1024, then k_gemm_mfma; all bit-identical
+  if ((g_gemm_impl == 3 || g_gemm_impl == 4) && !gemm_tile_override() && launch_gemm_g3(a, s)) return;
   if ((g_gemm_impl == 2 || ((g_gemm_impl == 3 || g_gemm_impl == 4) && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
 #ifdef DTK_EXPERIMENTS
   if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
