@@ -12,12 +12,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 if [ "${DTK_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DDTK_EXPERIMENTS"; fi
 if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; mkdir -p build; echo "$FLAGS" > build/.flags; fi
 pids=()
-for f in kernels_decode kernels_decode_mv kernels_batch_decode kernels_batch_gemm kernels_batched kernels_sample_mb dtk_api; do
-  if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ $SRC/common.h -nt build/$f.o ] || [ $SRC/kernels.h -nt build/$f.o ] || [ $SRC/gemv_inl.h -nt build/$f.o ] || [ include/dtk.h -nt build/$f.o ]; then
+for f in kernels_decode kernels_decode_mv kernels_batch_decode kernels_batch_gemm kernels_batch_mx kernels_batched kernels_sample_mb dtk_api; do
+  if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ $SRC/common.h -nt build/$f.o ] || [ $SRC/kernels.h -nt build/$f.o ] || [ $SRC/gemv_inl.h -nt build/$f.o ] || [ $SRC/batch_epi.h -nt build/$f.o ] || [ $SRC/mx_quant.h -nt build/$f.o ] || [ include/dtk.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $SRC/$f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libdtk_hip.so build/kernels_decode.o build/kernels_decode_mv.o build/kernels_batch_decode.o build/kernels_batch_gemm.o build/kernels_batched.o build/kernels_sample_mb.o build/dtk_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libdtk_hip.so build/kernels_decode.o build/kernels_decode_mv.o build/kernels_batch_decode.o build/kernels_batch_gemm.o build/kernels_batch_mx.o build/kernels_batched.o build/kernels_sample_mb.o build/dtk_api.o
 echo "built $OUT/libdtk_hip.so"

@@ -8,7 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
-DTK_ABI_VERSION = 4          # include/dtk.h DTK_ABI_VERSION
+DTK_ABI_VERSION = 5          # include/dtk.h DTK_ABI_VERSION
 DTK_VIT_BATCH = 8            # include/dtk.h: images per pass of dtk_vit_encode
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
@@ -49,6 +49,7 @@ class DtkStats(C.Structure):
         ("probe_kernel_ms_sum", C.c_double), ("probe_kernel_launches", C.c_uint64),
         ("probe_kernel_bytes", C.c_uint64), ("probe_event_pair_ms", C.c_double),
         ("last_batch_step_slots", C.c_uint32), ("device_errors", C.c_uint32),
+        ("last_batch_step_fp8_mfma", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
 
@@ -97,6 +98,7 @@ SYMBOLS = {
     "dtk_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "dtk_op_gemv_mv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
+    "dtk_op_gemv_mx": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "dtk_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dtk_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "dtk_op_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int64), _P]),

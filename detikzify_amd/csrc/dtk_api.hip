@@ -20,6 +20,7 @@
 
 #include "../../include/dtk.h"
 #include "kernels.h"
+#include "mx_quant.h"
 
 namespace {
 
@@ -54,6 +55,7 @@ struct LayerW {
   uint8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;  // fp8 e4m3 copies (weight_format 1)
   float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;    // per-row power-of-two scales
   uint8_t *t8_wqkv = nullptr, *t8_wo = nullptr, *t8_wgu = nullptr, *t8_wdown = nullptr;  // fp8 pair-tiled copies (batched decode, fp8)
+  uint8_t *m_wqkv = nullptr, *m_wo = nullptr, *m_wgu = nullptr, *m_wdown = nullptr;      // fp8 MX tiles (fp8 matrix-core step; down in groups of 16)
 };
 struct VitBlockW {
   bf16_t *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
@@ -143,6 +145,12 @@ struct dtk_ctx {
   BatchState* bs_dev = nullptr;
   bf16_t* t_lm_head = nullptr;       // fragment-major copy of lm_head
   uint8_t* t8_lm_head = nullptr;     // fp8 pair-tiled copy of lm_head (weight_format fp8)
+  // fp8 matrix-core step (kernels_batch_mx.hip; dtk_set_option "act_fp8"): the MFMA-family step of an fp8 model runs its GEMVs as
+  // v_mfma_scale_f32_16x16x128_f8f6f4 on MXFP8 activations.  mx_ok = the model's shapes are covered and the buffers exist
+  uint8_t* m_lm_head = nullptr;
+  uint8_t *xn8 = nullptr, *xns = nullptr, *ao8 = nullptr, *aos = nullptr, *act8 = nullptr, *acts = nullptr;
+  bool mx_ok = false;
+  int act_fp8 = 1;
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
   SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_SLOTS]: per-slot set_sampling uploads queued on the stream
@@ -454,6 +462,20 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
         if (reg) { c->layers[i].t8_wqkv = a1; c->layers[i].t8_wo = a2; c->layers[i].t8_wgu = a3; c->layers[i].t8_wdown = a4; }
       }
       c->t8_lm_head = P.take<uint8_t>(tiled_bytes_f8(V, d));
+      c->mx_ok = mx_unit_covers(d) && mx_kparts_covers(d, d, 32) && mx_kparts_covers(d, ff, 16) && (ff % 64) == 0 && (qkvn % 32) == 0;
+      if (c->mx_ok) {               // + one more fp8 copy in MX tile order, the slots' MXFP8 vectors and their scales
+        for (int i = 0; i < L; ++i) {
+          uint8_t* a1 = P.take<uint8_t>(mx_w_bytes(qkvn, d, 32));
+          uint8_t* a2 = P.take<uint8_t>(mx_w_bytes(d, d, 32));
+          uint8_t* a3 = P.take<uint8_t>(mx_w_bytes(2 * ff, d, 32));
+          uint8_t* a4 = P.take<uint8_t>(mx_w_bytes(d, ff, 16));
+          if (reg) { c->layers[i].m_wqkv = a1; c->layers[i].m_wo = a2; c->layers[i].m_wgu = a3; c->layers[i].m_wdown = a4; }
+        }
+        c->m_lm_head = P.take<uint8_t>(mx_w_bytes(V, d, 32));
+        c->xn8 = P.take<uint8_t>(mx_x_bytes(d, 32)); c->xns = P.take<uint8_t>(mx_s_bytes(d, 32));
+        c->ao8 = P.take<uint8_t>(mx_x_bytes(d, 32)); c->aos = P.take<uint8_t>(mx_s_bytes(d, 32));
+        c->act8 = P.take<uint8_t>(mx_x_bytes(ff, 16)); c->acts = P.take<uint8_t>(mx_s_bytes(ff, 16));
+      }
     } else {
       for (int i = 0; i < L; ++i) {   // fragment-major copies of the decoder weights (288 GB HBM: +13 GB for ds-7b)
         bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
@@ -613,8 +635,57 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
   launch_gemv(PRO_RMSNORM, EPI_LOGITS, g, s);
 }
 
+static inline bool mx_step(const dtk_ctx* c) { return c->wfmt == 1 && c->mx_ok && c->act_fp8 != 0; }
+
+// The MFMA-family step of an fp8 model on the fp8 matrix cores (kernels_batch_mx.hip): 7 launches per layer as the 64-slot bf16
+// step — q/k/v, attention, o_proj partials, reduce + residual + RMSNorm, gate/up, down partials, reduce + residual + RMSNorm —
+// at every tile count; the vectors between them travel as MXFP8.
+void batch_step_launches_mx(dtk_ctx* c) {
+  hipStream_t s = c->stream;
+  const int d = c->d, ff = c->ff, nslots = 16 * c->nt_step;
+  SampleArgs sa;
+  sa.logits = c->logits_b; sa.V = c->V; sa.sp = c->sp_b; sa.st = c->st_b; sa.embed = c->embed;
+  sa.x = c->xb; sa.d = d; sa.tok_ring = c->tokb_dev; sa.ring = DTK_MAX_INFLIGHT;
+  sa.probs_out = nullptr; sa.advance = 1; sa.step_override = -1; sa.bs = c->bs_dev; sa.logits_stride = c->V; sa.nslots = nslots; sa.mb = c->smb_b;
+  if (c->mb_batch) launch_sample_mb(sa, s); else launch_sample_b(sa, s);
+  const float scale = 1.0f / sqrtf(128.f);
+  const size_t kv_layer = (size_t)2 * c->KVH * c->Tmax * 128;
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    bf16_t* kc = c->kvb + (size_t)l * kv_layer;
+    bf16_t* vc = kc + (size_t)c->KVH * c->Tmax * 128;
+    GemvBArgs g{};
+    g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = d; g.ff = ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt_step;
+    g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.kv_slot_stride = c->kv_slot_stride; g.kpart = c->kpart; g.err = batch_err_word(c);
+    if (l == 0) launch_rmsnorm_b(c->xb, d, w.ln1, c->xnb, d, d, c->cfg.rms_eps, c->bs_dev, nslots, s, c->xn8, c->xns);
+    g.Wm = w.m_wqkv; g.wscale = w.s_wqkv; g.N = d + 2 * c->KVH * 128; g.K = d; g.X8 = c->xn8; g.XS = c->xns; g.q_out = c->qb; g.kcache = kc; g.vcache = vc;
+    launch_gemv_mxu(EPI_QKV, g, s);
+    AttnDecBArgs ad;
+    ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
+    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = nslots;
+    ad.scale = scale;
+    ad.impl = 1; ad.use_prefix = c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
+    ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
+    ad.out8 = c->ao8; ad.outs = c->aos;
+    launch_attn_decode_b(ad, s);
+    g.Wm = w.m_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X8 = c->ao8; g.XS = c->aos;
+    launch_gemv_mxk(g, 32, s);
+    launch_resid_norm_b(c->kpart, c->xb, d, w.ln2, c->xnb, d, c->cfg.rms_eps, c->bs_dev, nslots, s, c->xn8, c->xns);
+    g.Wm = w.m_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X8 = c->xn8; g.XS = c->xns; g.Y8 = c->act8; g.YS = c->acts;
+    launch_gemv_mxu(EPI_SWIGLU, g, s);
+    g.Wm = w.m_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X8 = c->act8; g.XS = c->acts;
+    launch_gemv_mxk(g, 16, s);
+    launch_resid_norm_b(c->kpart, c->xb, d, l + 1 < c->L ? c->layers[l + 1].ln1 : c->final_norm, c->xnb, d, c->cfg.rms_eps, c->bs_dev, nslots, s, c->xn8, c->xns);
+  }
+  GemvBArgs g{};
+  g.bs = c->bs_dev; g.st = c->st_b; g.Wm = c->m_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.X8 = c->xn8; g.XS = c->xns; g.logits = c->logits_b;
+  g.d = d; g.ff = ff; g.nt = c->nt_step; g.H = c->H; g.KVH = c->KVH; g.err = batch_err_word(c);
+  launch_gemv_mxu(EPI_LOGITS, g, s);
+}
+
 // launches of one batched decode step (all 16 slot columns; inactive slots are skipped in-kernel)
 void batch_step_launches(dtk_ctx* c) {
+  if (mx_step(c)) { batch_step_launches_mx(c); return; }
   hipStream_t s = c->stream;
   const int d = c->d, ff = c->ff;
   SampleArgs sa;
@@ -759,6 +830,16 @@ void ensure_tiled_weights(dtk_ctx* c) {
       launch_retile_f8(w.q_wdown, w.t8_wdown, c->d, c->ff, c->stream);
     }
     launch_retile_f8(c->q_lm_head, c->t8_lm_head, c->V, c->d, c->stream);
+    if (c->mx_ok) {
+      for (int l = 0; l < c->L; ++l) {
+        LayerW& w = c->layers[l];
+        launch_retile_mx(w.q_wqkv, w.m_wqkv, qkvn, c->d, 32, c->stream);
+        launch_retile_mx(w.q_wo, w.m_wo, c->d, c->d, 32, c->stream);
+        launch_retile_mx(w.q_wgu, w.m_wgu, 2 * c->ff, c->d, 32, c->stream);
+        launch_retile_mx(w.q_wdown, w.m_wdown, c->d, c->ff, 16, c->stream);
+      }
+      launch_retile_mx(c->q_lm_head, c->m_lm_head, c->V, c->d, 32, c->stream);
+    }
     c->tiled_ready = true;
     return;
   }
@@ -1398,6 +1479,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   }
   HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
   c->stats.last_batch_step_slots = (uint32_t)(c->mv_step ? c->mv_step : 16 * c->nt_step);
+  c->stats.last_batch_step_fp8_mfma = (!c->mv_step && mx_step(c)) ? 1u : 0u;
   c->blaunched++;
   c->stats.decode_steps++;
   for (int j = 0; j < DTK_MAX_BATCH; ++j)
@@ -1845,6 +1927,16 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bkl")) { set_gemv_bkl(value != 0); drop_batch_graphs(c); }
+  else if (!strcmp(name, "act_fp8")) {          // fp8 models: the MFMA-family step on the fp8 matrix cores with MXFP8 activations (kernels_batch_mx.hip)
+    if (value && c->wfmt == 1 && c->nb > 0 && !c->mx_ok) return fail(c, DTK_ERR_ARG, "act_fp8: the model's shapes are not covered by the fp8 matrix-core kernels");
+    c->act_fp8 = value != 0;
+    drop_batch_graphs(c);
+  }
+  else if (!strcmp(name, "mx_nc_qkv") || !strcmp(name, "mx_nc_gu") || !strcmp(name, "mx_nc_lm_head")) {   // compute waves per block of k_gemv_mxu (0 = from the CU count)
+    if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "%s must be 0..4", name);
+    set_mx_nc(!strcmp(name, "mx_nc_qkv") ? 0 : (!strcmp(name, "mx_nc_gu") ? 1 : 2), value);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "gemv_br_wd")) { if (value != 4 && value != 8) return fail(c, DTK_ERR_ARG, "gemv_br_wd must be 4 or 8"); set_gemv_br_wd(value); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
@@ -2014,6 +2106,67 @@ int dtk_op_gemv_mv(dtk_ctx* c, const uint16_t* W, const uint16_t* X, const uint1
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(Y, dY, (size_t)nb * N * 2, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DTK_OK;
+}
+
+// The fp8 matrix-core GEMVs of kernels_batch_mx.hip on host buffers.  W8 [N][K] e4m3 bytes + wscale [N]; X [nslots][K] bf16 rows,
+// quantised to MXFP8 (groups of G = 32 | 16) by the step's own quantiser; nslots = 16 | 32 | 64 (1 / 2 / 4 slot tiles).
+//   mode 0: unit kernel, logits epilogue (G = 32): Y [nslots][N] = bf16-rounded acc * wscale
+//   mode 1: K-slice kernel of the N = d roles: Y [nslots][N] = the 8 slice partials added in order (fp32)
+//   mode 2: unit kernel, SwiGLU epilogue (G = 32 in, N = 2 ff): y8_out / ys_out = the activation as MXFP8 groups of 16 (mx_x_bytes(ff, 16) / mx_s_bytes)
+// x8_out / xs_out (optional): the quantised input as the kernels read it.
+int dtk_op_gemv_mx(dtk_ctx* c, const uint8_t* W8, const float* wscale, const uint16_t* X, int N, int K, int G, int nslots, int mode,
+                   float* Y, uint8_t* x8_out, uint8_t* xs_out, uint8_t* y8_out, uint8_t* ys_out) {
+  if (!c || !W8 || !wscale || !X || (G != 32 && G != 16) || (nslots != 16 && nslots != 32 && nslots != 64) || mode < 0 || mode > 2)
+    return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mx: bad argument");
+  if (mode != 1 && (G != 32 || !mx_unit_covers(K) || (N & 31))) return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mx: unit kernel needs G = 32, K %% 512 == 0, N %% 32 == 0");
+  if (mode == 1 && !mx_kparts_covers(N, K, G)) return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mx: N = %d, K = %d, G = %d is not covered by the K-slice kernel", N, K, G);
+  if ((mode != 2 && !Y) || (mode == 2 && (!y8_out || !ys_out || (N & 127)))) return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mx: missing output");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t off = 0;
+  const int ff = N / 2;
+  OPBUF(uint8_t, dW, (size_t)N * K); OPBUF(uint8_t, dWm, mx_w_bytes(N, K, G)); OPBUF(float, dS, N);
+  OPBUF(bf16_t, dX, (size_t)64 * K); OPBUF(uint8_t, dX8, mx_x_bytes(K, G)); OPBUF(uint8_t, dXS, mx_s_bytes(K, G));
+  OPBUF(float, dY, (size_t)(mode == 1 ? 8 : 1) * 64 * N); OPBUF(BatchState, dBS, 1);
+  OPBUF(uint8_t, dY8, mx_x_bytes(ff, 16)); OPBUF(uint8_t, dYS, mx_s_bytes(ff, 16));
+  hipStream_t s = c->stream;
+  BatchState hbs; memset(&hbs, 0, sizeof hbs);
+  for (int i = 0; i < nslots; ++i) hbs.active[i] = 1;
+  for (int i = 0; i < DTK_MAX_BATCH; ++i) hbs.share_src[i] = -1;
+  HIPCHK(c, hipMemcpyAsync(dBS, &hbs, sizeof hbs, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dW, W8, (size_t)N * K, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(dS, wscale, (size_t)N * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(dX, 0, (size_t)64 * K * 2, s));
+  HIPCHK(c, hipMemcpyAsync(dX, X, (size_t)nslots * K * 2, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(dY, 0, (size_t)(mode == 1 ? 8 : 1) * 64 * N * 4, s));
+  HIPCHK(c, hipMemsetAsync(dY8, 0, mx_x_bytes(ff, 16), s));
+  HIPCHK(c, hipMemsetAsync(dYS, 0, mx_s_bytes(ff, 16), s));
+  launch_retile_mx(dW, dWm, N, K, G, s);
+  launch_quant_mx_rows(dX, K, dX8, dXS, G, 64, s);
+  GemvBArgs g{};
+  g.Wm = dWm; g.wscale = dS; g.N = N; g.K = K; g.X8 = dX8; g.XS = dXS; g.bs = dBS; g.nt = nslots / 16; g.logits = dY; g.kpart = dY;
+  g.d = K; g.ff = ff; g.H = 1; g.KVH = 1; g.Y8 = dY8; g.YS = dYS;
+  if (mode == 0) launch_gemv_mxu(EPI_LOGITS, g, s);
+  else if (mode == 2) launch_gemv_mxu(EPI_SWIGLU, g, s);
+  else launch_gemv_mxk(g, G, s);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (mode == 0) HIPCHK(c, hipMemcpy(Y, dY, (size_t)nslots * N * 4, hipMemcpyDeviceToHost));
+  else if (mode == 1) {
+    std::vector<float> part((size_t)8 * 64 * N);
+    HIPCHK(c, hipMemcpy(part.data(), dY, part.size() * 4, hipMemcpyDeviceToHost));
+    for (int sl = 0; sl < nslots; ++sl)
+      for (int n = 0; n < N; ++n) {
+        float sum = 0.f;
+        for (int ks = 0; ks < 8; ++ks) sum += part[((size_t)ks * 64 + sl) * N + n];
+        Y[(size_t)sl * N + n] = sum;
+      }
+  } else {
+    HIPCHK(c, hipMemcpy(y8_out, dY8, mx_x_bytes(ff, 16), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ys_out, dYS, mx_s_bytes(ff, 16), hipMemcpyDeviceToHost));
+  }
+  if (x8_out) HIPCHK(c, hipMemcpy(x8_out, dX8, mx_x_bytes(K, G), hipMemcpyDeviceToHost));
+  if (xs_out) HIPCHK(c, hipMemcpy(xs_out, dXS, mx_s_bytes(K, G), hipMemcpyDeviceToHost));
   return DTK_OK;
 }
 

@@ -107,6 +107,10 @@ struct GemvBArgs {
   int nt;                              // 16-slot column tiles: 1 (<= 16 slots), 2 (<= 32) or 4 (<= 64)
   float* kpart; unsigned* kctr;        // k_gemv_bk: K-split partials [8][N / 16][4][256] fp32, one arrival counter per row tile (zero between launches)
   unsigned* err;                       // sticky count of expired in-kernel hand-off waits (the LDS-ring kernels), or null
+  // fp8 matrix-core path (kernels_batch_mx.hip): MX weight tiles, the slots' MXFP8 input vectors + their E8M0 scales; SWIGLU writes
+  // the down projection's MXFP8 input (groups of 16) to Y8 / YS
+  const uint8_t* Wm; const uint8_t* X8; const uint8_t* XS;
+  uint8_t* Y8; uint8_t* YS;
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
 void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
@@ -126,7 +130,7 @@ void set_gemv_bk(int v);       // 0: off, 1: on
 bool resid_kparts_covers(const GemvBArgs& a);
 void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s);
 void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps, const BatchState* bs,
-                         int nslots, hipStream_t s);
+                         int nslots, hipStream_t s, uint8_t* Y8 = nullptr, uint8_t* YS = nullptr);
 void set_resid_split(int v);   // batched N = d roles at 64 slots: 0 = one row tile x 64 slots per block, 1 = two row tiles x 32 slots
 void set_gemv_bx(int v);       // 0: off, 1: on (units per block from the CU count), 2..4: on with that many units per block
 void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)
@@ -137,8 +141,17 @@ static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) 
 // bytes 8..15 = the same columns of the next k-step (k0 + 32 + ...)
 void launch_retile_f8(const uint8_t* src, uint8_t* dst, int N, int K, hipStream_t s);
 static inline size_t tiled_bytes_f8(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 63) >> 6) * 1024; }
+// Y8 / YS non-null: the normalised rows go out as MXFP8 (groups of 32, mx_quant.h) instead of bf16 fragments
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
-                      const BatchState* bs, int nslots, hipStream_t s);
+                      const BatchState* bs, int nslots, hipStream_t s, uint8_t* Y8 = nullptr, uint8_t* YS = nullptr);
+// ---- fp8 matrix-core path of the batched step (kernels_batch_mx.hip)
+void launch_retile_mx(const uint8_t* src, uint8_t* dst, int N, int K, int G, hipStream_t s);       // row-major fp8 -> MX weight tiles (G = 32 | 16)
+void launch_quant_mx_rows(const bf16_t* X, int K, uint8_t* X8, uint8_t* XS, int G, int nslots, hipStream_t s);   // op-level tests
+bool mx_unit_covers(int K);                                   // q/k/v, gate/up, lm_head: K a multiple of 512
+bool mx_kparts_covers(int N, int K, int G);                   // o_proj (G = 32), down (G = 16)
+void launch_gemv_mxu(int epi, const GemvBArgs& a, hipStream_t s);
+void launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s);
+void set_mx_nc(int role, int nc);                             // compute waves per block of the unit kernel: role 0 qkv, 1 gate/up, 2 lm_head; 0 = from the CU count
 struct AttnDecBArgs {
   const bf16_t* q;                     // [16][d]
   const bf16_t* kcache; const bf16_t* vcache; size_t kv_slot_stride;
@@ -155,6 +168,7 @@ struct AttnDecBArgs {
   int gqa_fused;             // k_attn_tail_b: 1 = the query heads of a GQA group share one block (default), 0 = a block per query head
   int nt_private = 0;        // k_attn_tail_b: non-temporal loads for key / value tiles beyond the shared prefix
   float* pfx_m; float* pfx_l; float* pfx_o;   // [slots][H][pfx_splits], ..., [slots][H][pfx_splits][128]: un-normalised prefix states
+  uint8_t* out8 = nullptr; uint8_t* outs = nullptr;   // k_attn_tail_b: the head outputs as MXFP8 (groups of 32) instead of bf16 fragments
 };
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s);
 

@@ -14,6 +14,7 @@
 // (columns are independent), so the captured graph is identical for every active set.
 // Epilogues as in kernels_decode.hip (same HF rounding points), applied per active slot.
 #include "kernels.h"
+#include "mx_quant.h"
 #include <stdlib.h>
 
 #define GB_WAVES 8
@@ -369,7 +370,7 @@ void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
 
 // RMSNorm of the active slots' vectors: one block per slot (HF LlamaRMSNorm rounding); output fragment-major.
 __global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y,
-                                                   int ldy, int D, float eps, const BatchState* bs) {
+                                                   int ldy, int D, float eps, const BatchState* bs, uint8_t* Y8, uint8_t* YS) {
   const int slot = blockIdx.x;
   if (!bs->active[slot]) return;
   __shared__ float red[4];
@@ -398,12 +399,13 @@ __global__ __launch_bounds__(256) void k_rmsnorm_b(const bf16_t* X, int ldx, con
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       o[e] = pack2(pk_lo(g[e]) * rbf(pk_lo(v[e]) * inv), pk_hi(g[e]) * rbf(pk_hi(v[e]) * inv));
-    *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, nsteps)) = o;
+    if (Y8) mx32_store8(Y8, YS, slot, c * 8, o);   // fp8 matrix-core step: the same bf16 values as MXFP8 (D % 32 == 0: whole groups per iteration)
+    else *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, nsteps)) = o;
   }
 }
 void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int ldy, int D, float eps,
-                      const BatchState* bs, int nslots, hipStream_t s) {
-  hipLaunchKernelGGL(k_rmsnorm_b, dim3(nslots), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs);
+                      const BatchState* bs, int nslots, hipStream_t s, uint8_t* Y8, uint8_t* YS) {
+  hipLaunchKernelGGL(k_rmsnorm_b, dim3(nslots), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs, Y8, YS);
 }
 
 // Split-K decode attention per slot: grid (H, S, 16); same algorithm as k_attn_decode.
@@ -842,7 +844,8 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
     u32x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = pack2(oo[2 * e] * invL, oo[2 * e + 1] * invL);
-    *reinterpret_cast<u32x4*>(a.out + xtile_off(slot, (h0 + g) * 128 + t16 * 8, (a.d + 31) >> 5)) = ov;   // 8 consecutive k of one fragment lane
+    if (a.out8) mx32_store8(a.out8, a.outs, slot, (h0 + g) * 128 + t16 * 8, ov);   // fp8 matrix-core step: o_proj's input as MXFP8 (lanes t16 ^ 1, t16 ^ 2 = the rest of the group)
+    else *reinterpret_cast<u32x4*>(a.out + xtile_off(slot, (h0 + g) * 128 + t16 * 8, (a.d + 31) >> 5)) = ov;   // 8 consecutive k of one fragment lane
   }
 }
 

@@ -16,162 +16,9 @@
 // Epilogues and rounding points as in kernels_batch_decode.hip / kernels_decode.hip.
 #include "kernels.h"
 
-// rows of tile t of row group g (a group = the T tiles one wave owns)
-template <int EPI, int T>
-__device__ __forceinline__ int gg_tile_row0(const GemvBArgs& a, int g, int t) {
-  if (EPI == EPI_QKV) return (g >> 2) * 128 + (g & 3) * 16 + t * 64;   // 16 RoPE pairs (i, i + 64) of one head block
-  if (EPI == EPI_SWIGLU) return g * 16 + t * a.ff;                     // gate rows, up rows
-  return (g * T + t) * 16;
-}
-template <int EPI, int T>
-__host__ __device__ __forceinline__ int gg_groups(int N, int ff, int H, int KVH) {
-  if (EPI == EPI_QKV) return (H + 2 * KVH) * 4;
-  if (EPI == EPI_SWIGLU) return (ff + 15) / 16;
-  return (N + 16 * T - 1) / (16 * T);
-}
+#include "batch_epi.h"
+#include "mx_quant.h"
 
-// one output element set: slot n, row m of the group's tiles, v[t] = reduced fp32 sums
-template <int EPI, int T>
-__device__ __forceinline__ void gg_epilogue(const GemvBArgs& a, int g, int n, int m, const float (&v)[T]) {
-  if (EPI == EPI_RESID) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int row = gg_tile_row0<EPI, T>(a, g, t) + m;
-      if (row < a.N) {
-        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
-        *y = f2bf(bf2f(*y) + rbf(v[t]));
-      }
-    }
-  } else if (EPI == EPI_LOGITS) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int row = gg_tile_row0<EPI, T>(a, g, t) + m;
-      if (row < a.N) a.logits[(size_t)n * a.N + row] = rbf(v[t]);
-    }
-  } else if (EPI == EPI_SWIGLU) {
-    const int i = g * 16 + m;
-    if (i < a.ff) {
-      const float gte = rbf(v[0]), up = rbf(v[T - 1]);
-      const float sl = rbf(gte / (1.f + expf(-gte)));
-      a.Y[xtile_off(n, i, (a.ff + 31) >> 5)] = f2bf(sl * up);   // input of the down projection: fragment-major
-    }
-  } else if (EPI == EPI_QKV) {
-    const int hb = g >> 2, i = (g & 3) * 16 + m;
-    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
-    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
-    const int pos = a.st[n].pos;
-    const float x1 = rbf(v[0]), x2 = rbf(v[T - 1]);
-    const size_t slot_kv = (size_t)n * a.kv_slot_stride;
-    if (sec == 2) {
-      bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos) * 128;
-      dst[i] = f2bf(x1);
-      dst[i + 64] = f2bf(x2);
-    } else {
-      const float c = bf2f(a.rope_cos[(size_t)pos * 64 + i]);
-      const float s = bf2f(a.rope_sin[(size_t)pos * 64 + i]);
-      const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
-      const float o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
-      bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
-                               : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos) * 128);
-      dst[i] = f2bf(o1);
-      dst[i + 64] = f2bf(o2);
-    }
-  }
-}
-
-// The epilogue of one unit (T = 2 paired row tiles x 64 slots) from the accumulators of a wave of k_gemv_bx / k_gemv_bl / k_gemv_br:
-// lane holds rows (lane >> 4) * 4 + r, column (slot) nt * 16 + (lane & 15) of each tile.  Everything the epilogue READS — the
-// slots' active flags and positions, the fp8 row scales, the RoPE table entries of 16 (slot, row) pairs — is issued up front:
-// written as a loop of `if (!active) continue; pos = ...; cos = table[pos]...` it was up to a dozen dependent L2 round trips at
-// the end of every wave (round 4: the same mistake that made the GEMM epilogues half of a ViT launch).  Same arithmetic, same
-// rounding points as gg_epilogue.
-template <int EPI, int T, bool F8>
-__device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const f32x4 (&tot)[T][4], int lane) {
-  static_assert(T == 2, "paired row tiles");
-  constexpr int NT = 4;
-  const int m0 = (lane >> 4) * 4;
-  int act[NT], pos[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    act[nt] = a.bs->active[n];
-    pos[nt] = (EPI == EPI_QKV) ? a.st[n].pos : 0;
-  }
-  float sc[T][4];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sc[t][r] = 1.f;
-      if (F8) {
-        int row = gg_tile_row0<EPI, T>(a, g, t) + m0 + r;
-        if (row >= a.N) row = a.N - 1;
-        sc[t][r] = a.wscale[row];                                 // power of two: exact
-      }
-    }
-  if (EPI == EPI_QKV) {
-    const int hb = g >> 2;
-    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
-    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
-    float cs[NT][4], sn[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cs[nt][r] = 1.f; sn[nt][r] = 0.f;
-        if (sec != 2) {      // (an inactive slot's stale position is clamped: its table entry is read and dropped)
-          const int p = min(max(pos[nt], 0), a.T_max - 1), i = (g & 3) * 16 + m0 + r;
-          cs[nt][r] = bf2f(a.rope_cos[(size_t)p * 64 + i]);
-          sn[nt][r] = bf2f(a.rope_sin[(size_t)p * 64 + i]);
-        }
-      }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + (lane & 15);
-      if (!act[nt]) continue;
-      const size_t slot_kv = (size_t)n * a.kv_slot_stride;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = (g & 3) * 16 + m0 + r;
-        const float x1 = rbf(tot[0][nt][r] * sc[0][r]), x2 = rbf(tot[1][nt][r] * sc[1][r]);
-        if (sec == 2) {
-          bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128;
-          dst[i] = f2bf(x1);
-          dst[i + 64] = f2bf(x2);
-        } else {
-          const float c = cs[nt][r], sv = sn[nt][r];
-          const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * sv));
-          const float o2 = rbf(rbf(x2 * c) + rbf(x1 * sv));
-          bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
-                                   : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128);
-          dst[i] = f2bf(o1);
-          dst[i + 64] = f2bf(o2);
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    if (!act[nt]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v[T] = {tot[0][nt][r] * sc[0][r], tot[1][nt][r] * sc[1][r]};
-      gg_epilogue<EPI, T>(a, g, n, m0 + r, v);                    // SwiGLU / logits: stores only
-    }
-  }
-}
-
-// One 1 KiB fragment, global -> LDS, no VGPR: lane l's 16 bytes land at lds_byte + 16 l (guides/cdna_hip_programming.md §5.7:
-// M0 carries the wave-uniform LDS address and is restored; the load is invisible to the compiler's vmcnt bookkeeping).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 #ifdef DTK_EXPERIMENTS      // k_gemm_b: measured not faster than k_gemv_b / k_gemv_bl at any slot count; built with DTK_EXPERIMENTS=1 ./build.sh only
 // T tiles per wave, KQ splits of K x RP row groups per block, NT column tiles of 16 slots, SK k-steps per stage, both streams
@@ -1588,7 +1435,7 @@ void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s) {
 // X: the residual streams [slot][ldx] (updated in place); Y: the normalised rows, fragment-major (the next GEMV's B operand).
 template <int ROUNDS>
 __global__ __launch_bounds__(ROUNDS * 256) void k_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps,
-                                                               const BatchState* bs) {
+                                                               const BatchState* bs, uint8_t* Y8, uint8_t* YS) {
   const int slot = blockIdx.x;
   if (!bs->active[slot]) return;
   __shared__ float chain[256];
@@ -1638,14 +1485,15 @@ __global__ __launch_bounds__(ROUNDS * 256) void k_resid_norm_b(const float* part
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     o[e] = pack2(pk_lo(g[e]) * rbf(y[2 * e] * inv), pk_hi(g[e]) * rbf(y[2 * e + 1] * inv));
-  *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, (D + 31) >> 5)) = o;
+  if (Y8) mx32_store8(Y8, YS, slot, c * 8, o);       // fp8 matrix-core step (kernels_batch_mx.hip): the same bf16 values as MXFP8
+  else *reinterpret_cast<u32x4*>(Y + xtile_off(slot, c * 8, (D + 31) >> 5)) = o;
 }
 void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int D, float eps, const BatchState* bs,
-                         int nslots, hipStream_t s) {
+                         int nslots, hipStream_t s, uint8_t* Y8, uint8_t* YS) {
   const int rounds = (D >> 3) >> 8;
-  if (rounds == 1) hipLaunchKernelGGL((k_resid_norm_b<1>), dim3(nslots), dim3(256), 0, s, part, X, ldx, w, Y, D, eps, bs);
-  else if (rounds == 2) hipLaunchKernelGGL((k_resid_norm_b<2>), dim3(nslots), dim3(512), 0, s, part, X, ldx, w, Y, D, eps, bs);
-  else hipLaunchKernelGGL((k_resid_norm_b<4>), dim3(nslots), dim3(1024), 0, s, part, X, ldx, w, Y, D, eps, bs);
+  if (rounds == 1) hipLaunchKernelGGL((k_resid_norm_b<1>), dim3(nslots), dim3(256), 0, s, part, X, ldx, w, Y, D, eps, bs, Y8, YS);
+  else if (rounds == 2) hipLaunchKernelGGL((k_resid_norm_b<2>), dim3(nslots), dim3(512), 0, s, part, X, ldx, w, Y, D, eps, bs, Y8, YS);
+  else hipLaunchKernelGGL((k_resid_norm_b<4>), dim3(nslots), dim3(1024), 0, s, part, X, ldx, w, Y, D, eps, bs, Y8, YS);
 }
 
 #ifdef DTK_EXPERIMENTS

@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-#define DTK_ABI_VERSION 4   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
-                             * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels) */
+#define DTK_ABI_VERSION 5   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
+                             * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels);
+                             * 5: dtk_op_gemv_mx, dtk_stats.last_batch_step_fp8_mfma */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -111,6 +112,9 @@ typedef struct dtk_stats {
                                      * kernels) or 16 | 32 | 64 (one, two, four MFMA column tiles)            */
   uint32_t device_errors;           /* sticky: in-kernel protocol timeouts seen so far (a ring hand-off that expired); any
                                      * non-zero value makes dtk_decode_batch_wait fail                          */
+  uint32_t last_batch_step_fp8_mfma; /* 1: the last dtk_decode_batch_launch ran the fp8 matrix-core kernels (MXFP8 activations,
+                                     * option "act_fp8"), 0: the bf16-activation kernels                        */
+  uint32_t reserved0;
 } dtk_stats;
 
 int  dtk_abi_version(void);
@@ -256,7 +260,9 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * shape, 1..3 = persistent with 8 / 4 / 16 waves).  Prefill / ViT: "attn_impl" (0 auto,
  * 1 VALU, 2 MFMA flash), "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages"
  * (1..4), "gemm_impl" (0 register-staged, 1 LDS-DMA fragment order, 2 128x128 LDS-DMA row order, 3 auto), "gemm_ring" (2..4),
- * "gemm_glds_min_tiles".  DESIGN.md 3.4 has the defaults and what each switch measured.
+ * "gemm_glds_min_tiles".  fp8 models: "act_fp8" (1 = default: the MFMA-family step runs on the fp8 matrix cores with MXFP8 activations, 0 = the
+ * bf16-activation kernels), "mx_nc_qkv" / "mx_nc_gu" / "mx_nc_lm_head" (0..4 compute waves per block of its unit kernel; 0 = from the CU count).
+ * DESIGN.md 3.4 has the defaults and what each switch measured.
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.
  * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create. */
@@ -280,6 +286,14 @@ int  dtk_op_gemv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* x, const uint1
  * to dtk_op_gemv */
 int  dtk_op_gemv_mv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* X, const uint16_t* norm_w,
                     int N, int K, int mode, float eps, int nb, uint16_t* Y);
+/* The fp8 matrix-core GEMVs of the batched step of an fp8 model (csrc/kernels_batch_mx.hip; BASELINE config 5's "CDNA4 fp8 MFMA"):
+ * W8 [N][K] e4m3 bytes + wscale [N] (per-row power of two); X [nslots][K] bf16 rows, quantised to MXFP8 in groups of G = 32 | 16
+ * consecutive k by the step's own quantiser; nslots = 16 | 32 | 64.  mode 0: unit kernel with the logits epilogue (G = 32):
+ * Y [nslots][N] = bf16-rounded sums; mode 1: the K-slice kernel of the N = d roles: Y = the 8 slice partials added in order (fp32);
+ * mode 2: unit kernel with the SwiGLU epilogue (N = 2 ff): y8_out / ys_out = the activation as MXFP8 groups of 16 (64 ff bytes /
+ * ceil(ff / 256) KiB).  x8_out (64 K bytes) / xs_out (ceil(K / (16 G)) KiB), optional: the quantised input in the kernels' order. */
+int  dtk_op_gemv_mx(dtk_ctx* ctx, const uint8_t* W8, const float* wscale, const uint16_t* X, int N, int K, int G, int nslots, int mode,
+                    float* Y, uint8_t* x8_out, uint8_t* xs_out, uint8_t* y8_out, uint8_t* ys_out);
 /* softmax(Q K^T * scale [+ causal mask with q_offset]) V, heads-major [H][T][hd] bf16 */
 int  dtk_op_attention(dtk_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* V,
                       int H, int Tq, int Tk, int hd, int causal, int q_offset, uint16_t* O);

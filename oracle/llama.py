@@ -69,6 +69,35 @@ def apply_rope(x, cos, sin, precision="bf16"):
     return torch.cat([o1, o2], dim=-1)
 
 
+def mx_exponent(amax: torch.Tensor) -> torch.Tensor:
+    """E8M0 exponent of a group with largest magnitude `amax` (fp32): the smallest e with amax * 2^-e <= 448, read off the bits of
+    amax = m * 2^E as e = E - 8 (+ 1 if m > 1.75); 0 for an all-zero group; clamped to -127 .. 126.  The integer arithmetic of
+    detikzify_amd/csrc/mx_quant.h::mx_exp, restated."""
+    bits = amax.contiguous().view(torch.int32) & 0x7fffffff
+    e = (bits >> 23) - 127 - 8 + ((bits & 0x7fffff) > 0x600000).to(torch.int32)
+    e = torch.where(bits == 0, torch.zeros_like(e), e)
+    return e.clamp(-127, 126)
+
+
+def mx_quantise(x: torch.Tensor, group: int):
+    """x [..., K] (bf16-representable fp32) -> (e4m3 codes as uint8 [..., K], E8M0 bytes [..., K / group]): OCP MXFP8 with the scale
+    rule above.  x * 2^-e is exact; the e4m3 rounding is round-to-nearest-even (torch.float8_e4m3fn == v_cvt_pk_fp8_f32)."""
+    K = x.shape[-1]
+    g = x.float().reshape(*x.shape[:-1], K // group, group)
+    e = mx_exponent(g.abs().amax(-1))
+    q = torch.ldexp(g, -e[..., None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).reshape(x.shape), (e + 127).to(torch.uint8)
+
+
+def mx_fake_quant(x: torch.Tensor, group: int) -> torch.Tensor:
+    """The values the fp8 matrix cores see for x: quantise to MXFP8 in groups of `group` consecutive elements, de-quantise."""
+    K = x.shape[-1]
+    g = x.float().reshape(*x.shape[:-1], K // group, group)
+    e = mx_exponent(g.abs().amax(-1))[..., None]
+    q = torch.ldexp(g, -e).to(torch.float8_e4m3fn).float()
+    return torch.ldexp(q, e).reshape(x.shape)
+
+
 def attention(q, k, v, scale, causal_offset: Optional[int] = None, precision="bf16"):
     """q [H,Tq,hd], k/v [H,Tk,hd] (or [KVH,Tk,hd] with H % KVH == 0: GQA, HF repeat_kv).
     causal_offset = absolute position of query 0 (None = full)."""
@@ -90,6 +119,10 @@ class LlamaOracle:
 
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], precision: str = "bf16"):
         self.cfg, self.w, self.precision = cfg, weights, precision
+        # act_quant = True: the four Linear inputs of a layer and the lm_head input are MXFP8 (groups of 32; 16 for the SwiGLU
+        # output) — what the batched step of an fp8 model computes on the fp8 matrix cores (csrc/kernels_batch_mx.hip).  The
+        # tests switch it on for the batched decode steps only: prefill and the single-sequence step keep bf16 activations.
+        self.act_quant = False
         self.d, self.L, self.H = cfg["hidden"], cfg["layers"], cfg["heads"]
         self.hd = cfg["head_dim"]
         self.KVH = cfg.get("kv_heads") or self.H
@@ -129,6 +162,8 @@ class LlamaOracle:
         for i in range(self.L):
             p = f"model.layers.{i}."
             h = rmsnorm(x, self.w[p + "input_layernorm.weight"], self.cfg["rms_eps"], P)
+            if self.act_quant:
+                h = mx_fake_quant(h, 32)
             q = linear(h, self.w[p + "self_attn.q_proj.weight"], None, P)
             k = linear(h, self.w[p + "self_attn.k_proj.weight"], None, P)
             v = linear(h, self.w[p + "self_attn.v_proj.weight"], None, P)
@@ -140,11 +175,17 @@ class LlamaOracle:
             self.v[i] = v if self.v[i] is None else torch.cat([self.v[i], v], dim=1)
             a = attention(q, self.k[i], self.v[i], self.scale, causal_offset=start, precision=P)
             a = a.transpose(0, 1).reshape(T, self.d)
+            if self.act_quant:
+                a = mx_fake_quant(a, 32)
             x = rb(x + linear(a, self.w[p + "self_attn.o_proj.weight"], None, P), P)
             h = rmsnorm(x, self.w[p + "post_attention_layernorm.weight"], self.cfg["rms_eps"], P)
+            if self.act_quant:
+                h = mx_fake_quant(h, 32)
             g = linear(h, self.w[p + "mlp.gate_proj.weight"], None, P)
             u = linear(h, self.w[p + "mlp.up_proj.weight"], None, P)
             act = rb(rb(torch.nn.functional.silu(g), P) * u, P)
+            if self.act_quant:
+                act = mx_fake_quant(act, 16)
             x = rb(x + linear(act, self.w[p + "mlp.down_proj.weight"], None, P), P)
         self.pos = start + T
         return x
@@ -152,4 +193,6 @@ class LlamaOracle:
     def logits(self, h_last: torch.Tensor) -> torch.Tensor:
         """final norm + lm_head + .float() (reference v1/modeling_detikzify.py:250-257)."""
         h = rmsnorm(h_last, self.w["model.norm.weight"], self.cfg["rms_eps"], self.precision)
+        if self.act_quant:
+            h = mx_fake_quant(h, 32)
         return linear(h, self.w["lm_head.weight"], None, self.precision)

@@ -30,6 +30,8 @@ from tests.test_gpu_parity import weights_from_device
 
 ULP = 2.0 ** -7          # one bf16 ulp relative to the value's binade top (8 significant bits)
 GAP_BINS = (0.0, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0, float("inf"))
+MX_TIE = 16.0            # near-tie rule of the fp8 matrix-core steps, in bf16 ulps of the top logit (= 2 ulps of an e4m3 activation, 2^-3 each... of the logit: 12.5 %)
+MX_R16 = 0.3             # sanity bound on device-vs-quantising-oracle logits there (the fp32 envelope is the test)
 
 
 def top2_gap_ulps(logits, bad, begin, first):
@@ -89,7 +91,7 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
         log = {s: [] for s in range(NS)}          # per slot: (sampled?, first step after set_sampling?, token)
         logit_log = {s: [] for s in watch}        # logits AFTER each step of a watched slot
         prev = {s: dev_prefill for s in range(NS)}
-        draws_checked, kinds = 0, []
+        draws_checked, kinds, mx = 0, [], None
         for active, n_sampled, n_greedy, kind in phases:
             active = list(active)
             assert max(active) < NS
@@ -107,6 +109,9 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                     out = model.decode_batch_wait()
                     got_kind = model.stats()["last_batch_step_slots"]
                     assert got_kind == kind, f"{len(active)} active slots up to {max(active)}: the step ran the {got_kind}-slot kernels, expected {kind}"
+                    step_mx = bool(model.stats()["last_batch_step_fp8_mfma"])     # fp8 model, MFMA family: the fp8 matrix cores on MXFP8 activations
+                    assert mx is None or mx == step_mx, "the kernel family of a context must not change with the active set"
+                    mx = step_mx
                     for s in active:
                         if sampled:
                             rt, _ = sampling.draw(prev[s], 0.8, 0, 0.95, seed_of(s), i, [img_tok], [eos], i == 0)
@@ -130,7 +135,14 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
         e_dev, e_orc, e_pair = rel_l2(dev_prefill, truth), rel_l2(ref, truth), rel_l2(dev_prefill, ref)
         assert e_dev < 1.5 * e_orc + 2e-3
 
-        worst_ratio, worst_r16, near_ties, near_tie_steps, identical, n_greedy_total, gaps = 0.0, 0.0, 0, 0, 0, 0, []
+        # fp8 matrix-core steps (csrc/kernels_batch_mx.hip): the bf16-policy oracle quantises the same activations to MXFP8 from here
+        # on (LlamaOracle.act_quant; prefill above ran with bf16 activations on both sides); the fp32 oracle stays the unquantised
+        # truth.  e4m3 activations make the two pipelines random-walk apart in steps of 2^-4 instead of 2^-8, so the near-tie rule
+        # is stated in the unit that fits: MX_TIE bf16 ulps of the top logit (asserted), and the sanity bound on the distance widens.
+        assert mx == (weight_format == "fp8" and batch_slots > 5), "fp8 models run the MFMA-family step on the fp8 matrix cores"
+        o16.llm.act_quant = bool(mx)
+        tie = MX_TIE if mx else 2.0
+        worst_ratio, worst_r16, near_ties, near_tie_steps, identical, n_greedy_total, gaps, worst_behind = 0.0, 0.0, 0, 0, 0, 0, [], 0.0
         for s in watch:
             oracle_restore(o16, snap16)
             if s in watch32:
@@ -140,7 +152,7 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                 gaps.append(top2_gap_ulps(logits, [img_tok], [eos], first))
                 if not sampled:
                     n_greedy_total += 1
-                    near_tie_steps += gaps[-1] <= 2.0 + 1e-3
+                    near_tie_steps += gaps[-1] <= tie + 1e-3
                     masked = sampling.mask_scores(logits, [img_tok], [eos], first)
                     best = float(masked.max())
                     if float(masked[t]) == best and t == int(torch.nonzero(masked == best)[0]):
@@ -149,14 +161,15 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                         # a flip: only at a near-tie, and only to a token the ORACLE itself scores within 2 bf16 ulps of its best (the
                         # runner-up, or — bf16 logits tie exactly now and then — any of several tokens at that distance)
                         behind = (best - float(masked[t])) / (abs(best) * ULP + 1e-30)
-                        assert gaps[-1] <= 2.0 + 1e-3 and behind <= 2.0 + 1e-3, (s, i, t, torch.topk(masked, 3), gaps[-1], behind)
+                        assert gaps[-1] <= tie + 1e-3 and behind <= tie + 1e-3, (s, i, t, torch.topk(masked, 3), gaps[-1], behind)
                         near_ties += 1
+                        worst_behind = max(worst_behind, behind)
                 logits = o16.step(t)
                 r16 = rel_l2(logit_log[s][i], logits)
                 worst_r16 = max(worst_r16, r16)
                 # sanity bound on the distance between the two bf16 pipelines (the fp32 envelope on `watch32` is the real test): what
                 # the prefill of this model showed, with headroom — ds-7b ~2.9e-2, the 128 k-vocabulary v2-8b ~3.4e-2
-                assert r16 < max(3e-2, 1.25 * e_pair), (s, i, r16, e_pair)
+                assert r16 < (MX_R16 if mx else max(3e-2, 1.25 * e_pair)), (s, i, r16, e_pair)
                 if s in watch32:
                     t32 = o32.step(t)
                     d, o = rel_l2(logit_log[s][i], t32), rel_l2(logits, t32)
@@ -212,7 +225,9 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                     lg16, lg32 = a16.step(t), a32.step(t)
             tail_report = (f"; after {private_tail} more sampled tokens per slot (contexts {n_img + len(log[tail_watch[0]]) + private_tail}, all but {n_img} keys private): "
                            f"slots {tuple(tail_watch)} 5 logit checks worst ratio to the envelope {t_worst:.2f}, {t_same}/{4 * len(tail_watch)} greedy tokens identical")
-        print(f"batched {name}{' fp8' if weight_format == 'fp8' else ''}, {batch_slots} slots, step kinds {kinds}: prefill logits vs fp32: "
+        o16.llm.act_quant = False
+        mx_note = f" [fp8 matrix cores, MXFP8 activations: oracle act_quant, tie rule {tie:g} ulps, worst flip {worst_behind:.1f} ulps behind]" if mx else ""
+        print(f"batched {name}{' fp8' if weight_format == 'fp8' else ''}{mx_note}, {batch_slots} slots, step kinds {kinds}: prefill logits vs fp32: "
               f"device {e_dev:.2e} oracle {e_orc:.2e}; slots {tuple(watch)}: step logits dev-vs-bf16-oracle worst {worst_r16:.2e}, worst "
               f"ratio to the fp32 envelope {worst_ratio:.2f}; greedy {identical}/{n_greedy_total} identical ({near_ties} flips to the runner-up in {near_tie_steps} near-tie steps); "
               f"{draws_checked} sampled draws exact; oracle top-2 gap histogram (bf16 ulps of the top logit, "

@@ -164,7 +164,7 @@ def test_c_abi_exports_every_declared_symbol():
     # struct layouts: the ctypes mirrors against the C compiler's own sizeof / offsetof (exported by the library)
     assert lib.dtk_abi_struct_size(0) == ctypes.sizeof(_lib.DtkConfig) == 29 * 4
     assert lib.dtk_abi_struct_size(1) == ctypes.sizeof(_lib.DtkSampling) == 4 * 4 + 8 + 3 * 4 + 24 * 4 + 4
-    assert lib.dtk_abi_struct_size(2) == ctypes.sizeof(_lib.DtkStats) == 11 * 8 + 2 * 4      # (+ last_batch_step_slots, device_errors: ABI 4)
+    assert lib.dtk_abi_struct_size(2) == ctypes.sizeof(_lib.DtkStats) == 11 * 8 + 4 * 4      # (+ last_batch_step_slots, device_errors: ABI 4; last_batch_step_fp8_mfma, reserved0: ABI 5)
     assert lib.dtk_abi_struct_size(3) == _lib.DtkSampling.seed.offset == 16
     assert lib.dtk_abi_struct_size(4) == _lib.DtkConfig.reserved.offset == 22 * 4
     assert lib.dtk_abi_struct_size(5) == _lib.DtkStats.probe_event_pair_ms.offset == 80

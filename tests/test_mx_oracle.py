@@ -1,0 +1,55 @@
+"""CPU tests of the MXFP8 restatement in oracle/llama.py (the checker of the fp8 matrix-core step, csrc/kernels_batch_mx.hip):
+known answers of the scale rule and of the e4m3 rounding, and the properties the GPU tests lean on."""
+import torch
+
+from oracle.llama import LlamaOracle, mx_exponent, mx_fake_quant, mx_quantise
+from oracle.ops import rb
+
+
+def test_scale_rule_known_answers():
+    # amax * 2^-e <= 448 = 1.75 * 2^8 with the smallest e: 448 -> 0, just above -> 1, 1.0 -> -8, 1.75 -> -8, 1.7578125 -> -7
+    amax = torch.tensor([448.0, 449.0, 1.0, 1.75, 1.7578125, 0.0, 3.0, 2.0 ** -20, 2.0 ** 100])
+    assert mx_exponent(amax).tolist() == [0, 1, -8, -8, -7, 0, -7, -28, 92]
+    x = torch.zeros(1, 32)
+    x[0, 0], x[0, 1], x[0, 2] = 448.0, 17.0, -19.0          # e = 0: codes are plain e4m3 (17 -> 16 and 19 -> 20: ties to even)
+    codes, scales = mx_quantise(x, 32)
+    assert scales.tolist() == [[127]]
+    back = codes.view(torch.float8_e4m3fn).float()
+    assert back[0, :3].tolist() == [448.0, 16.0, -20.0] and float(back[0, 3:].abs().max()) == 0.0
+
+
+def test_fake_quant_properties():
+    g = torch.Generator().manual_seed(0)
+    x = rb(torch.randn(7, 256, generator=g) * torch.exp2(torch.randint(-20, 20, (7, 8, 1), generator=g).float()).repeat_interleave(32, 1).reshape(7, 256))
+    for group in (32, 16):
+        q = mx_fake_quant(x, group)
+        assert torch.equal(mx_fake_quant(q, group), q), "idempotent: the quantised values are representable with the same scale"
+        assert torch.equal(rb(q), q), "MXFP8 values are bf16 values (3 mantissa bits, a power-of-two scale)"
+        codes, scales = mx_quantise(x, group)
+        top = codes.view(torch.float8_e4m3fn).float().reshape(7, 256 // group, group).abs().amax(-1)
+        assert float(top.max()) <= 448.0 and float(top.min()) >= 224.0, "the largest element of every group lands in e4m3's top binade"
+        err = (q - x).abs().reshape(7, 256 // group, group)
+        amax = x.abs().reshape(7, 256 // group, group).amax(-1, keepdim=True)
+        assert bool((err <= amax * 2.0 ** -4 + 1e-30).all()), "absolute error of an element <= half an e4m3 ulp of its group's top binade"
+    assert torch.equal(mx_fake_quant(torch.zeros(2, 64), 32), torch.zeros(2, 64))
+
+
+def test_act_quant_touches_exactly_the_linear_inputs():
+    """LlamaOracle.act_quant = the five quantisers of csrc/dtk_api.hip::batch_step_launches_mx: with weights whose rows only read
+    values that MXFP8 represents exactly, switching it on changes nothing; with generic activations it does"""
+    cfg = dict(hidden=64, layers=1, heads=2, head_dim=32, kv_heads=2, rms_eps=1e-6, rope_theta=10000.0, rope_factor=1.0, max_positions=16, vocab=48)
+    g = torch.Generator().manual_seed(1)
+    w = {"model.embed_tokens.weight": rb(torch.randn(48, 64, generator=g)), "model.norm.weight": torch.ones(64), "lm_head.weight": rb(torch.randn(48, 64, generator=g) * 0.1)}
+    p = "model.layers.0."
+    for n, shape in (("self_attn.q_proj", (64, 64)), ("self_attn.k_proj", (64, 64)), ("self_attn.v_proj", (64, 64)), ("self_attn.o_proj", (64, 64)),
+                     ("mlp.gate_proj", (128, 64)), ("mlp.up_proj", (128, 64)), ("mlp.down_proj", (64, 128))):
+        w[p + n + ".weight"] = rb(torch.randn(*shape, generator=g) * 0.1)
+    w[p + "input_layernorm.weight"] = torch.ones(64)
+    w[p + "post_attention_layernorm.weight"] = torch.ones(64)
+    o = LlamaOracle(cfg, w, "bf16")
+    x = o.embed(torch.tensor([3, 9, 11]))
+    plain = o.logits(o.forward(x)[-1])
+    o.reset(); o.act_quant = True
+    quant = o.logits(o.forward(x)[-1])
+    rel = float((quant - plain).norm() / plain.norm())
+    assert 1e-3 < rel < 0.2, rel          # e4m3 activations: a few per cent on one layer, not bf16's 1e-3 and not garbage
