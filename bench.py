@@ -641,6 +641,9 @@ def main():
                 try:
                     for key, ragged in (("fixed_length", False), ("ragged", True)):
                         c5[key] = search(m5, p5, [imgs5[i] for i in mine5], args.config5_trees, args.config5_expansions, ragged=ragged, Wk=Wk5)
+                    # 1 = the steps ran on the fp8 matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8 activations: csrc/kernels_batch_mx.hip;
+                    # DTK_OPTIONS=act_fp8=0 selects the bf16-activation kernels of rounds 1-3 instead)
+                    c5["decode_steps_on_fp8_matrix_cores"] = int(m5.stats().get("last_batch_step_fp8_mfma", 0))
                     if world == 1 and not args.no_rank_shapes:
                         # one rank's share at N = 2 / 4 / 8: 8/N images x the same trees (32 / 16 / 8 decode slots: two / one MFMA
                         # column tiles — the kernels a step runs follow its highest active slot, so the 72-slot context runs

@@ -4,7 +4,7 @@
 # step times with act_fp8 = 1 / 0 at 64 / 32 / 16 slots, a kernel trace of the 64-slot step, then the full-depth cl-7b fp8 test.
 set -uo pipefail
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_parity_mx.py -q -p no:cacheprovider -s -x --tb=short 2>&1 | grep -vE "amdgpu.ids|^$" | cut -c1-1200 | tail -60 | tee "$OUT/r04h_mx_tests.txt"
+timeout 900 python -m pytest tests/test_gpu_parity_mx.py -q -p no:cacheprovider -s --tb=short 2>&1 | grep -vE "amdgpu.ids|^$" | cut -c1-1200 | tail -90 | tee "$OUT/r04h_mx_tests.txt"
 for b in 64 32 16; do
   for o in 1 0; do
     echo "-- cl-7b fp8, $b slots, act_fp8=$o: $(DTK_OPTIONS=act_fp8=$o timeout 300 python tools/bench_batch.py --batch $b --fork --steps 32 --model detikzify-cl-7b --weight-format fp8 2>&1 | tail -1)"
