@@ -9,7 +9,8 @@
 //   * RMSNorm output (input of q/k/v, gate/up, lm_head) and attention output (input of o_proj): groups of 32 — the block-scale
 //     granule of the instruction (a lane's 32 operand bytes share one scale);
 //   * SwiGLU output (input of down): groups of 16 = the rows of one MFMA row tile, which is what a wave of the gate/up kernel
-//     owns; down runs the instruction with the upper 16 operand bytes of every lane zero (64 real k per MFMA).
+//     owns; down issues two instructions per 128 k, each with half of its weight lanes zeroed, so that a scale block of the
+//     instruction (32 operand bytes across two lane groups) carries one 16-group (64 real k per MFMA).
 // The scale of a group is the smallest power of two that brings its largest magnitude to <= 448 (e4m3 max): no saturation.  The
 // weights keep their per-row power-of-two scale (k_quant_fp8_rows), applied to the fp32 sums (exact).
 //
@@ -18,14 +19,17 @@
 // quantiser bit for bit (LlamaOracle.act_quant); the parity tests compare against THAT oracle and report the distance to the
 // bf16-activation oracle next to it (fp8 parity = bounded error).
 //
-// Layouts (all "k" are positions of the Linear's input dimension K; slot tiles of 16 slots, always laid out for 4 tiles):
-//   weights, G = 32:  tile (tn = row/16, ks = k/128) = 2 KiB = [half 0..1][lane 0..63][16 B]; lane l = row l&15, bytes of
-//                     k = ks*128 + (l>>4)*32 + half*16 + 0..15          (a lane's 32 operand bytes = its two 16-byte pieces)
-//   weights, G = 16:  tile (tn, ks = k/64) = 1 KiB = [lane][16 B]; lane l = row l&15, k = ks*64 + (l>>4)*16 + 0..15
-//   x, G = 32:        per k-step ks: [tile 0..3][half][lane][16 B]; lane l = slot tile*16 + (l&15), k as the weights
-//   x, G = 16:        per k-step ks: [tile 0..3][lane][16 B]
-//   x scales:         dword [ks>>2][tile][lane], byte ks&3 = E8M0 of (slot, group (ks, l>>4)): 1 KiB per 4 k-steps
-// Every 1 KiB piece is one `global_load_lds_dwordx4` / `global_load_dwordx4` / `ds_read_b128` of a wave, fully coalesced.
+// Layouts.  The instruction does NOT take 32 consecutive k per lane (what ck_tile's descriptor suggests, harmless without scales):
+// measured with tools/probe/mx_probe.hip (profiles/r04_mx_probe.txt), lane l = (g = l >> 4, i = l & 15) holds for row / column i the
+// operand bytes p = 0..31 = k 64 * (p >> 4) + 16 * g + (p & 15), and scale block b = k >> 5 is the E8M0 byte of lane 16 * b + i.  Both
+// operands are kept in memory as 2 KiB per (16 rows or slots, 128 k): [half h][lane][16 B] — every 1 KiB piece is one
+// `global_load_lds_dwordx4` / `global_load_dwordx4` / `ds_read_b128` of a wave, fully coalesced; slot tiles always laid out for 4:
+//   G = 32 (k-step ks = k / 128):   piece h, lane (g, i) = k ks*128 + 64 h + 16 g + 0..15;  one instruction per k-step
+//   G = 16 (pair step ps = k / 128): piece h, lane (g, i) = k ps*128 + 64 (g & 1) + 32 h + 16 (g >> 1) + 0..15; TWO instructions s = 0, 1
+//           per pair step, the weight operand of instruction s zeroed in the lane groups with (g & 1) != s: each of its four scale
+//           blocks then holds exactly one 16-group (64 real k per instruction), the x operand is read once for both
+//   scales: 1 KiB rows of dwords [tile][lane]; G = 32: row ks >> 2, byte ks & 3, lane b * 16 + slot;  G = 16: row ps >> 1, byte
+//           (ps & 1) * 2 + s, lane q * 16 + slot (q = 16-group within the instruction)
 #include "batch_epi.h"
 #include "mx_quant.h"
 
@@ -43,15 +47,15 @@ __device__ __forceinline__ f32x4 mx_mfma(const i32x8& a, const i32x8& b, const f
 // ---------------------------------------------------------------------------------------------------------------- retile
 // row-major fp8 [N][K] -> MX weight tiles; one thread per 16-byte lane slot
 __global__ void k_retile_mx(const uint8_t* src, uint8_t* dst, int N, int K, int G) {
-  const int HP = G == 32 ? 2 : 1, KS = 4 * G;
-  const int nks = (K + KS - 1) / KS, N16 = (N + 15) >> 4;
-  const long total = (long)N16 * nks * HP * 64;
+  const int nks = (K + 127) >> 7, N16 = (N + 15) >> 4;
+  const long total = (long)N16 * nks * 2 * 64;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63);
-    long p = i >> 6;                                        // piece = (tile * nks + ks) * HP + half
-    const int half = (int)(p % HP); p /= HP;
+    const int lane = (int)(i & 63), g = lane >> 4;
+    long p = i >> 6;                                        // piece = (tile * nks + ks) * 2 + half
+    const int half = (int)(p & 1); p >>= 1;
     const int ks = (int)(p % nks), tn = (int)(p / nks);
-    const int n = tn * 16 + (lane & 15), k = ks * KS + (lane >> 4) * G + half * 16;
+    const int n = tn * 16 + (lane & 15);
+    const int k = ks * 128 + (G == 32 ? 64 * half + 16 * g : 64 * (g & 1) + 32 * half + 16 * (g >> 1));
     u32x4 v = {0u, 0u, 0u, 0u};
     if (n < N && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * K + k);     // K % 16 == 0
     reinterpret_cast<u32x4*>(dst)[i] = v;
@@ -274,33 +278,33 @@ void launch_gemv_mxu(int epi, const GemvBArgs& a, hipStream_t s) {   // a.Wm, a.
 // wave issuing its share; then one drain + barrier and nothing but LDS reads and MFMAs.  No ring, no flags.
 template <int TPG, int NT, int G, int MAXL>
 __global__ __launch_bounds__(TPG * 64) void k_gemv_mxk(GemvBArgs a) {
-  constexpr int HP = G == 32 ? 2 : 1, KSTEP = 4 * G;
-  constexpr int MAXQ = (MAXL + 3) / 4 + 1;
-  constexpr unsigned XB = (unsigned)MAXL * NT * HP * 1024u;          // scales sit behind the x pieces
+  constexpr int SPQ = G == 32 ? 4 : 2;                               // (pair) steps per 1 KiB scale row
+  constexpr int MAXQ = (MAXL + SPQ - 1) / SPQ + 1;
+  constexpr unsigned XB = (unsigned)MAXL * NT * 2048u;               // scales sit behind the x pieces
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nks = a.K / KSTEP, per = (nks + 7) >> 3;
+  const int nks = a.K >> 7, per = (nks + 7) >> 3;
   const int b = blockIdx.x, idx = b >> 3;
   const int rgs_per_xcd = (int)(gridDim.x >> 6);                    // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
   const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
   const int s0 = min(nks, ks * per), s1 = min(nks, s0 + per);
   const int Lc = s1 - s0;                                           // 1 .. MAXL (launcher)
-  const int q0 = s0 >> 2, nq = ((s1 - 1) >> 2) - q0 + 1;            // 4-k-step scale rows the slice touches
+  const int q0 = s0 / SPQ, nq = (s1 - 1) / SPQ - q0 + 1;            // scale rows the slice touches
   const int tn = rg * TPG + wave;
-  const unsigned char* wrow = a.Wm + ((size_t)tn * nks + s0) * (HP * 1024) + lane * 16;
-  u32x4 w[MAXL][HP];
+  const unsigned char* wrow = a.Wm + ((size_t)tn * nks + s0) * 2048 + lane * 16;
+  u32x4 w[MAXL][2];
 #pragma unroll
   for (int j = 0; j < MAXL; ++j)
     if (j < Lc) {
 #pragma unroll
-      for (int h = 0; h < HP; ++h) w[j][h] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)(j * HP + h) * 1024));
+      for (int h = 0; h < 2; ++h) w[j][h] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)(j * 2 + h) * 1024));
     }
   {
     const unsigned char* xl = a.X8 + lane * 16;
-    const int per_step = NT * HP, npieces = Lc * per_step;          // (tile, half) pieces of a k-step are the first NT * HP of its 4 * HP
+    const int per_step = NT * 2, npieces = Lc * per_step;           // (tile, half) pieces of a step are the first NT * 2 of its 8
     for (int i = wave; i < npieces; i += TPG) {
       const int j = i / per_step, r = i - j * per_step;
-      glds16(xl + ((size_t)(s0 + j) * 4 * HP + r) * 1024, (unsigned)i * 1024u);
+      glds16(xl + ((size_t)(s0 + j) * 8 + r) * 1024, (unsigned)i * 1024u);
     }
     const unsigned char* sl = a.XS + lane * 16;
     for (int q = wave; q < nq; q += TPG) glds16(sl + (size_t)(q0 + q) * 1024, XB + (unsigned)q * 1024u);
@@ -311,19 +315,34 @@ __global__ __launch_bounds__(TPG * 64) void k_gemv_mxk(GemvBArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const u32x4 zero = {0u, 0u, 0u, 0u};
+  const bool odd = (lane >> 4) & 1;                                 // G = 16: this lane's weights belong to instruction s = 1
 #pragma unroll
   for (int j = 0; j < MAXL; ++j) {
     if (j < Lc) {                                                   // block-uniform
       const int kk = s0 + j;
-      const unsigned q = (unsigned)((kk >> 2) - q0), sh = (unsigned)(kk & 3) * 8u;
-      const i32x8 af = HP == 2 ? mx_op(w[j][0], w[j][HP - 1]) : mx_op(w[j][0], zero);
+      const unsigned q = (unsigned)(kk / SPQ - q0);
+      i32x8 xf[NT];
+      unsigned sdw[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const unsigned char* xp = smem + (size_t)((j * NT + nt) * HP) * 1024 + lane * 16;
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(xp);
-        const u32x4 hi = HP == 2 ? *reinterpret_cast<const u32x4*>(xp + 1024) : zero;
-        const unsigned sdw = *reinterpret_cast<const unsigned*>(smem + XB + q * 1024u + (unsigned)nt * 256u + lane * 4);
-        c[nt] = mx_mfma(af, mx_op(lo, hi), c[nt], ((sdw >> sh) & 0xffu) * 0x01010101u);
+        const unsigned char* xp = smem + (size_t)((j * NT + nt) * 2) * 1024 + lane * 16;
+        xf[nt] = mx_op(*reinterpret_cast<const u32x4*>(xp), *reinterpret_cast<const u32x4*>(xp + 1024));
+        sdw[nt] = *reinterpret_cast<const unsigned*>(smem + XB + q * 1024u + (unsigned)nt * 256u + lane * 4);
+      }
+      if (G == 32) {
+        const unsigned sel = 0x01010101u * (unsigned)(kk & 3);
+        const i32x8 af = mx_op(w[j][0], w[j][1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) c[nt] = mx_mfma(af, xf[nt], c[nt], __builtin_amdgcn_perm(sdw[nt], sdw[nt], sel));
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                               // the 64 real k of this half of the pair step
+          const unsigned sel = 0x01010101u * (unsigned)((kk & 1) * 2 + s);
+          const bool live = odd == (s == 1);
+          const i32x8 af = mx_op(live ? w[j][0] : zero, live ? w[j][1] : zero);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) c[nt] = mx_mfma(af, xf[nt], c[nt], __builtin_amdgcn_perm(sdw[nt], sdw[nt], sel));
+        }
       }
     }
   }
@@ -335,8 +354,8 @@ __global__ __launch_bounds__(TPG * 64) void k_gemv_mxk(GemvBArgs a) {
 
 template <int TPG, int NT, int G, int MAXL>
 static void launch_mxk_one(const GemvBArgs& a, hipStream_t s) {
-  constexpr int HP = G == 32 ? 2 : 1;
-  constexpr int lds = (MAXL * NT * HP + (MAXL + 3) / 4 + 1) * 1024;
+  constexpr int SPQ = G == 32 ? 4 : 2;
+  constexpr int lds = (MAXL * NT * 2 + (MAXL + SPQ - 1) / SPQ + 1) * 1024;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_mxk<TPG, NT, G, MAXL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   const int ntiles = a.N >> 4;
@@ -347,25 +366,25 @@ static bool launch_mxk_g(const GemvBArgs& a, int G, int per, hipStream_t s) {
   if (G == 32) {
     if (per <= 4) launch_mxk_one<TPG, NT, 32, 4>(a, s); else if (per <= 8) launch_mxk_one<TPG, NT, 32, 8>(a, s); else return false;
   } else {
-    if (per <= 12) launch_mxk_one<TPG, NT, 16, 12>(a, s); else if (per <= 24) launch_mxk_one<TPG, NT, 16, 24>(a, s);
-    else if (per <= 32) launch_mxk_one<TPG, NT, 16, 32>(a, s); else return false;
+    if (per <= 6) launch_mxk_one<TPG, NT, 16, 6>(a, s); else if (per <= 11) launch_mxk_one<TPG, NT, 16, 11>(a, s);
+    else if (per <= 14) launch_mxk_one<TPG, NT, 16, 14>(a, s); else return false;
   }
   return true;
 }
 static inline int mx_tpg(int ntiles) { return (ntiles % 8 == 0 && ntiles / 8 >= 32) ? 8 : 4; }   // row tiles (waves) per block: 256 blocks where the width allows
 // N = d role with K-slice partials: N / 16 row tiles in 8 k row groups of 8 (or 4) tiles, 8 non-empty K slices of <= 8 (G = 32) /
-// <= 32 (G = 16) k-steps, a width k_resid_norm_b handles
+// <= 14 (G = 16) steps of 128 k, a width k_resid_norm_b handles
 bool mx_kparts_covers(int N, int K, int G) {
-  if (N <= 0 || K <= 0 || (N & 127) || (K % (4 * G))) return false;
-  const int nks = K / (4 * G), per = (nks + 7) >> 3;
-  if (7 * per >= nks || per > (G == 32 ? 8 : 32)) return false;
+  if (N <= 0 || K <= 0 || (N & 127) || (K & 127)) return false;
+  const int nks = K >> 7, per = (nks + 7) >> 3;
+  if (7 * per >= nks || per > (G == 32 ? 8 : 14)) return false;
   const int ntiles = N >> 4, tpg = mx_tpg(ntiles);
   if ((ntiles % tpg) || (ntiles / tpg) % 8) return false;
   const int D8 = N >> 3;
   return D8 == 256 || D8 == 512 || D8 == 1024;
 }
 void launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s) {      // a.Wm, a.X8, a.XS, a.kpart, a.wscale
-  const int nks = a.K / (4 * G), per = (nks + 7) >> 3;
+  const int nks = a.K >> 7, per = (nks + 7) >> 3;
   const int ntiles = a.N >> 4;
   const bool t8 = mx_tpg(ntiles) == 8;
   bool ok;

@@ -4,11 +4,11 @@
 #pragma once
 #include "common.h"
 
-// bytes of the MX weight tiles of an [N][K] fp8 matrix (G = 32: 2 KiB per 16 rows x 128 k; G = 16: 1 KiB per 16 rows x 64 k)
-static inline size_t mx_w_bytes(int N, int K, int G) { return (size_t)((N + 15) >> 4) * ((K + 4 * G - 1) / (4 * G)) * (G == 32 ? 2048 : 1024); }
-// bytes of the MXFP8 vectors of 64 slots (always laid out for 4 slot tiles) and of their scales
-static inline size_t mx_x_bytes(int K, int G) { return (size_t)((K + 4 * G - 1) / (4 * G)) * 4 * (G == 32 ? 2048 : 1024); }
-static inline size_t mx_s_bytes(int K, int G) { return (size_t)(((K + 4 * G - 1) / (4 * G) + 3) / 4) * 1024; }
+// bytes of the MX weight tiles of an [N][K] fp8 matrix: 2 KiB per 16 rows x 128 k (both group sizes)
+static inline size_t mx_w_bytes(int N, int K, int G) { (void)G; return (size_t)((N + 15) >> 4) * ((K + 127) / 128) * 2048; }
+// bytes of the MXFP8 vectors of 64 slots (always laid out for 4 slot tiles) and of their scales (1 KiB per 512 k at G = 32, per 256 k at G = 16)
+static inline size_t mx_x_bytes(int K, int G) { (void)G; return (size_t)((K + 127) / 128) * 4 * 2048; }
+static inline size_t mx_s_bytes(int K, int G) { return (size_t)((K + 16 * G - 1) / (16 * G)) * 1024; }
 
 // E8M0 exponent of a group whose largest magnitude is amax: the smallest e with amax * 2^-e <= 448 (= 1.75 * 2^8, the largest e4m3
 // value), from the bits of amax = m * 2^E: e = E - 8, one more if m > 1.75.  An all-zero group takes e = 0.
@@ -20,14 +20,24 @@ __device__ __forceinline__ int mx_exp(float amax) {
 }
 __device__ __forceinline__ float mx_inv(int e) { return __uint_as_float((unsigned)(127 - e) << 23); }      // 2^-e, e in -127 .. 126
 
+// Where the instruction wants its operands (measured: tools/probe/mx_probe.hip, profiles/r04_mx_probe.txt — NOT 32 consecutive k per
+// lane): lane l = (g = l >> 4, i = l & 15) holds, for row / column i, operand byte p (0..31) = k 64 * (p >> 4) + 16 * g + (p & 15) of the
+// instruction's 128; the four block scales of row i are the E8M0 bytes (selected by op_sel) of lanes 16 * b + i, block b = k >> 5.  So a
+// 32-group of consecutive k sits in the same 16-byte half of two neighbouring lane groups.
+//   G = 32: k-step ks = k >> 7; piece (half h = (k >> 6) & 1), lane ((k >> 4) & 3) * 16 + slot % 16, byte k & 15.
+//   G = 16: a PAIR step ps = k >> 7 covers 128 k as two instructions s = (k >> 6) & 1 that each see 64 real k: in instruction s only the
+//           lane groups g with (g & 1) == s carry weights (the kernel zeroes the others' weight operand), so block q = (k >> 4) & 3 of
+//           that instruction holds the 16 values of ONE group: half h = q >> 1, lane group g = 2 * (q & 1) + s.  Scale byte of
+//           (ps, s): dword row ps >> 1, byte (ps & 1) * 2 + s = (k >> 6) & 3, lane q * 16 + slot % 16.
 __device__ __forceinline__ size_t mx32_off(int slot, int k) {
-  return ((size_t)((k >> 7) * 4 + (slot >> 4)) * 2 + ((k & 31) >> 4)) * 1024 + (size_t)((((k >> 5) & 3) * 16 + (slot & 15)) * 16 + (k & 15));
+  return ((size_t)((k >> 7) * 4 + (slot >> 4)) * 2 + ((k >> 6) & 1)) * 1024 + (size_t)((((k >> 4) & 3) * 16 + (slot & 15)) * 16 + (k & 15));
 }
 __device__ __forceinline__ size_t mx32_soff(int slot, int k) {
   return (((size_t)(k >> 9) * 4 + (slot >> 4)) * 64 + ((k >> 5) & 3) * 16 + (slot & 15)) * 4 + ((k >> 7) & 3);
 }
 __device__ __forceinline__ size_t mx16_off(int slot, int k) {
-  return ((size_t)((k >> 6) * 4 + (slot >> 4)) * 64 + ((k >> 4) & 3) * 16 + (slot & 15)) * 16 + (k & 15);
+  const int q = (k >> 4) & 3, s = (k >> 6) & 1;
+  return ((size_t)((k >> 7) * 4 + (slot >> 4)) * 2 + (q >> 1)) * 1024 + (size_t)(((2 * (q & 1) + s) * 16 + (slot & 15)) * 16 + (k & 15));
 }
 __device__ __forceinline__ size_t mx16_soff(int slot, int k) {
   return (((size_t)(k >> 8) * 4 + (slot >> 4)) * 64 + ((k >> 4) & 3) * 16 + (slot & 15)) * 4 + ((k >> 6) & 3);
