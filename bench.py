@@ -644,6 +644,13 @@ def main():
                     # 1 = the steps ran on the fp8 matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8 activations: csrc/kernels_batch_mx.hip;
                     # DTK_OPTIONS=act_fp8=0 selects the bf16-activation kernels of rounds 1-3 instead)
                     c5["decode_steps_on_fp8_matrix_cores"] = int(m5.stats().get("last_batch_step_fp8_mfma", 0))
+                    if c5["decode_steps_on_fp8_matrix_cores"]:
+                        # the same search on the bf16-activation kernels of rounds 1-3 (fp8 weights widened to bf16 in registers, bf16
+                        # MFMA): what MXFP8 activations buy in rollouts/s; what they cost in logit distance is printed by
+                        # tests/test_gpu_parity_mx.py and recorded in DESIGN.md 3.1e
+                        m5.set_option("act_fp8", 0)
+                        c5["fixed_length_bf16_activations"] = search(m5, p5, [imgs5[i] for i in mine5], args.config5_trees, args.config5_expansions, Wk=Wk5)
+                        m5.set_option("act_fp8", 1)
                     if world == 1 and not args.no_rank_shapes:
                         # one rank's share at N = 2 / 4 / 8: 8/N images x the same trees (32 / 16 / 8 decode slots: two / one MFMA
                         # column tiles — the kernels a step runs follow its highest active slot, so the 72-slot context runs
