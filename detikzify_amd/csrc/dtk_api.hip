@@ -137,7 +137,6 @@ struct dtk_ctx {
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
-  int attn_share = 0;                // MHA models: the rows a group of 4 slots reads from the same source slot are scored once per head by k_attn_share_b (dtk_set_option "attn_share")
   int pfx_splits = 2;                // key splits of that kernel
   int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
   int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4)
@@ -666,7 +665,6 @@ void batch_step_launches_mx(dtk_ctx* c) {
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = nslots;
     ad.scale = scale;
     ad.impl = 1; ad.use_prefix = c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
-    if (c->attn_share && c->H == c->KVH) { ad.use_prefix = 2; ad.pfx_splits = 1; }
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     ad.out8 = c->ao8; ad.outs = c->aos;
     launch_attn_decode_b(ad, s);
@@ -723,7 +721,6 @@ void batch_step_launches(dtk_ctx* c) {
     ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
     ad.scale = scale;
     ad.impl = c->attn_b_impl; ad.use_prefix = c->attn_b_impl == 1 && c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
-    if (c->attn_b_impl == 1 && c->attn_share && c->H == c->KVH) { ad.use_prefix = 2; ad.pfx_splits = 1; }
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
@@ -1930,7 +1927,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bkl")) { set_gemv_bkl(value != 0); drop_batch_graphs(c); }
-  else if (!strcmp(name, "attn_share")) { c->attn_share = value != 0; drop_batch_graphs(c); }   // batched attention of MHA models: shared rows of a slot group once per head (k_attn_share_b)
   else if (!strcmp(name, "act_fp8")) {          // fp8 models: the MFMA-family step on the fp8 matrix cores with MXFP8 activations (kernels_batch_mx.hip)
     if (value && c->wfmt == 1 && c->nb > 0 && !c->mx_ok) return fail(c, DTK_ERR_ARG, "act_fp8: the model's shapes are not covered by the fp8 matrix-core kernels");
     c->act_fp8 = value != 0;

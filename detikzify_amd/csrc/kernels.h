@@ -162,7 +162,7 @@ struct AttnDecBArgs {
   int G;                               // query heads per kv head (1 = MHA)
   int nslots;                          // grid z: 16, 32 or 64
   int impl;                            // 0: split-K per slot + combine kernel; 1: k_attn_tail_b (+ k_attn_prefix_b when use_prefix)
-  int use_prefix;                      // 1: score BatchState's shared prefix once for all slots on the matrix cores (k_attn_prefix_b); 2: per group of 4 slots, the rows they share, by k_attn_share_b (MHA, pfx_splits == 1)
+  int use_prefix;                      // score BatchState's shared prefix once for all slots on the matrix cores
   int pfx_splits;                      // key splits of the prefix kernel (its grid y)
   int tail_threads;                    // k_attn_tail_b block: 512 (default) | 256
   int gqa_fused;             // k_attn_tail_b: 1 = the query heads of a GQA group share one block (default), 0 = a block per query head

@@ -684,28 +684,6 @@ __global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
 // keys, the order of the online-softmax updates, the cross-lane and cross-wave merges — is exactly that of GQ = 1 (the compiler
 // contracts the multiply-adds differently in the two instantiations: equal to fp32 rounding, tested, not bit for bit); the key /
 // value traffic through L2 drops by GQ (ds-7b has no groups: GQ = 1).  A slot's result still does not depend on the other slots.
-// Group-shared prefix (use_prefix == 2, MHA models): the slots of a group of ATTN_SG consecutive slots that read their first rows
-// from the same source slot (forks of one image prefix, dtk_kv_fork) have those rows scored ONCE per head by k_attn_share_b —
-// K / V tiles loaded once for up to ATTN_SG queries — and k_attn_tail_b continues from that state over the slot's own rows.  Both
-// kernels evaluate this function, so they agree on who is a member and where the shared part ends: the group's source is the
-// share_src of its lowest active slot that has one; members = the active slots of the group with that source; the shared part
-// = the shortest share among them; it takes two members and 16 rows to be worth a block.  Returns the length (0 = not a member).
-#define ATTN_SG 4
-__device__ __forceinline__ int share_group_len(const BatchState* bs, int slot, int* src_out = nullptr) {
-  const int s0 = slot & ~(ATTN_SG - 1);
-  int src = -1;
-#pragma unroll
-  for (int j = 0; j < ATTN_SG; ++j)
-    if (src < 0 && bs->active[s0 + j] && bs->share_src[s0 + j] >= 0) src = bs->share_src[s0 + j];
-  if (src_out) *src_out = src;
-  if (src < 0 || !bs->active[slot] || bs->share_src[slot] != src) return 0;
-  int n = 0, len = 1 << 30;
-#pragma unroll
-  for (int j = 0; j < ATTN_SG; ++j)
-    if (bs->active[s0 + j] && bs->share_src[s0 + j] == src) { ++n; len = min(len, bs->share_len[s0 + j]); }
-  return (n >= 2 && len >= 16) ? len : 0;
-}
-
 template <int THREADS, int GQ = 1>
 __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
@@ -719,9 +697,8 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   const int ssrc = a.bs->share_src[slot];
   const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
   const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;
-  const int glen = a.use_prefix == 2 ? share_group_len(a.bs, slot) : 0;
-  const bool member = a.use_prefix == 2 ? glen > 0 : (a.use_prefix && pfx_member(a.bs, slot));
-  const int start = a.use_prefix == 2 ? glen : (member ? a.bs->pfx_len : 0);
+  const bool member = a.use_prefix && pfx_member(a.bs, slot);
+  const int start = member ? a.bs->pfx_len : 0;
   const int n = a.st[slot].pos + 1;
   u32x4 qv[GQ];
 #pragma unroll
@@ -872,142 +849,9 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   }
 }
 
-// k_attn_share_b — the shared rows of a slot group, once per head (see share_group_len): k_attn_tail_b's scoring loop with up to
-// ATTN_SG queries per K / V tile (the GQ loop of the GQA instantiations, over slots instead of heads), ending in the UN-normalised
-// state (m, l, o[128]) of every member at pfx_m / pfx_l / pfx_o [slot][H][1], which k_attn_tail_b merges before its own rows.
-// Why: at the image-prefix context every (head, slot) block pulled the same 243 rows (126 KB) through its CU — 255 MB per layer at 64
-// slots, L2 hits all, but a CU ingests ~35 GB/s whatever the source: 25 us per layer, the largest kernel of the fp8 matrix-core
-// step.  Grid (H, nslots / ATTN_SG), 256 threads.
-__global__ __launch_bounds__(256) void k_attn_share_b(AttnDecBArgs a) {
-  constexpr int WAVES = 4, ROWS = WAVES * 16, SG = ATTN_SG;
-  const int h = blockIdx.x, s0 = blockIdx.y * SG;
-  int src = -1;
-  int len = 0;
-  bool mem[SG];
-#pragma unroll
-  for (int g = 0; g < SG; ++g) {                         // block-uniform: every member reports the same length
-    const int lg = share_group_len(a.bs, s0 + g, &src);
-    mem[g] = lg > 0;
-    if (lg > 0) len = lg;
-  }
-  if (len <= 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = lane & 15, grp = lane >> 4;
-  const size_t src_off = (size_t)src * a.kv_slot_stride + (size_t)h * a.T_max * 128;      // MHA (launcher): kv head = head
-  const bf16_t* kbase = a.kcache + src_off;
-  const bf16_t* vbase = a.vcache + src_off;
-  u32x4 qv[SG];
-#pragma unroll
-  for (int g = 0; g < SG; ++g) qv[g] = reinterpret_cast<const u32x4*>(a.q + (size_t)(s0 + g) * a.d + h * 128)[sub];
-  u32x4 kA[4], vA[4], kB[4], vB[4];
-  auto load_tile = [&](u32x4 (&kk)[4], u32x4 (&vv)[4], int j0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = min(j0 + i * (ROWS / 4) + wave * 4 + grp, len - 1);
-      kk[i] = reinterpret_cast<const u32x4*>(kbase + (size_t)j * 128)[sub];
-      vv[i] = reinterpret_cast<const u32x4*>(vbase + (size_t)j * 128)[sub];
-    }
-  };
-  load_tile(kA, vA, 0);
-  if (ROWS < len) load_tile(kB, vB, ROWS);
-  float m[SG], l[SG], o[SG][8];
-#pragma unroll
-  for (int g = 0; g < SG; ++g) {
-    m[g] = -1e30f; l[g] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
-  }
-  auto score_tile = [&](const u32x4 (&kc)[4], const u32x4 (&vc)[4], int j0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = j0 + i * (ROWS / 4) + wave * 4 + grp;
-#pragma unroll
-      for (int g = 0; g < SG; ++g) {
-        if (!mem[g]) continue;                           // block-uniform
-        float s = dot8(qv[g], kc[i], 0.f);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 8, 64);
-        s *= a.scale;
-        if (j < len) {
-          const float mn = fmaxf(m[g], s);
-          const float corr = __expf(m[g] - mn);
-          const float p = __expf(s - mn);
-          l[g] = l[g] * corr + p;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[g][2 * e] = o[g][2 * e] * corr + p * pk_lo(vc[i][e]);
-            o[g][2 * e + 1] = o[g][2 * e + 1] * corr + p * pk_hi(vc[i][e]);
-          }
-          m[g] = mn;
-        }
-      }
-    }
-  };
-  for (int j0 = 0; j0 < len; j0 += 2 * ROWS) {
-    score_tile(kA, vA, j0);
-    if (j0 + 2 * ROWS < len) load_tile(kA, vA, j0 + 2 * ROWS);
-    if (j0 + ROWS < len) {
-      score_tile(kB, vB, j0 + ROWS);
-      if (j0 + 3 * ROWS < len) load_tile(kB, vB, j0 + 3 * ROWS);
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < SG; ++g) {
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float m2 = __shfl_xor(m[g], off, 64);
-      const float l2 = __shfl_xor(l[g], off, 64);
-      const float mn = fmaxf(m[g], m2);
-      const float c1 = __expf(m[g] - mn), c2 = __expf(m2 - mn);
-      l[g] = l[g] * c1 + l2 * c2;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float o2 = __shfl_xor(o[g][e], off, 64);
-        o[g][e] = o[g][e] * c1 + o2 * c2;
-      }
-      m[g] = mn;
-    }
-  }
-  __shared__ float sm_m[SG][WAVES][16], sm_l[SG][WAVES][16], sm_o[SG][WAVES][16][8];
-  if (grp == 0) {
-#pragma unroll
-    for (int g = 0; g < SG; ++g) {
-      sm_m[g][wave][sub] = m[g];
-      sm_l[g][wave][sub] = l[g];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sm_o[g][wave][sub][e] = o[g][e];
-    }
-  }
-  __syncthreads();
-  if (tid < 16 * SG) {
-    const int g = tid >> 4, t16 = tid & 15;
-    if (mem[g]) {
-      float M = sm_m[g][0][t16];
-#pragma unroll
-      for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[g][w][t16]);
-      float L = 0.f;
-      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        const float c = __expf(sm_m[g][w][t16] - M);
-        L += c * sm_l[g][w][t16];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o0[e] += c * sm_o[g][w][t16][e]; o1[e] += c * sm_o[g][w][t16][4 + e]; }
-      }
-      const size_t rec = (size_t)(s0 + g) * a.H + h;     // pfx_splits == 1 in this mode
-      if (t16 == 0) { a.pfx_m[rec] = M; a.pfx_l[rec] = L; }
-      f32x4* po4 = reinterpret_cast<f32x4*>(a.pfx_o + rec * 128 + t16 * 8);
-      po4[0] = o0; po4[1] = o1;
-    }
-  }
-}
-
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
-    if (a.use_prefix == 2) hipLaunchKernelGGL(k_attn_share_b, dim3(a.H, (a.nslots + ATTN_SG - 1) / ATTN_SG), dim3(256), 0, s, a);   // (G == 1, pfx_splits == 1: dtk_api.hip)
-    else if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
+    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
     if (a.G == 4 && a.gqa_fused == 2) {   // pairs of query heads: half the sharing, twice the blocks
       hipLaunchKernelGGL((k_attn_tail_b<256, 2>), dim3(a.H / 2, a.nslots), dim3(256), 0, s, a);

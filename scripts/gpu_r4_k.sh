@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
-# round 4, lease K: group-shared attention (k_attn_share_b, option attn_share): the identity / tolerance test, then the 64-slot step with
+# round 4, lease K (the kernel it measured lost and was removed in the next commit: `git show 985e8bf -- detikzify_amd/csrc/kernels_batch_decode.hip`;
+# profiles/r04_attn_share_experiment.txt): group-shared attention (k_attn_share_b, option attn_share): the identity / tolerance test, then the 64-slot step with
 # the option off / on — at the image-prefix context (32 steps) and over 256 steps of growing private contexts — ds-7b bf16 and cl-7b fp8.
 set -uo pipefail
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export PYTHONUNBUFFERED=1

@@ -1070,52 +1070,6 @@ def test_shared_prefix_on_matrix_cores_tracks_the_per_slot_path(family, tiny_bat
             model.set_option(k, v)
 
 
-def test_group_shared_attention_tracks_the_per_slot_path(tiny_batched):
-    """Batched attention with `attn_share` on (MHA models): the rows that the slots of a group of 4 consecutive slots read from the
-    same source slot (forks of one image) are scored once per head by k_attn_share_b — K / V tiles loaded once for up to 4 queries —
-    and k_attn_tail_b continues from that state over each slot's own rows (csrc/kernels_batch_decode.hip: share_group_len).  Against
-    the per-slot walk: the same greedy tokens, logits within 1e-2 (fp32 summation order: the shared rows are merged as one state
-    instead of tile by tile); the source slot itself and a slot of another image are not members and must be bit-identical.
-    Covered: shares of different lengths inside a group (the group shares the shortest), a shared part that is not a multiple of the
-    64-key tile, a member whose own rows continue past the share in the source's cache and one with a private tail."""
-    model, proc = tiny_batched
-    img_tok = model.config.image_token_id
-    (ids, px), (ids_b, px_b), _ = _batch_prompts(proc)
-    tail = torch.tensor([70, 300, 41] + [9] * 70 + [33, 12])
-    long_ids = torch.cat([ids, tail])
-
-    def run(share_on, threads=256, steps=14):
-        model.set_option("attn_share", share_on)
-        model.set_option("tail_threads", threads)
-        for s_ in range(5):
-            model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=s_)
-        model.prefill(long_ids, px, slot=0)                                   # the source: decodes too (not a member: it shares from nobody)
-        for dst in (1, 2):
-            model.kv_fork(0, dst, long_ids.numel())
-        model.kv_fork(0, 3, ids.numel() + 20)                                 # shorter share, then its own tail
-        model.prefill(torch.cat([long_ids[:ids.numel() + 20], torch.tensor([15, 6, 7])]), px, slot=3, reuse=True)
-        model.prefill(ids_b, px_b, slot=4)                                    # another image, another group
-        toks = []
-        for _ in range(steps):
-            model.decode_batch_launch([0, 1, 2, 3, 4])
-            toks.append(model.decode_batch_wait()[:5])
-        return toks, [model.get_logits_slot(s_) for s_ in range(5)]
-
-    try:
-        ref_t, ref_l = run(0)
-        for kw in (dict(), dict(threads=512), dict(threads=128)):
-            t, lg = run(1, **kw)
-            assert t == ref_t, kw
-            worst = max(rel_l2(lg[s_], ref_l[s_]) for s_ in range(5))
-            assert worst < 1e-2, (kw, worst)
-            if not kw:
-                assert torch.equal(lg[0], ref_l[0]) and torch.equal(lg[4], ref_l[4]), "the source slot and the other image's slot are not members"
-                assert not all(torch.equal(lg[s_], ref_l[s_]) for s_ in (1, 2, 3)), "the share kernel did not run for the members"
-    finally:
-        model.set_option("attn_share", 0)
-        model.set_option("tail_threads", 256)
-
-
 def test_simulate_parallel_trees(tiny_batched):
     from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
     from detikzify_amd.infer.batching import simulate_parallel
