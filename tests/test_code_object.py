@@ -107,3 +107,33 @@ def test_no_instruction_touches_a_hand_loaded_register_before_its_wait(tmp_path)
         violations, stats = ch.check_kernel(name, insts)
         assert stats["hand_loads"] >= 32 and stats["vmcnt_waits"] >= 32, (name, stats)
         assert not violations, (name, violations[:4])
+
+
+@pytest.mark.skipif(not (LLVM / "clang-offload-bundler").exists(), reason="needs the ROCm LLVM tools")
+def test_fp8_matrix_core_kernels_issue_the_scaled_fp8_mfma_and_nothing_spills(tmp_path):
+    """BASELINE config 5 names "CDNA4 fp8 MFMA": the shipped code object of csrc/kernels_batch_mx.hip, instantiation by instantiation —
+    every k_gemv_mxu / k_gemv_mxk issues v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 x fp8 on the matrix cores, E8M0 block scales) and not a
+    single fp8 -> bf16 widening or bf16 MFMA (what the round-1..3 fp8 kernels spent their instruction stream on), no instantiation has
+    scratch or spilled registers (the five-wave / four-tile RoPE instantiation that would is not built), and a unit kernel's block
+    stays within one wave per SIMD's worth of registers where it has four waves."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_hand_loads as ch
+    obj = ROOT / "build" / "kernels_batch_mx.o"
+    if not obj.exists():
+        subprocess.run(["bash", str(ROOT / "build.sh")], check=True, capture_output=True, cwd=str(ROOT))
+    meta = {k: v for k, v in _kernel_metadata(obj, tmp_path).items() if "k_gemv_mx" in k}
+    assert len(meta) >= 60, len(meta)                      # 3 roles x waves x tiles of the unit kernel + the K-slice kernel's shapes
+    for name, m in meta.items():
+        assert m.get("private_segment_fixed_size") == 0 and m.get("vgpr_spill_count") == 0 and m.get("sgpr_spill_count") == 0, (name, m)
+    assert not any(re.search(r"k_gemv_mxuILi2ELi4ELi4E", k) for k in meta), "q/k/v with five waves at four tiles spills: not to be built"
+    dis = ch.disassemble(obj, tmp_path)
+    for prefix in ("k_gemv_mxu", "k_gemv_mxk"):
+        kernels = ch.kernels_of(dis, prefix)
+        assert kernels
+        for name, insts in kernels.items():
+            mn = [i[1] for i in insts]
+            scaled = sum(1 for x in mn if x.startswith("v_mfma_scale_f32_16x16x128_f8f6f4"))
+            other_mfma = sum(1 for x in mn if x.startswith("v_mfma") and not x.startswith("v_mfma_scale_f32_16x16x128_f8f6f4"))
+            widen = sum(1 for x in mn if x.startswith("v_cvt_scalef32_pk_bf16_fp8") or x.startswith("v_cvt_pk_f32_fp8"))
+            assert scaled >= 4 and other_mfma == 0 and widen == 0, (name, scaled, other_mfma, widen)
