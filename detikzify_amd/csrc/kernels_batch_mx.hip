@@ -7,7 +7,7 @@
 // quarter of the MFMA issues) and the slots' input vectors are MXFP8: e4m3 values with one power-of-two scale (E8M0) per group of
 // consecutive k of one slot, produced by the kernels that produce the vectors anyway:
 //   * RMSNorm output (input of q/k/v, gate/up, lm_head) and attention output (input of o_proj): groups of 32 — the block-scale
-//     granule of the instruction (a lane's 32 operand bytes share one scale);
+//     granule of the instruction;
 //   * SwiGLU output (input of down): groups of 16 = the rows of one MFMA row tile, which is what a wave of the gate/up kernel
 //     owns; down issues two instructions per 128 k, each with half of its weight lanes zeroed, so that a scale block of the
 //     instruction (32 operand bytes across two lane groups) carries one 16-group (64 real k per MFMA).
