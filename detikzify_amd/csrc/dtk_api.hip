@@ -2109,6 +2109,16 @@ int dtk_op_gemv_mv(dtk_ctx* c, const uint16_t* W, const uint16_t* X, const uint1
   return DTK_OK;
 }
 
+// Where value k of slot `slot` and the E8M0 scale of its group live in the MXFP8 buffers (csrc/mx_quant.h): pure host arithmetic (no
+// GPU, no context) — tests/test_mx_layout.py checks on the CPU that this fragment order is the inverse of the operand map the
+// instruction was measured to have.
+int dtk_mx_layout(int G, int slot, int k, int64_t* data_off, int64_t* scale_off) {
+  if ((G != 32 && G != 16) || slot < 0 || slot >= DTK_MAX_BATCH || k < 0 || !data_off || !scale_off) return DTK_ERR_ARG;
+  *data_off = (int64_t)(G == 32 ? mx32_off(slot, k) : mx16_off(slot, k));
+  *scale_off = (int64_t)(G == 32 ? mx32_soff(slot, k) : mx16_soff(slot, k));
+  return DTK_OK;
+}
+
 // The fp8 matrix-core GEMVs of kernels_batch_mx.hip on host buffers.  W8 [N][K] e4m3 bytes + wscale [N]; X [nslots][K] bf16 rows,
 // quantised to MXFP8 (groups of G = 32 | 16) by the step's own quantiser; nslots = 16 | 32 | 64 (1 / 2 / 4 slot tiles).
 //   mode 0: unit kernel, logits epilogue (G = 32): Y [nslots][N] = bf16-rounded acc * wscale

@@ -29,17 +29,17 @@ __device__ __forceinline__ float mx_inv(int e) { return __uint_as_float((unsigne
 //           lane groups g with (g & 1) == s carry weights (the kernel zeroes the others' weight operand), so block q = (k >> 4) & 3 of
 //           that instruction holds the 16 values of ONE group: half h = q >> 1, lane group g = 2 * (q & 1) + s.  Scale byte of
 //           (ps, s): dword row ps >> 1, byte (ps & 1) * 2 + s = (k >> 6) & 3, lane q * 16 + slot % 16.
-__device__ __forceinline__ size_t mx32_off(int slot, int k) {
+__host__ __device__ __forceinline__ size_t mx32_off(int slot, int k) {
   return ((size_t)((k >> 7) * 4 + (slot >> 4)) * 2 + ((k >> 6) & 1)) * 1024 + (size_t)((((k >> 4) & 3) * 16 + (slot & 15)) * 16 + (k & 15));
 }
-__device__ __forceinline__ size_t mx32_soff(int slot, int k) {
+__host__ __device__ __forceinline__ size_t mx32_soff(int slot, int k) {
   return (((size_t)(k >> 9) * 4 + (slot >> 4)) * 64 + ((k >> 5) & 3) * 16 + (slot & 15)) * 4 + ((k >> 7) & 3);
 }
-__device__ __forceinline__ size_t mx16_off(int slot, int k) {
+__host__ __device__ __forceinline__ size_t mx16_off(int slot, int k) {
   const int q = (k >> 4) & 3, s = (k >> 6) & 1;
   return ((size_t)((k >> 7) * 4 + (slot >> 4)) * 2 + (q >> 1)) * 1024 + (size_t)(((2 * (q & 1) + s) * 16 + (slot & 15)) * 16 + (k & 15));
 }
-__device__ __forceinline__ size_t mx16_soff(int slot, int k) {
+__host__ __device__ __forceinline__ size_t mx16_soff(int slot, int k) {
   return (((size_t)(k >> 8) * 4 + (slot >> 4)) * 64 + ((k >> 4) & 3) * 16 + (slot & 15)) * 4 + ((k >> 6) & 3);
 }
 

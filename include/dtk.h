@@ -26,7 +26,7 @@ extern "C" {
 
 #define DTK_ABI_VERSION 5   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
                              * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels);
-                             * 5: dtk_op_gemv_mx, dtk_stats.last_batch_step_fp8_mfma */
+                             * 5: dtk_op_gemv_mx, dtk_mx_layout, dtk_stats.last_batch_step_fp8_mfma */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -292,6 +292,8 @@ int  dtk_op_gemv_mv(dtk_ctx* ctx, const uint16_t* W, const uint16_t* X, const ui
  * Y [nslots][N] = bf16-rounded sums; mode 1: the K-slice kernel of the N = d roles: Y = the 8 slice partials added in order (fp32);
  * mode 2: unit kernel with the SwiGLU epilogue (N = 2 ff): y8_out / ys_out = the activation as MXFP8 groups of 16 (64 ff bytes /
  * ceil(ff / 256) KiB).  x8_out (64 K bytes) / xs_out (ceil(K / (16 G)) KiB), optional: the quantised input in the kernels' order. */
+/* byte offsets of value k of `slot` and of its group's E8M0 scale in the MXFP8 activation buffers (G = 32 | 16); host arithmetic only */
+int  dtk_mx_layout(int G, int slot, int k, int64_t* data_off, int64_t* scale_off);
 int  dtk_op_gemv_mx(dtk_ctx* ctx, const uint8_t* W8, const float* wscale, const uint16_t* X, int N, int K, int G, int nslots, int mode,
                     float* Y, uint8_t* x8_out, uint8_t* xs_out, uint8_t* y8_out, uint8_t* ys_out);
 /* softmax(Q K^T * scale [+ causal mask with q_offset]) V, heads-major [H][T][hd] bf16 */
