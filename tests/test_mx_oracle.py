@@ -53,3 +53,49 @@ def test_act_quant_touches_exactly_the_linear_inputs():
     quant = o.logits(o.forward(x)[-1])
     rel = float((quant - plain).norm() / plain.norm())
     assert 1e-3 < rel < 0.2, rel          # e4m3 activations: a few per cent on one layer, not bf16's 1e-3 and not garbage
+
+
+def test_two_correct_pipelines_decorrelate_to_the_quantisation_noise():
+    """Why the GPU tests of the fp8 matrix-core step assert an ENVELOPE and not closeness to the quantising oracle: a quantiser is a
+    discontinuous map.  The oracle against ITSELF with every Linear's fp32 sums perturbed by 1.5e-5 relative — the accumulation precision
+    the scaled MFMA was measured to have (tests/test_gpu_parity_mx.py: rel-L2 1.45e-5 against float64 at every shape) — on a two-layer
+    model: with bf16 activations the logits move by ~1e-2, with MXFP8 activations by several 1e-2 (the device sits 7.6e-2 from the
+    quantising oracle at the cl-7b width, 8.7e-3 with bf16 activations: the same two numbers).  No device is involved here."""
+    import oracle.llama as L
+    d, ff, V, layers = 1024, 2048, 512, 2
+    cfg = dict(hidden=d, layers=layers, heads=d // 128, head_dim=128, kv_heads=d // 128, rms_eps=1e-6, rope_theta=10000.0, rope_factor=1.0, max_positions=64, vocab=V)
+    g = torch.Generator().manual_seed(1)
+    w = {"model.embed_tokens.weight": rb(torch.randn(V, d, generator=g)), "model.norm.weight": rb(1 + 0.1 * torch.randn(d, generator=g)),
+         "lm_head.weight": rb(torch.randn(V, d, generator=g) * 0.05)}
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        for n, shape in (("self_attn.q_proj", (d, d)), ("self_attn.k_proj", (d, d)), ("self_attn.v_proj", (d, d)), ("self_attn.o_proj", (d, d)),
+                         ("mlp.gate_proj", (ff, d)), ("mlp.up_proj", (ff, d)), ("mlp.down_proj", (d, ff))):
+            w[p + n + ".weight"] = rb(torch.randn(*shape, generator=g) * 0.05)
+        w[p + "input_layernorm.weight"] = rb(1 + 0.1 * torch.randn(d, generator=g))
+        w[p + "post_attention_layernorm.weight"] = rb(1 + 0.1 * torch.randn(d, generator=g))
+    ids = torch.tensor([3, 9, 11, 40, 77, 5, 6, 100])
+
+    def run(quant, eps):
+        noise = torch.Generator().manual_seed(7)
+        plain = L.linear
+
+        def perturbed(x, wt, b=None, precision="bf16"):
+            y = x @ wt.t()
+            return rb(y * (1 + eps * torch.randn(y.shape, generator=noise)), precision)
+        L.linear = perturbed if eps else plain
+        try:
+            o = LlamaOracle(cfg, w, "bf16")
+            o.forward(o.embed(ids[:4]))                      # prompt: bf16 activations on both sides, as on the device
+            o.act_quant = quant
+            return torch.stack([o.logits(o.forward(o.embed(t.reshape(1)))[-1]) for t in ids[4:]])
+        finally:
+            L.linear = plain
+
+    dist = {}
+    for quant in (False, True):
+        a, b = run(quant, 0.0), run(quant, 1.5e-5)
+        dist[quant] = float((a - b).norm() / a.norm())
+    assert 2e-3 < dist[False] < 3e-2, dist            # bf16 activations: the 1e-2 two bf16 pipelines sit apart (DESIGN.md 5)
+    assert 2e-2 < dist[True] < 0.25, dist             # MXFP8 activations: the quantisation noise itself
+    assert dist[True] > 3 * dist[False], dist
