@@ -462,7 +462,9 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
         if (reg) { c->layers[i].t8_wqkv = a1; c->layers[i].t8_wo = a2; c->layers[i].t8_wgu = a3; c->layers[i].t8_wdown = a4; }
       }
       c->t8_lm_head = P.take<uint8_t>(tiled_bytes_f8(V, d));
-      c->mx_ok = mx_unit_covers(d) && mx_kparts_covers(d, d, 32) && mx_kparts_covers(d, ff, 16) && (ff % 64) == 0 && (qkvn % 32) == 0;
+      // (MHA models only: the MXFP8 epilogue of the GQA-fused attention instantiations has not run on hardware yet — a v2 model with fp8
+      // weights keeps the bf16-activation kernels)
+      c->mx_ok = c->KVH == c->H && mx_unit_covers(d) && mx_kparts_covers(d, d, 32) && mx_kparts_covers(d, ff, 16) && (ff % 64) == 0 && (qkvn % 32) == 0;
       if (c->mx_ok) {               // + one more fp8 copy in MX tile order, the slots' MXFP8 vectors and their scales
         for (int i = 0; i < L; ++i) {
           uint8_t* a1 = P.take<uint8_t>(mx_w_bytes(qkvn, d, 32));
