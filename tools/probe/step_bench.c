@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
            (long long)tok[0], st.last_batch_step_fp8_mfma, st.device_errors);
     /* back to the defaults for the next variant */
     strncpy(buf, opts, sizeof buf - 1);
-    for (char* t2 = strtok(buf, ","); t2; t2 = strtok(NULL, ",")) { char* eq = strchr(t2, '='); if (eq) { *eq = 0; CHECK(dtk_set_option(ctx, t2, !strcmp(t2, "act_fp8") ? 1 : 0)); } }
+    for (char* t2 = strtok(buf, ","); t2; t2 = strtok(NULL, ",")) { char* eq = strchr(t2, '='); if (eq) { *eq = 0; CHECK(dtk_set_option(ctx, t2, !strcmp(t2, "act_fp8") ? 1 : (!strcmp(t2, "mx_ring") ? 3 : 0))); } }
   }
   dtk_destroy(ctx);
   return 0;
