@@ -17,23 +17,27 @@ int main(int argc, char** argv) {
   dtk_ctx* ctx = NULL;
   dtk_config cfg;
   memset(&cfg, 0, sizeof cfg);
-  const int layers = getenv("STEP_BENCH_LAYERS") ? atoi(getenv("STEP_BENCH_LAYERS")) : 32, steps = 48, T = 243;
-  cfg.hidden = 4096; cfg.layers = layers; cfg.heads = 32; cfg.head_dim = 128; cfg.ffn = 11008; cfg.vocab = 32024; cfg.max_positions = 512;
-  cfg.rms_eps = 1e-6f; cfg.rope_theta = 10000.f; cfg.rope_factor = 1.f;
+  /* STEP_BENCH_MODEL = cl-7b-fp8 (default) | ds-7b (bf16) | ds-1.3b (bf16): the presets of detikzify_amd/model/config.py */
+  const char* model = getenv("STEP_BENCH_MODEL") ? getenv("STEP_BENCH_MODEL") : "cl-7b-fp8";
+  const int small = !strcmp(model, "ds-1.3b"), fp8 = !strcmp(model, "cl-7b-fp8");
+  const int layers = getenv("STEP_BENCH_LAYERS") ? atoi(getenv("STEP_BENCH_LAYERS")) : (small ? 24 : 32), steps = 48, T = 243;
+  cfg.hidden = small ? 2048 : 4096; cfg.layers = layers; cfg.heads = small ? 16 : 32; cfg.head_dim = 128; cfg.ffn = small ? 5504 : 11008;
+  cfg.vocab = fp8 ? 32024 : 32256; cfg.max_positions = 512;
+  cfg.rms_eps = fp8 ? 1e-5f : 1e-6f; cfg.rope_theta = fp8 ? 1000000.f : 100000.f; cfg.rope_factor = fp8 ? 1.f : 4.f;
   cfg.vit_dim = 1152; cfg.vit_depth = 1; cfg.vit_heads = 16; cfg.vit_mlp = 4304; cfg.vit_patch = 14; cfg.vit_image = 384;
   cfg.vit_feature_layer = 0; cfg.vit_ln_eps = 1e-6f; cfg.concat_patches = 3; cfg.image_token_id = 1;
-  cfg.reserved[0] = 65; cfg.reserved[1] = 1;
+  cfg.reserved[0] = 65; cfg.reserved[1] = fp8;
   double t0 = now();
   if (dtk_create(&cfg, 0, &ctx) != DTK_OK) { fprintf(stderr, "dtk_create: %s\n", dtk_last_error(NULL)); return 1; }
   CHECK(dtk_fill_synthetic(ctx, 1234));
   CHECK(dtk_synchronize(ctx));
-  printf("context + synthetic weights (%d layers): %.1f s\n", layers, now() - t0);
+  printf("%s, %d layers: context + synthetic weights %.1f s\n", model, layers, now() - t0);
   dtk_sampling greedy;
   memset(&greedy, 0, sizeof greedy);
   greedy.temperature = 1.f; greedy.top_p = 1.f;
   static int64_t ids[512];
   for (int t = 0; t < T; ++t) ids[t] = 3 + (int64_t)((t * 7919 + 13) % 30000);
-  static float logits[32024];
+  static float logits[32256];
   for (int v = 1; v < (argc > 1 ? argc : 2); ++v) {
     const char* opts = argc > 1 ? argv[v] : "";
     char buf[256];
@@ -62,7 +66,7 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 3; ++w) {
       CHECK(dtk_get_logits_slot(ctx, watch[w], logits));
       const unsigned char* p = (const unsigned char*)logits;
-      for (size_t i = 0; i < sizeof logits; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+      for (size_t i = 0; i < (size_t)cfg.vocab * sizeof(float); ++i) { h ^= p[i]; h *= 1099511628211ull; }
     }
     dtk_stats st;
     CHECK(dtk_get_stats(ctx, &st));
