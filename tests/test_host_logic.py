@@ -766,3 +766,23 @@ def test_concurrent_pooled_calls_are_combined_and_every_caller_gets_its_own_row(
     assert all(torch.equal(got2[i], torch.full((1, 4), 2.0 * i)) for i in range(12) if i not in errs2)
     assert torch.equal(vm.pooled_only(imgs[3]), torch.full((1, 4), 6.0))     # and the model still answers afterwards
     assert vm.pooled_only(torch.cat(imgs[:3])).shape == (3, 4)                # an explicit batch goes straight through
+
+
+def test_the_c_programs_compile_against_the_header_as_plain_c(tmp_path):
+    """include/dtk.h is a C header (the boundary a cgo / JNI / N-API binding would consume): the two C programs of the repo — the C ABI
+    smoke of examples/ and the Python-free step benchmark — compile with gcc as C99 with warnings as errors and link against the
+    in-tree library (no GPU needed to build; run on a box without one they fail loudly at dtk_create)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not (ROOT / "detikzify_amd" / "lib" / "libdtk_hip.so").exists():
+        pytest.skip("needs gcc and the built library")
+    for src in ("examples/c_abi_smoke.c", "tools/probe/step_bench.c"):
+        exe = tmp_path / Path(src).stem
+        r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / src), "-o", str(exe),
+                            f"-L{ROOT / 'detikzify_amd' / 'lib'}", "-ldtk_hip", f"-Wl,-rpath,{ROOT / 'detikzify_amd' / 'lib'}"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        import torch
+        if not torch.cuda.is_available():
+            run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+            assert run.returncode != 0 and "no HIP device" in (run.stderr + run.stdout), (run.returncode, run.stderr)
