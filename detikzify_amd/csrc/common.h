@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -12,6 +13,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define DTK_WAVE 64
+
+// Raising a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of the function, so the
+// "already done" mark of a launcher is a bit per device, not a process-wide bool: a second dtk_ctx on another GPU of the same process
+// sets it again.  A refused attribute is reported once on stderr and remembered (dtk_lds_attr_failed: the step launchers fail on it).
+static inline bool dtk_lds_attr_todo(unsigned long long& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown device: set it every time
+  const unsigned long long bit = 1ull << dev;
+  if (done & bit) return false;
+  done |= bit;
+  return true;
+}
+int& dtk_lds_attr_error();                                                          // dtk_api.hip: first hipError_t a launcher's attribute call returned (0 = none)
+static inline void dtk_lds_attr(hipError_t e, const char* file, int line) {
+  if (e == hipSuccess) return;
+  if (!dtk_lds_attr_error()) fprintf(stderr, "libdtk_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed at %s:%d: %s\n", file, line, hipGetErrorString(e));
+  dtk_lds_attr_error() = (int)e;
+}
+#define DTK_LDS_ATTR(call) dtk_lds_attr((call), __FILE__, __LINE__)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // fp32 -> bf16, round-to-nearest-even (v_cvt_pk_bf16_f32), same as torch .to(bfloat16)

@@ -22,6 +22,8 @@
 #include "kernels.h"
 #include "mx_quant.h"
 
+int& dtk_lds_attr_error() { static int e = 0; return e; }     // common.h: set by a launcher whose hipFuncSetAttribute was refused
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -150,7 +152,11 @@ struct dtk_ctx {
   uint8_t* m_lm_head = nullptr;
   uint8_t *xn8 = nullptr, *xns = nullptr, *ao8 = nullptr, *aos = nullptr, *act8 = nullptr, *acts = nullptr;
   bool mx_ok = false;
-  int act_fp8 = 1;
+  // act_fp8: 0 (default since round 5) = bf16 activations (fp8 weights widened in registers, bf16 MFMA: rounds 1-3); 1 = opt-in.  MXFP8
+  // activations keep 3 mantissa bits: logits move ~1e-1 rel-L2 from the bf16-activation result (tests/test_gpu_parity_mx.py,
+  // test_mxfp8_activations_against_bf16_activations), so the faster step is the caller's choice, not the library's.
+  int act_fp8 = 0;
+  bool launch_refused = false;       // a launcher of the step being issued had no kernel for its shape (nothing was launched for that role)
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
   SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_SLOTS]: per-slot set_sampling uploads queued on the stream
@@ -671,12 +677,12 @@ void batch_step_launches_mx(dtk_ctx* c) {
     ad.out8 = c->ao8; ad.outs = c->aos;
     launch_attn_decode_b(ad, s);
     g.Wm = w.m_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X8 = c->ao8; g.XS = c->aos;
-    launch_gemv_mxk(g, 32, s);
+    if (!launch_gemv_mxk(g, 32, s)) c->launch_refused = true;
     launch_resid_norm_b(c->kpart, c->xb, d, w.ln2, c->xnb, d, c->cfg.rms_eps, c->bs_dev, nslots, s, c->xn8, c->xns);
     g.Wm = w.m_wgu; g.wscale = w.s_wgu; g.N = 2 * ff; g.K = d; g.X8 = c->xn8; g.XS = c->xns; g.Y8 = c->act8; g.YS = c->acts;
     launch_gemv_mxu(EPI_SWIGLU, g, s);
     g.Wm = w.m_wdown; g.wscale = w.s_wdown; g.N = d; g.K = ff; g.X8 = c->act8; g.XS = c->acts;
-    launch_gemv_mxk(g, 16, s);
+    if (!launch_gemv_mxk(g, 16, s)) c->launch_refused = true;
     launch_resid_norm_b(c->kpart, c->xb, d, l + 1 < c->L ? c->layers[l + 1].ln1 : c->final_norm, c->xnb, d, c->cfg.rms_eps, c->bs_dev, nslots, s, c->xn8, c->xns);
   }
   GemvBArgs g{};
@@ -871,10 +877,16 @@ int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step / c->mv_step
   const int gi = step_graph_index(c);
   if (c->bgraph_ready[gi]) return DTK_OK;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->launch_refused = false;
   if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
   HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph[gi]));
+  if (c->launch_refused || dtk_lds_attr_error()) {       // an incomplete step must never be replayed
+    (void)hipGraphDestroy(c->bgraph[gi]); c->bgraph[gi] = nullptr;
+    return fail(c, DTK_ERR_STATE, c->launch_refused ? "batched step: a projection's shape has no kernel in its family (nothing launched for it)"
+                                                    : "batched step: raising a kernel's dynamic-LDS limit failed (hipFuncSetAttribute, see stderr)");
+  }
   HIPCHK(c, hipGraphInstantiate(&c->bgraph_exec[gi], c->bgraph[gi], nullptr, nullptr, 0));
   c->bgraph_ready[gi] = true;
   return DTK_OK;
@@ -1476,7 +1488,11 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     if (rc) return rc;
     HIPCHK(c, hipGraphLaunch(c->bgraph_exec[step_graph_index(c)], c->stream));
   } else {
+    c->launch_refused = false;
     if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
+    if (c->launch_refused || dtk_lds_attr_error())
+      return fail(c, DTK_ERR_STATE, c->launch_refused ? "batched step: a projection's shape has no kernel in its family (nothing launched for it)"
+                                                      : "batched step: raising a kernel's dynamic-LDS limit failed (hipFuncSetAttribute, see stderr)");
     HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipEventRecord(c->bstep_done[c->blaunched % DTK_MAX_INFLIGHT], c->stream));
@@ -1544,7 +1560,7 @@ int dtk_decode_batch_run(dtk_ctx* c, const int32_t* active, int max_steps, const
   for (int j = 0; j < DTK_MAX_BATCH; ++j) {
     remaining[j] = 1 << 30;
     if (!active[j]) continue;
-    if (j >= c->nb) return fail(c, DTK_ERR_ARG, "slot %d of %d", j, c->nb);
+    if (j >= max_decode_slots(c)) return fail(c, DTK_ERR_ARG, "dtk_decode_batch_run: slot %d of %d decoding slots", j, max_decode_slots(c));
     int b = budget ? budget[j] : (1 << 30);
     const int room = c->Tmax - (c->bseq[(size_t)j].host_next_pos - (int)(c->blaunched - c->bwaited));   // tokens the cache still takes, before the step in flight
     if (room < b) b = room;
@@ -1559,13 +1575,21 @@ int dtk_decode_batch_run(dtk_ctx* c, const int32_t* active, int max_steps, const
     // does) — unless that step would take some slot past its budget
     while (launched < collected + 2 && launched <= max_steps && launched < min_budget) {
       const int rc = dtk_decode_batch_launch(c, active);
-      if (rc) return rc;
+      if (rc) {        // the caller must still learn what the run produced before the failure: rows [0, collected) of tokens_out are valid
+        *steps_out = collected;
+        if (inflight_out) *inflight_out = launched > collected ? 1 : 0;
+        return rc;
+      }
       ++launched;
     }
     if (collected >= launched) break;
     int64_t* out = tokens_out + (size_t)collected * DTK_MAX_BATCH;
     const int rc = dtk_decode_batch_wait(c, out);
-    if (rc) return rc;
+    if (rc) {
+      *steps_out = collected;
+      if (inflight_out) *inflight_out = (c->blaunched > c->bwaited) ? 1 : 0;
+      return rc;
+    }
     ++collected;
     for (int j = 0; j < DTK_MAX_BATCH && !done; ++j) {
       if (!active[j]) continue;
@@ -1956,6 +1980,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   }
   else if (!strcmp(name, "mv_tail_threads")) {
     if (value != 256 && value != 512 && value != 1024) return fail(c, DTK_ERR_ARG, "mv_tail_threads must be 256, 512 or 1024");
+    // GQA models run the group-fused blocks of k_attn_tail_b, which exist for fewer block sizes (launch_attn_decode_b): a value without
+    // an instantiation used to be accepted and silently ignored
+    const int grp = c->KVH > 0 ? c->H / c->KVH : 1;
+    if (grp == 4 && value == 1024) return fail(c, DTK_ERR_ARG, "mv_tail_threads: GQA groups of 4 have blocks of 256 or 512 threads");
+    if (grp == 2 && value != 256) return fail(c, DTK_ERR_ARG, "mv_tail_threads: GQA groups of 2 have blocks of 256 threads only");
     c->mv_tail_threads = value;
     drop_batch_graphs(c);
   }
@@ -2160,7 +2189,7 @@ int dtk_op_gemv_mx(dtk_ctx* c, const uint8_t* W8, const float* wscale, const uin
   g.d = K; g.ff = ff; g.H = 1; g.KVH = 1; g.Y8 = dY8; g.YS = dYS;
   if (mode == 0) launch_gemv_mxu(EPI_LOGITS, g, s);
   else if (mode == 2) launch_gemv_mxu(EPI_SWIGLU, g, s);
-  else launch_gemv_mxk(g, G, s);
+  else if (!launch_gemv_mxk(g, G, s)) return fail(c, DTK_ERR_ARG, "dtk_op_gemv_mx: no K-slice kernel for N %d K %d G %d", N, K, G);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(s));
   if (mode == 0) HIPCHK(c, hipMemcpy(Y, dY, (size_t)nslots * N * 4, hipMemcpyDeviceToHost));

@@ -150,7 +150,7 @@ void launch_quant_mx_rows(const bf16_t* X, int K, uint8_t* X8, uint8_t* XS, int 
 bool mx_unit_covers(int K);                                   // q/k/v, gate/up, lm_head: K a multiple of 512
 bool mx_kparts_covers(int N, int K, int G);                   // o_proj (G = 32), down (G = 16)
 void launch_gemv_mxu(int epi, const GemvBArgs& a, hipStream_t s);
-void launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s);
+bool launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s);
 void set_mx_nc(int role, int nc);                             // compute waves per block of the unit kernel: role 0 qkv, 1 gate/up, 2 lm_head; 0 = from the CU count
 struct AttnDecBArgs {
   const bf16_t* q;                     // [16][d]

@@ -571,11 +571,10 @@ static int gemv_xw() {                           // 0: x by LDS-DMA, 1 / 2: that
 template <int EPI, int NC, int CHP4, int XW>
 static void launch_bl_one_xw(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (4 * 4 * 1024) + 3 * (NC * 2 * 4 * 1024) + 4 * (NC + 3) + 12;        // (the fp8 kernel needs less; one size for both)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) {
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, false, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI, NC, CHP4, true, XW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
   constexpr int threads = (NC + 1 + XW) * 64;
@@ -600,11 +599,10 @@ static int gemv_loaders() {
 template <int CHP4, int XW, int LW, int R>
 static void launch_bl_q3_xw(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = R * (4 * 4 * 1024) + R * (3 * 4 * 1024) + 4 * (2 + LW + 2) + 12;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) {
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, false, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bl<EPI_QKV, 2, CHP4, true, XW, true, LW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   const int blocks = (a.H + a.KVH) * 4;
   constexpr int threads = (2 + LW + XW) * 64;
@@ -871,11 +869,10 @@ bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s) {
 template <int EPI, int UNITS, int CHP>
 static void launch_bx_one(const GemvBArgs& a, hipStream_t s) {
   constexpr int lds = 2 * 8 * 4 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) {
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bx<EPI, UNITS, CHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
   if (a.W8) hipLaunchKernelGGL((k_gemv_bx<EPI, UNITS, CHP, true>), dim3((groups + UNITS - 1) / UNITS), dim3((UNITS + 1) * 64), lds, s, a);
@@ -1066,14 +1063,14 @@ bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
   if ((a.N & 15) || (a.K & 31) || 7 * per >= nsteps) return false;
   constexpr int lds = 2 * 8 * 4 * 1024;
   if (ntiles == 256) {
-    static bool attr8 = false;
-    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    static unsigned long long attr8 = 0;
+    if (dtk_lds_attr_todo(attr8)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
     hipLaunchKernelGGL((k_gemv_bk<8>), dim3(256), dim3(9 * 64), lds, s, a);
     return true;
   }
   if (ntiles == 128) {
-    static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    static unsigned long long attr4 = 0;
+    if (dtk_lds_attr_todo(attr4)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
     hipLaunchKernelGGL((k_gemv_bk<4>), dim3(256), dim3(5 * 64), lds, s, a);
     return true;
   }
@@ -1382,19 +1379,19 @@ static bool launch_gemv_bkl(const GemvBArgs& a, hipStream_t s) {
   if (g_gemv_bkl < 0) { const char* e = getenv("DTK_GEMV_BKL"); g_gemv_bkl = e ? atoi(e) : 1; }   // default on: 64-slot step 4.35 -> 4.26 ms
   if (g_gemv_bkl <= 0) return false;
   const int xw = gemv_xw();
-#define BKL_ATTR(TPG_, XW_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-                                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); } while (0)
+#define BKL_ATTR(TPG_, XW_) do { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+                                 DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkl<TPG_, XW_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); } while (0)
 #define BKL_GO(TPG_, XW_) do { if (a.W8) hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_, true>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a); \
                                else hipLaunchKernelGGL((k_gemv_bkl<TPG_, XW_, false>), dim3(256), dim3((TPG_ + 1 + XW_) * 64), lds, s, a); } while (0)
   if (((a.N + 15) >> 4) == 256) {
     constexpr int lds = 3 * (16 + 8 * 4) * 1024 + 4 * 11 + 12;
-    static bool attr8 = false;
-    if (!attr8) { BKL_ATTR(8, 0); BKL_ATTR(8, 1); BKL_ATTR(8, 2); attr8 = true; }
+    static unsigned long long attr8 = 0;
+    if (dtk_lds_attr_todo(attr8)) { BKL_ATTR(8, 0); BKL_ATTR(8, 1); BKL_ATTR(8, 2); }
     if (xw == 2) BKL_GO(8, 2); else if (xw == 1) BKL_GO(8, 1); else BKL_GO(8, 0);
   } else {
     constexpr int lds = 3 * (16 + 4 * 4) * 1024 + 4 * 7 + 12;
-    static bool attr4 = false;
-    if (!attr4) { BKL_ATTR(4, 0); BKL_ATTR(4, 1); BKL_ATTR(4, 2); attr4 = true; }
+    static unsigned long long attr4 = 0;
+    if (dtk_lds_attr_todo(attr4)) { BKL_ATTR(4, 0); BKL_ATTR(4, 1); BKL_ATTR(4, 2); }
     if (xw == 2) BKL_GO(4, 2); else if (xw == 1) BKL_GO(4, 1); else BKL_GO(4, 0);
   }
 #undef BKL_GO
@@ -1421,12 +1418,12 @@ void launch_gemv_bkp(const GemvBArgs& a, hipStream_t s) {
   if (launch_gemv_bkl(a, s)) return;       // operands through LDS rings filled by a loader wave (option gemv_bkl)
   constexpr int lds = 2 * 8 * 4 * 1024;
   if (((a.N + 15) >> 4) == 256) {
-    static bool attr8 = false;
-    if (!attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr8 = true; }
+    static unsigned long long attr8 = 0;
+    if (dtk_lds_attr_todo(attr8)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
     hipLaunchKernelGGL((k_gemv_bkp<8>), dim3(256), dim3(9 * 64), lds, s, a);
   } else {
-    static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr4 = true; }
+    static unsigned long long attr4 = 0;
+    if (dtk_lds_attr_todo(attr4)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bkp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
     hipLaunchKernelGGL((k_gemv_bkp<4>), dim3(256), dim3(5 * 64), lds, s, a);
   }
 }
@@ -1502,10 +1499,9 @@ static void launch_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
   constexpr size_t staging = (size_t)(XA + 1) * KQ * SK * NT * 1024, reduction = (size_t)KQ * RP * T * NT * 1024;
   const size_t lds = staging > reduction ? staging : reduction;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (lds > 48 * 1024 && dtk_lds_attr_todo(attr_set)) {
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   hipLaunchKernelGGL((k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a);
 }
@@ -1547,7 +1543,7 @@ static bool launch_nt(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
 void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH);
 #define GMM(KQ, RP, SK, XA, M) do { const size_t lds = (size_t)(XA + 1) * KQ * SK * 4 * 1024; \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a); } while (0)
 #define GMS(KQ, RP, SK, XA) switch (mode) { case 1: GMM(KQ, RP, SK, XA, 1); break; case 2: GMM(KQ, RP, SK, XA, 2); break; case 4: GMM(KQ, RP, SK, XA, 4); break; \
     case 5: GMM(KQ, RP, SK, XA, 5); break; case 8: GMM(KQ, RP, SK, XA, 8); break; case 9: GMM(KQ, RP, SK, XA, 9); break; case 13: GMM(KQ, RP, SK, XA, 13); break; \

@@ -236,8 +236,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void k_gemv_mxu(GemvBArgs a) {
 template <int EPI, int NC, int NT>
 static void launch_mxu_one(const GemvBArgs& a, int units, hipStream_t s) {
   constexpr int lds = 3 * (4 * NT * 2048 + 1024);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_mxu<EPI, NC, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  static unsigned long long attr = 0;
+  if (dtk_lds_attr_todo(attr)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_mxu<EPI, NC, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   hipLaunchKernelGGL((k_gemv_mxu<EPI, NC, NT>), dim3((units + NC - 1) / NC), dim3((NC + 1) * 64), lds, s, a);
 }
 static int g_mx_nc[3] = {0, 0, 0};                                    // compute waves per block by role (qkv, gate/up, lm_head); 0 = from the CU count
@@ -356,8 +356,8 @@ template <int TPG, int NT, int G, int MAXL>
 static void launch_mxk_one(const GemvBArgs& a, hipStream_t s) {
   constexpr int SPQ = G == 32 ? 4 : 2;
   constexpr int lds = (MAXL * NT * 2 + (MAXL + SPQ - 1) / SPQ + 1) * 1024;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_mxk<TPG, NT, G, MAXL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  static unsigned long long attr = 0;
+  if (dtk_lds_attr_todo(attr)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_mxk<TPG, NT, G, MAXL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   const int ntiles = a.N >> 4;
   hipLaunchKernelGGL((k_gemv_mxk<TPG, NT, G, MAXL>), dim3((ntiles / TPG) * 8), dim3(TPG * 64), lds, s, a);
 }
@@ -383,7 +383,7 @@ bool mx_kparts_covers(int N, int K, int G) {
   const int D8 = N >> 3;
   return D8 == 256 || D8 == 512 || D8 == 1024;
 }
-void launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s) {      // a.Wm, a.X8, a.XS, a.kpart, a.wscale
+bool launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s) {      // a.Wm, a.X8, a.XS, a.kpart, a.wscale; false = no kernel for this shape, NOTHING launched
   const int nks = a.K >> 7, per = (nks + 7) >> 3;
   const int ntiles = a.N >> 4;
   const bool t8 = mx_tpg(ntiles) == 8;
@@ -391,5 +391,5 @@ void launch_gemv_mxk(const GemvBArgs& a, int G, hipStream_t s) {      // a.Wm, a
   if (a.nt >= 3) ok = t8 ? launch_mxk_g<8, 4>(a, G, per, s) : launch_mxk_g<4, 4>(a, G, per, s);
   else if (a.nt == 2) ok = t8 ? launch_mxk_g<8, 2>(a, G, per, s) : launch_mxk_g<4, 2>(a, G, per, s);
   else ok = t8 ? launch_mxk_g<8, 1>(a, G, per, s) : launch_mxk_g<4, 1>(a, G, per, s);
-  (void)ok;                                                          // mx_kparts_covers was asked first
+  return ok;                                                         // (mx_kparts_covers is asked at dtk_create; a disagreement must fail the step, not skip a projection)
 }

@@ -432,8 +432,8 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
   const long mbs = (a.M + 127) / 128, nbs = (a.N + 127) / 128;
   if (mbs * nbs < g_glds_min_tiles) return false;
   constexpr int lds = 2 * 2 * 128 * 64 * 2;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   hipLaunchKernelGGL(k_gemm_glds, dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(256), lds, s, a);
   return true;
 }
@@ -616,8 +616,8 @@ void set_gemm_g3_min_blocks(int v) { g_g3_min_blocks = v; }
 template <int BM, int BN>
 static void launch_gemm_g3_t(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * 64 * 2;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL((k_gemm_g3<BM, BN>), dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(512), lds, s, a);
 }
@@ -649,10 +649,9 @@ void set_gemm_ring(int v) { g_gemm_ring = v; }
 template <int BM, int BN, int RING>
 static void launch_gemm_dma_t(const GemmArgs& a, hipStream_t s, dim3 grid) {
   constexpr size_t lds = (size_t)RING * ((BM / 16) * 2 + (BN / 16) * 2) * 1024;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<BM, BN, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (lds > 48 * 1024 && dtk_lds_attr_todo(attr_set)) {
+    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<BM, BN, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   hipLaunchKernelGGL((k_gemm_dma<BM, BN, RING>), grid, dim3(256), lds, s, a);
 }

@@ -401,8 +401,10 @@ static void launch_mv_t(const GemvMvArgs& a, hipStream_t s, int blocks_per_cu) {
   const int lds = (int)((size_t)NB * (a.K >> 3) * 16 + (size_t)NB * WAVES * 4 + 64);
   auto fn = k_gemv_mv<PRO, EPI, NB, R, U, WAVES, PERSIST, F8>;
   if (lds > 64 * 1024) {      // down projection with 4 vectors (ff = 11008: 88 KB of x): one block per CU
-    static int raised = 0;
-    if (raised < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = lds; }
+    static int raised[64] = {};          // per device (the attribute is a per-device property of the function)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (raised[dev] < lds) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); raised[dev] = lds; }
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(WAVES * 64), lds, s, a);
 }

@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import os
 import threading
-from concurrent.futures import Future, ProcessPoolExecutor
+from concurrent.futures import CancelledError, Future, ProcessPoolExecutor
 from concurrent.futures.process import BrokenProcessPool
 from io import BytesIO
 from multiprocessing import get_context
@@ -96,6 +96,8 @@ class CompilePool:
         self.raster_size, self.engines = raster_size, list(TikzDocument.engines) if engines is None else engines
         self.restarts = 0
         self._lock = threading.Lock()
+        self._retry_lock = threading.Lock()
+        self._isolated: Optional[ProcessPoolExecutor] = None      # the executor of the retry in progress (retry_isolated)
         self._pool = self._new_executor()
 
     def _new_executor(self) -> ProcessPoolExecutor:
@@ -131,9 +133,23 @@ class CompilePool:
         restarted for the jobs that follow; the lost job is reported as a failed compile by the caller"""
         try:
             return future.result()
-        except BrokenProcessPool:
+        except (BrokenProcessPool, CancelledError):     # CancelledError: restart() shut the broken executor down with cancel_futures=True while this job was still queued
             self.restart(getattr(future, "_dtk_executor", self._pool))
             return None
+
+    def retry_isolated(self, code: str, timeout: Optional[int] = 60) -> Optional[CompiledFigure]:
+        """second attempt of a job that was lost with a dying worker, in an executor of its OWN (one worker, one job, serialised):
+        the document that killed the worker kills only this one, so the innocent siblings that retry next to it keep their second
+        attempt (a retry on the shared, restarted pool let the poison document break it again: ADVICE r4).  None = lost again."""
+        with self._retry_lock:
+            ex = self._isolated = ProcessPoolExecutor(max_workers=1, mp_context=get_context("spawn"))
+            try:
+                return ex.submit(_compile_job, code, timeout, self.raster_size, self.engines, self.document_class).result()
+            except (BrokenProcessPool, CancelledError):
+                return None
+            finally:
+                self._isolated = None
+                ex.shutdown(wait=False, cancel_futures=True)
 
     def imap(self, codes: Iterable[str], timeout: Optional[int] = 60) -> Iterator[CompiledFigure]:
         """all documents in flight at once, results in input order (multiprocessing.Pool.imap, refine.py:176)"""
@@ -141,8 +157,8 @@ class CompilePool:
         futures = [self.submit(code, timeout) for code in codes]
         for code, f in zip(codes, futures):
             fig = self.result(f)
-            if fig is None:         # lost with a dying sibling: once more on the restarted pool
-                fig = self.result(self.submit(code, timeout))
+            if fig is None:         # lost with a dying sibling: once more, in isolation
+                fig = self.retry_isolated(code, timeout)
             yield fig if fig is not None else CompiledFigure(-1, "compile worker died", None, None)
 
     def close(self):
@@ -171,9 +187,9 @@ def pooled_document_class(pool: CompilePool) -> Type[TikzDocument]:
             if fig is None:
                 # a worker died and concurrent.futures failed EVERY pending job of that executor — most of them innocent siblings
                 # whose document would otherwise be cached as a failed compile (reward -1 for good: ADVICE r3).  The pool has been
-                # restarted: run this document once more; only a second loss is reported as a failed compile.
-                self._future = pool.submit(self.code, self.timeout)
-                fig = pool.result(self._future)
+                # restarted for the jobs that follow; THIS document runs once more in an executor of its own (a poison document then
+                # takes nobody with it); only a second loss is reported as a failed compile.
+                fig = pool.retry_isolated(self.code, self.timeout)
             if fig is None:         # the worker died under this very job twice: a failed compile, not a failed search
                 return Output()
             return Output(pdf=_PooledPdf(fig) if fig.png is not None else None, status=fig.status, log=fig.log)

@@ -39,16 +39,22 @@ class DetikzifyOracle:
         c, n = self.cfg["concat_patches"], self.n_img
         return feats[-n * c:].reshape(n, feats.shape[-1] * c)
 
-    def image_embeds(self, pixels: torch.Tensor) -> torch.Tensor:
+    def image_embeds(self, pixels: torch.Tensor, vit_feats: Optional[torch.Tensor] = None) -> torch.Tensor:
         # v1: nn.Linear(3D, d) with bias; v2 connector (modeling_detikzify.py:62-86): reshape(seq // 3, 3D) + bias-free Linear
-        return linear(self.vision_features(pixels), self.w["model.mm_projector.weight"],
-                      self.w.get("model.mm_projector.bias"), self.P)
+        # vit_feats: the tower's output for `pixels` computed earlier by self.vit.intermediate (the tests keep it: one tower pass
+        # instead of one per prefill)
+        if vit_feats is None:
+            feats = self.vision_features(pixels)
+        else:
+            c, n = self.cfg["concat_patches"], self.n_img
+            feats = vit_feats[-n * c:].reshape(n, vit_feats.shape[-1] * c)
+        return linear(feats, self.w["model.mm_projector.weight"], self.w.get("model.mm_projector.bias"), self.P)
 
     # -- decoder -----------------------------------------------------------------------------
-    def input_embeds(self, ids: torch.Tensor, pixels: Optional[torch.Tensor]) -> torch.Tensor:
+    def input_embeds(self, ids: torch.Tensor, pixels: Optional[torch.Tensor], vit_feats: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = self.llm.embed(ids)
         if pixels is not None and ids.numel() != 1:
-            img = self.image_embeds(pixels)
+            img = self.image_embeds(pixels, vit_feats)
             tok = self.cfg["image_token_id"]
             where = torch.where(ids == tok)[0]
             if where.numel() == 0:
@@ -61,11 +67,25 @@ class DetikzifyOracle:
             x = torch.cat([x[:s], img, x[s + self.n_img:]], dim=0)
         return x
 
-    def prefill(self, ids: torch.Tensor, pixels: Optional[torch.Tensor]) -> torch.Tensor:
+    def prefill(self, ids: torch.Tensor, pixels: Optional[torch.Tensor], vit_feats: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fresh forward over the whole prompt; returns fp32 logits of the last position."""
         self.llm.reset()
-        h = self.llm.forward(self.input_embeds(ids, pixels))
+        h = self.llm.forward(self.input_embeds(ids, pixels, vit_feats))
         return self.llm.logits(h[-1])
+
+    def extend(self, tokens, last_only: bool = False) -> torch.Tensor:
+        """Teacher-force `tokens` after the cached context in ONE pass: row i = the fp32 logits after tokens[i] — what len(tokens)
+        calls of step() return, with the weights read once for all rows (the same causal forward the reference runs over a whole
+        sequence, v1/modeling_detikzify.py:218-283; fp32 accumulation, every rounding point per row unchanged)."""
+        h = self.llm.forward(self.llm.embed(torch.as_tensor(tokens, dtype=torch.long).reshape(-1)))
+        return self.llm.logits(h[-1]) if last_only else self.llm.logits(h)
+
+    def snapshot(self):
+        """(keys, values, position) of the decoder cache: restore() returns to it, so several continuations of one prefix share its prefill"""
+        return list(self.llm.k), list(self.llm.v), self.llm.pos
+
+    def restore(self, snap) -> None:
+        self.llm.k, self.llm.v, self.llm.pos = list(snap[0]), list(snap[1]), snap[2]
 
     def step(self, token: int) -> torch.Tensor:
         h = self.llm.forward(self.llm.embed(torch.tensor([token])))

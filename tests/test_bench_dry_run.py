@@ -29,6 +29,10 @@ class _BenchDevice(ScriptedDevice):
     def set_graph_mode(self, mode):
         pass
 
+    def set_option(self, name, value):          # bench.py opts into the fp8 matrix-core step for one config-5 block (act_fp8)
+        self.options = getattr(self, "options", []) + [(name, value)]
+        self._stats["last_batch_step_fp8_mfma"] = float(bool(value)) if name == "act_fp8" else self._stats["last_batch_step_fp8_mfma"]
+
 
 def _run_bench(monkeypatch, capsys, argv):
     import bench
@@ -92,6 +96,9 @@ def test_bench_json_contract_and_phases(monkeypatch, capsys):
     assert c4["ragged"]["tokens_generated_per_gpu"] < c4["fixed_length"]["tokens_generated_per_gpu"]     # rollouts of different lengths
     assert d["mcts_config4_rollouts_per_sec"] == c4["fixed_length"]["rollouts_per_sec"]
     assert d["mcts_config5_rollouts_per_sec"] == c5["fixed_length"]["rollouts_per_sec"]
+    # MXFP8 activations are opt-in since round 5: the default blocks run with bf16 activations, one extra block opts in
+    assert c5["decode_steps_on_fp8_matrix_cores"] == 0 and c5["fixed_length_fp8_matrix_cores_opt_in"]["decode_steps_on_fp8_matrix_cores"] == 1
+    assert d["mcts_config5_rollouts_per_sec_fp8_matrix_cores_opt_in"] == c5["fixed_length_fp8_matrix_cores_opt_in"]["rollouts_per_sec"] > 0
     # the one-rank shapes of an N = 2 / 4 / 8 job and the whole-job rate they predict
     rs4, rs5 = c4["rank_shape"], c5["rank_shape"]
     assert [rs4[f"N{n}"]["trees_per_rank"] for n in (2, 4, 8)] == [8, 4, 2] and rs4["N4"]["context_slots"] == rs4["N8"]["context_slots"] == 5

@@ -204,16 +204,18 @@ def _wait_for(path, what):
 
 def test_a_dying_worker_fails_one_compile_not_the_search(tex_box):
     """a worker killed under a TeX run (OOM killer) breaks concurrent.futures' executor for good: the pool replaces it and the
-    lost job is run ONCE more on the new executor (the executor fails every pending job, innocent siblings included,
-    and a cached failed compile is a reward of -1 for good); a job that keeps killing its worker reads as a failed compile
-    (status -1, nothing to rasterise) and the jobs after it compile normally"""
+    lost job is run ONCE more (the executor fails every pending job, innocent siblings included, and a cached failed
+    compile is a reward of -1 for good) — in an executor of its own (on the shared pool a poison document broke the new
+    executor again and took the siblings' second attempt with it); a job that keeps killing its worker reads as a failed compile
+    (status -1, nothing to rasterise), costs the shared pool ONE restart, and the jobs after it compile normally"""
     import signal
     from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
     pidfile = tex_box / "grandchild.pid"
 
-    def kill_worker_and_tex(pool):
+    def kill_worker_and_tex(pool, isolated=False):
         _wait_for(pidfile, "the fake TeX run never started")
-        worker = next(iter(pool._pool._processes))           # the one worker process
+        ex = pool._isolated if isolated else pool._pool      # the retry of a lost job runs in an executor of its own
+        worker = next(iter(ex._processes))                   # the one worker process
         os.kill(worker, signal.SIGKILL)
         os.kill(int(pidfile.read_text()), signal.SIGKILL)
         pidfile.unlink()
@@ -224,17 +226,17 @@ def test_a_dying_worker_fails_one_compile_not_the_search(tex_box):
         victim = Pooled(GOOD + "% HANG_ONCE\n", timeout=30).prefetch()       # hangs the first time only: an OOM kill, not a bad document
         sibling = Pooled(GOOD + "% sibling\n").prefetch()                    # queued behind it on the same executor
         kill_worker_and_tex(pool)
-        assert victim.status == 0 and victim.is_rasterizable                 # the retry on the restarted pool compiled it
+        assert victim.status == 0 and victim.is_rasterizable                 # the isolated retry compiled it
         assert sibling.status == 0 and sibling.is_rasterizable               # ... and the innocent sibling is not a failed compile
         assert pool.restarts == 1
         deadly = Pooled(GOOD + "% HANG\n", timeout=30).prefetch()            # this one takes its worker down every time
         kill_worker_and_tex(pool)
         import threading
-        second = threading.Thread(target=kill_worker_and_tex, args=(pool,))  # the retry hangs again: kill that worker too
+        second = threading.Thread(target=kill_worker_and_tex, args=(pool, True))  # the retry hangs again: kill ITS worker too
         second.start()
         assert deadly.status == -1 and not deadly.is_rasterizable
         second.join(timeout=30)
-        assert pool.restarts == 3
+        assert pool.restarts == 2                                            # the isolated retry's death did not touch the shared pool
         after = Pooled(GOOD)
         assert after.status == 0 and after.is_rasterizable
         figs = list(pool.imap([GOOD, BROKEN]))

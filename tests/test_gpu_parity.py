@@ -35,11 +35,7 @@ def tiny():
     return model, proc
 
 
-def weights_from_device(model, cfg):
-    out = {}
-    for name, shape, _, _ in tensor_specs(cfg):
-        out[name] = model.read_tensor(name).float().reshape(shape)
-    return out
+from tests.fullsize import weights_from_device  # noqa: E402  (also imported from here by the other GPU test modules)
 
 
 @pytest.fixture(scope="module")
@@ -607,32 +603,30 @@ def _against_cpu_oracle(name, n_greedy, n_sampled=0, weight_format="bf16"):
     oracle is (x1.5 + 1e-3 / 2e-3: two correct bf16 pipelines random-walk apart with depth, see DESIGN.md §5);
     `n_greedy` greedy tokens identical under teacher forcing except at near-ties (top-2 gap within 2 bf16 ulps of the
     logit); `n_sampled` sampled tokens (T=.8, top-p .95, the pipeline's defaults) equal to the oracle's counter-based
-    draw from the device's own logits of that step, draw for draw (integer work: exact)."""
+    draw from the device's own logits of that step, draw for draw (integer work: exact).
+    The host side (weights, ViT features, prefix prefill by both oracles) is shared with the other full-size tests of the
+    model (tests/fullsize.py); the greedy tokens are teacher-forced in one oracle pass (DetikzifyOracle.extend)."""
     import gc
     import time
     from detikzify_amd.model import load
+    from tests.fullsize import host_side
     t_start = time.perf_counter()
     model, proc = load(name, synthetic=1234, max_positions=512, weight_format=weight_format)
     try:
-        cfg = model.config.oracle_dict()
-        w = weights_from_device(model, cfg)
-        enc = proc(images=sketch_image(0, 224), return_tensors="pt")
-        ids, px = enc.input_ids[0], enc.pixel_values
+        hs = host_side(model, proc, name, weight_format)
+        cfg, _, o16, _ = hs.oracles(model, fp32=False)
+        ids, px = hs.ids, hs.px
         img_tok, eos = cfg["image_token_id"], 2      # begin-suppressed id: the one run_greedy() passes
-        o16 = DetikzifyOracle(cfg, w, precision="bf16")
-        o32 = DetikzifyOracle(cfg, w, precision="fp32")
         feats, _ = model.vit_encode(px, want_pooled=False)
-        ref_feats = o16.vit.intermediate(px[0], cfg["vit_feature_layer"])
-        true_feats = o32.vit.intermediate(px[0], cfg["vit_feature_layer"])
+        ref_feats, true_feats = hs.feats16, hs.feats32
         rf, ef_dev, ef_orc = rel_l2(feats[0].float(), ref_feats), rel_l2(feats[0].float(), true_feats), rel_l2(ref_feats, true_feats)
         dev = model.prefill(ids, px, return_logits=True)
-        ref = o16.prefill(ids, px[0])
-        truth = o32.prefill(ids, px[0])
-        del o32
+        ref, truth = hs.ref, hs.truth
         r, e_dev, e_orc = rel_l2(dev, ref), rel_l2(dev, truth), rel_l2(ref, truth)
         assert ef_dev < 1.5 * ef_orc + 1e-3
         assert e_dev < 1.5 * e_orc + 2e-3
         toks = run_greedy(model, ids, px, n_greedy)
+        rows = o16.extend(toks)                      # row i: the oracle's logits after toks[i]
         logits, near_ties = ref, 0
         for i, t in enumerate(toks):
             rt = sampling.greedy(logits, [img_tok], [eos], i == 0)
@@ -640,7 +634,7 @@ def _against_cpu_oracle(name, n_greedy, n_sampled=0, weight_format="bf16"):
                 top2 = torch.topk(sampling.mask_scores(logits, [img_tok], [eos], i == 0), 2)[0]
                 assert float(top2[0] - top2[1]) <= 2 * float(top2[0].abs()) * 2.0 ** -7 + 1e-6, (i, t, rt)
                 near_ties += 1
-            logits = o16.step(t)
+            logits = rows[i]
         assert near_ties <= max(1, n_greedy // 8), f"{near_ties} of {n_greedy} greedy tokens differ (all at near-ties): too many"
         if n_sampled:
             model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=4242, bad_ids=[img_tok],
@@ -684,10 +678,12 @@ def test_vit_error_grows_block_by_block_like_the_reference_dtype_policy():
     from oracle.vit import VitOracle
     model, proc = load("detikzify-ds-1.3b", synthetic=1234, max_positions=512)
     try:
+        from tests.fullsize import host_side
         cfg = model.config.oracle_dict()
         depth = cfg["vit_depth"]
-        w = {k: v for k, v in weights_from_device(model, cfg).items() if k.startswith("vision_model.")}
-        px = proc(images=sketch_image(0, 224), return_tensors="pt").pixel_values
+        hs = host_side(model, proc, "detikzify-ds-1.3b", "bf16")      # the tower's weights: read back once for the model's full-size tests
+        w = {k: v for k, v in hs.w.items() if k.startswith("vision_model.")}
+        px = hs.px
         _, o16, _ = VitOracle(cfg, w, "bf16").intermediate(px[0], depth - 1, return_all=True)
         v32 = VitOracle(cfg, w, "fp32")
         _, o32, _ = v32.intermediate(px[0], depth - 1, return_all=True)
@@ -730,7 +726,7 @@ def test_decoder_error_grows_with_depth_like_the_reference_dtype_policy(layers):
     try:
         model.fill_synthetic(77 + layers)
         cfg = model.config.oracle_dict()
-        w = {k: v for k, v in weights_from_device(model, cfg).items() if not k.startswith("vision_model.")}
+        w = weights_from_device(model, cfg, skip_prefix="vision_model.")
         g = torch.Generator().manual_seed(layers)
         ids = torch.randint(3, cfg["vocab"] - 1, (48,), generator=g)
         ids = ids[ids != cfg["image_token_id"]]
@@ -740,12 +736,13 @@ def test_decoder_error_grows_with_depth_like_the_reference_dtype_policy(layers):
         e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
         assert e_dev < 1.5 * e_orc + 1e-3, (layers, e_dev, e_orc)
         model.set_sampling(do_sample=False)
-        worst = 0.0
-        for _ in range(4):                      # the decode kernels at this depth, teacher-forced with the device's own tokens
+        worst, toks, dev_rows = 0.0, [], []
+        for _ in range(4):                      # the decode kernels at this depth ...
             model.decode_launch()
-            t = model.decode_wait()
-            lg = model.get_logits()
-            r32, r16 = o32.step(t), o16.step(t)
+            toks.append(model.decode_wait())
+            dev_rows.append(model.get_logits())
+        rows32, rows16 = o32.extend(toks), o16.extend(toks)     # ... both oracles teacher-forced with the device's own tokens (one pass each)
+        for lg, r32, r16 in zip(dev_rows, rows32, rows16):
             d, o = rel_l2(lg, r32), rel_l2(r16, r32)
             worst = max(worst, d / (1.5 * o + 1e-3))
             assert d < 1.5 * o + 1e-3, (layers, d, o)

@@ -61,7 +61,7 @@ def oracle_restore(o, snap):
     o.llm.k, o.llm.v, o.llm.pos = list(snap[0]), list(snap[1]), snap[2]
 
 
-def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, max_positions=512, private_tail=0, tail_watch=()):
+def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, max_positions=512, private_tail=0, tail_watch=(), act_fp8=None):
     """One context of `batch_slots` slots: the image prefix is prefilled once into the last slot and forked into every decoding
     slot; then `phases` = [(active slots, sampled steps, greedy steps, slots the step's kernels must cover)] run one after the
     other — which kernels a step runs is decided by its highest active slot (MFMA family: 1 / 2 / 4 column tiles of 16) or by the
@@ -72,13 +72,15 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
     tokens (device only), the oracle re-reads the whole sequence of the `tail_watch` slots in one pass and 4 greedy steps are
     compared there: attention over hundreds of PRIVATE keys per slot that the decode kernels themselves appended."""
     from detikzify_amd.model import load
+    from tests.fullsize import host_side
     t_start = time.perf_counter()
     model, proc = load(name, synthetic=1234, max_positions=max_positions, weight_format=weight_format, batch_slots=batch_slots)
     try:
-        cfg = model.config.oracle_dict()
-        w = weights_from_device(model, cfg)
-        enc = proc(images=sketch_image(0, 224), return_tensors="pt")
-        ids, px = enc.input_ids[0], enc.pixel_values
+        if act_fp8 is not None:
+            model.set_option("act_fp8", int(act_fp8))
+        hs = host_side(model, proc, name, weight_format)       # weights + the prefix prefill of both oracles, shared by the model's full-size tests
+        cfg, w, o16, o32 = hs.oracles(model)
+        ids, px = hs.ids, hs.px
         n_img = ids.numel()
         img_tok, eos = cfg["image_token_id"], 2
         SRC = batch_slots - 1
@@ -129,12 +131,7 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
         if NS >= 8:
             assert len({tuple(t for _, _, t in log[s][:4]) for s in range(NS)}) > NS // 2, "the per-slot seeds did not make the contexts diverge"
 
-        o16 = DetikzifyOracle(cfg, w, precision="bf16")
-        ref = o16.prefill(ids, px[0])
-        snap16 = oracle_snapshot(o16)
-        o32 = DetikzifyOracle(cfg, w, precision="fp32")
-        truth = o32.prefill(ids, px[0])
-        snap32 = oracle_snapshot(o32)
+        ref, truth, snap16, snap32 = hs.ref, hs.truth, hs.snap16, hs.snap32
         e_dev, e_orc, e_pair = rel_l2(dev_prefill, truth), rel_l2(ref, truth), rel_l2(dev_prefill, ref)
         assert e_dev < 1.5 * e_orc + 2e-3
 
@@ -142,14 +139,27 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
         # on (LlamaOracle.act_quant; prefill above ran with bf16 activations on both sides); the fp32 oracle stays the unquantised
         # truth.  e4m3 activations make the two pipelines random-walk apart in steps of 2^-4 instead of 2^-8, so the near-tie rule
         # is stated in the unit that fits: MX_TIE bf16 ulps of the top logit (asserted), and the sanity bound on the distance widens.
-        assert mx == (weight_format == "fp8" and batch_slots > 5), "fp8 models run the MFMA-family step on the fp8 matrix cores"
+        assert mx == bool(act_fp8 and weight_format == "fp8" and batch_slots > 5), "MXFP8 activations are opt-in (dtk_set_option act_fp8): only then the MFMA-family step of an fp8 model runs on the fp8 matrix cores"
         o16.llm.act_quant = bool(mx)
         tie = MX_TIE if mx else 2.0
         worst_ratio, worst_r16, near_ties, near_tie_steps, identical, n_greedy_total, gaps, worst_behind, wide_flips = 0.0, 0.0, 0, 0, 0, 0, [], 0.0, 0
+        worst_b16 = 0.0
         for s in watch:
+            # the slot's tokens teacher-forced in ONE oracle pass each (rows16[i] / rows32[i] = logits after log[s][i]'s token)
             oracle_restore(o16, snap16)
+            rows16 = o16.extend([t for _, _, t in log[s]])
+            if mx:      # ... and once more with bf16 activations: the distance MXFP8 activations put between the device and the reference's arithmetic is ASSERTED (MX_BOUND)
+                o16.llm.act_quant = False
+                oracle_restore(o16, snap16)
+                rows_b16 = o16.extend([t for _, _, t in log[s]])
+                o16.llm.act_quant = True
+                for i in range(len(log[s])):
+                    rb16 = rel_l2(logit_log[s][i], rows_b16[i])
+                    worst_b16 = max(worst_b16, rb16)
+                    assert rb16 <= MX_BOUND, (s, i, rb16)
             if s in watch32:
                 oracle_restore(o32, snap32)
+                rows32 = o32.extend([t for _, _, t in log[s]])
             logits = ref
             for i, (sampled, first, t) in enumerate(log[s]):
                 gaps.append(top2_gap_ulps(logits, [img_tok], [eos], first))
@@ -172,14 +182,14 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                         near_ties += 1
                         wide_flips += behind > tie + 1e-3
                         worst_behind = max(worst_behind, behind)
-                logits = o16.step(t)
+                logits = rows16[i]
                 r16 = rel_l2(logit_log[s][i], logits)
                 worst_r16 = max(worst_r16, r16)
                 # sanity bound on the distance between the two bf16 pipelines (the fp32 envelope on `watch32` is the real test): what
                 # the prefill of this model showed, with headroom — ds-7b ~2.9e-2, the 128 k-vocabulary v2-8b ~3.4e-2
                 assert r16 < (MX_R16 if mx else max(3e-2, 1.25 * e_pair)), (s, i, r16, e_pair)
                 if s in watch32:
-                    t32 = o32.step(t)
+                    t32 = rows32[i]
                     d, o = rel_l2(logit_log[s][i], t32), rel_l2(logits, t32)
                     worst_ratio = max(worst_ratio, d / (1.5 * o + 2e-3))
                     assert d < 1.5 * o + 2e-3, (s, i, d, o)
@@ -217,8 +227,13 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
             for s in tail_watch:
                 full = torch.cat([ids, torch.tensor(seqs[s], dtype=torch.long)])
                 assert model.context_len_slot(s) == full.numel() + 4 and full.numel() - n_img >= private_tail
-                a16, a32 = DetikzifyOracle(cfg, w, precision="bf16"), DetikzifyOracle(cfg, w, precision="fp32")
-                lg16, lg32 = a16.prefill(full, px[0]), a32.prefill(full, px[0])
+                # both oracles read the slot's whole private sequence in one pass behind the shared image prefix, then the 4 compared
+                # tokens in a second one
+                o16.llm.act_quant = False
+                oracle_restore(o16, snap16)
+                oracle_restore(o32, snap32)
+                lg16, lg32 = o16.extend(seqs[s], last_only=True), o32.extend(seqs[s], last_only=True)
+                nx16, nx32 = o16.extend(tail_toks[s]), o32.extend(tail_toks[s])
                 for i in range(5):
                     d, o = rel_l2(tail_logits[s][i], lg32), rel_l2(lg16, lg32)
                     t_worst = max(t_worst, d / (1.5 * o + 2e-3))
@@ -231,11 +246,12 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                         assert top2_gap_ulps(lg16, [img_tok], [], False) <= 2.0 + 1e-3, (s, i, t, rt)
                     else:
                         t_same += 1
-                    lg16, lg32 = a16.step(t), a32.step(t)
+                    lg16, lg32 = nx16[i], nx32[i]
             tail_report = (f"; after {private_tail} more sampled tokens per slot (contexts {n_img + len(log[tail_watch[0]]) + private_tail}, all but {n_img} keys private): "
                            f"slots {tuple(tail_watch)} 5 logit checks worst ratio to the envelope {t_worst:.2f}, {t_same}/{4 * len(tail_watch)} greedy tokens identical")
         o16.llm.act_quant = False
-        mx_note = f" [fp8 matrix cores, MXFP8 activations: oracle act_quant, tie rule {tie:g} ulps, worst flip {worst_behind:.1f} ulps behind]" if mx else ""
+        mx_note = (f" [fp8 matrix cores, MXFP8 activations (opt-in): oracle act_quant, tie rule {tie:g} ulps, worst flip {worst_behind:.1f} ulps behind; "
+                   f"vs the bf16-ACTIVATION oracle worst {worst_b16:.2e}, asserted <= {MX_BOUND}]") if mx else ""
         print(f"batched {name}{' fp8' if weight_format == 'fp8' else ''}{mx_note}, {batch_slots} slots, step kinds {kinds}: prefill logits vs fp32: "
               f"device {e_dev:.2e} oracle {e_orc:.2e}; slots {tuple(watch)}: step logits dev-vs-bf16-oracle worst {worst_r16:.2e}, worst "
               f"ratio to the fp32 envelope {worst_ratio:.2f}; greedy {identical}/{n_greedy_total} identical ({near_ties} flips to the runner-up in {near_tie_steps} near-tie steps, "
@@ -250,8 +266,8 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
 R64, R32, R16 = range(64), range(32), range(16)
 
 
-@pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-cl-7b", "fp8")])
-def test_batched_headline_matches_cpu_oracle(name, weight_format):
+@pytest.mark.parametrize("name,weight_format,act_fp8", [("detikzify-ds-7b", "bf16", None), ("detikzify-cl-7b", "fp8", None), ("detikzify-cl-7b", "fp8", 1)])
+def test_batched_headline_matches_cpu_oracle(name, weight_format, act_fp8):
     """The batched decode step exactly as `bench.py`'s rollouts/sec phases run it — full depth, 65 slots allocated (64 decoding
     + the prefix-cache slot), every default — against the CPU oracle, at EVERY column-tile count: 64 active slots (4 tiles:
     k_gemv_bl / k_gemv_bkl / k_resid_norm_b, the 64-slot kernels), then 32 (2 tiles: k_gemv_b<.., NT = 2>, the shape of BASELINE
@@ -263,7 +279,7 @@ def test_batched_headline_matches_cpu_oracle(name, weight_format):
     _phases_vs_oracle(name, weight_format, 65,
                       phases=[(R64, 4, 4, 64), (R32, 2, 2, 32), (R16, 2, 2, 16)],
                       watch=(0, 9, 17, 40, 63), watch32=(9,), max_positions=1024 if ds else 512,
-                      private_tail=500 if ds else 0, tail_watch=(40,) if ds else ())
+                      private_tail=500 if ds else 0, tail_watch=(40,) if ds else (), act_fp8=act_fp8)
 
 
 @pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-cl-7b", "fp8")])
@@ -288,50 +304,48 @@ N_LONG = 8       # decode steps per long-context checkpoint (round 3: 3)
 
 def test_long_context_steps_match_cpu_oracle():
     """ds-7b decode steps at contexts ~700 (where bench.py's 512-token rollouts end) and ~1900 (the API allows 2048) against
-    the CPU oracle: the prompt is the image prefix + seeded text tokens; the oracle prefills it ONCE (KV kept across the two
-    checkpoints), the device prefills to the checkpoint and decodes 8 greedy steps there (the attention kernel walks 700 /
-    1900 keys of KV the prefill GEMMs wrote).  Same logits envelope as the short-context tests, tokens by the near-tie rule."""
+    the CPU oracle: the prompt is the image prefix + seeded text tokens; the oracle extends the shared prefix prefill ONCE per
+    checkpoint (KV kept across the two), the device prefills to the checkpoint and decodes 8 greedy steps there (the attention
+    kernel walks 700 / 1900 keys of KV the prefill GEMMs wrote); the 8 tokens are teacher-forced in one oracle pass.  Same logits
+    envelope as the short-context tests, tokens by the near-tie rule."""
     from detikzify_amd.model import load
+    from tests.fullsize import host_side
     t_start = time.perf_counter()
     model, proc = load("detikzify-ds-7b", synthetic=1234, max_positions=2048)
     try:
-        cfg = model.config.oracle_dict()
-        w = weights_from_device(model, cfg)
-        enc = proc(images=sketch_image(0, 224), return_tensors="pt")
-        ids, px = enc.input_ids[0], enc.pixel_values
+        hs = host_side(model, proc, "detikzify-ds-7b", "bf16")
+        cfg, w, o16, o32 = hs.oracles(model)
+        ids, px = hs.ids, hs.px
         img_tok, eos = cfg["image_token_id"], 2
         g = torch.Generator().manual_seed(7)
         text = torch.randint(3, cfg["vocab"] - 1, (1900,), generator=g)
         text[text == img_tok] = 5
         full = torch.cat([ids, text])
-        o16, o32 = DetikzifyOracle(cfg, w, precision="bf16"), DetikzifyOracle(cfg, w, precision="fp32")
         model.set_sampling(do_sample=False, bad_ids=[img_tok])
-        report, done = [], 0
+        report, done = [], ids.numel()           # both oracles hold the image prefix (tests/fullsize.py)
         for T in (700, 1900):
             prompt = full[:T]
             dev = model.prefill(prompt, px, return_logits=True)
-            if done == 0:
-                ref, truth = o16.prefill(prompt, px[0]), o32.prefill(prompt, px[0])
-            else:       # extend both oracles from where the previous checkpoint's prompt ended
-                for o in (o16, o32):
-                    o.llm.truncate(done)
-                h16 = o16.llm.forward(o16.llm.embed(prompt[done:]))
-                h32 = o32.llm.forward(o32.llm.embed(prompt[done:]))
-                ref, truth = o16.llm.logits(h16[-1]), o32.llm.logits(h32[-1])
+            for o in (o16, o32):                 # extend both oracles from where the previous checkpoint's prompt ended
+                o.llm.truncate(done)
+            ref, truth = o16.extend(prompt[done:], last_only=True), o32.extend(prompt[done:], last_only=True)
             done = T
             e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
             assert e_dev < 1.5 * e_orc + 2e-3, (T, e_dev, e_orc)
-            logits, worst, ties = ref, 0.0, 0
+            toks, dev_logits = [], []
             for i in range(N_LONG):
                 model.decode_launch()
-                t = model.decode_wait()
+                toks.append(model.decode_wait())
+                dev_logits.append(model.get_logits())
+            rows16, rows32 = o16.extend(toks), o32.extend(toks)
+            logits, worst, ties = ref, 0.0, 0
+            for i, t in enumerate(toks):
                 rt = sampling.greedy(logits, [img_tok], [], False)
                 if rt != t:
                     assert top2_gap_ulps(logits, [img_tok], [], False) <= 2.0 + 1e-3, (T, i, t, rt)
                     ties += 1
-                lg = model.get_logits()
-                logits, t32 = o16.step(t), o32.step(t)
-                d, o = rel_l2(lg, t32), rel_l2(logits, t32)
+                logits, t32 = rows16[i], rows32[i]
+                d, o = rel_l2(dev_logits[i], t32), rel_l2(logits, t32)
                 worst = max(worst, d / (1.5 * o + 2e-3))
                 assert d < 1.5 * o + 2e-3, (T, i, d, o)
             assert model.context_len() == T + N_LONG
@@ -364,12 +378,13 @@ def test_peaked_logits_weight_set_is_token_identical():
     t_start = time.perf_counter()
     model, proc = load("detikzify-ds-7b", synthetic=1234, max_positions=512, batch_slots=65)
     try:
+        from tests.fullsize import host_side
+        hs = host_side(model, proc, "detikzify-ds-7b", "bf16")       # BEFORE the head is replaced: the shared entry holds the seed-1234 weights
         cfg = model.config.oracle_dict()
-        head = model.read_tensor("lm_head.weight").float().reshape(cfg["vocab"], cfg["hidden"])
-        model.load_tensor("lm_head.weight", peaked_lm_head(head, PEAKED_BETA, PEAKED_SEED).to(torch.bfloat16))
-        w = weights_from_device(model, cfg)
-        enc = proc(images=sketch_image(0, 224), return_tensors="pt")
-        ids, px = enc.input_ids[0], enc.pixel_values
+        head = peaked_lm_head(hs.w["lm_head.weight"], PEAKED_BETA, PEAKED_SEED)
+        model.load_tensor("lm_head.weight", head.to(torch.bfloat16))
+        assert torch.equal(model.read_tensor("lm_head.weight").float().reshape(head.shape), head)
+        ids, px = hs.ids, hs.px
         n_img, img_tok, N = ids.numel(), cfg["image_token_id"], PEAKED_PREFIX + PEAKED_CONTEXTS
         bans_at = lambda toks, k: [img_tok] + toks[max(0, k - PEAKED_WINDOW):k]
         runs = []           # (label, tokens)
@@ -393,8 +408,7 @@ def test_peaked_logits_weight_set_is_token_identical():
             toks.append(model.decode_batch_wait()[37])
         runs.append(("slot 37 of 64", toks))
 
-        o16 = DetikzifyOracle(cfg, w, precision="bf16")
-        o16.prefill(ids, px[0])
+        _, _, o16, _ = hs.oracles(model, override={"lm_head.weight": head}, fp32=False)    # the prefix KV does not depend on the head
         snap = oracle_snapshot(o16)
         report, all_gaps = [], []
         for label, toks in runs:
@@ -440,7 +454,7 @@ def test_greedy_margins_are_not_biased_against_the_oracle():
     try:
         model.fill_synthetic(4321)
         cfg = model.config.oracle_dict()
-        w = {k: v for k, v in weights_from_device(model, cfg).items() if not k.startswith("vision_model.")}
+        w = weights_from_device(model, cfg, skip_prefix="vision_model.")
         img_tok = cfg["image_token_id"]
         g = torch.Generator().manual_seed(3)
         ids = torch.randint(3, cfg["vocab"] - 1, (48,), generator=g)
@@ -451,33 +465,126 @@ def test_greedy_margins_are_not_biased_against_the_oracle():
         for s_ in range(64):
             model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=700 + s_, bad_ids=[img_tok], slot=s_)
             model.kv_fork(64, s_, ids.numel())
-        oracles = {s_: DetikzifyOracle(cfg, w, precision="bf16") for s_ in watch}
-        orc = {s_: o.prefill(ids, None) for s_, o in oracles.items()}
-        dev = {s_: dev0 for s_ in watch}
-        plus = minus = equal = flips = near = 0
+        # the device first (64 steps, tokens and logits of the watched slots kept), then each watched slot's tokens teacher-forced
+        # through the oracle in ONE pass: orc_rows[s][k] = the oracle's logits for the context the device held before step k
+        dev_rows = {s_: [dev0] for s_ in watch}
+        toks = {s_: [] for s_ in watch}
         for _ in range(STEPS):
-            for s_ in watch:       # compare the logits both sides hold for the CURRENT context, then advance
-                masked = sampling.mask_scores(orc[s_], [img_tok], [], False)
+            model.decode_batch_launch(range(64))
+            out = model.decode_batch_wait()
+            for s_ in watch:
+                toks[s_].append(out[s_])
+                dev_rows[s_].append(model.get_logits_slot(s_))
+        o16 = DetikzifyOracle(cfg, w, precision="bf16")
+        orc0 = o16.prefill(ids, None)
+        snap = oracle_snapshot(o16)
+        plus = minus = equal = flips = near = 0
+        for s_ in watch:
+            oracle_restore(o16, snap)
+            orc_rows = [orc0] + list(o16.extend(toks[s_][:-1]))
+            for k in range(STEPS):       # compare the logits both sides hold for the SAME context
+                masked = sampling.mask_scores(orc_rows[k], [img_tok], [], False)
                 top = torch.topk(masked, 2)
                 a, b = top[1].tolist()
                 m_orc = float(top[0][0] - top[0][1])
-                m_dev = float(dev[s_][a] - dev[s_][b])
+                m_dev = float(dev_rows[s_][k][a] - dev_rows[s_][k][b])
                 gap = m_orc / (float(top[0][0].abs()) * ULP + 1e-30)
                 near += gap <= 2.0 + 1e-3
                 if m_dev < 0 or (m_dev == 0 and b < a):
                     assert gap <= 2.0 + 1e-3, (s_, a, b, m_orc, m_dev)
                     flips += 1
                 plus, minus, equal = plus + (m_dev > m_orc), minus + (m_dev < m_orc), equal + (m_dev == m_orc)
-            model.decode_batch_launch(range(64))
-            out = model.decode_batch_wait()
-            for s_ in watch:
-                orc[s_] = oracles[s_].step(out[s_])
-                dev[s_] = model.get_logits_slot(s_)
         n = plus + minus
         print(f"margin sign test, ds-7b width x 4 layers, 64-slot step, {len(watch) * STEPS} contexts: device margin above the oracle's {plus}, below {minus}, "
               f"equal {equal}; {flips} argmax flips in {near} near-tie contexts; {time.perf_counter() - t_start:.0f} s")
         assert n >= 128 and abs(plus - minus) <= 4.0 * n ** 0.5, (plus, minus)
         assert flips <= max(1, (near + 1) // 2), (flips, near)
+    finally:
+        del model
+        gc.collect()
+
+
+MX_BOUND = 0.25          # asserted: rel-L2 between the logits of a step with MXFP8 activations and the same step with bf16 activations, full depth
+MX_CONTEXTS, MX_STEPS = 32, 16
+
+
+def test_mxfp8_activations_against_bf16_activations():
+    """What the opt-in fp8 matrix-core step (dtk_set_option act_fp8 = 1: MXFP8 activations, csrc/kernels_batch_mx.hip) costs against
+    the default bf16-activation step of the SAME fp8-weight model — cl-7b at full depth, 65 slots, device against device on identical
+    token sequences: 32 slots sample 16 tokens each (T = .8, top-p .95, the pipeline's defaults: detikzify/infer/generate.py:218-227)
+    with bf16 activations; 32 other slots are then teacher-forced through the same 512 contexts (dtk_resume_slot forces the next
+    token) with MXFP8 activations, their KV cache built by the MXFP8 steps themselves.  Per context: rel-L2 of the logits (ASSERTED
+    <= MX_BOUND, SURVEY §7: "fp8 parity = bounded logit error"), greedy agreement, KL(T = .8) of the two next-token distributions,
+    and whether the sampler's draw (same seed, same counter) picks the same token.  Run on the uniform synthetic head and on the
+    PEAKED head (tests/helpers.py::peaked_lm_head; the uniform one puts the top two of 32 k logits within 2 bf16 ulps in a quarter of
+    the steps, so its greedy agreement says little).  The figures are the reason the path is opt-in; DESIGN.md quotes them."""
+    from detikzify_amd.model import load
+    from tests.fullsize import host_side
+    from tests.helpers import peaked_lm_head
+    t_start = time.perf_counter()
+    model, proc = load("detikzify-cl-7b", synthetic=1234, max_positions=512, weight_format="fp8", batch_slots=65)
+    try:
+        hs = host_side(model, proc, "detikzify-cl-7b", "fp8")
+        cfg = model.config.oracle_dict()
+        ids, px = hs.ids, hs.px
+        n_img, img_tok, key = ids.numel(), cfg["image_token_id"], model.image_key(px)
+        A, B, SRC = list(range(MX_CONTEXTS)), list(range(32, 32 + MX_CONTEXTS)), 64
+        seed_of = lambda s: 300 + s
+        reports = []
+        for label in ("uniform head", "peaked head"):
+            if label == "peaked head":
+                model.load_tensor("lm_head.weight", peaked_lm_head(hs.w["lm_head.weight"], PEAKED_BETA, PEAKED_SEED).to(torch.bfloat16))
+            model.set_option("act_fp8", 0)
+            model.set_sampling(do_sample=False, slot=SRC)
+            model.prefill(ids, px, slot=SRC)
+            for s in A:
+                model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=seed_of(s), bad_ids=[img_tok], slot=s)
+                model.kv_fork(SRC, s, n_img)
+            toks, LA, LB = {s: [] for s in A}, {s: [] for s in A}, {s: [] for s in A}
+            for k in range(MX_STEPS):
+                model.decode_batch_launch(A)
+                out = model.decode_batch_wait()
+                assert model.stats()["last_batch_step_fp8_mfma"] == 0
+                for s in A:
+                    toks[s].append(out[s])
+                    LA[s].append(model.get_logits_slot(s))
+            model.set_option("act_fp8", 1)
+            for s in A:
+                model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=32 + s)
+                model.kv_fork(SRC, 32 + s, n_img)
+            for k in range(MX_STEPS):
+                for s in A:      # the slot holds prefix + toks[:k]; the next step is forced to emit toks[k] and runs the forward on it
+                    model.resume_slot(32 + s, torch.cat([ids, torch.tensor(toks[s][:k + 1], dtype=torch.long)]), key)
+                model.decode_batch_launch(B)
+                out = model.decode_batch_wait()
+                st = model.stats()
+                assert st["last_batch_step_fp8_mfma"] == 1 and st["last_batch_step_slots"] == 64
+                for s in A:
+                    assert out[32 + s] == toks[s][k], (label, s, k)
+                    LB[s].append(model.get_logits_slot(32 + s))
+            worst = mean = kl_sum = kl_max = 0.0
+            same_greedy = same_draw = n = 0
+            for s in A:
+                for k in range(MX_STEPS):
+                    a, b = LA[s][k], LB[s][k]
+                    r = rel_l2(b, a)
+                    worst, mean = max(worst, r), mean + r
+                    ma, mb = sampling.mask_scores(a, [img_tok], [], False), sampling.mask_scores(b, [img_tok], [], False)
+                    same_greedy += int(torch.argmax(ma)) == int(torch.argmax(mb))
+                    pa, lb = torch.softmax(ma.double() / 0.8, -1), torch.log_softmax(mb.double() / 0.8, -1)
+                    kl = float((pa * (torch.log(pa.clamp_min(1e-300)) - lb)).sum())
+                    kl_sum, kl_max = kl_sum + kl, max(kl_max, kl)
+                    da, _ = sampling.draw(a, 0.8, 0, 0.95, seed_of(s), k + 1, [img_tok], [], False)
+                    db, _ = sampling.draw(b, 0.8, 0, 0.95, seed_of(s), k + 1, [img_tok], [], False)
+                    same_draw += da == db
+                    n += 1
+            assert len({tuple(toks[s][:4]) for s in A}) > MX_CONTEXTS // 2, "the per-slot seeds did not make the contexts diverge"
+            assert worst <= MX_BOUND, f"{label}: logits with MXFP8 activations are {worst:.3f} rel-L2 from the bf16-activation step (bound {MX_BOUND})"
+            assert same_draw >= 0.5 * n, (label, same_draw, n)
+            reports.append(f"{label}: {n} contexts, logits rel-L2 mean {mean / n:.3e} worst {worst:.3e} (asserted <= {MX_BOUND}); greedy token identical "
+                           f"{same_greedy}/{n} = {same_greedy / n:.3f}; KL(T=.8) mean {kl_sum / n:.3e} max {kl_max:.3e}; same sampled token under the same draw {same_draw}/{n} = {same_draw / n:.3f}")
+        print("MXFP8 activations (act_fp8 = 1) against bf16 activations (default), cl-7b fp8 full depth, same token sequences: " + "; ".join(reports)
+              + f"; {time.perf_counter() - t_start:.0f} s")
     finally:
         del model
         gc.collect()

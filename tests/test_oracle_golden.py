@@ -234,3 +234,34 @@ def test_real_width_decoder_matches_hf_llama():
         for tok in (17, 4096, 31999):
             out = hf(input_ids=torch.tensor([[tok]]), past_key_values=out.past_key_values, use_cache=True)
             assert rel_l2(llm.logits(llm.forward(llm.embed(torch.tensor([tok])))[-1]), out.logits[0, -1]) < 2e-5
+
+
+def test_one_pass_teacher_forcing_is_the_stepwise_oracle():
+    """DetikzifyOracle.extend (the GPU suite teacher-forces every watched slot in ONE causal pass since round 5) against the same
+    tokens fed one step() at a time, from a restored snapshot: identical up to the order of the fp32 accumulation (GEMM rows vs
+    GEMV) — fp32 policy to ~1e-6, bf16 policy to rounding flips of single logits, MXFP8-activation mode too; last_only = the
+    last row; the cache ends at the same position either way."""
+    import torch
+    from oracle.model import DetikzifyOracle
+    from oracle.synth import make_weights
+    from tests.helpers import TINY_CFG, TINY_V2_CFG, rel_l2
+    for cfg in (TINY_CFG, TINY_V2_CFG):
+        w = make_weights(cfg, 1234)
+        g = torch.Generator().manual_seed(11)
+        ids = torch.randint(3, cfg["vocab"] - 1, (20,), generator=g)
+        ids = ids[ids != cfg["image_token_id"]]
+        toks = [5, 9, 100, 33, 7, 250, 8]
+        for precision, bound in (("fp32", 2e-6), ("bf16", 5e-3)):
+            for quant in (False, True):
+                o = DetikzifyOracle(cfg, w, precision=precision)
+                o.prefill(ids, None)
+                snap = o.snapshot()
+                o.llm.act_quant = quant
+                steps = torch.stack([o.step(t) for t in toks])
+                end = o.llm.pos
+                o.restore(snap)
+                rows = o.extend(toks)
+                assert rows.shape == steps.shape and o.llm.pos == end == ids.numel() + len(toks)
+                assert rel_l2(rows, steps) < bound, (precision, quant, rel_l2(rows, steps))
+                o.restore(snap)
+                assert rel_l2(o.extend(toks, last_only=True), rows[-1]) < bound          # (lm_head over one row instead of seven: GEMV vs GEMM order)
