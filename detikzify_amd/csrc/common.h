@@ -71,6 +71,27 @@ __device__ __forceinline__ float wave_max(float v) {
 // streamed-once weights: non-temporal 16-byte load
 __device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
+// Read [base, base + bytes) once and drop it: block `block` of `nblocks` takes a contiguous share, 8 x 16 B per thread in flight.
+// The XOR of what was read reaches `sink` only when it equals a constant (practically never: the store exists so that the loads do).
+__device__ __forceinline__ void dtk_prefetch_range(const void* base, size_t bytes, int block, int nblocks, int tid, int nthreads, bool nt, unsigned* sink) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(base);
+  const size_t n16 = bytes >> 4, per = (n16 + (size_t)nblocks - 1) / (size_t)nblocks;
+  const size_t b0 = (size_t)block * per, b1 = b0 + per < n16 ? b0 + per : n16;
+  unsigned acc = 0;
+  for (size_t i = b0 + (size_t)tid; i < b1; i += (size_t)nthreads * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t j = i + (size_t)u * nthreads;
+      const size_t jj = j < b1 ? j : i;            // clamp: a line this thread reads anyway
+      v[u] = nt ? ld_nt(p + jj) : p[jj];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;
+}
+
 // Decode-step state that lives in device memory so a captured hipGraph can be
 // replayed unchanged: kernels read the position / token from here.
 struct DecState {
@@ -86,29 +107,43 @@ struct DecState {
 #ifndef DTK_MAX_BATCH
 #define DTK_MAX_BATCH 64   // == include/dtk.h
 #endif
+#define DTK_PFX_GROUPS 16  // prefix groups a step can hand to k_attn_prefix_g
+// One shared prefix scored on the matrix cores: the active slots that read the first `len` rows of their cache from slot `src`
+// (forks of one image: dtk_kv_fork), at most 16 of them = the columns of one MFMA tile.  A source with more forks has several groups.
+struct PfxGroup {
+  int32_t src;       // the slot whose cache holds the rows
+  int32_t len;       // keys [0, len) are the group's shared prefix
+  int32_t n;         // members (1..16)
+  int32_t pad;
+  int32_t slot[16];  // member slots (entries >= n repeat slot[0])
+};
 struct BatchState {
   int32_t active[DTK_MAX_BATCH];
   int32_t step;      // global step counter (token ring index)
-  // the prefix most active slots share (chosen by the host per step): slot `pfx_src` holds it in its first `pfx_len` rows.
-  // k_attn_prefix_b scores it ONCE for all slots on the matrix cores; a slot is a member iff it reads those rows from
-  // pfx_src (share_src == pfx_src, share_len >= pfx_len) or is pfx_src itself.  pfx_len == 0: no such prefix this step.
-  int32_t pfx_src;
-  int32_t pfx_len;
-  int32_t pad[13];
+  // Shared prefixes on the matrix cores (k_attn_prefix_g): the host groups the step's active slots by (share_src, share_len) — a
+  // property of the slot alone, so whether and how a slot's prefix is scored never depends on which other slots decode with it —
+  // into at most DTK_PFX_GROUPS groups of <= 16 slots; group_plus1[slot] = the slot's group + 1 (0: none, the slot's whole context
+  // is walked by k_attn_tail_b).  n_groups == 0: no prefix kernel work this step.
+  int32_t n_groups;
+  int32_t pad[14];
   // forked slots (dtk_kv_fork) hold a bit-identical copy of their source's first share_len keys: attention reads those
   // rows from the SOURCE slot's cache instead (-1 = none), so the 32 rollouts of one image stream the 243-key image
   // prefix from HBM once per layer and hit the XCD's L2 afterwards
   int32_t share_src[DTK_MAX_BATCH];
   int32_t share_len[DTK_MAX_BATCH];
+  int32_t group_plus1[DTK_MAX_BATCH];
+  PfxGroup groups[DTK_PFX_GROUPS];
 };
 
+// keys [0, pfx_start) of `slot` were scored by k_attn_prefix_g this step (0: none)
+__device__ __forceinline__ int pfx_start(const BatchState* bs, int slot) {
+  const int g = bs->n_groups > 0 ? bs->group_plus1[slot] : 0;
+  return g > 0 ? bs->groups[g - 1].len : 0;
+}
 // Batched decode keeps the GEMV INPUT vectors (normalised x, attention output, SwiGLU activation) of the slots in
 // the MFMA B-operand fragment order: tile (slot/16, k/32) is 1 KiB, lane = ((k%32)/8)*16 + slot%16 holds 8
 // consecutive k.  A wave's x load is then 1 KiB contiguous (8 full cache lines) instead of 16 rows x 64 B
 // (16 half-used lines): measured gate/up at 32 slots 48.3 -> 35.2 us.
-__device__ __forceinline__ bool pfx_member(const BatchState* bs, int slot) {
-  return bs->pfx_len > 0 && (slot == bs->pfx_src || (bs->share_src[slot] == bs->pfx_src && bs->share_len[slot] >= bs->pfx_len));
-}
 __device__ __forceinline__ size_t xtile_off(int slot, int k, int nsteps) {
   return ((size_t)((slot >> 4) * nsteps + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (slot & 15)) * 8 + (k & 7);
 }

@@ -98,7 +98,9 @@ struct dtk_ctx {
   bf16_t *x, *q, *act;
   float *logits, *pm, *pl, *po;
   bf16_t* attn_out = nullptr;        // combined attention output [d] (in-kernel combine)
-  unsigned* attn_ctr = nullptr;      // [H] arrival tickets
+  unsigned* attn_ctr = nullptr;      // [H] arrival tickets (+ 1 word: the prefetch blocks' sink)
+  int attn_prefetch = 0;             // single-sequence step: o_proj's weights prefetched by extra blocks of the attention launch (0 off, 1 default policy, 2 nt loads); dtk_set_option "attn_prefetch"
+  int attn_prefetch_blocks = 4;      // ... that many extra block rows (x H blocks)
   int attn_combine = 0;              // 0: consumer (o_proj prologue), 1: last-arriver in k_attn_decode, 2: own kernel
   DecState* st = nullptr;
   SamplingDev* sp = nullptr;
@@ -138,8 +140,8 @@ struct dtk_ctx {
   bool resid_kparts = true;    // batched N = d roles at 64 slots as two launches (k_gemv_bkp + k_resid_norm_b; measured 20.2 -> 21.2 rollouts/s): dtk_set_option("resid_kparts")
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
   int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
-  int prefix_mfma = 0;               // score the prefix most slots share once for all of them on the matrix cores (measured: no gain, off)
-  int pfx_splits = 2;                // key splits of that kernel
+  int prefix_mfma = 1;               // shared prefixes (forks of one image) scored once per group of <= 16 slots on the matrix cores (k_attn_prefix_g); dtk_set_option "prefix_mfma"
+  int pfx_splits = 4;                // key splits of that kernel (its grid z)
   int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
   int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4)
   DecState* st_b = nullptr;          // [16]
@@ -397,7 +399,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->pl = P.take<float>((size_t)c->H * 16);
   c->po = P.take<float>((size_t)c->H * 16 * 130);
   c->attn_out = P.take<bf16_t>(d);
-  c->attn_ctr = P.take<unsigned>(c->H);
+  c->attn_ctr = P.take<unsigned>(c->H + 1);
   c->st = P.take<DecState>(1);
   c->sp = P.take<SamplingDev>(1);
   c->smb = P.take<SampleMB>(1);
@@ -621,6 +623,11 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.threads = c->attn_threads;
     ad.combine = (!ad.threads && short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     if (ad.threads && ad.combine == 1) ad.combine = 2;      // the tile kernel has no in-kernel combine
+    if (c->attn_prefetch && ad.threads) {                   // o_proj's weights (what the NEXT launch streams) under the attention
+      ad.pf_ptr = w.q_wo ? (const void*)w.q_wo : (const void*)w.wo;
+      ad.pf_bytes = (size_t)c->d * c->d * (w.q_wo ? 1 : 2);
+      ad.pf_blocks = c->attn_prefetch_blocks; ad.pf_policy = c->attn_prefetch; ad.pf_sink = c->attn_ctr + c->H;
+    }
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
@@ -871,6 +878,14 @@ void drop_batch_graphs(dtk_ctx* c) {
     if (c->bgraph[i]) { (void)hipGraphDestroy(c->bgraph[i]); c->bgraph[i] = nullptr; }
     c->bgraph_ready[i] = false;
   }
+}
+
+void drop_graph(dtk_ctx* c) {          // the single-sequence step's two captures
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  if (c->graph_short_exec) { (void)hipGraphExecDestroy(c->graph_short_exec); c->graph_short_exec = nullptr; }
+  if (c->graph_short) { (void)hipGraphDestroy(c->graph_short); c->graph_short = nullptr; }
+  c->graph_ready = false;
 }
 
 int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step / c->mv_step
@@ -1460,23 +1475,30 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
     hb->share_len[j] = sh_ok ? c->bseq[(size_t)j].share_len : 0;
   }
   hb->step = (int32_t)(c->blaunched % DTK_MAX_INFLIGHT);
-  // the prefix most ACTIVE slots read from one source slot (forks of one image): scored once for all of them by
-  // k_attn_prefix_b; its length is the shortest share among those slots (what lies beyond is per-slot work)
-  hb->pfx_src = -1; hb->pfx_len = 0;
-  if (c->prefix_mfma && c->attn_b_impl == 1) {
-    int count[DTK_MAX_SLOTS] = {0};
-    for (int j = 0; j < DTK_MAX_BATCH; ++j) {
-      if (!active[j]) continue;
-      if (hb->share_src[j] >= 0 && hb->share_src[j] < DTK_MAX_SLOTS) count[hb->share_src[j]]++;
+  // Shared prefixes for k_attn_prefix_g: the active slots grouped by (share_src, share_len) — both properties of the slot alone, so a
+  // slot's arithmetic never depends on which other slots decode with it — in chunks of 16 (one MFMA column tile), sources in slot
+  // order.  A source slot that decodes itself is not a member of its forks' groups (that WOULD depend on the others); more than
+  // DTK_PFX_GROUPS groups (over 16 distinct prefixes in one step): the rest walk their whole context in k_attn_tail_b.
+  hb->n_groups = 0;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) hb->group_plus1[j] = 0;
+  if (c->prefix_mfma && c->attn_b_impl == 1 && !mv_family(c)) {
+    for (int j = 0; j < DTK_MAX_BATCH && hb->n_groups < DTK_PFX_GROUPS; ++j) {
+      if (!active[j] || hb->group_plus1[j] || hb->share_src[j] < 0 || hb->share_len[j] < 4) continue;
+      const int src = hb->share_src[j], len = hb->share_len[j];
+      PfxGroup* g = nullptr;
+      for (int k = j; k < DTK_MAX_BATCH; ++k) {
+        if (!active[k] || hb->group_plus1[k] || hb->share_src[k] != src || hb->share_len[k] != len) continue;
+        if (!g || g->n == 16) {
+          if (hb->n_groups == DTK_PFX_GROUPS) break;
+          g = &hb->groups[hb->n_groups++];
+          g->src = src; g->len = len; g->n = 0; g->pad = 0;
+        }
+        g->slot[g->n++] = k;
+        hb->group_plus1[k] = hb->n_groups;
+      }
     }
-    int best = -1;
-    for (int sidx = 0; sidx < DTK_MAX_SLOTS; ++sidx) if (count[sidx] > (best < 0 ? 0 : count[best])) best = sidx;
-    if (best >= 0 && count[best] + (best < DTK_MAX_BATCH && active[best] ? 1 : 0) >= 2) {
-      int len = 1 << 30;
-      for (int j = 0; j < DTK_MAX_BATCH; ++j)
-        if (active[j] && hb->share_src[j] == best) len = hb->share_len[j] < len ? hb->share_len[j] : len;
-      if (len >= 4 && len < (1 << 30)) { hb->pfx_src = best; hb->pfx_len = len; }
-    }
+    for (int gi = 0; gi < hb->n_groups; ++gi)
+      for (int k = hb->groups[gi].n; k < 16; ++k) hb->groups[gi].slot[k] = hb->groups[gi].slot[0];
   }
   int hi = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) if (active[j]) hi = j;
@@ -1977,6 +1999,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (c->blaunched != c->bwaited) return fail(c, DTK_ERR_STATE, "mv_slots: a batch step is in flight");
     c->mv_slots = value;
     drop_batch_graphs(c);
+  }
+  else if (!strcmp(name, "attn_prefetch") || !strcmp(name, "attn_prefetch_blocks")) {
+    if (name[13] == 0) { if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_prefetch must be 0, 1 or 2"); c->attn_prefetch = value; }
+    else { if (value < 1 || value > 16) return fail(c, DTK_ERR_ARG, "attn_prefetch_blocks must be 1..16"); c->attn_prefetch_blocks = value; }
+    drop_graph(c);
   }
   else if (!strcmp(name, "mv_tail_threads")) {
     if (value != 256 && value != 512 && value != 1024) return fail(c, DTK_ERR_ARG, "mv_tail_threads must be 256, 512 or 1024");

@@ -541,26 +541,31 @@ __global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Shared prefix on the matrix cores.  The rollouts of one image hold bit-identical copies of the image prefix (dtk_kv_fork):
-// scoring it per slot on the VALU re-read the same 243 rows 64 times from L2 — 64 x 32 x 8 tiny blocks, 36 us per layer at
-// 64 slots.  k_attn_prefix_b does it ONCE per head as a 64-query flash attention (queries = slots) over the source slot's rows
-// [0, pfx_len): S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_16x16x32_bf16, computed transposed so a lane's MFMA column is its
-// own query (the scheme of k_attention_mfma, kernels_batched.hip), fp32 online softmax, P as a bf16 hi + lo pair.  It leaves
-// every slot's UN-normalised state (m, l, o[128]) per key split; k_attn_tail_b starts from it and continues over the slot's
-// private keys.  Grid (H, NPS): block z scans the 64-key tiles [z * tps, (z + 1) * tps).
-#define PFX_HDP 136   // LDS row stride of a 128-dim K / V row (elements): 68 dwords, conflict-free 16-byte fragment reads
-__global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PFX_HDP];
+// Shared prefixes on the matrix cores.  The rollouts of one image hold bit-identical copies of the image prefix (dtk_kv_fork):
+// scoring it per slot on the VALU re-reads the same 243 rows once per slot from L2 (64 slots x 32 heads blocks, 255 MB of L2 -> CU
+// traffic per layer for 4 MB of keys and values) and spends the step's largest kernel on a [slots x 128] . [128 x 243] GEMM done one
+// dot product at a time.  k_attn_prefix_g does it per GROUP (PfxGroup: <= 16 slots that read keys [0, len) from one source slot) as a
+// 16-query flash attention on v_mfma_f32_16x16x32_bf16: S^T = K Q^T and O^T = V^T P^T, computed transposed so that a lane's MFMA
+// column is its own query and the S^T accumulator IS the P^T operand (the scheme of k_attention_mfma, kernels_batched.hip), fp32
+// online softmax, P as a bf16 hi + lo pair (the fp32 probabilities of the VALU path to ~16 mantissa bits).
+// One WAVE per block, grid (H, DTK_PFX_GROUPS, key splits): 32 x 4 x 4 = 512 live blocks for 64 forks of one image, 32 x 8 x 4 for
+// BASELINE config 5's 8 images x 8 trees (round 2's k_attn_prefix_b had 64-128 blocks of four waves behind __syncthreads: no gain).
+// A block's K fragments come straight from global memory in the A-operand order (16 keys x 8 dims per lane load, no LDS); only V
+// goes through (wave-private) LDS, for the transposition.  It leaves every member's UN-normalised state (m, l, o[128]) per key
+// split; k_attn_tail_b starts from it and continues over the slot's private keys.
+#define PFX_HDP 136   // LDS row stride of a 128-dim V row (elements): 68 dwords, conflict-free 16-byte fragment reads
+__global__ __launch_bounds__(64) void k_attn_prefix_g(AttnDecBArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PFX_HDP];
-  const int Tk = a.bs->pfx_len;
-  if (Tk <= 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x, z = blockIdx.y, NPS = gridDim.y;
+  const BatchState* bs = a.bs;
+  const int h = blockIdx.x, gi = blockIdx.y, z = blockIdx.z, NPS = gridDim.z;
+  if (gi >= bs->n_groups) return;
+  const PfxGroup* grp = bs->groups + gi;
+  const int Tk = grp->len, nmem = grp->n;
+  const int lane = threadIdx.x, lq = lane & 15, g = lane >> 4;
+  const bool real = lq < nmem;
+  const int slot = grp->slot[real ? lq : 0];            // this lane's query (columns beyond the group repeat member 0 and are dropped)
   const int kvh = h / a.G;
-  const int slot = wave * 16 + lq;                      // this lane's query
-  const bool real = slot < a.nslots;
-  const size_t src_off = (size_t)a.bs->pfx_src * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const size_t src_off = (size_t)grp->src * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   const bf16_t* Kp = a.kcache + src_off;
   const bf16_t* Vp = a.vcache + src_off;
   const int tiles = (Tk + 63) >> 6, tps = (tiles + NPS - 1) / NPS;
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
 
   bf16x8_t qf[4];
   {
-    const bf16_t* qp = a.q + (size_t)(real ? slot : 0) * a.d + h * 128;
+    const bf16_t* qp = a.q + (size_t)slot * a.d + h * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(qp + (ks * 4 + g) * 8));
   }
@@ -577,36 +582,34 @@ __global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 rk[4], rv[4];
-  auto tile_load = [&](int j0) {
+  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+    // everything the tile needs is requested before anything is used: 16 K fragments + 16 V row pieces of 16 bytes per lane
+    u32x4 kf[4][4], rv[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256, r = idx >> 4, c = idx & 15;     // 64 rows x 16 chunks of 16 bytes
-      int j = j0 + r; if (j >= Tk) j = Tk - 1;
-      rk[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)j * 128 + c * 8);
+    for (int t = 0; t < 4; ++t) {
+      const int j = min(j0 + t * 16 + lq, Tk - 1);        // A operand: row = key t * 16 + lq, k = dims (ks * 4 + g) * 8 .. + 8
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *reinterpret_cast<const u32x4*>(Kp + (size_t)j * 128 + (ks * 4 + g) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = lane + i * 64, r = idx >> 4, c = idx & 15;      // 64 rows x 16 pieces
+      const int j = min(j0 + r, Tk - 1);
       rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)j * 128 + c * 8);
     }
-  };
-  if (j_begin < j_end) tile_load(j_begin);
-  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
-    __syncthreads();
+    if (j0 != j_begin) __syncthreads();                   // (one wave: the previous tile's V reads are done before Vs is overwritten)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256, r = idx >> 4, c = idx & 15;
-      *reinterpret_cast<u32x4*>(&Ks[r * PFX_HDP + c * 8]) = rk[i];
+    for (int i = 0; i < 16; ++i) {
+      const int idx = lane + i * 64, r = idx >> 4, c = idx & 15;
       *reinterpret_cast<u32x4*>(&Vs[r * PFX_HDP + c * 8]) = rv[i];
     }
-    __syncthreads();
-    if (j0 + 64 < j_end) tile_load(j0 + 64);
     f32x4 sc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kv = *reinterpret_cast<const u32x4*>(&Ks[(t * 16 + lq) * PFX_HDP + (ks * 4 + g) * 8]);
-        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kv), qf[ks], sc[t], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks)
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ks]), qf[ks], sc[t], 0, 0, 0);
     }
     float tmax = -1e30f;
 #pragma unroll
@@ -638,9 +641,10 @@ __global__ __launch_bounds__(256) void k_attn_prefix_b(AttnDecBArgs a) {
     m = mn;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] *= corr;
+    __syncthreads();                                      // V tile visible to every lane of the wave
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      u32x4 pw, pl;   // p = hi + lo (two bf16): the fp32 probabilities of the VALU path to ~16 mantissa bits
+      u32x4 pw, pl;   // p = hi + lo (two bf16)
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -697,8 +701,8 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   const int ssrc = a.bs->share_src[slot];
   const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
   const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;
-  const bool member = a.use_prefix && pfx_member(a.bs, slot);
-  const int start = member ? a.bs->pfx_len : 0;
+  const int start = a.use_prefix ? pfx_start(a.bs, slot) : 0;      // keys [0, start) were scored by k_attn_prefix_g (0: none)
+  const bool member = start > 0;
   const int n = a.st[slot].pos + 1;
   u32x4 qv[GQ];
 #pragma unroll
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
-    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_b, dim3(a.H, a.pfx_splits), dim3(256), 0, s, a);
+    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_g, dim3(a.H, DTK_PFX_GROUPS, a.pfx_splits), dim3(64), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
     if (a.G == 4 && a.gqa_fused == 2) {   // pairs of query heads: half the sharing, twice the blocks
       hipLaunchKernelGGL((k_attn_tail_b<256, 2>), dim3(a.H / 2, a.nslots), dim3(256), 0, s, a);
