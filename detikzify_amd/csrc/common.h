@@ -71,27 +71,6 @@ __device__ __forceinline__ float wave_max(float v) {
 // streamed-once weights: non-temporal 16-byte load
 __device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
-// Read [base, base + bytes) once and drop it: block `block` of `nblocks` takes a contiguous share, 8 x 16 B per thread in flight.
-// The XOR of what was read reaches `sink` only when it equals a constant (practically never: the store exists so that the loads do).
-__device__ __forceinline__ void dtk_prefetch_range(const void* base, size_t bytes, int block, int nblocks, int tid, int nthreads, bool nt, unsigned* sink) {
-  const u32x4* p = reinterpret_cast<const u32x4*>(base);
-  const size_t n16 = bytes >> 4, per = (n16 + (size_t)nblocks - 1) / (size_t)nblocks;
-  const size_t b0 = (size_t)block * per, b1 = b0 + per < n16 ? b0 + per : n16;
-  unsigned acc = 0;
-  for (size_t i = b0 + (size_t)tid; i < b1; i += (size_t)nthreads * 8) {
-    u32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const size_t j = i + (size_t)u * nthreads;
-      const size_t jj = j < b1 ? j : i;            // clamp: a line this thread reads anyway
-      v[u] = nt ? ld_nt(p + jj) : p[jj];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
-  }
-  if (acc == 0x9e3779b9u && sink) *sink = acc;
-}
-
 // Decode-step state that lives in device memory so a captured hipGraph can be
 // replayed unchanged: kernels read the position / token from here.
 struct DecState {
@@ -132,14 +111,10 @@ struct BatchState {
   int32_t share_src[DTK_MAX_BATCH];
   int32_t share_len[DTK_MAX_BATCH];
   int32_t group_plus1[DTK_MAX_BATCH];
+  int32_t pfx_len_of[DTK_MAX_BATCH];   // = groups[group_plus1[slot] - 1].len, or 0: what k_attn_tail_b needs, without the dependent lookup
   PfxGroup groups[DTK_PFX_GROUPS];
 };
 
-// keys [0, pfx_start) of `slot` were scored by k_attn_prefix_g this step (0: none)
-__device__ __forceinline__ int pfx_start(const BatchState* bs, int slot) {
-  const int g = bs->n_groups > 0 ? bs->group_plus1[slot] : 0;
-  return g > 0 ? bs->groups[g - 1].len : 0;
-}
 // Batched decode keeps the GEMV INPUT vectors (normalised x, attention output, SwiGLU activation) of the slots in
 // the MFMA B-operand fragment order: tile (slot/16, k/32) is 1 KiB, lane = ((k%32)/8)*16 + slot%16 holds 8
 // consecutive k.  A wave's x load is then 1 KiB contiguous (8 full cache lines) instead of 16 rows x 64 B

@@ -98,9 +98,7 @@ struct dtk_ctx {
   bf16_t *x, *q, *act;
   float *logits, *pm, *pl, *po;
   bf16_t* attn_out = nullptr;        // combined attention output [d] (in-kernel combine)
-  unsigned* attn_ctr = nullptr;      // [H] arrival tickets (+ 1 word: the prefetch blocks' sink)
-  int attn_prefetch = 0;             // single-sequence step: o_proj's weights prefetched by extra blocks of the attention launch (0 off, 1 default policy, 2 nt loads); dtk_set_option "attn_prefetch"
-  int attn_prefetch_blocks = 4;      // ... that many extra block rows (x H blocks)
+  unsigned* attn_ctr = nullptr;      // [H] arrival tickets
   int attn_combine = 0;              // 0: consumer (o_proj prologue), 1: last-arriver in k_attn_decode, 2: own kernel
   DecState* st = nullptr;
   SamplingDev* sp = nullptr;
@@ -399,7 +397,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->pl = P.take<float>((size_t)c->H * 16);
   c->po = P.take<float>((size_t)c->H * 16 * 130);
   c->attn_out = P.take<bf16_t>(d);
-  c->attn_ctr = P.take<unsigned>(c->H + 1);
+  c->attn_ctr = P.take<unsigned>(c->H);
   c->st = P.take<DecState>(1);
   c->sp = P.take<SamplingDev>(1);
   c->smb = P.take<SampleMB>(1);
@@ -623,11 +621,6 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.threads = c->attn_threads;
     ad.combine = (!ad.threads && short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     if (ad.threads && ad.combine == 1) ad.combine = 2;      // the tile kernel has no in-kernel combine
-    if (c->attn_prefetch && ad.threads) {                   // o_proj's weights (what the NEXT launch streams) under the attention
-      ad.pf_ptr = w.q_wo ? (const void*)w.q_wo : (const void*)w.wo;
-      ad.pf_bytes = (size_t)c->d * c->d * (w.q_wo ? 1 : 2);
-      ad.pf_blocks = c->attn_prefetch_blocks; ad.pf_policy = c->attn_prefetch; ad.pf_sink = c->attn_ctr + c->H;
-    }
     launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
@@ -1480,7 +1473,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   // order.  A source slot that decodes itself is not a member of its forks' groups (that WOULD depend on the others); more than
   // DTK_PFX_GROUPS groups (over 16 distinct prefixes in one step): the rest walk their whole context in k_attn_tail_b.
   hb->n_groups = 0;
-  for (int j = 0; j < DTK_MAX_BATCH; ++j) hb->group_plus1[j] = 0;
+  for (int j = 0; j < DTK_MAX_BATCH; ++j) { hb->group_plus1[j] = 0; hb->pfx_len_of[j] = 0; }
   if (c->prefix_mfma && c->attn_b_impl == 1 && !mv_family(c)) {
     for (int j = 0; j < DTK_MAX_BATCH && hb->n_groups < DTK_PFX_GROUPS; ++j) {
       if (!active[j] || hb->group_plus1[j] || hb->share_src[j] < 0 || hb->share_len[j] < 4) continue;
@@ -1495,6 +1488,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
         }
         g->slot[g->n++] = k;
         hb->group_plus1[k] = hb->n_groups;
+        hb->pfx_len_of[k] = len;
       }
     }
     for (int gi = 0; gi < hb->n_groups; ++gi)
@@ -1999,11 +1993,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     if (c->blaunched != c->bwaited) return fail(c, DTK_ERR_STATE, "mv_slots: a batch step is in flight");
     c->mv_slots = value;
     drop_batch_graphs(c);
-  }
-  else if (!strcmp(name, "attn_prefetch") || !strcmp(name, "attn_prefetch_blocks")) {
-    if (name[13] == 0) { if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "attn_prefetch must be 0, 1 or 2"); c->attn_prefetch = value; }
-    else { if (value < 1 || value > 16) return fail(c, DTK_ERR_ARG, "attn_prefetch_blocks must be 1..16"); c->attn_prefetch_blocks = value; }
-    drop_graph(c);
   }
   else if (!strcmp(name, "mv_tail_threads")) {
     if (value != 256 && value != 512 && value != 1024) return fail(c, DTK_ERR_ARG, "mv_tail_threads must be 256, 512 or 1024");

@@ -55,11 +55,6 @@ struct AttnDecArgs {
   unsigned* counters;    // [H] arrival tickets, zero between launches
   int G;                 // query heads per kv head (1 = MHA)
   int threads;           // 0: contiguous key ranges per split (k_attn_decode); 256 | 512 | 1024: k_attn_decode_t, tiles dealt round-robin to the splits
-  // Weight prefetch under the attention (k_attn_decode_t): the attention of one sequence occupies H * S blocks (128 of 256 CUs) for ~5 us
-  // and moves a few hundred KB, so HBM idles exactly where o_proj's weights (the next launch) could already be on their way into the
-  // die-level Infinity Cache.  pf_blocks extra blocks per head row (grid y = S + pf_blocks) read [pf_ptr, pf_ptr + pf_bytes) once and
-  // drop it; pf_policy 1 = default cache policy, 2 = non-temporal loads.  The attention blocks themselves are unchanged.
-  const void* pf_ptr = nullptr; size_t pf_bytes = 0; int pf_blocks = 0; int pf_policy = 0; unsigned* pf_sink = nullptr;
 };
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s);
 

@@ -558,14 +558,16 @@ __global__ __launch_bounds__(64) void k_attn_prefix_g(AttnDecBArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PFX_HDP];
   const BatchState* bs = a.bs;
   const int h = blockIdx.x, gi = blockIdx.y, z = blockIdx.z, NPS = gridDim.z;
-  if (gi >= bs->n_groups) return;
-  const PfxGroup* grp = bs->groups + gi;
-  const int Tk = grp->len, nmem = grp->n;
   const int lane = threadIdx.x, lq = lane & 15, g = lane >> 4;
+  // the whole group record is requested at once, BEFORE n_groups is known (the table is plain memory whatever it holds): one memory
+  // round trip, then the q / K / V loads — the block is a chain of dependent loads, and each link costs 1-2 us under a full chip
+  const PfxGroup* grp = bs->groups + gi;
+  const int ngroups = bs->n_groups, Tk = grp->len, nmem = grp->n, src = grp->src;
+  const int slot = grp->slot[lq];                       // this lane's query (the host fills the columns beyond the group with member 0; they are dropped)
+  if (gi >= ngroups) return;
   const bool real = lq < nmem;
-  const int slot = grp->slot[real ? lq : 0];            // this lane's query (columns beyond the group repeat member 0 and are dropped)
   const int kvh = h / a.G;
-  const size_t src_off = (size_t)grp->src * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const size_t src_off = (size_t)src * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
   const bf16_t* Kp = a.kcache + src_off;
   const bf16_t* Vp = a.vcache + src_off;
   const int tiles = (Tk + 63) >> 6, tps = (tiles + NPS - 1) / NPS;
@@ -692,21 +694,27 @@ template <int THREADS, int GQ = 1>
 __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
   constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
   const int h0 = blockIdx.x * GQ, slot = blockIdx.y;
-  if (!a.bs->active[slot]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 15, grp = lane >> 4;
-  const int kvh = h0 / a.G;
-  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
-  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
-  const int ssrc = a.bs->share_src[slot];
-  const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
-  const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;
-  const int start = a.use_prefix ? pfx_start(a.bs, slot) : 0;      // keys [0, start) were scored by k_attn_prefix_g (0: none)
-  const bool member = start > 0;
+  // Every scalar the block needs and its q rows are requested TOGETHER, before the first of them is looked at: with a few private keys
+  // per slot the block is a chain of dependent memory round trips (1-2 us each under 2048 resident blocks), and round 4's order —
+  // active, then share_src / share_len / pos, then the group's length, then K / V, then the prefix state split by split — was eight
+  // of them: 19.7 us of k_attn_tail_b with 4 keys to score (profiles/r05b_batch64_fp8_prefix_kernel_stats.csv).
+  const BatchState* bs = a.bs;
+  const int is_active = bs->active[slot];
+  const int ssrc = bs->share_src[slot], slen_raw = bs->share_len[slot];
+  const int start = a.use_prefix ? bs->pfx_len_of[slot] : 0;       // keys [0, start) were scored by k_attn_prefix_g (0: none)
   const int n = a.st[slot].pos + 1;
   u32x4 qv[GQ];
 #pragma unroll
   for (int g = 0; g < GQ; ++g) qv[g] = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + (h0 + g) * 128)[sub];
+  if (!is_active) return;
+  const int kvh = h0 / a.G;
+  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
+  const int slen = ssrc >= 0 ? slen_raw : 0;
+  const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;
+  const bool member = start > 0;
 
   // Two register sets of K / V rows, ping-pong: while tile j is scored from one set, tile j + 1 is already in the other and tile
   // j + 2 is requested as soon as its set is free — one to two tiles (8-16 KiB per wave) in flight instead of one.  (Round 2 copied
@@ -749,10 +757,20 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 #pragma unroll
     for (int g = 0; g < GQ; ++g) {
       const size_t rec0 = ((size_t)slot * a.H + h0 + g) * a.pfx_splits;
-      for (int zsp = 0; zsp < a.pfx_splits; ++zsp) {
-        const float m2 = a.pfx_m[rec0 + zsp], l2 = a.pfx_l[rec0 + zsp];
-        const f32x4* po4 = reinterpret_cast<const f32x4*>(a.pfx_o + (rec0 + zsp) * 128 + sub * 8);
-        const f32x4 p0 = po4[0], p1 = po4[1];
+      float sm2[4], sl2[4];
+      f32x4 sp0[4], sp1[4];
+#pragma unroll
+      for (int zsp = 0; zsp < 4; ++zsp) {    // all splits' records in flight at once (pfx_splits <= 4), merged in order below
+        const size_t rec = rec0 + (zsp < a.pfx_splits ? zsp : 0);
+        sm2[zsp] = a.pfx_m[rec]; sl2[zsp] = a.pfx_l[rec];
+        const f32x4* po4 = reinterpret_cast<const f32x4*>(a.pfx_o + rec * 128 + sub * 8);
+        sp0[zsp] = po4[0]; sp1[zsp] = po4[1];
+      }
+#pragma unroll
+      for (int zsp = 0; zsp < 4; ++zsp) {
+        if (zsp >= a.pfx_splits) break;
+        const float m2 = sm2[zsp], l2 = sl2[zsp];
+        const f32x4 p0 = sp0[zsp], p1 = sp1[zsp];
         const float mn = fmaxf(m[g], m2);
         const float c1 = __expf(m[g] - mn), c2 = __expf(m2 - mn);
         l[g] = l[g] * c1 + l2 * c2;

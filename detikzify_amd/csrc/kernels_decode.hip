@@ -858,10 +858,6 @@ __global__ __launch_bounds__(THREADS) void k_attn_decode_t(AttnDecArgs a) {
   constexpr int WAVES = THREADS / 64, ROWS = WAVES * 16;
   const int h = blockIdx.x, sp = blockIdx.y, S = a.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (sp >= S) {         // a prefetch block (AttnDecArgs::pf_*): the next launch's weights on their way while HBM idles under the attention
-    dtk_prefetch_range(a.pf_ptr, a.pf_bytes, (sp - S) * (int)gridDim.x + h, a.pf_blocks * (int)gridDim.x, tid, THREADS, a.pf_policy == 2, a.pf_sink);
-    return;
-  }
   const int sub = lane & 15, grp = lane >> 4;
   const int kvh = h / a.G;
   const bf16_t* kbase = a.kcache + (size_t)kvh * a.T_max * 128;
@@ -974,7 +970,7 @@ __global__ __launch_bounds__(THREADS) void k_attn_decode_t(AttnDecArgs a) {
 
 void launch_attn_decode(const AttnDecArgs& a, hipStream_t s) {
   if (a.threads) {   // tile-interleaved splits (k_attn_decode_t); a.combine: 0 consumer reduces the partials, 2 own kernel; S == 1: direct
-    const dim3 grid(a.H, a.S + ((a.pf_ptr && a.pf_bytes && a.pf_blocks > 0) ? a.pf_blocks : 0));
+    const dim3 grid(a.H, a.S);
     if (a.threads >= 1024) hipLaunchKernelGGL(k_attn_decode_t<1024>, grid, dim3(1024), 0, s, a);
     else if (a.threads >= 512) hipLaunchKernelGGL(k_attn_decode_t<512>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(k_attn_decode_t<256>, grid, dim3(256), 0, s, a);

@@ -517,12 +517,14 @@ def test_mxfp8_activations_against_bf16_activations():
     """What the opt-in fp8 matrix-core step (dtk_set_option act_fp8 = 1: MXFP8 activations, csrc/kernels_batch_mx.hip) costs against
     the default bf16-activation step of the SAME fp8-weight model — cl-7b at full depth, 65 slots, device against device on identical
     token sequences: 32 slots sample 16 tokens each (T = .8, top-p .95, the pipeline's defaults: detikzify/infer/generate.py:218-227)
-    with bf16 activations; 32 other slots are then teacher-forced through the same 512 contexts (dtk_resume_slot forces the next
-    token) with MXFP8 activations, their KV cache built by the MXFP8 steps themselves.  Per context: rel-L2 of the logits (ASSERTED
+    with bf16 activations on the uniform synthetic head; those 32 x 16 = 512 contexts are then teacher-forced (dtk_resume_slot forces
+    the next token) through 32 other slots with MXFP8 activations, their KV cache built by the MXFP8 steps themselves.  The same 512
+    contexts are then forced through BOTH modes under the PEAKED head (tests/helpers.py::peaked_lm_head: the uniform one puts the top
+    two of 32 k logits within 2 bf16 ulps in a quarter of the steps, so its greedy agreement says little; sampling under the peaked
+    head would not make the contexts differ — it draws the same token everywhere).  Per context: rel-L2 of the logits (ASSERTED
     <= MX_BOUND, SURVEY §7: "fp8 parity = bounded logit error"), greedy agreement, KL(T = .8) of the two next-token distributions,
-    and whether the sampler's draw (same seed, same counter) picks the same token.  Run on the uniform synthetic head and on the
-    PEAKED head (tests/helpers.py::peaked_lm_head; the uniform one puts the top two of 32 k logits within 2 bf16 ulps in a quarter of
-    the steps, so its greedy agreement says little).  The figures are the reason the path is opt-in; DESIGN.md quotes them."""
+    and whether the sampler's draw (same seed, same counter) picks the same token.  The figures are the reason the path is opt-in;
+    DESIGN.md quotes them."""
     from detikzify_amd.model import load
     from tests.fullsize import host_side
     from tests.helpers import peaked_lm_head
@@ -533,40 +535,56 @@ def test_mxfp8_activations_against_bf16_activations():
         cfg = model.config.oracle_dict()
         ids, px = hs.ids, hs.px
         n_img, img_tok, key = ids.numel(), cfg["image_token_id"], model.image_key(px)
-        A, B, SRC = list(range(MX_CONTEXTS)), list(range(32, 32 + MX_CONTEXTS)), 64
+        A, SRC = list(range(MX_CONTEXTS)), 64
         seed_of = lambda s: 300 + s
-        reports = []
-        for label in ("uniform head", "peaked head"):
-            if label == "peaked head":
-                model.load_tensor("lm_head.weight", peaked_lm_head(hs.w["lm_head.weight"], PEAKED_BETA, PEAKED_SEED).to(torch.bfloat16))
-            model.set_option("act_fp8", 0)
+
+        def prefix():
             model.set_sampling(do_sample=False, slot=SRC)
             model.prefill(ids, px, slot=SRC)
+
+        def forced(mode, base, toks):
+            """the 512 contexts teacher-forced through slots base .. base + 31 with act_fp8 = mode: logits after every forced token"""
+            model.set_option("act_fp8", mode)
             for s in A:
-                model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=seed_of(s), bad_ids=[img_tok], slot=s)
-                model.kv_fork(SRC, s, n_img)
-            toks, LA, LB = {s: [] for s in A}, {s: [] for s in A}, {s: [] for s in A}
-            for k in range(MX_STEPS):
-                model.decode_batch_launch(A)
-                out = model.decode_batch_wait()
-                assert model.stats()["last_batch_step_fp8_mfma"] == 0
-                for s in A:
-                    toks[s].append(out[s])
-                    LA[s].append(model.get_logits_slot(s))
-            model.set_option("act_fp8", 1)
-            for s in A:
-                model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=32 + s)
-                model.kv_fork(SRC, 32 + s, n_img)
+                model.set_sampling(do_sample=False, bad_ids=[img_tok], slot=base + s)
+                model.kv_fork(SRC, base + s, n_img)
+            out_logits = {s: [] for s in A}
             for k in range(MX_STEPS):
                 for s in A:      # the slot holds prefix + toks[:k]; the next step is forced to emit toks[k] and runs the forward on it
-                    model.resume_slot(32 + s, torch.cat([ids, torch.tensor(toks[s][:k + 1], dtype=torch.long)]), key)
-                model.decode_batch_launch(B)
+                    model.resume_slot(base + s, torch.cat([ids, torch.tensor(toks[s][:k + 1], dtype=torch.long)]), key)
+                model.decode_batch_launch([base + s for s in A])
                 out = model.decode_batch_wait()
                 st = model.stats()
-                assert st["last_batch_step_fp8_mfma"] == 1 and st["last_batch_step_slots"] == 64
+                assert st["last_batch_step_fp8_mfma"] == mode and st["last_batch_step_slots"] == (64 if base else 32)
                 for s in A:
-                    assert out[32 + s] == toks[s][k], (label, s, k)
-                    LB[s].append(model.get_logits_slot(32 + s))
+                    assert out[base + s] == toks[s][k], (mode, s, k)
+                    out_logits[s].append(model.get_logits_slot(base + s))
+            return out_logits
+
+        # the contexts: sampled with bf16 activations under the uniform head
+        model.set_option("act_fp8", 0)
+        prefix()
+        for s in A:
+            model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=seed_of(s), bad_ids=[img_tok], slot=s)
+            model.kv_fork(SRC, s, n_img)
+        toks, free_run = {s: [] for s in A}, {s: [] for s in A}
+        for k in range(MX_STEPS):
+            model.decode_batch_launch(A)
+            out = model.decode_batch_wait()
+            assert model.stats()["last_batch_step_fp8_mfma"] == 0
+            for s in A:
+                toks[s].append(out[s])
+                free_run[s].append(model.get_logits_slot(s))
+        assert len({tuple(toks[s][:4]) for s in A}) > MX_CONTEXTS // 2, "the per-slot seeds did not make the contexts diverge"
+        reports = []
+        for label in ("uniform head", "peaked head"):
+            if label == "uniform head":
+                LA, LB = free_run, forced(1, 32, toks)
+            else:
+                model.load_tensor("lm_head.weight", peaked_lm_head(hs.w["lm_head.weight"], PEAKED_BETA, PEAKED_SEED).to(torch.bfloat16))
+                prefix()
+                LA = forced(0, 0, toks)
+                LB = forced(1, 32, toks)
             worst = mean = kl_sum = kl_max = 0.0
             same_greedy = same_draw = n = 0
             for s in A:
@@ -583,7 +601,6 @@ def test_mxfp8_activations_against_bf16_activations():
                     db, _ = sampling.draw(b, 0.8, 0, 0.95, seed_of(s), k + 1, [img_tok], [], False)
                     same_draw += da == db
                     n += 1
-            assert len({tuple(toks[s][:4]) for s in A}) > MX_CONTEXTS // 2, "the per-slot seeds did not make the contexts diverge"
             assert worst <= MX_BOUND, f"{label}: logits with MXFP8 activations are {worst:.3f} rel-L2 from the bf16-activation step (bound {MX_BOUND})"
             # (the draw agreement is reported, not asserted: the uniform head spreads T = .8 / top-p .95 over thousands of tokens of ~1e-4
             # mass each, so any perturbation of the CDF moves the draw — round 5 measured 54 / 512 there)
