@@ -141,7 +141,9 @@ struct dtk_ctx {
   int prefix_mfma = 1;               // shared prefixes (forks of one image) scored once per group of <= 16 slots on the matrix cores (k_attn_prefix_g); dtk_set_option "prefix_mfma"
   int pfx_splits = 4;                // key splits of that kernel (its grid z)
   int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
-  int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4)
+  int tail_threads = 128;            // block of k_attn_tail_b (rows per memory round trip = threads / 4).  Round 5: 128 — with the shared prefixes on the matrix cores the
+                                     // blocks walk private keys only, and 2048 blocks of 2 waves are all resident at once (126 VGPRs: 4 waves per SIMD); 256 measured 2-3 %
+                                     // slower at 4..260 private keys (profiles/r05d_step_bench.txt); without the prefix kernel 256 is ~2 % better at long contexts
   DecState* st_b = nullptr;          // [16]
   SamplingDev* sp_b = nullptr;       // [16]
   BatchState* bs_dev = nullptr;

@@ -606,6 +606,12 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
     # another tree to finish its rollout and go off to its reward — with rewards that take seconds that keeps the batch full
     engine = (BatchEngine(pipeline.model, max_batch=min(trees, slots) if slots else trees, gather=trees, resume_in_place=resume_in_place)
               if trees > 1 else None)
+    # the trees' rewards arrive in waves: their Pillow work (trim, LANCZOS pad, BICUBIC resize: all under the GIL) goes to the
+    # process-wide worker pool when there is one (util/image_prep.py; bit-identical pixels)
+    metric = getattr(pipeline, "metric", None)
+    if trees > 1 and metric is not None and hasattr(metric, "prep_pool") and metric.prep_pool is None:
+        from ..util.image_prep import shared_pool
+        metric.prep_pool = shared_pool()
     out: "queue.Queue" = queue.Queue()
     trace_path = os.environ.get("DTK_TRACE_MCTS")
     trace: Optional[List[Tuple[float, int, str]]] = [(time.perf_counter(), -1, "start")] if trace_path else None

@@ -246,8 +246,9 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * contiguous key range per split | 256 | 512 | 1024 = tile-interleaved splits), "attn_splits" (1..16), "attn_combine" (0 = the
  * split partials are reduced in o_proj's prologue, 1 = by the last-arriving split block, 2 = by an own kernel),
  * "attn_full_max" (contexts below it use the one-block-per-head kernel).  Batched decode: "attn_b_impl" (0 = split-K per slot +
- * combine kernel, 1 = one block per (head, slot)), "tail_threads" (64 | 128 | 256 | 512), "prefix_mfma" (score the prefix most slots share
- * once on the matrix cores), "pfx_splits" (1..4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
+ * combine kernel, 1 = one block per (head, slot)), "tail_threads" (64 | 128 | 256 | 512; default 128), "prefix_mfma" (default 1: the prefix a group of
+ * <= 16 forked slots shares — same source slot, same length — is scored once for the group on the matrix cores by k_attn_prefix_g, the
+ * slots' private keys per slot; 0 = every slot walks its whole context), "pfx_splits" (1..4 key splits of that kernel, default 4), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
  * registers, 1..4 = x through LDS by LDS-DMA), "gemv_bx" (0 off, 1 = x once per CU for gate/up + lm_head at 49..64 slots, 2..4 =
  * forced units per block), "gemv_bk" (K split across CUs for o_proj / down; slower, off), "gqa_fused" (GQA models: 0 = an attention block per query
  * head, 1 = per K/V head, 2 = per pair of query heads), "share_prefix_reads", "resid_split" (o_proj / down: two row tiles x half of
@@ -260,8 +261,9 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * shape, 1..3 = persistent with 8 / 4 / 16 waves).  Prefill / ViT: "attn_impl" (0 auto,
  * 1 VALU, 2 MFMA flash), "gemm_tile" (0 auto, 1 64x64, 2 128x64, 3 128x128, 4 64x32, 5 32x32), "gemm_bk" (64 | 128), "gemm_stages"
  * (1..4), "gemm_impl" (0 register-staged, 1 LDS-DMA fragment order, 2 128x128 LDS-DMA row order, 3 auto), "gemm_ring" (2..4),
- * "gemm_glds_min_tiles".  fp8 models: "act_fp8" (1 = default: the MFMA-family step runs on the fp8 matrix cores with MXFP8 activations, 0 = the
- * bf16-activation kernels), "mx_nc_qkv" / "mx_nc_gu" / "mx_nc_lm_head" (0..4 compute waves per block of its unit kernel; 0 = from the CU count).
+ * "gemm_glds_min_tiles".  fp8 models: "act_fp8" (0 = default: bf16 activations, the fp8 weights widened in registers; 1 = OPT-IN: the MFMA-family
+ * step runs on the fp8 matrix cores with MXFP8 activations — 15-26 % shorter steps, logits ~0.12 rel-L2 from the bf16-activation step:
+ * tests/test_gpu_parity_batched.py::test_mxfp8_activations_against_bf16_activations asserts <= 0.20), "mx_nc_qkv" / "mx_nc_gu" / "mx_nc_lm_head" (0..4 compute waves per block of its unit kernel; 0 = from the CU count).
  * DESIGN.md 3.4 has the defaults and what each switch measured.
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.

@@ -1013,12 +1013,12 @@ def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched):
 
 @pytest.mark.parametrize("family", ["v1", "v2"])
 def test_shared_prefix_on_matrix_cores_tracks_the_per_slot_path(family, tiny_batched, request):
-    """Batched attention with `prefix_mfma` on (optional: measured no faster than the per-slot walk at 64 slots, off by default):
-    the prefix most active slots share (forks of one image) is scored ONCE per head for all
-    slots by k_attn_prefix_b (MFMA, 64 queries = slots), k_attn_tail_b continues over each slot's private keys.  Against the
+    """Batched attention with `prefix_mfma` on (the default since round 5; tests/test_gpu_parity_attn.py has the 64-slot cases):
+    the prefix a group of active slots shares (forks of one image) is scored ONCE per head for the
+    group by k_attn_prefix_g (MFMA, <= 16 queries = slots), k_attn_tail_b continues over each slot's private keys.  Against the
     per-slot path (prefix_mfma 0): same greedy tokens, logits within 1e-2 (fp32 summation order + the bf16 hi/lo split of
     the probabilities; NOT bit-identical: a slot's rounding now depends on whether it shares a prefix — DESIGN §3.1b).
-    Covered: 1..4 key splits, a prefix that is not a multiple of the 64-key tile, a source slot that decodes itself, a slot
+    Covered: 1..4 key splits, a prefix that is not a multiple of the 64-key tile, a source slot that decodes itself (not a member), a slot
     of ANOTHER image in the same step (not a member), both block shapes of the tail kernel, every wide-tile GEMV mode."""
     model, proc = tiny_batched if family == "v1" else request.getfixturevalue("tiny_v2")
     img_tok = model.config.image_token_id
@@ -1063,7 +1063,7 @@ def test_shared_prefix_on_matrix_cores_tracks_the_per_slot_path(family, tiny_bat
             assert t == ref_t, wide
             assert all(rel_l2(lg[s_], ref_l[s_]) < 1e-2 for s_ in range(5)), wide
     finally:
-        for k, v in dict(prefix_mfma=0, pfx_splits=2, tail_threads=256, gemv_b_wide=2).items():
+        for k, v in dict(prefix_mfma=0, pfx_splits=4, tail_threads=128, gemv_b_wide=2).items():      # tiny_batched's settings: library defaults, the prefix kernel off
             model.set_option(k, v)
 
 
