@@ -72,7 +72,7 @@ struct dtk_ctx {
   std::string err;
 
   // derived sizes
-  int d, L, H, ff, V, Tmax, S, Sb = 8;   // S / Sb: split-K factor of the decode attention (one sequence / batched step)
+  int d, L, H, ff, V, Tmax, S;           // S: split-K factor of the single-sequence decode attention
   int vD, vDepth, vH, vHd, vMlp, vN, vPatchK, vPatchLd, nImg;
 
   // weights
@@ -132,12 +132,11 @@ struct dtk_ctx {
   bf16_t* kvb = nullptr;             // [nb][L][2][H][Tmax][128]
   size_t kv_slot_stride = 0;
   bf16_t *xb = nullptr, *xnb = nullptr, *qb = nullptr, *aob = nullptr, *actb = nullptr;  // [16][d|ff]
-  float *logits_b = nullptr, *pmb = nullptr, *plb = nullptr, *pob = nullptr;
+  float* logits_b = nullptr;
   float* kpart = nullptr; unsigned* kctr = nullptr;   // k_gemv_bk / k_gemv_bkp partial sums + arrival counters
   int attn_nt = 1;             // batched attention: non-temporal loads of private K / V tiles (64 slots x 500 private keys: 7.14 -> 6.74 ms per step) (dtk_set_option "attn_nt")
   bool resid_kparts = true;    // batched N = d roles at 64 slots as two launches (k_gemv_bkp + k_resid_norm_b; measured 20.2 -> 21.2 rollouts/s): dtk_set_option("resid_kparts")
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
-  int attn_b_impl = 1;               // batched attention: 0 split-K per slot + combine kernel, 1 one block per (head, slot) (+ prefix kernel)
   int prefix_mfma = 1;               // shared prefixes (forks of one image) scored once per group of <= 16 slots on the matrix cores (k_attn_prefix_g); dtk_set_option "prefix_mfma"
   int pfx_splits = 4;                // key splits of that kernel (its grid z)
   int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
@@ -449,9 +448,6 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->aob = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)d, 32));
     c->actb = P.take<bf16_t>((size_t)DTK_MAX_BATCH * align_up((size_t)ff, 32));
     c->logits_b = P.take<float>((size_t)c->nb * V);
-    c->pmb = P.take<float>((size_t)c->nb * c->H * c->Sb);
-    c->plb = P.take<float>((size_t)c->nb * c->H * c->Sb);
-    c->pob = P.take<float>((size_t)c->nb * c->H * c->Sb * 128);
     c->pfx_m = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_l = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4);
     c->pfx_o = P.take<float>((size_t)DTK_MAX_BATCH * c->H * 4 * 128);
@@ -672,9 +668,9 @@ void batch_step_launches_mx(dtk_ctx* c) {
     launch_gemv_mxu(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = nslots;
+    ad.out = c->aob; ad.H = c->H; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = nslots;
     ad.scale = scale;
-    ad.impl = 1; ad.use_prefix = c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
+    ad.use_prefix = c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     ad.out8 = c->ao8; ad.outs = c->aos;
     launch_attn_decode_b(ad, s);
@@ -728,9 +724,9 @@ void batch_step_launches(dtk_ctx* c) {
     launch_gemv_b(EPI_QKV, g, s);
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
+    ad.out = c->aob; ad.H = c->H; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = 16 * c->nt_step;
     ad.scale = scale;
-    ad.impl = c->attn_b_impl; ad.use_prefix = c->attn_b_impl == 1 && c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
+    ad.use_prefix = c->prefix_mfma; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     g.W = w.t_wo; g.W8 = w.t8_wo; g.wscale = w.s_wo; g.N = d; g.K = d; g.X = c->aob; g.ldx = d; g.Y = c->xb; g.ldy = d;
@@ -790,9 +786,9 @@ void batch_step_launches_mv(dtk_ctx* c) {
     // 2. attention: one block per (head, slot), output in fragment order
     AttnDecBArgs ad;
     ad.q = c->qb; ad.kcache = kc; ad.vcache = vc; ad.kv_slot_stride = c->kv_slot_stride; ad.st = c->st_b; ad.bs = c->bs_dev;
-    ad.pm = c->pmb; ad.pl = c->plb; ad.po = c->pob; ad.out = c->aob; ad.H = c->H; ad.S = c->Sb; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = NB;
+    ad.out = c->aob; ad.H = c->H; ad.T_max = c->Tmax; ad.d = d; ad.G = c->H / c->KVH; ad.nslots = NB;
     ad.scale = scale;
-    ad.impl = c->attn_b_impl; ad.use_prefix = 0; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->mv_tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
+    ad.use_prefix = 0; ad.pfx_splits = c->pfx_splits; ad.tail_threads = c->mv_tail_threads; ad.gqa_fused = c->gqa_fused; ad.nt_private = c->attn_nt;
     ad.pfx_m = c->pfx_m; ad.pfx_l = c->pfx_l; ad.pfx_o = c->pfx_o;
     launch_attn_decode_b(ad, s);
     // 3. o_proj + residual
@@ -994,8 +990,7 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   // (ds-7b 369.6 -> 373.0, ds-1.3b 1092 -> 1111, v2-8b 343.4 -> 345.1 tok/s over 8) and 8 for the batched step
   // (32 slots already give 8192 blocks: 4.53 ms/step vs 4.69 with 16)
   c->S = cfg->attn_splits > 0 ? cfg->attn_splits : 4;     // tile-interleaved splits: 4 x 128 rows cover 512 keys per memory round trip
-  c->Sb = cfg->attn_splits > 0 ? cfg->attn_splits : 8;
-  if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = c->Sb = v; }   // tuning aid
+  if (const char* es = getenv("DTK_ATTN_SPLITS")) { const int v = atoi(es); if (v >= 1 && v <= 16) c->S = v; }   // tuning aid
   c->wfmt = cfg->reserved[1] == 1 ? 1 : 0;
   // up to 64 decoding slots (one, two or four 16-column MFMA tiles) + up to 8 slots that are only ever prefilled / forked from
   // (prefix cache: one per image in flight, BASELINE config 5 = 8 images)
@@ -1016,7 +1011,6 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->attn_threads = 512;
   if (const char* at = getenv("DTK_ATTN_THREADS")) c->attn_threads = atoi(at);
   if (c->S > 16) c->S = 16;
-  if (c->Sb > 16) c->Sb = 16;
   if (const char* fm = getenv("DTK_ATTN_FULL_MAX")) c->attn_full_max = atoi(fm);
   if (const char* gv = getenv("DTK_GEMV_VARIANTS")) {  // "epi:variant,epi:variant" (tuning aid)
     int e = 0, v = 0;
@@ -1476,7 +1470,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   // DTK_PFX_GROUPS groups (over 16 distinct prefixes in one step): the rest walk their whole context in k_attn_tail_b.
   hb->n_groups = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) { hb->group_plus1[j] = 0; hb->pfx_len_of[j] = 0; }
-  if (c->prefix_mfma && c->attn_b_impl == 1 && !mv_family(c)) {
+  if (c->prefix_mfma && !mv_family(c)) {
     for (int j = 0; j < DTK_MAX_BATCH && hb->n_groups < DTK_PFX_GROUPS; ++j) {
       if (!active[j] || hb->group_plus1[j] || hb->share_src[j] < 0 || hb->share_len[j] < 4) continue;
       const int src = hb->share_src[j], len = hb->share_len[j];
@@ -1939,10 +1933,9 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     set_gemm_tile(value);
   }
   else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;
-  else if (!strcmp(name, "attn_b_impl") || !strcmp(name, "prefix_mfma") || !strcmp(name, "pfx_splits") || !strcmp(name, "gemv_b_wide") ||
+  else if (!strcmp(name, "prefix_mfma") || !strcmp(name, "pfx_splits") || !strcmp(name, "gemv_b_wide") ||
            !strcmp(name, "tail_threads") || !strcmp(name, "gemm_b")) {
-    if (!strcmp(name, "attn_b_impl")) { if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "attn_b_impl must be 0 or 1"); c->attn_b_impl = value; }
-    else if (!strcmp(name, "prefix_mfma")) c->prefix_mfma = value != 0;
+    if (!strcmp(name, "prefix_mfma")) c->prefix_mfma = value != 0;
     else if (!strcmp(name, "gemm_b")) { if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_b must be 0..4"); set_gemm_b_shape(value); }
     else if (!strcmp(name, "tail_threads")) { if (value != 64 && value != 128 && value != 256 && value != 512) return fail(c, DTK_ERR_ARG, "tail_threads must be 64, 128, 256 or 512"); c->tail_threads = value; }
     else if (!strcmp(name, "pfx_splits")) { if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "pfx_splits must be 1..4"); c->pfx_splits = value; }

@@ -156,13 +156,11 @@ struct AttnDecBArgs {
   const bf16_t* q;                     // [16][d]
   const bf16_t* kcache; const bf16_t* vcache; size_t kv_slot_stride;
   const DecState* st; const BatchState* bs;
-  float* pm; float* pl; float* po;     // [slots][H][S], ..., [slots][H][S][128]
   bf16_t* out;                         // [16][d]
-  int H; int S; int T_max; int d; float scale;
+  int H; int T_max; int d; float scale;
   int G;                               // query heads per kv head (1 = MHA)
-  int nslots;                          // grid z: 16, 32 or 64
-  int impl;                            // 0: split-K per slot + combine kernel; 1: k_attn_tail_b (+ k_attn_prefix_b when use_prefix)
-  int use_prefix;                      // score BatchState's shared prefix once for all slots on the matrix cores
+  int nslots;                          // grid y of k_attn_tail_b: 1 / 2 / 4 (multi-vector step), 16, 32 or 64
+  int use_prefix;                      // score BatchState's prefix groups once per group on the matrix cores (k_attn_prefix_g)
   int pfx_splits;                      // key splits of the prefix kernel (its grid y)
   int tail_threads;                    // k_attn_tail_b block: 512 (default) | 256
   int gqa_fused;             // k_attn_tail_b: 1 = the query heads of a GQA group share one block (default), 0 = a block per query head

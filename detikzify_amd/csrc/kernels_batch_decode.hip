@@ -408,138 +408,6 @@ void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int 
   hipLaunchKernelGGL(k_rmsnorm_b, dim3(nslots), dim3(256), 0, s, X, ldx, w, Y, ldy, D, eps, bs, Y8, YS);
 }
 
-// Split-K decode attention per slot: grid (H, S, 16); same algorithm as k_attn_decode.
-__global__ __launch_bounds__(256) void k_attn_decode_b(AttnDecBArgs a) {
-  const int h = blockIdx.x, sp = blockIdx.y, slot = blockIdx.z;
-  if (!a.bs->active[slot]) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = lane & 15, grp = lane >> 4;
-  const int n = a.st[slot].pos + 1;
-  int chunk = (n + a.S - 1) / a.S;
-  chunk = (chunk + 15) & ~15;
-  const int j_begin = sp * chunk;
-  const int j_end = min(n, j_begin + chunk);
-  const u32x4 qv = reinterpret_cast<const u32x4*>(a.q + (size_t)slot * a.d + h * 128)[sub];
-  const int kvh = h / a.G;
-  const bf16_t* kbase = a.kcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
-  const bf16_t* vbase = a.vcache + (size_t)slot * a.kv_slot_stride + (size_t)kvh * a.T_max * 128;
-  // shared prefix (BatchState): rows j < slen come from the source slot's cache (identical bits, one HBM stream for all forks)
-  const int ssrc = a.bs->share_src[slot];
-  const int slen = ssrc >= 0 ? a.bs->share_len[slot] : 0;
-  const size_t sdelta = ((size_t)(ssrc >= 0 ? ssrc : slot) - (size_t)slot) * a.kv_slot_stride;   // wraps consistently (size_t)
-  float m = -1e30f, l = 0.f;
-  float o[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
-    u32x4 kv[4], vv[4];
-    bool ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = j0 + i * 16 + wave * 4 + grp;
-      ok[i] = j < j_end;
-      const int jj = ok[i] ? j : j_begin;
-      const size_t off = (size_t)jj * 128 + (jj < slen ? sdelta : (size_t)0);
-      kv[i] = reinterpret_cast<const u32x4*>(kbase + off)[sub];
-      vv[i] = reinterpret_cast<const u32x4*>(vbase + off)[sub];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float s = dot8(qv, kv[i], 0.f);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 8, 64);
-      s *= a.scale;
-      if (ok[i]) {
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn);
-        const float p = __expf(s - mn);
-        l = l * corr + p;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[2 * e] = o[2 * e] * corr + p * pk_lo(vv[i][e]);
-          o[2 * e + 1] = o[2 * e + 1] * corr + p * pk_hi(vv[i][e]);
-        }
-        m = mn;
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {
-    const float m2 = __shfl_xor(m, off, 64);
-    const float l2 = __shfl_xor(l, off, 64);
-    const float mn = fmaxf(m, m2);
-    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
-    l = l * c1 + l2 * c2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float o2 = __shfl_xor(o[e], off, 64);
-      o[e] = o[e] * c1 + o2 * c2;
-    }
-    m = mn;
-  }
-  __shared__ float sm_m[4][16], sm_l[4][16], sm_o[4][16][8];
-  if (grp == 0) {
-    sm_m[wave][sub] = m;
-    sm_l[wave][sub] = l;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sm_o[wave][sub][e] = o[e];
-  }
-  __syncthreads();
-  if (tid < 16) {
-    float M = sm_m[0][tid];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_m[w][tid]);
-    float L = 0.f;
-    float oo[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) oo[e] = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float c = __expf(sm_m[w][tid] - M);
-      L += c * sm_l[w][tid];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) oo[e] += c * sm_o[w][tid][e];
-    }
-    const size_t slot_i = ((size_t)slot * a.H + h) * a.S + sp;
-    float* dst = a.po + slot_i * 128 + tid * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = oo[e];
-    if (tid == 0) {
-      a.pm[slot_i] = M;
-      a.pl[slot_i] = L;
-    }
-  }
-}
-
-__global__ __launch_bounds__(128) void k_attn_combine_b(AttnDecBArgs a) {
-  const int h = blockIdx.x, slot = blockIdx.y, t = threadIdx.x;
-  if (!a.bs->active[slot]) return;
-  const int S = a.S;
-  const size_t base = ((size_t)slot * a.H + h) * S;
-  float pm[16], pl[16], po[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const bool ok = s < S;
-    const int ss = ok ? s : 0;
-    pm[s] = ok ? a.pm[base + ss] : -1e30f;
-    pl[s] = ok ? a.pl[base + ss] : 0.f;
-    po[s] = ok ? a.po[(base + ss) * 128 + t] : 0.f;
-  }
-  float M = -1e30f;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) M = fmaxf(M, pm[s]);
-  float L = 0.f, o = 0.f;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const float w = __expf(pm[s] - M);
-    L += w * pl[s];
-    o += w * po[s];
-  }
-  a.out[xtile_off(slot, h * 128 + t, (a.d + 31) >> 5)] = f2bf(o / L);   // o_proj's B operand: fragment-major
-}
-
 // ------------------------------------------------------------------------------------------
 // Shared prefixes on the matrix cores.  The rollouts of one image hold bit-identical copies of the image prefix (dtk_kv_fork):
 // scoring it per slot on the VALU re-reads the same 243 rows once per slot from L2 (64 slots x 32 heads blocks, 255 MB of L2 -> CU
@@ -878,7 +746,7 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 }
 
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
-  if (a.impl == 1) {   // shared prefix once on the matrix cores (optional) + one block per (head, slot) for the rest
+  {   // shared prefixes once per group on the matrix cores (optional) + one block per (head, slot) for the private keys
     if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_g, dim3(a.H, DTK_PFX_GROUPS, a.pfx_splits), dim3(64), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
     if (a.G == 4 && a.gqa_fused == 2) {   // pairs of query heads: half the sharing, twice the blocks
@@ -905,8 +773,6 @@ void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(k_attn_tail_b<512>, dim3(a.H, a.nslots), dim3(512), 0, s, a);
     return;
   }
-  hipLaunchKernelGGL(k_attn_decode_b, dim3(a.H, a.S, a.nslots), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_attn_combine_b, dim3(a.H, a.nslots), dim3(128), 0, s, a);
 }
 
 // Row-major [N][K] bf16 -> fragment-major tiles (see the header): storage = ceil(N/16)*ceil(K/32) tiles

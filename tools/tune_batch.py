@@ -69,8 +69,7 @@ def ms_per_step(active):
     return 1e3 * (time.perf_counter() - t0) / args.steps
 
 
-configs = [("round-1: split-K per slot + combine", dict(attn_b_impl=0, gemv_b_wide=0, gemm_b=0)),
-           ("tail kernel 256, no prefix kernel", dict(attn_b_impl=1, prefix_mfma=0, tail_threads=256)),
+configs = [("tail kernel 256, no prefix kernel", dict(prefix_mfma=0, tail_threads=256)),
            ("prefix on MFMA 4 splits, tail 256", dict(prefix_mfma=1, pfx_splits=4)),
            ("x via LDS-DMA, 2x4 sk4 xa3 / 4x2 (1)", dict(prefix_mfma=0, gemm_b=1)),
            ("x via LDS-DMA, 4x2 sk2 xa3 / 4x2 (2)", dict(gemm_b=2)),
