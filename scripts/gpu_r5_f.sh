@@ -33,6 +33,7 @@ STEP_BENCH_SLOTS=64 STEP_BENCH_MODEL=ds-7b prof batch64_kernel_stats "" $SB ""
 STEP_BENCH_SLOTS=64 prof batch64_fp8_pmc_fetch "FETCH_SIZE" $SB ""
 cd "$REPO"
 python tools/make_dominant_kernel_json.py "$OUT/r05_kernel_stats.csv" "$OUT/r05_pmc_fetch.csv" detikzify-ds-7b > /dev/null && cp profiles/dominant_kernel.json "$OUT/dominant_kernel.json" && sed -i 's#gpurun_out/r05_pmc_fetch.csv#profiles/r05_pmc_fetch.csv#' profiles/dominant_kernel.json "$OUT/dominant_kernel.json"
+timeout 600 python -m pytest tests/test_gpu_parity.py::test_engine_prefix_paths_give_the_same_tokens_as_plain_generate tests/test_gpu_parity_attn.py -q -p no:cacheprovider --tb=short 2>&1 | tail -3
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/r05_bench_*.json")):

@@ -1665,8 +1665,12 @@ def test_shared_prefix_reads_are_invisible_and_invalidate_correctly(tiny_batched
 
 def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched):
     """every way a sequence can obtain its image prefix in the BatchEngine — encode into the prefix cache + fork (with
-    logits), fork from another slot that still holds the image, re-use in place, eviction by another image — yields exactly
-    the tokens of a plain model.generate of the same prompt and seed"""
+    logits), fork from another slot that still holds the image, re-use in place, eviction by another image — yields EXACTLY the
+    tokens of the same engine without any prefix sharing (every sequence prefilled in full: the forked / re-used KV rows are
+    bit-identical copies and a slot's arithmetic does not depend on its company), and the tokens of a plain model.generate of the
+    same prompt and seed up to what two summation orders allow: the single-sequence kernels are another fp32 order, so a sampled
+    draw that lands within rounding of a CDF boundary may differ (round 5: one of 120 draws when the batched attention's block went
+    from 4 to 2 waves) — at most one of the ten sequences, and not before its fifth generated token."""
     from detikzify_amd.infer.batching import BatchEngine
     model, proc = tiny_batched
     (ids, px), (ids_b, px_b), (ids_c, px_c) = _batch_prompts(proc)
@@ -1675,7 +1679,18 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
     jobs = [(ids, px, 1), (ids, px, 2), (ids_b, px_b, 3), (ids, px, 4), (ids_c, px_c, 5), (ids_b, px_b, 6), (ids, px, 7),
             (ids_c, px_c, 8), (ids_c, px_c, 9), (ids, px, 10)]
     assert model.batch_engine is None
-    ref = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
+    plain = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
+    engine = BatchEngine(model, max_batch=1, share_prefix=False)
+    try:
+        ref = [model.generate(input_ids=i[None], pixel_values=p, seed=s, **kw)[0].tolist() for i, p, s in jobs]
+        assert engine.prefix_encodes == 0 and not engine.share_prefix
+    finally:
+        engine.close()
+    differing = [k for k in range(len(jobs)) if ref[k] != plain[k]]
+    assert len(differing) <= 1, differing
+    for k in differing:
+        n_prompt = jobs[k][0].numel()
+        assert ref[k][:n_prompt + 4] == plain[k][:n_prompt + 4], (k, ref[k], plain[k])
     # 1: strictly sequential joins (in-place re-use, eviction); 2: donors among live slots; 5 = every slot decodes, no
     # prefix-cache slot: the first rollout of an image prefills in full and the others fork from it
     # (1 with a single prefix-cache slot; 2 with three: one per image, every join a pure fork)
