@@ -563,9 +563,17 @@ def main():
                 # image in total: rank r grows shard_expansions(16, N)[r] trees of one expansion each as one batch (N=1: 16 trees,
                 # N=8: 2 per rank; reference examples/eval.py:108-137 is the per-image loop this shards)
                 mine = ddist.shard_expansions(16, world)[rank]
+                # a context of the size this rank's share needs (trees + one prefix-cache slot: load(batch_slots = rollouts + images),
+                # what a caller of this configuration would load) — the kernels a context decodes with follow ITS size (2 / 4 trees: the
+                # multi-vector family; 8 / 16: one MFMA column tile with the per-slot attention walk), not the 65-slot batch's above
+                n4 = min(mine, args.batch)
+                t_l = time.perf_counter()
+                c4_model, c4_proc = (dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=n4 + 1, weight_format=args.weight_format)
+                                     if 1 <= n4 < model.num_slots() - 1 else (model, proc))
                 c4 = {"shape": "16 rollouts of one image over all ranks, root-parallel: 16/N trees x 1 expansion per rank",
-                      "fixed_length": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, Wk=(W, Kb)),
-                      "ragged": search(model, proc, [img0] if mine else [], min(mine, args.batch), 1, ragged=True, Wk=(W, Kb))}
+                      "context_slots": c4_model.num_slots(), "context_load_seconds": round(time.perf_counter() - t_l, 1),
+                      "fixed_length": search(c4_model, c4_proc, [img0] if mine else [], n4, 1, Wk=(W, Kb)),
+                      "ragged": search(c4_model, c4_proc, [img0] if mine else [], n4, 1, ragged=True, Wk=(W, Kb))}
                 if world == 1 and not args.no_rank_shapes:
                     # What rank 0 of an N-GPU job would decode, run here on ONE GPU: 16/N trees of one expansion (N = 4 / 8: 4 / 2
                     # trees in a 5-slot context = the multi-vector kernels; N = 2: 8 trees = one MFMA column tile).  Every rank of
@@ -579,7 +587,7 @@ def main():
                                 t_l = time.perf_counter()
                                 small = dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=5, weight_format=args.weight_format)
                                 shapes["small_context_load_seconds"] = round(time.perf_counter() - t_l, 1)
-                            m_, p_ = small if per <= 4 else (model, proc)
+                            m_, p_ = small if per <= 4 else (c4_model, c4_proc)
                             per = per if per <= 4 else min(per, args.batch)
                             r = search(m_, p_, [img0], per, 1, Wk=(W, Kb))
                             rate = r.get("rollouts_per_sec")
@@ -596,6 +604,10 @@ def main():
                             import gc
                             gc.collect()
                     c4["rank_shape"] = shapes
+                if c4_model is not model:
+                    del c4_model, c4_proc
+                    import gc
+                    gc.collect()
                 mcts["config4"] = c4
             for S in args.reward_latency:
                 # f3: what a reward that costs what LaTeX costs does to rollouts/s.  The renderer sleeps S seconds per document

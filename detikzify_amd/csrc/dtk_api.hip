@@ -137,12 +137,12 @@ struct dtk_ctx {
   int attn_nt = 1;             // batched attention: non-temporal loads of private K / V tiles (64 slots x 500 private keys: 7.14 -> 6.74 ms per step) (dtk_set_option "attn_nt")
   bool resid_kparts = true;    // batched N = d roles at 64 slots as two launches (k_gemv_bkp + k_resid_norm_b; measured 20.2 -> 21.2 rollouts/s): dtk_set_option("resid_kparts")
   float *pfx_m = nullptr, *pfx_l = nullptr, *pfx_o = nullptr;   // shared-prefix states [64][H][4] (+ x 128)
-  int prefix_mfma = 1;               // shared prefixes (forks of one image) scored once per group of <= 16 slots on the matrix cores (k_attn_prefix_g); dtk_set_option "prefix_mfma"
+  int prefix_mfma = 0;               // shared prefixes (forks of one image) scored once per group of <= 16 slots on the matrix cores (k_attn_prefix_g); dtk_set_option "prefix_mfma".
+                                     // Set at dtk_create from the context's size: 1 with 64 decoding slots, 0 below (see there)
   int pfx_splits = 4;                // key splits of that kernel (its grid z)
   int gqa_fused = 1;                 // batched attention: one block per (K/V head, slot) for GQA models
-  int tail_threads = 128;            // block of k_attn_tail_b (rows per memory round trip = threads / 4).  Round 5: 128 — with the shared prefixes on the matrix cores the
-                                     // blocks walk private keys only, and 2048 blocks of 2 waves are all resident at once (126 VGPRs: 4 waves per SIMD); 256 measured 2-3 %
-                                     // slower at 4..260 private keys (profiles/r05d_step_bench.txt); without the prefix kernel 256 is ~2 % better at long contexts
+  int tail_threads = 256;            // block of k_attn_tail_b (rows per memory round trip = threads / 4); dtk_create: 128 with 64 decoding slots (the blocks then walk
+                                     // private keys only and 2048 blocks of 2 waves are all resident), 256 below
   DecState* st_b = nullptr;          // [16]
   SamplingDev* sp_b = nullptr;       // [16]
   BatchState* bs_dev = nullptr;
@@ -1076,6 +1076,16 @@ int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   c->stats.kv_bytes_per_ctx_token = (uint64_t)2 * c->L * kvd * 2;
   c->stats.probe_kernel_bytes = (uint64_t)2 * c->ff * c->d * (c->wfmt == 1 ? 1 : 2);
   *out = c;
+  // Batched attention shape, a property of the CONTEXT (like the multi-vector family): 64 decoding slots -> shared prefixes on the
+  // matrix cores + 2-wave tail blocks; fewer -> the per-slot walk with 4-wave blocks.  Measured over a rollout's private lengths
+  // (profiles/r05g_step_bench.txt, ds-7b, ms per step at 4 / 260 / 480 private keys): 64 slots 3.96 / 5.43 / 6.52 against 4.35 / 5.67 /
+  // 6.57 for round 4's shape; 16 slots 3.31 / 3.99 / 4.40 against 3.45 / 3.69 / 3.94 — with 512 blocks the prefix kernel's launch is not
+  // paid back and 2-wave blocks keep too few loads in flight.  A slot's arithmetic depends on its context's size, never on the active set.
+  if (c->nb > 0) {
+    const bool big = max_decode_slots(c) >= 64;
+    c->prefix_mfma = big ? 1 : 0;
+    c->tail_threads = big ? 128 : 256;
+  }
   if (const char* opts = getenv("DTK_OPTIONS")) {   // "name=value,name=value": dtk_set_option at create (profiling runs of unmodified tools)
     std::string all(opts);
     size_t at = 0;

@@ -13,7 +13,9 @@ the scores against it are computed once per GROUP of <= 16 forks on the matrix c
     grouping is by (share_src, share_len), properties of the slot alone;
   * sources with more than 16 forks (several groups), a singleton group, a source that decodes itself (not a member), more
     images than DTK_PFX_GROUPS allows (the overflow takes the per-slot walk), every key-split count, GQA (tiny-v2);
-  * against the CPU oracle: the full-size tests of tests/test_gpu_parity_batched.py run this path by default.
+  * against the CPU oracle: the full-size tests of tests/test_gpu_parity_batched.py run this path by default (65-slot contexts).
+The path is the default of contexts with 64 decoding slots (dtk_create: prefix kernel on, 2-wave tail blocks); smaller contexts
+walk every slot's whole context in 4-wave blocks (profiles/r05g_step_bench.txt has the measurement behind that split).
 """
 import gc
 
