@@ -482,9 +482,9 @@ def main():
                                  "slots: b * 8 TB/s / (W + b*K*n_new/2 + images*K*prefix) — the weights once per step, every slot's own "
                                  "keys at the mean depth of a from-the-root rollout, the image prefix once per image"}
 
-        # the rewards' Pillow work (trim, LANCZOS pad, BICUBIC resize: Pillow holds the GIL through all three) runs in a small pool of
-        # worker processes shared by every parallel search of this process (detikzify_amd/util/image_prep.py; bit-identical pixels;
-        # DTK_REWARD_PREP_WORKERS=0 turns it off); started here so that no search is timed with its start-up
+        # DTK_REWARD_PREP_WORKERS=N (opt-in; off by default — measured no gain on this host): the rewards' Pillow work (trim,
+        # LANCZOS pad, BICUBIC resize: Pillow holds the GIL through all three) in N worker processes shared by every parallel search of
+        # this process (detikzify_amd/util/image_prep.py; bit-identical pixels); started here so that no search is timed with its start-up
         from detikzify_amd.util import image_prep
         prep_pool = image_prep.shared_pool()
         mcts["reward_prep_workers"] = prep_pool.warm() if prep_pool is not None else 0

@@ -10,8 +10,11 @@ the decode batch idle: 4 waves = 2 s of BASELINE config 5's 11.5 s, profiles/r03
 of spawned processes; the tree's thread waits for its result without the GIL.  What stays in the parent: `load` (a copy for RGB
 figures) and the processor's rescale / normalise (a numpy gather that releases the GIL).
 
-`shared_pool()` is the process-wide pool (DTK_REWARD_PREP_WORKERS: 0 = off; default min(16, cpus / 8) on hosts with >= 16 CPUs, off on
-smaller ones); `infer.batching.simulate_parallel_images` attaches it to the pipeline's metric when more than one tree runs.
+`shared_pool()` is the process-wide pool, OPT-IN: DTK_REWARD_PREP_WORKERS=N starts N workers, unset / 0 = off.  Measured: a wave of
+64 rewards on an 8-core box 345 -> 227 ms with 6 workers; BASELINE config 5 on the MI355X box's 256-thread host 20.0 / 23.9 rollouts/s
+without and 19.9 / 23.7 with 16 workers (profiles/r05_bench_config5_prep_pool_*.json) — that search's wall is decode wait, not
+rewards, so the default stays off.  `infer.batching.simulate_parallel_images` attaches the pool to the pipeline's metric when one is
+configured and more than one tree runs.
 The workers import PIL, numpy and this package's `util` only (50 ms; no torch, no HIP).
 """
 from __future__ import annotations
@@ -169,17 +172,11 @@ _LOCK = threading.Lock()
 
 def default_workers() -> int:
     env = os.environ.get("DTK_REWARD_PREP_WORKERS")
-    if env is not None:
-        return max(0, int(env))
-    try:
-        cpus = len(os.sched_getaffinity(0))
-    except AttributeError:  # pragma: no cover
-        cpus = os.cpu_count() or 1
-    return min(16, cpus // 8) if cpus >= 16 else 0
+    return max(0, int(env)) if env else 0
 
 
 def shared_pool() -> Optional[PrepPool]:
-    """the process-wide pool, started on first use; None when disabled (DTK_REWARD_PREP_WORKERS=0, small hosts) or broken"""
+    """the process-wide pool, started on first use; None when not configured (DTK_REWARD_PREP_WORKERS unset / 0) or broken"""
     global _SHARED
     with _LOCK:
         if _SHARED is None:
