@@ -33,6 +33,8 @@ ap.add_argument("--step-ms", type=float, default=4.1, help="emulated duration of
 ap.add_argument("--new-tokens", type=int, default=256)
 ap.add_argument("--procs", type=int, default=1, help="processes side by side, one per emulated GPU")
 ap.add_argument("--json", action="store_true", help="one JSON line (used by --procs)")
+ap.add_argument("--pin", action="store_true", help="--procs: every process on its own disjoint share of the CPUs (what dist.pin_to_gpu_numa_node does per rank)")
+ap.add_argument("--cpus", default="", help="(internal, --pin) CPU list of this process, e.g. 32-63")
 args = ap.parse_args()
 
 if args.procs > 1:
@@ -42,16 +44,24 @@ if args.procs > 1:
     cmd = [sys.executable, __file__, "--trees", str(args.trees), "--expansions", str(args.expansions), "--step-ms", str(args.step_ms),
            "--new-tokens", str(args.new_tokens), "--json"]
     t0 = time.perf_counter()
-    kids = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(args.procs)]
+    all_cpus = sorted(os.sched_getaffinity(0))
+    share = max(1, len(all_cpus) // args.procs)
+    pins = [["--cpus", ",".join(str(c) for c in all_cpus[i * share:(i + 1) * share])] if args.pin else [] for i in range(args.procs)]
+    kids = [subprocess.Popen(cmd + pins[i], stdout=subprocess.PIPE, text=True) for i in range(args.procs)]
     outs = [json.loads([ln for ln in k.communicate()[0].splitlines() if ln.startswith("{")][-1]) for k in kids]
     wall = time.perf_counter() - t0
     rates = [o["rollouts_per_sec"] for o in outs]
     cpu = [o["cpu_seconds_per_rollout"] for o in outs]
     ideal = outs[0]["emulated_gpu_rollouts_per_sec"]
-    print(f"{args.procs} processes x {args.trees} trees on {len(os.sched_getaffinity(0))} CPUs: per-process rollouts/s min {min(rates):.1f} / max {max(rates):.1f} "
+    print(f"{args.procs} processes{' (each pinned to its own ' + str(share) + ' CPUs)' if args.pin else ''} x {args.trees} trees on {len(os.sched_getaffinity(0))} CPUs: per-process rollouts/s min {min(rates):.1f} / max {max(rates):.1f} "
           f"(the emulated GPU alone allows {ideal:.1f}); whole host {sum(rates):.1f} rollouts/s; host CPU per rollout "
           f"{1e3 * sum(cpu) / len(cpu):.1f} ms (user + sys) -> {sum(rates) * sum(cpu) / len(cpu):.1f} cores busy; {wall:.0f} s incl. start-up")
     sys.exit(0)
+
+
+if args.cpus:
+    import os
+    os.sched_setaffinity(0, {int(c) for c in args.cpus.split(",")})
 
 
 def pooled_only(self, pixel_values):
