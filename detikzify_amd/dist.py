@@ -142,25 +142,69 @@ def gpu_numa_cpus(pci_bdf: str, sysfs: str = "/sys") -> Optional[List[int]]:
         return None
 
 
-def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys") -> Optional[List[int]]:
+def _device_bdf(i: int) -> Optional[str]:
+    try:
+        props = torch.cuda.get_device_properties(i)
+        return f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}.0"
+    except (AttributeError, TypeError, ValueError, RuntimeError, AssertionError):
+        return None
+
+
+def share_of_cpus(cpus: Sequence[int], k: int, m: int) -> List[int]:
+    """the k-th of m disjoint shares of a NUMA node's CPU list: every contiguous run of ids is cut into m equal pieces and share k
+    takes the k-th piece of each — Linux lists a node as "cores, then their SMT siblings" (0-63,128-191), so a share keeps its
+    cores' siblings.  Runs shorter than m are left whole (shared by everybody)."""
+    cpus = sorted(cpus)
+    runs: List[List[int]] = []
+    for c in cpus:
+        if runs and c == runs[-1][-1] + 1:
+            runs[-1].append(c)
+        else:
+            runs.append([c])
+    out: List[int] = []
+    for run in runs:
+        if len(run) < m:
+            out += run
+        else:
+            per = len(run) // m
+            out += run[k * per:(k + 1) * per] if k < m - 1 else run[k * per:]
+    return out
+
+
+def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys", local_world: Optional[int] = None) -> Optional[List[int]]:
     """One rank per GPU means 8 processes x (64 tree threads + reward work) on one host: keep each rank's threads on the NUMA
     node of ITS GPU (PCIe root + memory local to the pinned staging buffers) instead of letting 8 x 64 threads roam over both
-    sockets.  Restricts this process (and every thread it starts later) to that node's CPUs, intersected with what the process
-    is allowed to use; returns the CPU list, or None when nothing was changed (unknown topology, DTK_NO_PIN=1)."""
+    sockets — and, when the launcher says how many ranks share the host (LOCAL_WORLD_SIZE, torchrun), on this rank's OWN share of
+    that node's CPUs: the ranks whose GPUs hang off the same node split its cores between them (`share_of_cpus`).  Measured with the
+    shipped Python stack over an emulated GPU on the MI355X box's 2 x 64-core host (profiles/r05_host_emulation_gpu_box_pinned.txt):
+    8 ranks x 64 trees reach 21.8-22.9 rollouts/s each when they roam and 29.8-31.8 with a CPU set of their own.
+    Restricts this process (and every thread it starts later) to those CPUs, intersected with what the process is allowed to use;
+    returns the CPU list, or None when nothing was changed (unknown topology, DTK_NO_PIN=1)."""
     if os.environ.get("DTK_NO_PIN") or not torch.cuda.is_available():
         return None
     try:
         i = torch.cuda.current_device() if device_index is None else device_index
-        props = torch.cuda.get_device_properties(i)
-        bdf = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}.0"
-    except (AttributeError, TypeError, ValueError, RuntimeError, AssertionError):
+    except (RuntimeError, AssertionError):
         return None
-    cpus = gpu_numa_cpus(bdf, sysfs)
+    bdf = _device_bdf(i)
+    cpus = gpu_numa_cpus(bdf, sysfs) if bdf else None
     if not cpus:
         return None
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
     if not allowed:
         return None
+    if local_world is None:
+        try:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        except ValueError:
+            local_world = 1
+    if local_world > 1 and not os.environ.get("DTK_PIN_WHOLE_NODE"):
+        # the local ranks (device j = local rank j, as bench.py and the examples place them) whose GPUs sit on MY node, in rank order
+        mates = [j for j in range(local_world) if j == i or gpu_numa_cpus(_device_bdf(j) or "", sysfs) == cpus]
+        if i in mates and len(mates) > 1:
+            mine = share_of_cpus(allowed, mates.index(i), len(mates))
+            if len(mine) >= 4:          # never squeeze a rank onto a handful of CPUs (its tree threads, reward work, compile workers)
+                allowed = mine
     try:
         os.sched_setaffinity(0, allowed)
     except OSError:             # a container that forbids it: placement is advice, never a reason to fail the run

@@ -127,3 +127,41 @@ def test_numa_pinning_helpers(tmp_path):
     assert dd.gpu_numa_cpus("0000:c1:00.0", str(tmp_path)) is None          # single-node machine: nothing to pin to
     assert dd.gpu_numa_cpus("0000:00:00.0", str(tmp_path)) is None          # unknown device
     assert dd.pin_to_gpu_numa_node() is None                                # no GPU here: a no-op
+
+
+def test_ranks_on_one_numa_node_get_disjoint_cpu_shares(tmp_path, monkeypatch):
+    """8 ranks on a 2-socket host (the MI355X box: node0 = 0-63,128-191, node1 = 64-127,192-255, four GPUs per node): every rank is
+    pinned to its OWN quarter of its GPU's node — cores and their SMT siblings together, shares disjoint, their union the node —
+    and to the whole node when the launcher does not say how many ranks share the host (tools/host_emulation.py --pin measured 8
+    ranks x 64 trees at 30-32 rollouts/s each with a CPU set per rank against 22-23 when they roam)"""
+    from types import SimpleNamespace
+
+    import torch
+
+    from detikzify_amd import dist as dd
+    assert dd.share_of_cpus(list(range(0, 64)) + list(range(128, 192)), 1, 4) == list(range(16, 32)) + list(range(144, 160))
+    assert dd.share_of_cpus([0, 1, 2, 3, 4, 5, 6], 2, 3) == [4, 5, 6]               # the last share takes the remainder
+    assert dd.share_of_cpus([0, 1, 8, 9, 10, 11], 0, 4) == [0, 1, 8]               # a run shorter than the share count stays whole
+    lists = {0: "0-63,128-191\n", 1: "64-127,192-255\n"}
+    for n, text in lists.items():
+        node = tmp_path / "devices" / "system" / "node" / f"node{n}"
+        node.mkdir(parents=True)
+        (node / "cpulist").write_text(text)
+    for j in range(8):
+        dev = tmp_path / "bus" / "pci" / "devices" / f"0000:{0x10 + j:02x}:00.0"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{j // 4}\n")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda j: SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + j, pci_device_id=0))
+    monkeypatch.setattr(dd.os, "sched_getaffinity", lambda pid: set(range(256)))
+    pinned = {}
+    monkeypatch.setattr(dd.os, "sched_setaffinity", lambda pid, cpus: pinned.__setitem__("cpus", sorted(cpus)))
+    monkeypatch.delenv("DTK_NO_PIN", raising=False)
+    shares = [dd.pin_to_gpu_numa_node(j, str(tmp_path), local_world=8) for j in range(8)]
+    assert all(len(sh) == 32 for sh in shares) and pinned["cpus"] == shares[7]
+    assert sorted(c for sh in shares[:4] for c in sh) == dd.parse_cpulist(lists[0]) and sorted(c for sh in shares[4:] for c in sh) == dd.parse_cpulist(lists[1])
+    assert shares[1] == list(range(16, 32)) + list(range(144, 160))                 # 16 cores + their 16 siblings
+    assert dd.pin_to_gpu_numa_node(5, str(tmp_path), local_world=1) == dd.parse_cpulist(lists[1])       # one rank per host: the whole node
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")                                     # two ranks, one GPU per node: each keeps its whole node
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda j: SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + 4 * j, pci_device_id=0))
+    assert dd.pin_to_gpu_numa_node(1, str(tmp_path)) == dd.parse_cpulist(lists[1])
