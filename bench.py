@@ -568,8 +568,9 @@ def main():
                 # multi-vector family; 8 / 16: one MFMA column tile with the per-slot attention walk), not the 65-slot batch's above
                 n4 = min(mine, args.batch)
                 t_l = time.perf_counter()
-                c4_model, c4_proc = (dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=n4 + 1, weight_format=args.weight_format)
-                                     if 1 <= n4 < model.num_slots() - 1 else (model, proc))
+                slots4 = 5 if n4 <= 4 else n4 + 1           # <= 4 trees: the 5-slot context of the multi-vector family (what rank_shape's N = 4 / 8 blocks load)
+                c4_model, c4_proc = (dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=slots4, weight_format=args.weight_format)
+                                     if 1 <= n4 and slots4 < model.num_slots() else (model, proc))
                 c4 = {"shape": "16 rollouts of one image over all ranks, root-parallel: 16/N trees x 1 expansion per rank",
                       "context_slots": c4_model.num_slots(), "context_load_seconds": round(time.perf_counter() - t_l, 1),
                       "fixed_length": search(c4_model, c4_proc, [img0] if mine else [], n4, 1, Wk=(W, Kb)),
