@@ -695,6 +695,8 @@ def main():
                     gc.collect()
                 mcts["config5"] = c5
             except Exception as e:  # noqa: BLE001
+                import traceback
+                print(f"[rank {rank}] mcts.config5 failed: {e!r}\n{traceback.format_exc()}", file=sys.stderr, flush=True)     # (only rank 0's line is printed)
                 mcts["config5"] = {"error": repr(e)}
         result["mcts"] = mcts
         result["mcts_rollouts_per_sec"] = (mcts.get("parallel") or {}).get("rollouts_per_sec")
