@@ -569,10 +569,15 @@ def main():
                 n4 = min(mine, args.batch)
                 t_l = time.perf_counter()
                 slots4 = 5 if n4 <= 4 else n4 + 1           # <= 4 trees: the 5-slot context of the multi-vector family (what rank_shape's N = 4 / 8 blocks load)
-                c4_model, c4_proc = (dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=slots4, weight_format=args.weight_format)
-                                     if 1 <= n4 and slots4 < model.num_slots() else (model, proc))
+                c4_model, c4_proc, load_error = model, proc, None
+                if 1 <= n4 and slots4 < model.num_slots():
+                    try:
+                        c4_model, c4_proc = dmodel.load(args.model, synthetic=1234, device_map=local_rank, batch_slots=slots4, weight_format=args.weight_format)
+                    except Exception as e:  # noqa: BLE001  (the searches below end in collectives: a rank without its own context decodes in the batch's)
+                        load_error = repr(e)
+                        print(f"[rank {rank}] config 4: no context of {slots4} slots ({load_error}); using the {model.num_slots()}-slot one", file=sys.stderr, flush=True)
                 c4 = {"shape": "16 rollouts of one image over all ranks, root-parallel: 16/N trees x 1 expansion per rank",
-                      "context_slots": c4_model.num_slots(), "context_load_seconds": round(time.perf_counter() - t_l, 1),
+                      "context_slots": c4_model.num_slots(), "context_load_seconds": round(time.perf_counter() - t_l, 1), "context_load_error": load_error,
                       "fixed_length": search(c4_model, c4_proc, [img0] if mine else [], n4, 1, Wk=(W, Kb)),
                       "ragged": search(c4_model, c4_proc, [img0] if mine else [], n4, 1, ragged=True, Wk=(W, Kb))}
                 if world == 1 and not args.no_rank_shapes:
@@ -651,8 +656,18 @@ def main():
                 mine5 = ddist.chunk(list(range(len(imgs5))), world)[rank]
                 slots5 = len(mine5) * args.config5_trees
                 t_load = time.perf_counter()
-                m5, p5 = dmodel.load(args.config5_model, synthetic=1234, device_map=local_rank, weight_format="fp8",
-                                     batch_slots=max(2, min(64, slots5) + min(8, max(1, len(mine5)))))
+                # the searches below end in collectives: a rank whose model does not load (e.g. no memory) must take every other rank
+                # out of this block with it, not leave them waiting in a gather — the ranks agree on the outcome first
+                m5 = p5 = load_error = None
+                try:
+                    m5, p5 = dmodel.load(args.config5_model, synthetic=1234, device_map=local_rank, weight_format="fp8",
+                                         batch_slots=max(2, min(64, slots5) + min(8, max(1, len(mine5)))))
+                except Exception as e:  # noqa: BLE001
+                    load_error = repr(e)
+                failed = [(r, err) for r, err in enumerate(ddist.gather_objects(load_error, all_ranks=True)) if err]
+                if failed:
+                    del m5, p5
+                    raise RuntimeError(f"{args.config5_model} did not load on rank(s) {[r for r, _ in failed]}: {failed[0][1]}")
                 t_load = time.perf_counter() - t_load
                 st5 = m5.stats()
                 Wk5 = (st5["weight_bytes_per_token"], st5["kv_bytes_per_ctx_token"])

@@ -142,7 +142,11 @@ def _rank_main(rank, world, port, outdir):
     import bench
     import detikzify_amd.model as dm
     from tests.test_bench_dry_run import _BenchDevice
-    dm.load = lambda name, batch_slots=0, **kw: (_BenchDevice(batch_slots), fake_processor(VOCAB, NIMG, 64))
+    def load(name, batch_slots=0, **kw):
+        if os.environ.get("DTK_TEST_FAIL_CONFIG5_ON_RANK") == str(rank) and kw.get("weight_format") == "fp8":
+            raise MemoryError("no room for the config-5 model on this rank")
+        return _BenchDevice(batch_slots), fake_processor(VOCAB, NIMG, 64)
+    dm.load = load
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.set_device = lambda *a, **k: None
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--new-tokens", "16", "--no-cpu-baseline",
@@ -176,3 +180,20 @@ def test_bench_two_ranks_gloo(tmp_path):
     c4, c5 = d["mcts"]["config4"]["fixed_length"], d["mcts"]["config5"]["fixed_length"]
     assert c4["rollouts"] == 2 * 4 and c4["trees_per_gpu"] == 4 and c4["gather_seconds"] >= 0
     assert c5["rollouts"] == 4 * 2 * 1 and c5["images_per_gpu"] == 2 and len(c5["per_rank_rollouts_per_sec_min_max"]) == 2
+
+
+def test_a_rank_that_cannot_load_config5_takes_every_rank_out_of_it(tmp_path, monkeypatch):
+    """the searches of mcts.config5 end in collectives: when the model does not load on ONE rank (8 gloo ranks crammed onto one GPU ran
+    out of memory in round 5 and the others then died in a gather with 'Connection closed by peer'), the ranks agree on that before
+    the first search — every rank records the error, the run finishes, the other blocks of the line are intact"""
+    import socket
+
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("DTK_TEST_FAIL_CONFIG5_ON_RANK", "1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = json.loads([ln for ln in (tmp_path / "rank0.out").read_text().splitlines() if ln.startswith("{")][0])
+    assert "did not load on rank(s) [1]" in d["mcts"]["config5"]["error"] and "MemoryError" in d["mcts"]["config5"]["error"]
+    assert d["mcts"]["config4"]["fixed_length"]["rollouts"] == 8 and d["value"] > 0 and d["mcts_config5_rollouts_per_sec"] is None
