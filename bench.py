@@ -412,8 +412,8 @@ def main():
     # weights are streamed once per step for all B sequences
     if args.batch > 1 and not args.skip_batched:
         import threading
-        from detikzify_amd.infer.batching import BatchEngine
-        engine = BatchEngine(model, max_batch=args.batch)
+        from detikzify_amd.infer.batching import make_engine
+        engine = make_engine(model, max_batch=args.batch)      # the native run loop (DTK_ENGINE=python: the Python-driven engine)
         try:
             # MCTS rollouts sample with the pipeline's defaults (temperature .8, top-p .95: generate.py:362-364)
             mcts_kw = {**gen_kw, "do_sample": True, "temperature": 0.8, "top_p": 0.95, "top_k": 0}
@@ -432,9 +432,8 @@ def main():
                 [t.join() for t in ths]
                 fence()
                 t_end = time.perf_counter()
-                phases = {"start_to_first_step_ms": round(1e3 * (engine.t_first_launch - tb), 1),
-                          "last_collect_to_end_ms": round(1e3 * (t_end - engine.t_last_collect), 1)}
                 tb = t_end - tb
+            est = engine.stats()
             tb = max_over_ranks(tb)
             # HBM bytes one step must move: the weights once, every slot's PRIVATE keys (its generated tokens), and the image
             # prefix once per image — forked slots read the prefix rows from their source slot (share_prefix_reads), so it is
@@ -446,7 +445,7 @@ def main():
                 "batch_per_gpu": args.batch, "images_in_flight": n_img, "prefix_encodes_both_passes": engine.prefix_encodes,
                 "rollouts_per_sec": world * args.batch / tb,
                 "tokens_per_sec": world * args.batch * n_new / tb, "ms_per_batch": 1e3 * tb,
-                "decode_steps": engine.steps, "algorithmic_bytes_per_step": bytes_step,
+                "decode_steps": est["steps"], "algorithmic_bytes_per_step": bytes_step,
                 # one lock-step decode step per generated token; joins / forks / host time are inside tb, so this is the
                 # end-to-end fraction of the decode-step HBM roofline (W once per step + every sequence's own KV)
                 "achieved_GBps": bytes_step * n_new / tb / 1e9,
@@ -457,8 +456,7 @@ def main():
                 "bytes_note": "algorithmic_bytes_per_step = W + B*K*(mean context - prefix) + images*K*prefix: the shared image prefix is read once "
                               "per image, not once per slot; frac_of_survey_formula keeps SURVEY 8d's W + sum_b K*t_b (rounds 1-2 quoted that)",
                 "prefix_sharing": bool(engine.share_prefix),
-                "engine_seconds": {"wait": round(engine.t_wait, 3), "launch": round(engine.t_launch, 3), "prefill": round(engine.t_prefill, 3),
-                                   "host_bound_steps": engine.host_bound_steps, **phases},
+                "engine": est,      # both passes
                 "decode": f"sampling T=.8 top_p=.95 (DetikzifyPipeline defaults), {n_new} tokens, EOS suppressed",
                 "note": "B independent rollouts (own KV slot, seed) per GPU through model.generate from B threads; one "
                         f"dtk_decode_batch step serves all of them; the {T0}-token image prefix is encoded once, its KV "

@@ -18,6 +18,11 @@ for f in kernels_decode kernels_decode_mv kernels_batch_decode kernels_batch_gem
     pids+=($!)
   fi
 done
+# the run loop of a batch (host code only; same flags so the exports stay include/dtk.h's)
+if [ ! -f build/dtk_engine.o ] || [ $SRC/dtk_engine.cpp -nt build/dtk_engine.o ] || [ include/dtk.h -nt build/dtk_engine.o ]; then
+  $HIPCC $FLAGS -x c++ -pthread -c $SRC/dtk_engine.cpp -o build/dtk_engine.o &
+  pids+=($!)
+fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libdtk_hip.so build/kernels_decode.o build/kernels_decode_mv.o build/kernels_batch_decode.o build/kernels_batch_gemm.o build/kernels_batch_mx.o build/kernels_batched.o build/kernels_sample_mb.o build/dtk_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libdtk_hip.so build/kernels_decode.o build/kernels_decode_mv.o build/kernels_batch_decode.o build/kernels_batch_gemm.o build/kernels_batch_mx.o build/kernels_batched.o build/kernels_sample_mb.o build/dtk_api.o build/dtk_engine.o -pthread
 echo "built $OUT/libdtk_hip.so"

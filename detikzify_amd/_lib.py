@@ -8,7 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libdtk_hip.so"
 
-DTK_ABI_VERSION = 5          # include/dtk.h DTK_ABI_VERSION
+DTK_ABI_VERSION = 6          # include/dtk.h DTK_ABI_VERSION
 DTK_VIT_BATCH = 8            # include/dtk.h: images per pass of dtk_vit_encode
 DTK_F32, DTK_BF16, DTK_F16 = 0, 1, 2
 DTK_ARCH_PROJ_NO_BIAS = 1   # include/dtk.h: dtk_config.reserved[3] flag
@@ -53,6 +53,49 @@ class DtkStats(C.Structure):
     ]
 
 
+class DtkJoin(C.Structure):
+    """dtk_join: one sequence handed to the native run loop (dtk_engine_join)"""
+    _fields_ = [
+        ("slot", C.c_int32), ("n_ids", C.c_int32), ("ids", C.c_void_p), ("pixels", C.c_void_p), ("image_key", C.c_uint64),
+        ("try_resume", C.c_int32), ("n_candidates", C.c_int32), ("candidates", C.c_int32 * DTK_MAX_BATCH),
+        ("prefix_len", C.c_int32), ("prefix_src", C.c_int32), ("prefix_src_whole", C.c_int32), ("prefix_encode", C.c_int32),
+        ("prefix_in_place", C.c_int32), ("full_flags", C.c_int32), ("sampling", DtkSampling),
+        ("max_new_tokens", C.c_int32), ("n_stop", C.c_int32), ("stop_ids", C.c_int64 * 8),
+        ("flush_mode", C.c_int32), ("flush_max", C.c_int32), ("slot_out", C.c_int32), ("how_out", C.c_int32),
+        ("error_out", C.c_char * 240),
+    ]
+
+
+class DtkEngineStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("steps", "tokens_out", "joins", "resumed", "steps_below_half_occupancy", "host_bound_steps",
+                                          "reader_wakeups", "wasted_slot_steps")] + \
+               [(n, C.c_double) for n in ("wait_s", "launch_s", "join_s", "idle_s", "drain_s", "first_launch_t", "last_collect_t")]
+
+
+_I32P, _I64P = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+class DtkEngineOps(C.Structure):
+    """dtk_engine_ops: the device under the native run loop (the CPU tests script one in Python)"""
+    LAUNCH = C.CFUNCTYPE(C.c_int, C.c_void_p, _I32P)
+    WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, _I64P)
+    PREFILL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _I64P, C.c_int, C.c_void_p, C.c_uint64, C.c_int)
+    SAMPLING = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(DtkSampling))
+    FORK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+    LCP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _I64P, C.c_int, C.c_uint64, C.POINTER(C.c_int))
+    RESUME = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _I64P, C.c_int, C.c_uint64)
+    CTXLEN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+    LASTERR = C.CFUNCTYPE(C.c_void_p, C.c_void_p)     # (const char*: the callee owns the text)
+    _fields_ = [
+        ("dev", C.c_void_p), ("launch", LAUNCH), ("wait", WAIT), ("prefill_slot", PREFILL), ("set_sampling_slot", SAMPLING),
+        ("kv_fork", FORK), ("slot_lcp", LCP), ("resume_slot", RESUME), ("context_len_slot", CTXLEN), ("last_error", LASTERR),
+        ("max_positions", C.c_int32), ("decode_slots", C.c_int32),
+    ]
+
+
+DTK_JOIN_FULL, DTK_JOIN_FORK_TAIL, DTK_JOIN_FORK_WHOLE, DTK_JOIN_RESUMED, DTK_JOIN_IN_PLACE = range(5)
+DTK_SEQ_RUNNING, DTK_SEQ_FINISHED, DTK_SEQ_LEFT = 1, 2, 3
+
 # every symbol include/dtk.h declares: (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -80,6 +123,20 @@ SYMBOLS = {
     "dtk_get_stats": (C.c_int, [_P, C.POINTER(DtkStats)]),
     "dtk_num_slots": (C.c_int, [_P]),
     "dtk_max_decode_slots": (C.c_int, [_P]),
+    "dtk_max_positions": (C.c_int, [_P]),
+    "dtk_engine_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "dtk_engine_create_ops": (C.c_int, [C.POINTER(DtkEngineOps), C.POINTER(_P)]),
+    "dtk_engine_destroy": (None, [_P]),
+    "dtk_engine_last_error": (C.c_char_p, [_P]),
+    "dtk_engine_set_flush_tokens": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int]),
+    "dtk_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "dtk_engine_expect": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dtk_engine_join": (C.c_int, [_P, C.POINTER(DtkJoin)]),
+    "dtk_engine_submit": (C.c_int, [_P, C.POINTER(DtkJoin), C.POINTER(C.c_uint64)]),
+    "dtk_engine_await": (C.c_int, [_P, C.c_uint64]),
+    "dtk_engine_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
+    "dtk_engine_leave": (C.c_int, [_P, C.c_int]),
+    "dtk_engine_get_stats": (C.c_int, [_P, C.POINTER(DtkEngineStats)]),
     "dtk_prefill_slot": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64, C.c_int, _P]),
     "dtk_set_sampling_slot": (C.c_int, [_P, C.c_int, C.POINTER(DtkSampling)]),
     "dtk_decode_batch_launch": (C.c_int, [_P, C.POINTER(C.c_int32)]),

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -27,6 +28,10 @@ int& dtk_lds_attr_error() { static int e = 0; return e; }     // common.h: set b
 namespace {
 
 thread_local std::string g_create_error;
+// dtk_last_error is per calling thread (ABI 6): the engine's loop thread, reward threads inside dtk_vit_encode and a caller's own
+// thread may all fail on one context; each reads the text of ITS failed call
+thread_local std::string g_thread_error;
+thread_local const void* g_thread_error_ctx = nullptr;
 
 struct TensorEntry {
   std::string name;
@@ -70,6 +75,10 @@ struct dtk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  std::mutex err_mu;
+  // dtk_vit_encode (own stream, any thread: the SelfSim rewards) and a prefill (the engine's loop thread) share the ViT activation
+  // buffers and `cur_stream`: one at a time
+  std::mutex vit_mu;
 
   // derived sizes
   int d, L, H, ff, V, Tmax, S;           // S: split-K factor of the single-sequence decode attention
@@ -217,7 +226,13 @@ int fail(dtk_ctx* c, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (c) c->err = buf; else g_create_error = buf;
+  if (c) {
+    { std::lock_guard<std::mutex> g(c->err_mu); c->err = buf; }
+    g_thread_error = buf;
+    g_thread_error_ctx = c;
+  } else {
+    g_create_error = buf;
+  }
   return code;
 }
 
@@ -947,11 +962,20 @@ int dtk_abi_struct_size(int which) {
     case 3: return (int)offsetof(dtk_sampling, seed);
     case 4: return (int)offsetof(dtk_config, reserved);
     case 5: return (int)offsetof(dtk_stats, probe_event_pair_ms);
+    case 6: return (int)sizeof(dtk_join);
+    case 7: return (int)sizeof(dtk_engine_stats);
+    case 8: return (int)sizeof(dtk_engine_ops);
+    case 9: return (int)offsetof(dtk_join, sampling);
+    case 10: return (int)offsetof(dtk_join, error_out);
     default: return -1;
   }
 }
 
-const char* dtk_last_error(const dtk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* dtk_last_error(const dtk_ctx* ctx) {
+  if (!ctx) return g_create_error.c_str();
+  if (g_thread_error_ctx == ctx) return g_thread_error.c_str();     // this thread's own last failure on ctx
+  return ctx->err.c_str();
+}
 
 int dtk_create(const dtk_config* cfg, int device, dtk_ctx** out) {
   if (!cfg || !out) return fail(nullptr, DTK_ERR_ARG, "dtk_create: null argument");
@@ -1222,6 +1246,7 @@ int dtk_vit_encode(dtk_ctx* c, const float* pixels, int batch, void* feats_out, 
       if (!t.loaded && t.name.compare(0, 23, "vision_model.attn_pool.") == 0)
         return fail(c, DTK_ERR_STATE, "pooler_output requested but '%s' was never loaded (checkpoint without the pooling head)", t.name.c_str());
   }
+  std::lock_guard<std::mutex> vit_guard(c->vit_mu);
   HIPCHK(c, hipSetDevice(c->device));
   const size_t img = (size_t)3 * c->cfg.vit_image * c->cfg.vit_image;
   hipStream_t sv = c->stream_vit;
@@ -1254,6 +1279,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   auto vc = [&](int l) { return kvbase + (size_t)l * kv_layer + (size_t)c->KVH * c->Tmax * 128; };
   if (!c || !ids || T < 1) return fail(c, DTK_ERR_ARG, "dtk_prefill: bad argument");
   if (T > c->Tmax) return fail(c, DTK_ERR_RANGE, "prompt of %d tokens exceeds max_positions %d", T, c->Tmax);
+  std::lock_guard<std::mutex> vit_guard(c->vit_mu);
   HIPCHK(c, hipSetDevice(c->device));
   // drain pending decode steps (their tokens are dropped)
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1447,6 +1473,7 @@ int dtk_set_sampling_slot(dtk_ctx* c, int slot, const dtk_sampling* sp) {
 }
 
 int dtk_num_slots(const dtk_ctx* c) { return c ? c->nb : 0; }
+int dtk_max_positions(const dtk_ctx* c) { return c ? c->Tmax : 0; }
 int dtk_max_decode_slots(const dtk_ctx* c) { return (c && c->nb > 0) ? max_decode_slots(c) : 0; }
 
 // One batched decode step for the slots with active[slot] != 0 (every one must have been prefilled).

@@ -159,7 +159,7 @@ class BatchEngine:
             self._t_free_since = time.perf_counter()
 
     def stats(self) -> Dict[str, Any]:
-        return {"steps": self.steps, "tokens_out": self.tokens_out, "wait_s": round(self.t_wait, 3), "launch_s": round(self.t_launch, 3),
+        return {"engine": "python", "steps": self.steps, "tokens_out": self.tokens_out, "wait_s": round(self.t_wait, 3), "launch_s": round(self.t_launch, 3),
                 "prefill_s": round(self.t_prefill, 3), "host_bound_steps": self.host_bound_steps, "prefix_encodes": self.prefix_encodes,
                 "inplace_reuses": self.inplace_reuses, "joins": self.joins, "resumed_in_place": self.resumes, "idle_between_steps_s": round(self.t_idle, 3),
                 "steps_below_half_occupancy": self.slot_steps_short, "native_runs": self.runs}
@@ -170,9 +170,10 @@ class BatchEngine:
         self.model.batch_engine = None
 
     @contextmanager
-    def sequence(self, ids, pixel_values, sampling: Dict[str, Any], owner: Optional[int] = None) -> Iterator[_Sequence]:
+    def sequence(self, ids, pixel_values, sampling: Dict[str, Any], owner: Optional[int] = None, **_native_only) -> Iterator[_Sequence]:
         """`owner`: whoever starts sequence after sequence (an MCTS tree: generate(sequence_owner=t)) — a join that cannot
-        resume takes the slot its owner used last, so it does not overwrite a rollout ANOTHER owner may come back to"""
+        resume takes the slot its owner used last, so it does not overwrite a rollout ANOTHER owner may come back to.
+        (max_new_tokens / stop_ids / per_token are for infer/engine.NativeBatchEngine: here the sequence's end is emit's verdict.)"""
         want = self._prefix_key(ids, pixel_values) if (self.share_prefix and pixel_values is not None) else None
         with self._locked():
             while not self.free:
@@ -574,6 +575,19 @@ class BatchEngine:
         return item
 
 
+def make_engine(model, processor=None, **kw):
+    """The engine of a model's batch slots: the native run loop (infer/engine.NativeBatchEngine; its readers wake once per source
+    line, so it is given the processor's newline table) unless DTK_ENGINE=python asks for the Python-driven BatchEngine (A/B runs)."""
+    if os.environ.get("DTK_ENGINE", "native") == "python":
+        return BatchEngine(model, **kw)
+    from .engine import NativeBatchEngine
+    flush = None
+    if processor is not None:
+        from .generate import newline_table
+        flush = newline_table(processor).keys()
+    return NativeBatchEngine(model, flush_tokens=flush, **kw)
+
+
 def simulate_parallel(pipeline, image, trees: int, expansions_per_tree: int, seed_base: int = 1000,
                       seeds: Optional[List[int]] = None, resume_in_place: bool = True, slots: Optional[int] = None,
                       **gen_kwargs) -> Iterator[Tuple[float, Any]]:
@@ -604,8 +618,8 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
     assert len(seeds) == trees, "one seed per tree"
     # more trees than decode slots (the model's, or `slots`): a join waits for a slot to come free (BatchEngine.sequence), i.e. for
     # another tree to finish its rollout and go off to its reward — with rewards that take seconds that keeps the batch full
-    engine = (BatchEngine(pipeline.model, max_batch=min(trees, slots) if slots else trees, gather=trees, resume_in_place=resume_in_place)
-              if trees > 1 else None)
+    engine = make_engine(pipeline.model, processor=pipeline.processor, max_batch=min(trees, slots) if slots else trees, gather=trees,
+                         resume_in_place=resume_in_place) if trees > 1 else None
     # the trees' rewards arrive in waves: their Pillow work (trim, LANCZOS pad, BICUBIC resize: all under the GIL) goes to the
     # process-wide worker pool when there is one (util/image_prep.py; bit-identical pixels)
     metric = getattr(pipeline, "metric", None)

@@ -615,15 +615,19 @@ class DetikzifyForCausalLM:
             return stop
 
         emit.many, emit.budget, emit.stop_ids = emit_many, (lambda: max_length - cur), eos_set
+        emit.aborted = lambda: any(c.should_stop for c in light)
         engine = self.batch_engine
         if n_new_max > 0 and engine is not None:
-            # batched mode: this sequence decodes in a KV slot, in lock-step with the other threads'
-            # sequences (infer/batching.py); one pass over the weights serves all of them
+            # batched mode: this sequence decodes in a KV slot together with the other threads' sequences (infer/engine.py: the
+            # native run loop; infer/batching.py: the Python-driven one); one pass over the weights serves all of them.  The
+            # sequence's own end (EOS, length budget) goes with it: the native loop stops the slot there.  Tokens come back in
+            # bursts (one per source line) unless something here needs to see every token as it is made.
+            per_token = bool(heavy) or (streamer is not None and (put_token is None or bool(getattr(streamer, "per_token", put_tokens is None))))
             with engine.sequence(ids[0], pixel_values, dict(
                     do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k, seed=seed, bad_ids=bad,
                     begin_suppress_ids=begin_suppress_tokens or (), always_suppress_ids=suppress_tokens or ()),
-                    owner=sequence_owner) as seq:
-                seq.run(emit)       # emit() is called per token by the thread that drives the batch (no per-token hand-off)
+                    owner=sequence_owner, max_new_tokens=n_new_max, stop_ids=eos_set, per_token=per_token) as seq:
+                seq.run(emit)       # emit.many() per burst in this thread (native engine) / emit() per token by the driving thread
         elif n_new_max > 0:
             # the context has ONE un-slotted sequence: a second generate() on it from another thread would interleave its
             # prefill / decode steps with ours and both would return garbage — refuse loudly (the reference never does

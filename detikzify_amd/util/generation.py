@@ -73,6 +73,11 @@ class TokenStreamer(_QueueStreamer):
         self._out: list = []        # producer side: tokens of the burst being built
         self._in: list = []         # consumer side: the burst being handed out (reversed)
 
+    @property
+    def per_token(self) -> bool:
+        """without flush_on the consumer is woken per token and expects each one as it is made (no bursts from the engine either)"""
+        return self.flush_on is None
+
     def put(self, value):
         if len(value.shape) > 1:
             if value.shape[0] > 1:
@@ -177,6 +182,32 @@ class StreamerList(list):
     def put(self, value):
         for s in self:
             s.put(value)
+
+    def put_token(self, token_id: int):
+        """one generated token as a plain int (the generate loop's fast path); members without put_token get the HF protocol's
+        one-element tensor"""
+        for s in self:
+            f = getattr(s, "put_token", None)
+            if f is not None:
+                f(token_id)
+            else:
+                import torch
+                s.put(torch.tensor([token_id], dtype=torch.int64))
+
+    def put_tokens(self, token_ids):
+        """a burst of generated tokens, in order: exactly what one put_token per id would have produced"""
+        for s in self:
+            f = getattr(s, "put_tokens", None)
+            if f is not None:
+                f(token_ids)
+            else:
+                for token_id in token_ids:
+                    StreamerList.put_token([s], token_id)
+
+    @property
+    def per_token(self) -> bool:
+        """True if some member needs the per-token protocol (no put_tokens): bursts would delay what it shows"""
+        return any(bool(getattr(s, "per_token", getattr(s, "put_tokens", None) is None)) for s in self)
 
     def end(self):
         for s in self:

@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-#define DTK_ABI_VERSION 5   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
+#define DTK_ABI_VERSION 6   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
                              * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels);
-                             * 5: dtk_op_gemv_mx, dtk_mx_layout, dtk_stats.last_batch_step_fp8_mfma */
+                             * 5: dtk_op_gemv_mx, dtk_mx_layout, dtk_stats.last_batch_step_fp8_mfma;
+                             * 6: dtk_engine_* (the native run loop of a batch), dtk_max_positions; dtk_last_error is per calling thread */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -119,7 +120,8 @@ typedef struct dtk_stats {
 
 int  dtk_abi_version(void);
 /* layout check for bindings: sizeof of 0 dtk_config, 1 dtk_sampling, 2 dtk_stats; offsetof of 3 dtk_sampling.seed,
- * 4 dtk_config.reserved, 5 dtk_stats.probe_event_pair_ms; -1 for anything else */
+ * 4 dtk_config.reserved, 5 dtk_stats.probe_event_pair_ms; sizeof of 6 dtk_join, 7 dtk_engine_stats, 8 dtk_engine_ops; offsetof of
+ * 9 dtk_join.sampling, 10 dtk_join.error_out; -1 for anything else */
 int  dtk_abi_struct_size(int which);
 /* last error of a context; ctx may be NULL for the error of a failed dtk_create */
 const char* dtk_last_error(const dtk_ctx* ctx);
@@ -233,6 +235,106 @@ int  dtk_resume_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int n_tokens, u
 int  dtk_slot_cached_ids(dtk_ctx* ctx, int slot, int64_t* ids_out, int n_max);   /* diagnostic: what the slot's cache holds; returns the count */
 int  dtk_get_logits_slot(dtk_ctx* ctx, int slot, float* logits_out);
 int  dtk_context_len_slot(const dtk_ctx* ctx, int slot);
+
+int  dtk_max_positions(const dtk_ctx* ctx);               /* KV capacity of a sequence in tokens (dtk_config.max_positions) */
+
+/* ---- The run loop of a batch of rollouts, native (ABI 6) ------------------------------------------------------------------------
+ * Replaces, for every sequence decoded in a slot, the per-token host iteration of HF GenerationMixin._sample
+ * (generation/utils.py:2875-2936) that DetikzifyGenerator.generate runs in a worker thread and consumes line by line
+ * (reference detikzify/infer/generate.py:246-282): ONE native thread per engine launches and collects the batched steps — two in
+ * flight, so the device never waits for the host — appends every slot's token to that slot's ring, applies the sequence's own stop
+ * rules (stop ids = EOS, token budget = max_length) and wakes the slot's reader only when a FLUSH token (the caller's newline table),
+ * `flush_max` tokens or the end of the sequence has arrived.  Callers block in dtk_engine_read (no interpreter lock held) and are
+ * woken once per source line instead of once per token; joins and leaves are queued and executed by the same thread between steps,
+ * so nothing but that thread ever touches the context's main stream.  A slot's tokens do not depend on which other slots decode
+ * next to it, so a sequence is the same ids as through dtk_decode_batch_launch / _wait driven from the host.
+ * dtk_engine_create drives `ctx` (which must outlive the engine and must not be used for prefill / decode calls by anybody else
+ * meanwhile; dtk_vit_encode from other threads stays legal: own stream, serialised with image prefills inside the library).
+ * dtk_engine_create_ops drives a caller-supplied device (the CPU tests' scripted device: tests/test_native_engine.py). */
+typedef struct dtk_engine dtk_engine;
+typedef struct dtk_engine_ops {      /* the device under the loop: same contracts as the dtk_* entry points of the same names */
+  void* dev;
+  int (*launch)(void* dev, const int32_t* active /* [DTK_MAX_BATCH] */);
+  int (*wait)(void* dev, int64_t* tokens_out /* [DTK_MAX_BATCH] */);
+  int (*prefill_slot)(void* dev, int slot, const int64_t* ids, int T, const float* pixels, uint64_t image_key, int flags);
+  int (*set_sampling_slot)(void* dev, int slot, const dtk_sampling* s);
+  int (*kv_fork)(void* dev, int src_slot, int dst_slot, int n_tokens);
+  int (*slot_lcp)(void* dev, int slot, const int64_t* ids, int n_tokens, uint64_t image_key, int* lcp_out);
+  int (*resume_slot)(void* dev, int slot, const int64_t* ids, int n_tokens, uint64_t image_key);
+  int (*context_len_slot)(void* dev, int slot);
+  const char* (*last_error)(void* dev);
+  int32_t max_positions;
+  int32_t decode_slots;
+} dtk_engine_ops;
+
+/* how a join got its prompt into the slot (dtk_join.how_out) */
+enum { DTK_JOIN_FULL = 0,        /* whole prompt prefilled (ViT included unless the image is cached)                  */
+       DTK_JOIN_FORK_TAIL = 1,   /* image prefix forked from prefix_src, what follows prefilled                       */
+       DTK_JOIN_FORK_WHOLE = 2,  /* prompt == prefix: KV and next-token logits forked, nothing computed                */
+       DTK_JOIN_RESUMED = 3,     /* the slot still held all but the last prompt token: continued in place, no prefill */
+       DTK_JOIN_IN_PLACE = 4 };  /* the slot still held the image prefix: only what follows prefilled                 */
+/* sequence states (dtk_engine_read state_out) */
+enum { DTK_SEQ_RUNNING = 1, DTK_SEQ_FINISHED = 2 /* stop id or budget */, DTK_SEQ_LEFT = 3 /* dtk_engine_leave / engine destroyed */ };
+
+typedef struct dtk_join {
+  int32_t slot;                  /* decoding slot of the sequence; with n_candidates > 0: the slot taken when no candidate can resume */
+  int32_t n_ids;
+  const int64_t* ids;            /* the whole prompt (host)                                                                        */
+  const float* pixels;           /* 1 x 3 x S x S fp32 (host) or NULL, as dtk_prefill_slot                                         */
+  uint64_t image_key;
+  int32_t try_resume;            /* 1: dtk_resume_slot when the slot's cache holds ids[0, n_ids - 1) (an MCTS tree coming back)     */
+  int32_t n_candidates;          /* > 0 (with try_resume): resume in the candidate with the longest such match (lowest index on ties) */
+  int32_t candidates[DTK_MAX_BATCH];
+  int32_t prefix_len;            /* leading ids that are the shareable image prefix; 0 = no sharing: a full prefill with full_flags */
+  int32_t prefix_src;            /* slot to fork the prefix from (-1: none)                                                         */
+  int32_t prefix_src_whole;      /* 1: prefix_src is a prefix-cache slot (holds exactly the prefix + its next-token logits)         */
+  int32_t prefix_encode;         /* 1: first prefill ids[0, prefix_len) + pixels into prefix_src (greedy), then fork                */
+  int32_t prefix_in_place;       /* 1: `slot` itself still holds the prefix: prefill with DTK_PREFILL_REUSE_*                       */
+  int32_t full_flags;            /* DTK_PREFILL_* of the full prefill                                                               */
+  dtk_sampling sampling;
+  int32_t max_new_tokens;        /* token budget of the sequence (max_length - n_ids)                                               */
+  int32_t n_stop;
+  int64_t stop_ids[8];           /* the sequence ends WITH the first of these it emits (EOS)                                        */
+  int32_t flush_mode;            /* 0: every token wakes the reader; 1: flush tokens (dtk_engine_set_flush_tokens) / flush_max      */
+  int32_t flush_max;             /* mode 1: wake the reader after at most this many undelivered tokens (0 = 64)                     */
+  int32_t slot_out;              /* out: the slot the sequence decodes in                                                           */
+  int32_t how_out;               /* out: DTK_JOIN_*                                                                                 */
+  char    error_out[240];        /* out: text of a failed join (the engine itself stays usable unless the device failed)            */
+} dtk_join;
+
+typedef struct dtk_engine_stats {
+  uint64_t steps, tokens_out, joins, resumed, steps_below_half_occupancy, host_bound_steps, reader_wakeups, wasted_slot_steps;
+  double   wait_s;               /* inside the device's wait: the step time the host sees                                           */
+  double   launch_s, join_s;     /* inside launch / inside join execution (prefills, forks)                                         */
+  double   idle_s;               /* sequences running but no step in flight (joins being executed, start-up)                        */
+  double   drain_s;              /* waiting for steps in flight because a join / leave was queued                                    */
+  double   first_launch_t, last_collect_t;   /* CLOCK_MONOTONIC seconds (0 = none yet)                                              */
+} dtk_engine_stats;
+
+int  dtk_engine_create(dtk_ctx* ctx, dtk_engine** out);
+int  dtk_engine_create_ops(const dtk_engine_ops* ops, dtk_engine** out);
+void dtk_engine_destroy(dtk_engine* e);            /* stops the loop (steps in flight are collected); readers see DTK_SEQ_LEFT     */
+const char* dtk_engine_last_error(const dtk_engine* e);   /* text of the device failure that stopped the loop ("" = none)          */
+/* tokens that end a reader's burst (the newline table of DetikzifyGenerator.rollout, reference infer/generate.py:262-274) */
+int  dtk_engine_set_flush_tokens(dtk_engine* e, const int64_t* ids, int n);
+/* option "depth" = steps kept in flight (1 | 2, default 2) */
+int  dtk_engine_set_option(dtk_engine* e, const char* name, int value);
+/* n sequences are about to join: no step before all of them have, or timeout_ms have passed (rollouts started together move together) */
+int  dtk_engine_expect(dtk_engine* e, int n, int timeout_ms);
+/* queue a sequence and block until the loop has put its prompt into the slot (DTK_OK) or failed to (error_out).  Joins execute in
+ * the order they were queued; dtk_engine_submit queues without waiting (a caller that plans joins against its own bookkeeping —
+ * which slot holds which image prefix — queues under the lock that protects the bookkeeping and waits outside it);
+ * dtk_engine_await blocks for that join's result.  `j` must stay valid until await returns; every ticket must be awaited once. */
+int  dtk_engine_join(dtk_engine* e, dtk_join* j);
+int  dtk_engine_submit(dtk_engine* e, dtk_join* j, uint64_t* ticket_out);
+int  dtk_engine_await(dtk_engine* e, uint64_t ticket);
+/* block until slot's sequence has undelivered flushed tokens, has ended, or timeout_ms passed (< 0: no timeout); copies up to cap
+ * tokens; *state_out = DTK_SEQ_*.  A sequence that ended hands out its remaining tokens first: FINISHED / LEFT is reported
+ * together with the last of them.  A device failure returns its error code (text: dtk_engine_last_error). */
+int  dtk_engine_read(dtk_engine* e, int slot, int64_t* tokens_out, int cap, int32_t* n_out, int32_t* state_out, int timeout_ms);
+/* end slot's sequence now (its undelivered tokens stay readable); the slot can be joined again at once */
+int  dtk_engine_leave(dtk_engine* e, int slot);
+int  dtk_engine_get_stats(dtk_engine* e, dtk_engine_stats* out);
 
 /* Tuning aids (tools/, bench): time one decode GEMV role (0 qkv, 1 o_proj, 2 gate/up, 3 down,
  * 4 lm_head; 5 / 6 = the batched gate/up kernel / its LDS-DMA twin with parts switched off, tools/probe_batch.py) in kernel
