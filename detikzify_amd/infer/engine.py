@@ -229,6 +229,10 @@ class NativeBatchEngine:
     def prefix_slot(self) -> Optional[int]:
         return self.prefix_slots[-1] if self.prefix_slots else None
 
+    @property
+    def steps(self) -> int:
+        return int((self.native_stats() if self._h else self._final)["steps"])
+
     # ---- joins ---------------------------------------------------------------------------------------------------------------
     def _prefix_key(self, ids, pixel_values):
         tok = self.model.config.image_token_id

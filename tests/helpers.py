@@ -88,3 +88,11 @@ def peaked_lm_head(lm_head: torch.Tensor, beta: float = 2.0, seed: int = 0, clip
     g = torch.Generator().manual_seed(seed)
     e = torch.clamp(torch.round(beta * torch.randn(lm_head.shape[0], generator=g)), -clip, clip)
     return lm_head.float() * torch.exp2(e)[:, None]
+
+
+def engines():
+    """both engines of a model's batch slots — the native run loop (default) and the Python-driven one — for tests that pin a
+    property of the SEQUENCES (tokens, prefix paths), which must not depend on who turns the crank"""
+    from detikzify_amd.infer.batching import BatchEngine
+    from detikzify_amd.infer.engine import NativeBatchEngine
+    return [NativeBatchEngine, BatchEngine]

@@ -25,7 +25,7 @@ from oracle.ops import bits_to_f32, f32_to_bits, rb
 from oracle.synth import synth_bits, tensor_specs
 from oracle.vit import layernorm
 from oracle.llama import attention, rmsnorm
-from tests.helpers import TINY, TINY_CFG, TINY_V2, TINY_V2_CFG, rel_l2, sketch_image
+from tests.helpers import TINY, TINY_CFG, TINY_V2, TINY_V2_CFG, engines, rel_l2, sketch_image
 
 
 @pytest.fixture(scope="module")
@@ -849,10 +849,10 @@ def test_batched_decode_tracks_oracle_and_is_batch_invariant(tiny_batched):
         assert torch.equal(model.get_logits_slot(2), logit_log[2][i])
 
 
-def test_batch_engine_threads_match_slot_alone(tiny_batched):
-    """model.generate() from several threads through the BatchEngine == each prompt generated alone"""
+@pytest.mark.parametrize("BatchEngine", engines(), ids=lambda c: c.__name__)
+def test_batch_engine_threads_match_slot_alone(tiny_batched, BatchEngine):
+    """model.generate() from several threads through the engine (native run loop / Python-driven) == each prompt generated alone"""
     import threading
-    from detikzify_amd.infer.batching import BatchEngine
     model, proc = tiny_batched
     prompts = _batch_prompts(proc)
     kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=24, bad_words_ids=[[1]],
@@ -963,11 +963,11 @@ def test_resume_slot_continues_without_a_prefill(tiny_batched):
     # restarts the counter by design: a new sequence starts at draw 0)
 
 
-def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched):
+@pytest.mark.parametrize("BatchEngine", engines(), ids=lambda c: c.__name__)
+def test_kv_fork_prefix_sharing_is_bit_identical(tiny_batched, BatchEngine):
     """dtk_kv_fork + tail prefill == full prefill, bit for bit (logits and the tokens that follow), and the
-    BatchEngine's prefix cache gives the same generations as share_prefix=False"""
+    engine's prefix cache gives the same generations as share_prefix=False"""
     import threading
-    from detikzify_amd.infer.batching import BatchEngine
     model, proc = tiny_batched
     (ids, px), (ids_b, px_b), _ = _batch_prompts(proc)
     long_ids = torch.cat([ids, torch.tensor([70, 300, 41, 9, 9])])
@@ -1667,7 +1667,8 @@ def test_shared_prefix_reads_are_invisible_and_invalidate_correctly(tiny_batched
         assert all(torch.equal(a, b) for a, b in zip(l, ref_l)), (share, clobber)
 
 
-def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched):
+@pytest.mark.parametrize("BatchEngine", engines(), ids=lambda c: c.__name__)
+def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched, BatchEngine):
     """every way a sequence can obtain its image prefix in the BatchEngine — encode into the prefix cache + fork (with
     logits), fork from another slot that still holds the image, re-use in place, eviction by another image — yields EXACTLY the
     tokens of the same engine without any prefix sharing (every sequence prefilled in full: the forked / re-used KV rows are
@@ -1675,7 +1676,6 @@ def test_engine_prefix_paths_give_the_same_tokens_as_plain_generate(tiny_batched
     same prompt and seed up to what two summation orders allow: the single-sequence kernels are another fp32 order, so a sampled
     draw that lands within rounding of a CDF boundary may differ (round 5: one of 120 draws when the batched attention's block went
     from 4 to 2 waves) — at most one of the ten sequences, and not before its fifth generated token."""
-    from detikzify_amd.infer.batching import BatchEngine
     model, proc = tiny_batched
     (ids, px), (ids_b, px_b), (ids_c, px_c) = _batch_prompts(proc)
     kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=12, bad_words_ids=[[1]],

@@ -20,7 +20,7 @@ from oracle import sampling
 from oracle.model import DetikzifyOracle
 from oracle.ops import f32_to_bits, rb
 from oracle.synth import tensor_specs
-from tests.helpers import TINY_CFG, TINY_V2_CFG, rel_l2, sketch_image
+from tests.helpers import TINY_CFG, TINY_V2_CFG, engines, rel_l2, sketch_image
 
 
 def weights_from_device(model, cfg):
@@ -217,11 +217,12 @@ def test_multi_vector_fp8_rows_and_gqa():
         del model
 
 
-def test_engine_and_parallel_trees_on_the_multi_vector_step(tiny_mv):
+@pytest.mark.parametrize("BatchEngine", engines(), ids=lambda c: c.__name__)
+def test_engine_and_parallel_trees_on_the_multi_vector_step(tiny_mv, BatchEngine):
     """the host stack on a 5-slot context: BatchEngine capacity 4 + one prefix slot; model.generate from four threads == each
     prompt generated alone; kv_fork / resume_slot in this family; simulate_parallel with 4 trees (config 4 at N = 4)"""
     from detikzify_amd.infer import DetikzifyPipeline, SyntheticTikzDocument
-    from detikzify_amd.infer.batching import BatchEngine, simulate_parallel
+    from detikzify_amd.infer.batching import simulate_parallel
     model, proc = tiny_mv
     prompts = _prompts(proc)
     kw = dict(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, max_new_tokens=24, bad_words_ids=[[1]],
