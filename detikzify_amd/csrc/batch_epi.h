@@ -72,14 +72,14 @@ __device__ __forceinline__ void gg_epilogue(const GemvBArgs& a, int g, int n, in
 // written as a loop of `if (!active) continue; pos = ...; cos = table[pos]...` it was up to a dozen dependent L2 round trips at
 // the end of every wave (round 4: the same mistake that made the GEMM epilogues half of a ViT launch).  Same arithmetic, same
 // rounding points as gg_epilogue.
-template <int EPI, int T, bool F8, int NT = 4>      // NT = 16-slot column tiles the wave holds (k_gemv_mxu: 1, 2 or 4)
-__device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const f32x4 (&tot)[T][NT], int lane) {
+template <int EPI, int T, bool F8, int NT = 4>      // NT = 16-slot column tiles the wave holds (k_gemv_mxu: 1, 2 or 4), the first of them being tile nt0 (k_gemv_bc: a wave per column tile)
+__device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const f32x4 (&tot)[T][NT], int lane, int nt0 = 0) {
   static_assert(T == 2, "paired row tiles");
   const int m0 = (lane >> 4) * 4;
   int act[NT], pos[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
+    const int n = (nt0 + nt) * 16 + (lane & 15);
     act[nt] = a.bs->active[n];
     pos[nt] = (EPI == EPI_QKV) ? a.st[n].pos : 0;
   }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
       }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + (lane & 15);
+      const int n = (nt0 + nt) * 16 + (lane & 15);
       if (!act[nt]) continue;
       const size_t slot_kv = (size_t)n * a.kv_slot_stride;
 #pragma unroll
@@ -139,7 +139,7 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
+    const int n = (nt0 + nt) * 16 + (lane & 15);
     if (!act[nt]) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

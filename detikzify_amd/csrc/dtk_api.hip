@@ -2014,6 +2014,11 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemv_br_wd")) { if (value != 4 && value != 8) return fail(c, DTK_ERR_ARG, "gemv_br_wd must be 4 or 8"); set_gemv_br_wd(value); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
+  else if (!strcmp(name, "gemv_bc")) {
+    if (value < 0 || value > 127) return fail(c, DTK_ERR_ARG, "gemv_bc must be 0..127 (0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head through k_gemv_bc; bits 4..6 = units per block, 0 = one CU's share)");
+    set_gemv_bc(value);
+    drop_batch_graphs(c);
+  }
   else if (!strcmp(name, "gemv_bl")) {
     if (value < 0 || value > 127) return fail(c, DTK_ERR_ARG, "gemv_bl must be 0..127 (bit 6: bf16 qkv through k_gemv_br; bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair + V tile per block where that fills the chip, bit 4: for any MHA model, bit 5: fp8 weights through registers (k_gemv_br, K = 4096))");
     set_gemv_bl(value);

@@ -360,6 +360,7 @@ void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
   if (launch_gemm_b(epi, g_gemm_b_shape, a, s)) return;     // x staged through LDS (kernels_batch_gemm.hip); false: not covered
   if (g_gemv_bk < 0) { const char* e = getenv("DTK_GEMV_BK"); g_gemv_bk = e ? atoi(e) : 0; }
   if (launch_gemv_bk(epi, g_gemv_bk, a, s)) return;         // 64 slots, N = d roles: K split over the CUs of a row group (kernels_batch_gemm.hip)
+  if (launch_gemv_bc(epi, a, s)) return;                    // 64 slots, rows >> d roles: a compute wave per column tile (x from L2 into registers, weights through an LDS ring)
   if (launch_gemv_bl(epi, a, s)) return;                    // 64 slots, rows >> d roles: both operands through LDS rings filled by a loader wave
   if (g_gemv_bx < 0) { const char* e = getenv("DTK_GEMV_BX"); g_gemv_bx = e ? atoi(e) : 1; }
   if (launch_gemv_bx(epi, g_gemv_bx, a, s)) return;         // 64 slots, rows >> d roles: x once per CU (kernels_batch_gemm.hip); false: not covered

@@ -825,6 +825,215 @@ static bool launch_br_units(int units, const GemvBArgs& a, hipStream_t s) {
     default: return false;
   }
 }
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemv_bc — the rows >> d roles at 64 slots with the compute waves split by COLUMN tile (round 6).
+//
+// Every 64-slot kernel above gives a compute wave a unit (two paired row tiles) and all four 16-slot column tiles, so the x fragments
+// of all 64 slots — 16 KiB per phase of 4 k-steps, 512 KiB over K = 4096 — must reach every wave of the block: through an LDS ring
+// filled by LDS-DMA.  That ring is what the kernels sit on: a CU's LDS-DMA path lands ~25 GB/s (40 with L2 hits: the guide's
+// ldsdma-fill row, HISTORY 3.1b), 512 KiB of x per block therefore cost 13-20 us whatever the weights weigh — qkv takes 27.5 us with
+// fp8 weights (50 MB) and 29.4 with bf16 (100 MB), gate/up 29.4 / 34.8.  Here the operands swap paths:
+//   * compute wave w owns COLUMN tile w (slots 16 w .. 16 w + 15) of ALL the block's row tiles: its B operand is its own 1 KiB per
+//     k-step of the fragment-major x (128 KiB over K = 4096), streamed from L2 straight into a register ring of XD = 4 phases with
+//     ordinary 16-byte loads — no LDS, no DMA, nothing shared; the four waves together read x once per block as before;
+//   * the WEIGHTS, which all four waves need, go through the LDS ring: one loader wave, LDS-DMA, U x 2 row tiles per phase — 8 KiB
+//     (fp8, U = 2) .. 24 KiB (bf16, U = 3) instead of 16 KiB of x plus the weights — and every compute wave reads all of them
+//     with conflict-free ds_read_b128;
+//   * flags as in k_gemv_bl (FILLED by the loader's counted vmcnt, DONE per compute wave), no barrier in the k loop.
+// Per accumulator the same MFMAs on the same operands in the same k order, chains closed at the same k_gemv_b slice boundaries,
+// slice sums added in slice order, the epilogue of gg_finish_unit per column tile: BIT-IDENTICAL to k_gemv_b and its twins (tested).
+template <int N>
+__device__ __forceinline__ void bc_wait(u32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N)); }   // ties the fragment to the wait
+__device__ __forceinline__ void bc_load(u32x4& dst, const void* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
+template <int EPI, int U, int CHP4, bool F8 = false, int R = 4>
+__global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
+  constexpr int T = 2, NC = 4, PH = 4, XD = 4;
+  constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight pieces per row tile and phase
+  constexpr int TILES = U * T;
+  constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase
+  constexpr unsigned OFF_FILLED = R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr int PIECES = TILES * WT;
+  constexpr unsigned SPIN = 1u << 22;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4 (NPH = 16 or 32)
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  __syncthreads();
+  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
+
+  if (wave == NC) {
+    // ---- loader wave: the weight tiles of the block's U units, phase by phase, by LDS-DMA
+    const unsigned char* wsrc[TILES];
+#pragma unroll
+    for (int j = 0; j < TILES; ++j) {
+      const int g = blockIdx.x * U + j / T, gc = g < groups ? g : groups - 1;      // a surplus unit streams valid memory and stores nothing
+      int tn = gg_tile_row0<EPI, T>(a, gc, j % T) >> 4;
+      const int tn_max = ((a.N + 15) >> 4) - 1;
+      if (tn > tn_max) tn = tn_max;
+      wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
+                   : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
+    }
+    unsigned slot = 0;
+    for (int p = 0; p < NPH; ++p) {
+      if (p >= R) {
+        unsigned spins = 0;
+        for (; spins < SPIN; ++spins) {
+          unsigned lo = bl_ld(OFF_DONE);
+#pragma unroll
+          for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
+          if (lo + R > (unsigned)p) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins == SPIN) bl_timeout(a.err);
+      }
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) {
+        if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, slot * WPH + (unsigned)j * WT * 1024u);
+        else glds_run4<true>(wsrc[j] + (size_t)p * PH * 1024, slot * WPH + (unsigned)j * PH * 1024u);
+      }
+      if (p >= 1) {                           // the previous phase has landed when only this phase's pieces are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)p);
+      }
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bl_st(OFF_FILLED, (unsigned)NPH);
+    return;
+  }
+
+  // ---- compute wave = column tile `wave`
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a.X) + ((size_t)wave * nsteps * 512 + lane * 8) * 2;
+  u32x4 xr[XD][PH];
+#pragma unroll
+  for (int b = 0; b < XD; ++b)
+#pragma unroll
+    for (int j = 0; j < PH; ++j) bc_load(xr[b][j], xsrc + (size_t)(b * PH + j) * 1024);
+  f32x4 tot[TILES], c[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) { tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  unsigned slot = 0;
+  auto group = [&](int p0, auto refill_tag) {       // XD phases on the x ring's slots 0 .. XD - 1; REFILL: a used-up fragment is reloaded for phase p + XD
+    constexpr bool REFILL = decltype(refill_tag)::value;
+#pragma unroll
+    for (int b = 0; b < XD; ++b) {
+      const int p = p0 + b;
+      unsigned spins = 0;
+      for (; spins < SPIN; ++spins) {
+        if (bl_ld(OFF_FILLED) > (unsigned)p) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (spins == SPIN) bl_timeout(a.err);
+      const unsigned char* wb = smem + slot * WPH + lane * 16;
+      u32x4 wv[TILES];
+#pragma unroll
+      for (int j = 0; j < PH; ++j) {
+        // loads issued after fragment (b, j): with refills always XD * PH - 1; in the last group the rest of this phase and the later ones
+        if (REFILL) bc_wait<XD * PH - 1>(xr[b][j]);
+        else {
+          switch ((XD - 1 - b) * PH + (PH - 1 - j)) {        // compile-time after unrolling
+#define BCW(N) case N: bc_wait<N>(xr[b][j]); break;
+            BCW(0) BCW(1) BCW(2) BCW(3) BCW(4) BCW(5) BCW(6) BCW(7) BCW(8) BCW(9) BCW(10) BCW(11) BCW(12) BCW(13) BCW(14) BCW(15)
+#undef BCW
+          }
+        }
+        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, xr[b][j]);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          bf16x8_t af;
+          if (F8) {
+            if (!(j & 1)) wv[t] = *reinterpret_cast<const u32x4*>(wb + (size_t)(t * WT + j / 2) * 1024);
+            af = gg_f8x8_to_bf16x8(wv[t][2 * (j & 1)], wv[t][2 * (j & 1) + 1]);
+          } else {
+            af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(wb + (size_t)(t * PH + j) * 1024));
+          }
+          c[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf, c[t], 0, 0, 0);
+        }
+        if (REFILL) bc_load(xr[b][j], xsrc + (size_t)((p + XD) * PH + j) * 1024);
+      }
+      if ((p + 1) % CHP4 == 0) {              // a k_gemv_b wave slice is complete: slice sums are added in slice order
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) { tot[t] += c[t]; c[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      }
+      bl_drain();                             // every weight fragment of this phase has been read
+      if (lane == 0) bl_st(OFF_DONE + 4u * (unsigned)wave, (unsigned)p + 1u);
+      slot = slot + 1 == R ? 0 : slot + 1;
+    }
+  };
+  constexpr bx_flag<true> yes{};
+  constexpr bx_flag<false> no{};
+  for (int p0 = 0; p0 + XD < NPH; p0 += XD) group(p0, yes);      // NPH (16 or 32) is a multiple of XD
+  group(NPH - XD, no);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int g = blockIdx.x * U + u;
+    if (g >= groups) break;
+    const f32x4 unit[T][1] = {{tot[u * T]}, {tot[u * T + 1]}};
+    gg_finish_unit<EPI, T, F8, 1>(a, g, unit, lane, wave);
+  }
+}
+// false = this instantiation must not run (see br_usable: hand-issued loads and a spilling compiler do not mix)
+template <int EPI, int U, int CHP4, bool F8>
+static bool bc_usable(int lds) {
+  static int usable = -1;
+  if (usable < 0) {
+    const void* fn = reinterpret_cast<const void*>(&k_gemv_bc<EPI, U, CHP4, F8>);
+    hipFuncAttributes fa;
+    const bool ok = hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.localSizeBytes == 0
+                    && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    usable = ok ? 1 : 0;
+  }
+  return usable == 1;
+}
+template <int EPI, int U, int CHP4>
+static bool launch_bc_one(const GemvBArgs& a, hipStream_t s) {
+  const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
+  const dim3 grid((groups + U - 1) / U), block(5 * 64);
+  if (a.W8) {
+    constexpr int lds = 4 * (U * 2 * 2 * 1024) + 4 * 5 + 12;
+    if (!bc_usable<EPI, U, CHP4, true>(lds)) return false;
+    hipLaunchKernelGGL((k_gemv_bc<EPI, U, CHP4, true>), grid, block, lds, s, a);
+  } else {
+    constexpr int lds = 4 * (U * 2 * 4 * 1024) + 4 * 5 + 12;
+    if (!bc_usable<EPI, U, CHP4, false>(lds)) return false;
+    hipLaunchKernelGGL((k_gemv_bc<EPI, U, CHP4, false>), grid, block, lds, s, a);
+  }
+  return true;
+}
+template <int EPI, int CHP4>
+static bool launch_bc_units(int units, const GemvBArgs& a, hipStream_t s) {
+  switch (units) {
+    case 1: return launch_bc_one<EPI, 1, CHP4>(a, s);
+    case 2: return launch_bc_one<EPI, 2, CHP4>(a, s);
+    case 3: return launch_bc_one<EPI, 3, CHP4>(a, s);
+    default: return launch_bc_one<EPI, 4, CHP4>(a, s);
+  }
+}
+static int g_gemv_bc = -1;
+void set_gemv_bc(int v) { g_gemv_bc = v; }
+// variant: 0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head, bits 4..6 = forced units per block (0 = one CU's share, at most 4).  false = not
+// covered (fewer than 49 slots, N = d roles, K other than 2048 / 4096, a ragged ff / vocabulary): the caller goes on to k_gemv_bl / ...
+bool launch_gemv_bc(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (g_gemv_bc < 0) { const char* e = getenv("DTK_GEMV_BC"); g_gemv_bc = e ? atoi(e) : 7; }
+  if (g_gemv_bc <= 0 || a.nt < 3) return false;
+  if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
+  if (!(g_gemv_bc & (epi == EPI_QKV ? 1 : (epi == EPI_SWIGLU ? 2 : 4)))) return false;
+  if (a.K != 4096 && a.K != 2048) return false;
+  if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
+  if (epi == EPI_LOGITS && (a.N & 31)) return false;
+  const int groups = epi == EPI_QKV ? gg_groups<EPI_QKV, 2>(a.N, a.ff, a.H, a.KVH)
+                   : epi == EPI_SWIGLU ? gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH) : gg_groups<EPI_LOGITS, 2>(a.N, a.ff, a.H, a.KVH);
+  int units = (groups + cu_count() - 1) / cu_count();
+  if (units > 4) units = 4;
+  if ((g_gemv_bc >> 4) & 7) units = (g_gemv_bc >> 4) & 7;
+  if (units > 4) units = 4;
+#define BC(E) (a.K == 4096 ? launch_bc_units<E, 4>(units, a, s) : launch_bc_units<E, 2>(units, a, s))
+  if (epi == EPI_QKV) return BC(EPI_QKV);
+  if (epi == EPI_SWIGLU) return BC(EPI_SWIGLU);
+  return BC(EPI_LOGITS);
+#undef BC
+}
+
 static int g_gemv_bl = -1;
 void set_gemv_bl(int v) { g_gemv_bl = v; }
 // variant bit 0: gate/up + lm_head, bit 1: qkv (2 units per block), bit 2: also with fp8 weights.  false = not covered (fp8 weights, fewer than 33 slots, N = d roles,

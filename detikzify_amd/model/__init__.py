@@ -49,14 +49,16 @@ def _check_dtype(torch_dtype) -> None:
 
 def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v1: bool = False,
          synthetic: Optional[int] = None, device_map=None, torch_dtype=None, max_positions: Optional[int] = None,
-         batch_slots: int = 0, weight_format: str = "bf16", synthetic_tokenizer: bool = False,
+         batch_slots: int = 0, weight_format: str = "bf16", synthetic_tokenizer: bool = False, vit_gelu_tanh: Optional[int] = None,
          **from_pretrained_kwargs) -> Tuple[DetikzifyForCausalLM, DetikzifyProcessor]:
     """(model, processor).  `device_map` may be an int GPU index (the reference passes
     device_map=RANK, examples/eval.py:112); torch_dtype must be bf16 / "auto" / None.
 
     A checkpoint directory must carry its tokenizer files, as the reference's loader requires
     (v1/__init__.py:26-34 fails hard otherwise); `synthetic_tokenizer=True` (or `"synthetic_tokenizer": true` in the
-    directory's config.json, written by our weight-only test fixtures) opts into the byte-level stand-in."""
+    directory's config.json, written by our weight-only test fixtures) opts into the byte-level stand-in.
+    `vit_gelu_tanh` (0 | 1) overrides the vision tower's GELU flavour (a v1 config.json does not record it: `_announce_gelu`;
+    tests/real_checkpoint.py runs both to see which one a real checkpoint wants)."""
     unknown = set(from_pretrained_kwargs) - _IGNORED_FROM_PRETRAINED
     if unknown:
         raise TypeError(f"load() got arguments it does not implement: {sorted(unknown)}")
@@ -72,6 +74,8 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         _require_supported(cfg)
         if max_positions:
             cfg.max_positions = max_positions
+        if vit_gelu_tanh is not None:
+            cfg.vit_gelu_tanh = int(bool(vit_gelu_tanh))
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         if synthetic_tokenizer or json.loads((path / "config.json").read_text()).get("synthetic_tokenizer"):
             tokenizer = _synthetic_tokenizer(cfg)
@@ -92,6 +96,8 @@ def load(model_name_or_path: str, modality_projector: Optional[str] = None, is_v
         _require_supported(cfg)
         if max_positions:
             cfg.max_positions = max_positions
+        if vit_gelu_tanh is not None:
+            cfg.vit_gelu_tanh = int(bool(vit_gelu_tanh))
         cfg.batch_slots, cfg.weight_format = batch_slots, weight_format
         if synthetic is None:
             raise FileNotFoundError(
@@ -131,7 +137,7 @@ def _announce_gelu(cfg: DetikzifyConfig, path: Path) -> None:
         return
     import json
     import warnings
-    if "vit_gelu_tanh" in json.loads((path / "config.json").read_text()):
+    if "vit_gelu_tanh" in json.loads((path / "config.json").read_text()) or getattr(cfg, "_gelu_stated", False):
         return
     warnings.warn(f"{path}: config.json does not state the vision tower's GELU flavour; using "
                   f"{'tanh-approximated' if cfg.vit_gelu_tanh else 'exact (erf)'} GELU, timm's default for "

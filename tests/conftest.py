@@ -27,7 +27,9 @@ _FULL_SIZE = (          # (substring of the node id, group): group = position in
     ("test_decoder_error_grows_with_depth", 1), ("test_greedy_margins_are_not_biased", 1),
     ("test_full_size_incremental_equals_batched[detikzify-ds-7b]", 2), ("test_headline_models_match_cpu_oracle[detikzify-ds-7b", 2),
     ("test_few_slot_contexts_match_cpu_oracle[detikzify-ds-7b", 2), ("test_long_context_steps_match_cpu_oracle", 2),
-    ("test_peaked_logits_weight_set_is_token_identical", 2), ("test_batched_headline_matches_cpu_oracle[detikzify-ds-7b", 2),
+    ("test_peaked_logits_weight_set_is_token_identical[detikzify-ds-7b", 2), ("test_batched_headline_matches_cpu_oracle[detikzify-ds-7b", 2),
+    ("test_peaked_logits_weight_set_is_token_identical[detikzify-ds-1.3b", 0), ("test_peaked_logits_weight_set_is_token_identical[detikzify-cl-7b", 3),
+    ("test_peaked_logits_weight_set_is_token_identical[detikzify-v2-8b", 4),
     ("test_headline_models_match_cpu_oracle[detikzify-cl-7b", 3), ("test_few_slot_contexts_match_cpu_oracle[detikzify-cl-7b", 3),
     ("test_batched_headline_matches_cpu_oracle[detikzify-cl-7b", 3), ("test_mxfp8_activations_against_bf16_activations", 3),
     ("test_full_size_incremental_equals_batched[detikzify-v2-8b]", 4), ("test_headline_models_match_cpu_oracle[detikzify-v2-8b", 4),

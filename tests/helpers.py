@@ -96,3 +96,41 @@ def engines():
     from detikzify_amd.infer.batching import BatchEngine
     from detikzify_amd.infer.engine import NativeBatchEngine
     return [NativeBatchEngine, BatchEngine]
+
+
+# ---- the parity envelope.  north_star's literal "1e-3 on encoder logits" cannot hold between two bf16
+# pipelines of this depth (the bf16-policy oracle itself sits 1.2e-2 .. 5e-2 from fp32), so the asserted statement is: the device is
+# no further from the fp32 oracle than ENVELOPE x the bf16-policy oracle is, plus a small absolute slack for the shallow cases where
+# both errors are a few rounding flips.  Rounds 1-5 asserted 1.5 x + 2e-3 / 1e-3 and MEASURED 1.00-1.07 x (profiles/r05_pytest_gpu
+# _summary.txt: "worst ratio to the envelope 0.64-0.69"): a kernel could have lost 45 % and stayed green.  Round 6
+# asserts what is measured, with the headroom of one more rounding-flip random walk: 1.15 x + half the old slack.
+ENVELOPE = 1.15
+SLACK_LOGITS = 1e-3         # logits of a prefill / decode step (was 2e-3)
+SLACK_SMALL = 5e-4          # ViT features, single blocks, shallow decoders (was 1e-3)
+SLACK_MX = 2e-3             # the opt-in MXFP8 step against the oracle that quantises the same activations (was 4e-3)
+
+
+def envelope_ratio(e_dev: float, e_orc: float, slack: float = SLACK_LOGITS) -> float:
+    """< 1: inside the envelope"""
+    return e_dev / (ENVELOPE * e_orc + slack)
+
+
+BF16_ULP = 2.0 ** -7          # one bf16 ulp relative to the value's binade top (8 significant bits)
+GAP_BINS = (0.0, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0, float("inf"))
+
+
+def top2_gap_ulps(logits, bad, begin, first) -> float:
+    """top-1 minus top-2 of the processed scores (oracle/sampling.py::mask_scores), in bf16 ulps of the top logit"""
+    from oracle import sampling
+    top2 = torch.topk(sampling.mask_scores(logits, bad, begin, first), 2)[0]
+    return float(top2[0] - top2[1]) / (float(top2[0].abs()) * BF16_ULP + 1e-30)
+
+
+def gap_histogram(gaps) -> str:
+    counts = [0] * (len(GAP_BINS) - 1)
+    for g in gaps:
+        for b in range(len(counts)):
+            if GAP_BINS[b] <= g < GAP_BINS[b + 1]:
+                counts[b] += 1
+                break
+    return " ".join(f"[{GAP_BINS[b]:g},{GAP_BINS[b + 1]:g}):{c}" for b, c in enumerate(counts))

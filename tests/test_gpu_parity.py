@@ -25,7 +25,8 @@ from oracle.ops import bits_to_f32, f32_to_bits, rb
 from oracle.synth import synth_bits, tensor_specs
 from oracle.vit import layernorm
 from oracle.llama import attention, rmsnorm
-from tests.helpers import TINY, TINY_CFG, TINY_V2, TINY_V2_CFG, engines, rel_l2, sketch_image
+from tests.helpers import (ENVELOPE, SLACK_LOGITS, SLACK_SMALL, TINY, TINY_CFG, TINY_V2, TINY_V2_CFG, engines, gap_histogram, rel_l2,
+                           sketch_image, top2_gap_ulps)
 
 
 @pytest.fixture(scope="module")
@@ -312,7 +313,7 @@ def test_prefill_logits(tiny, tiny_oracle):
     truth = o32.prefill(ids, enc.pixel_values[0])
     e_dev, e_orc = rel_l2(lo, truth), rel_l2(ref, truth)
     print(f"prefill logits rel_l2 {r:.2e} (T={ids.numel()}); vs fp32 oracle: device {e_dev:.2e}, bf16 oracle {e_orc:.2e}")
-    assert r < 1e-2 and e_dev < 1.5 * e_orc + 2e-3
+    assert r < 1e-2 and e_dev < ENVELOPE * e_orc + SLACK_LOGITS
     assert torch.isfinite(lo).all()
     # text-only prompt (no image tokens, no pixels)
     t = torch.tensor([5, 9, 100, 44, 3, 8])
@@ -623,19 +624,25 @@ def _against_cpu_oracle(name, n_greedy, n_sampled=0, weight_format="bf16"):
         dev = model.prefill(ids, px, return_logits=True)
         ref, truth = hs.ref, hs.truth
         r, e_dev, e_orc = rel_l2(dev, ref), rel_l2(dev, truth), rel_l2(ref, truth)
-        assert ef_dev < 1.5 * ef_orc + 1e-3
-        assert e_dev < 1.5 * e_orc + 2e-3
+        assert ef_dev < ENVELOPE * ef_orc + SLACK_SMALL
+        assert e_dev < ENVELOPE * e_orc + SLACK_LOGITS
         toks = run_greedy(model, ids, px, n_greedy)
         rows = o16.extend(toks)                      # row i: the oracle's logits after toks[i]
-        logits, near_ties = ref, 0
+        logits, near_ties, gaps = ref, 0, []
         for i, t in enumerate(toks):
+            gaps.append(top2_gap_ulps(logits, [img_tok], [eos], i == 0))
             rt = sampling.greedy(logits, [img_tok], [eos], i == 0)
-            if rt != t:
-                top2 = torch.topk(sampling.mask_scores(logits, [img_tok], [eos], i == 0), 2)[0]
-                assert float(top2[0] - top2[1]) <= 2 * float(top2[0].abs()) * 2.0 ** -7 + 1e-6, (i, t, rt)
+            if rt != t:      # a flip: only where the ORACLE's own top two are within 2 bf16 ulps (one ulp on each of the two logits)
+                assert gaps[-1] <= 2.0 + 1e-3, (i, t, rt, gaps[-1])
                 near_ties += 1
             logits = rows[i]
-        assert near_ties <= max(1, n_greedy // 8), f"{near_ties} of {n_greedy} greedy tokens differ (all at near-ties): too many"
+        # flips are counted against the steps where they CAN happen — the oracle's own near-ties, read off its gap histogram — not
+        # against the length of the run (rounds 3-5: n // 8): two correct bf16 pipelines order such a pair either way, at most
+        # every second one may go the other way (the rule of tests/test_gpu_parity_batched.py; whether the flips lean one way is
+        # test_greedy_margins_are_not_biased_against_the_oracle's 256 steps)
+        near_tie_steps = sum(g <= 2.0 + 1e-3 for g in gaps)
+        assert near_ties <= (near_tie_steps + 1) // 2, (f"{near_ties} of {n_greedy} greedy tokens differ in {near_tie_steps} near-tie steps: "
+                                                       f"too many; oracle top-2 gap histogram {gap_histogram(gaps)}")
         if n_sampled:
             model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, top_k=0, seed=4242, bad_ids=[img_tok],
                                begin_suppress_ids=[eos])
@@ -648,7 +655,8 @@ def _against_cpu_oracle(name, n_greedy, n_sampled=0, weight_format="bf16"):
                 assert t == rt, f"sampled draw {i}: device {t}, oracle draw from the device's logits {rt}"
         print(f"{name}{' fp8' if weight_format == 'fp8' else ''}: ViT feats dev-vs-bf16-oracle {rf:.2e}, vs fp32: device {ef_dev:.2e} "
               f"oracle {ef_orc:.2e}; prefill logits dev-vs-bf16-oracle {r:.2e}, vs fp32: device {e_dev:.2e} oracle {e_orc:.2e}; "
-              f"greedy {n_greedy - near_ties}/{n_greedy} identical ({near_ties} near-ties); {n_sampled} sampled draws exact; "
+              f"greedy {n_greedy - near_ties}/{n_greedy} identical ({near_ties} flips in {near_tie_steps} near-tie steps; oracle top-2 gap "
+              f"histogram, bf16 ulps: {gap_histogram(gaps)}); {n_sampled} sampled draws exact; "
               f"{time.perf_counter() - t_start:.0f} s")
     finally:
         del model
@@ -703,7 +711,7 @@ def test_vit_error_grows_block_by_block_like_the_reference_dtype_policy():
         # pipelines differ by rounding flips only (~1e-3)
         assert r_dev[0] < 3e-3, f"block 0 alone is {r_dev[0]:.2e} away from the reference dtype policy"
         for i in range(depth):
-            assert e_dev[i] < 1.5 * e_orc[i] + 1e-3, (i, e_dev[i], e_orc[i])
+            assert e_dev[i] < ENVELOPE * e_orc[i] + SLACK_SMALL, (i, e_dev[i], e_orc[i])
         worst_policy_step = max(max(e_orc[i + 1] - e_orc[i] for i in range(depth - 1)), 1e-3)
         for i in range(depth - 1):
             assert e_dev[i + 1] - e_dev[i] < 2.0 * worst_policy_step, (i, e_dev[i], e_dev[i + 1], worst_policy_step)
@@ -734,7 +742,7 @@ def test_decoder_error_grows_with_depth_like_the_reference_dtype_policy(layers):
         dev = model.prefill(ids, None, return_logits=True)
         ref, truth = o16.prefill(ids, None), o32.prefill(ids, None)
         e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
-        assert e_dev < 1.5 * e_orc + 1e-3, (layers, e_dev, e_orc)
+        assert e_dev < ENVELOPE * e_orc + SLACK_SMALL, (layers, e_dev, e_orc)
         model.set_sampling(do_sample=False)
         worst, toks, dev_rows = 0.0, [], []
         for _ in range(4):                      # the decode kernels at this depth ...
@@ -744,8 +752,8 @@ def test_decoder_error_grows_with_depth_like_the_reference_dtype_policy(layers):
         rows32, rows16 = o32.extend(toks), o16.extend(toks)     # ... both oracles teacher-forced with the device's own tokens (one pass each)
         for lg, r32, r16 in zip(dev_rows, rows32, rows16):
             d, o = rel_l2(lg, r32), rel_l2(r16, r32)
-            worst = max(worst, d / (1.5 * o + 1e-3))
-            assert d < 1.5 * o + 1e-3, (layers, d, o)
+            worst = max(worst, d / (ENVELOPE * o + SLACK_SMALL))
+            assert d < ENVELOPE * o + SLACK_SMALL, (layers, d, o)
         print(f"decoder depth {layers}: prefill logits vs fp32: device {e_dev:.2e}, bf16 oracle {e_orc:.2e}; decode steps worst ratio to the envelope {worst:.2f}")
     finally:
         del model
@@ -1247,7 +1255,7 @@ def test_v2_prefill_logits_and_greedy(tiny_v2, tiny_v2_oracle):
     truth = DetikzifyOracle(TINY_V2_CFG, tiny_v2_oracle.w, precision="fp32").prefill(ids, enc.pixel_values[0])
     r, e_dev, e_orc = rel_l2(lo, ref), rel_l2(lo, truth), rel_l2(ref, truth)
     print(f"v2 prefill logits rel_l2 {r:.2e}; vs fp32 oracle: device {e_dev:.2e}, bf16 oracle {e_orc:.2e}")
-    assert r < 1e-2 and e_dev < 1.5 * e_orc + 2e-3
+    assert r < 1e-2 and e_dev < ENVELOPE * e_orc + SLACK_LOGITS
     # greedy decode with teacher forcing (same near-tie rule as the v1 test), 100 tokens: positions cross
     # rope_original_max_position (64) so every llama3 band is used by the decode-step RoPE epilogue
     ids, px = enc.input_ids[0], enc.pixel_values
@@ -1446,7 +1454,12 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                         (1, 0, 1, 2, 1 + 4 + 16, 0, 2), (1, 0, 1, 2, 1 + 4 + 16, 1, 2), (1, 0, 1, 2, 5, 2), (1, 0, 1, 2, 1 + 2 + 4, 2),
                         (1, 0, 1, 2, 1 + 4 + 16, 2, 2), (1, 0, 1, 2, 1 + 32), (0, 0, 0, 0, 32 + 1),
                         (1, 0, 1, 2, 1 + 32, 0, 1, 8), (0, 0, 0, 0, 32 + 1, 0, 1, 8),       # 8th entry: fp8 register ring of 8 phases (round 4 experiment; default 4)
-                        (1, 0, 1, 2, 1 + 64), (1, 0, 1, 0, 1 + 64)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
+                        (1, 0, 1, 2, 1 + 64), (1, 0, 1, 0, 1 + 64),
+                        # 9th entry: gemv_bc (round 6: k_gemv_bc, a compute wave per COLUMN tile, x from L2 into registers, the weights through
+                        # an LDS ring) — bit 0 qkv, bit 1 gate/up, bit 2 lm_head, bits 4..6 force 1..4 units per block
+                        (1, 0, 1, 2, 33, 0, 1, 4, 7), (0, 0, 0, 0, 0, 0, 1, 4, 7), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 16), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 32),
+                        (1, 0, 1, 2, 33, 0, 1, 4, 7 + 48), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 64), (1, 0, 1, 2, 33, 0, 1, 4, 1), (1, 0, 1, 2, 33, 0, 1, 4, 2),
+                        (1, 0, 1, 2, 33, 0, 1, 4, 4)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
                         # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
             if variant[1] and not has_experiments(model):
                 continue                    # k_gemv_bk: DTK_EXPERIMENTS builds only
@@ -1459,6 +1472,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
             model.set_option("gemv_xw", variant[5] if len(variant) > 5 else 0)
             model.set_option("gemv_loaders", variant[6] if len(variant) > 6 else 1)
             model.set_option("gemv_br_wd", variant[7] if len(variant) > 7 else 4)
+            model.set_option("gemv_bc", variant[8] if len(variant) > 8 else 0)
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1480,6 +1494,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_xw", 0)
         model.set_option("gemv_loaders", 1)
         model.set_option("gemv_br_wd", 4)
+        model.set_option("gemv_bc", 7)
         del model
         gc.collect()
 
@@ -1869,7 +1884,6 @@ def test_long_context_properties_ds13b():
 
 
 # ------------------------------------------------------------------------------------------ the reference's own model code
-# (last in the file: written after this round's GPU budget was spent, so their first run on the device is the round-end one)
 def _device_vs_reference_golden(model, g, image_token, tag):
     """device vs a golden written by the reference's own model code (fp32): logits at every greedy step, teacher-forced
     along the reference's tokens through the prefill path, within bf16 round-off (the bf16-policy CPU oracle is at 7e-3);
@@ -1882,7 +1896,7 @@ def _device_vs_reference_golden(model, g, image_token, tag):
         cur = torch.cat([ids, torch.tensor(ref_toks[:n], dtype=torch.int64)])
         worst = max(worst, rel_l2(model.prefill(cur, px, return_logits=True), g["step_logits"][n]))
     print(f"{tag} device vs the reference model's fp32 logits over {len(ref_toks)} steps: worst rel_l2 {worst:.2e}")
-    assert worst < 2e-2
+    assert worst < 1e-2         # measured 7.2e-3 (v2) / 7.4e-3 (v1), the bf16-policy CPU oracle itself sits at 7e-3; rounds 1-5 asserted 2e-2
     out = model.generate(input_ids=ids[None], pixel_values=px, do_sample=False, max_new_tokens=len(ref_toks),
                          bad_words_ids=[bad], begin_suppress_tokens=[2], eos_token_id=-1)
     got = out[0, ids.numel():].tolist()

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import sampling
 from oracle.model import DetikzifyOracle
-from tests.helpers import rel_l2, sketch_image
+from tests.helpers import ENVELOPE, SLACK_LOGITS, rel_l2, sketch_image
 from tests.test_gpu_parity import weights_from_device
 
 ULP = 2.0 ** -7          # one bf16 ulp relative to the value's binade top (8 significant bits)
@@ -133,7 +133,7 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
 
         ref, truth, snap16, snap32 = hs.ref, hs.truth, hs.snap16, hs.snap32
         e_dev, e_orc, e_pair = rel_l2(dev_prefill, truth), rel_l2(ref, truth), rel_l2(dev_prefill, ref)
-        assert e_dev < 1.5 * e_orc + 2e-3
+        assert e_dev < ENVELOPE * e_orc + SLACK_LOGITS
 
         # fp8 matrix-core steps (csrc/kernels_batch_mx.hip): the bf16-policy oracle quantises the same activations to MXFP8 from here
         # on (LlamaOracle.act_quant; prefill above ran with bf16 activations on both sides); the fp32 oracle stays the unquantised
@@ -191,8 +191,8 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                 if s in watch32:
                     t32 = rows32[i]
                     d, o = rel_l2(logit_log[s][i], t32), rel_l2(logits, t32)
-                    worst_ratio = max(worst_ratio, d / (1.5 * o + 2e-3))
-                    assert d < 1.5 * o + 2e-3, (s, i, d, o)
+                    worst_ratio = max(worst_ratio, d / (ENVELOPE * o + SLACK_LOGITS))
+                    assert d < ENVELOPE * o + SLACK_LOGITS, (s, i, d, o)
         # uniform synthetic rows put the oracle's own top-2 within 2 bf16 ulps in ~25 % of the steps (histogram below); two correct
         # bf16 pipelines order such a pair either way, so flips are counted against the NEAR-TIE steps — at most every second one
         # (was three of four) — and must go to the oracle's runner-up (asserted above).  Whether the flips lean one
@@ -236,8 +236,8 @@ def _phases_vs_oracle(name, weight_format, batch_slots, phases, watch, watch32, 
                 nx16, nx32 = o16.extend(tail_toks[s]), o32.extend(tail_toks[s])
                 for i in range(5):
                     d, o = rel_l2(tail_logits[s][i], lg32), rel_l2(lg16, lg32)
-                    t_worst = max(t_worst, d / (1.5 * o + 2e-3))
-                    assert d < 1.5 * o + 2e-3, (s, i, d, o)
+                    t_worst = max(t_worst, d / (ENVELOPE * o + SLACK_LOGITS))
+                    assert d < ENVELOPE * o + SLACK_LOGITS, (s, i, d, o)
                     if i == 4:
                         break
                     t = tail_toks[s][i]
@@ -300,6 +300,7 @@ def test_v2_8b_batched_matches_cpu_oracle():
 
 
 N_LONG = 8       # decode steps per long-context checkpoint (round 3: 3)
+LONG_CONTEXT_KNOWN_WIDE = 2.5      # bf16 ulps: the one measured flip beyond the 2-ulp rule (2.30, round 5), see the test
 
 
 def test_long_context_steps_match_cpu_oracle():
@@ -331,7 +332,7 @@ def test_long_context_steps_match_cpu_oracle():
             ref, truth = o16.extend(prompt[done:], last_only=True), o32.extend(prompt[done:], last_only=True)
             done = T
             e_dev, e_orc = rel_l2(dev, truth), rel_l2(ref, truth)
-            assert e_dev < 1.5 * e_orc + 2e-3, (T, e_dev, e_orc)
+            assert e_dev < ENVELOPE * e_orc + SLACK_LOGITS, (T, e_dev, e_orc)
             toks, dev_logits = [], []
             for i in range(N_LONG):
                 model.decode_launch()
@@ -343,15 +344,16 @@ def test_long_context_steps_match_cpu_oracle():
                 rt = sampling.greedy(logits, [img_tok], [], False)
                 if rt != t:
                     # the near-tie rule of _phases_vs_oracle: a flip proves that the two logits' errors add up to the oracle's margin — within
-                    # 2 bf16 ulps, and ONE flip of the whole test may lie between 2 and 3 (round 5's driver-order run: 2.30 at context 701)
+                    # 2 bf16 ulps.  ONE named exception: round 5's driver-order run flipped a pair 2.30 ulps apart at the
+                    # first checkpoint (context 701 of the 700-token prompt); a single flip there may reach LONG_CONTEXT_KNOWN_WIDE.
                     gap = top2_gap_ulps(logits, [img_tok], [], False)
-                    assert gap <= 3.0 + 1e-3, (T, i, t, rt, gap)
+                    assert gap <= (LONG_CONTEXT_KNOWN_WIDE if T == 700 else 2.0) + 1e-3, (T, i, t, rt, gap)
                     wide += gap > 2.0 + 1e-3
                     ties += 1
                 logits, t32 = rows16[i], rows32[i]
                 d, o = rel_l2(dev_logits[i], t32), rel_l2(logits, t32)
-                worst = max(worst, d / (1.5 * o + 2e-3))
-                assert d < 1.5 * o + 2e-3, (T, i, d, o)
+                worst = max(worst, d / (ENVELOPE * o + SLACK_LOGITS))
+                assert d < ENVELOPE * o + SLACK_LOGITS, (T, i, d, o)
             assert model.context_len() == T + N_LONG
             report.append(f"context {T}: prefill logits vs fp32: device {e_dev:.2e} oracle {e_orc:.2e}; {N_LONG} decode steps worst ratio to the "
                           f"envelope {worst:.2f}, {N_LONG - ties}/{N_LONG} tokens identical")
@@ -366,7 +368,9 @@ PEAKED_SEED, PEAKED_BETA = 0, 2.0      # the weight set (tests/helpers.py::peake
 PEAKED_PREFIX, PEAKED_CONTEXTS, PEAKED_WINDOW = 48, 64, 7
 
 
-def test_peaked_logits_weight_set_is_token_identical():
+@pytest.mark.parametrize("name,weight_format", [("detikzify-ds-7b", "bf16"), ("detikzify-ds-1.3b", "bf16"), ("detikzify-cl-7b", "fp8"),
+                                                ("detikzify-v2-8b", "bf16")])
+def test_peaked_logits_weight_set_is_token_identical(name, weight_format):
     """A second synthetic weight set whose logits are PEAKED (lm_head rows scaled by log-normal powers of two, exact in bf16): the
     uniform set gives 32 k equal-variance logits — a top-2 gap below 2 bf16 ulps in ~25 % of the steps — and the near-tie rule of
     the other tests then forgives a mismatch.  Round 3 compared 16 plain greedy tokens here and the sequence fell into a two-token
@@ -375,16 +379,17 @@ def test_peaked_logits_weight_set_is_token_identical():
     processor the reference itself configures: detikzify/infer/generate.py:218-227), so no token returns within 8 steps and every
     context is new — nothing is searched for, the only seed is the weight set's.  48 tokens of run-in, then at each of the next 64
     positions (64 distinct contexts, asserted) the device's token must be the argmax of the CPU oracle's logits under the same ban,
-    the oracle reading the whole sequence in one pass.  ds-7b at full depth, once on the single-sequence graph and once in slot 37
-    of a 64-slot batched step whose neighbours sample.  Positions where the oracle's own top-2 gap is below 2 ulps are reported and
-    excluded; at least 90 % must remain."""
+    the oracle reading the whole sequence in one pass.  Every BASELINE model at full depth (round 6: ds-1.3b = config 2, cl-7b with
+    fp8 weights = config 5 and v2-8b as well as ds-7b), once on the single-sequence graph and once in slot 37 of a 64-slot batched
+    step whose neighbours sample.  Positions where the oracle's own top-2 gap is below 2 ulps are reported and excluded; at least
+    90 % must remain.  This is north_star's "token-identical under greedy decode", literally, on a head where it CAN hold."""
     from detikzify_amd.model import load
     from tests.helpers import peaked_lm_head
     t_start = time.perf_counter()
-    model, proc = load("detikzify-ds-7b", synthetic=1234, max_positions=512, batch_slots=65)
+    model, proc = load(name, synthetic=1234, max_positions=512, batch_slots=65, weight_format=weight_format)
     try:
         from tests.fullsize import host_side
-        hs = host_side(model, proc, "detikzify-ds-7b", "bf16")       # BEFORE the head is replaced: the shared entry holds the seed-1234 weights
+        hs = host_side(model, proc, name, weight_format)       # BEFORE the head is replaced: the shared entry holds the seed-1234 weights
         cfg = model.config.oracle_dict()
         head = peaked_lm_head(hs.w["lm_head.weight"], PEAKED_BETA, PEAKED_SEED)
         model.load_tensor("lm_head.weight", head.to(torch.bfloat16))
@@ -436,7 +441,7 @@ def test_peaked_logits_weight_set_is_token_identical():
                 same += 1
             assert judged >= 0.9 * PEAKED_CONTEXTS, (label, judged)
             report.append(f"{label}: {same}/{judged} tokens identical ({PEAKED_CONTEXTS - judged} positions below 2 ulps excluded, {len(set(toks[PEAKED_PREFIX:]))} distinct tokens)")
-        print(f"peaked weight set (lm_head rows x 2^round({PEAKED_BETA} z)), greedy under a moving ban of the last {PEAKED_WINDOW} tokens, {PEAKED_PREFIX} + {PEAKED_CONTEXTS} tokens: "
+        print(f"{name}{' fp8' if weight_format == 'fp8' else ''}: peaked weight set (lm_head rows x 2^round({PEAKED_BETA} z)), greedy under a moving ban of the last {PEAKED_WINDOW} tokens, {PEAKED_PREFIX} + {PEAKED_CONTEXTS} tokens: "
               + "; ".join(report) + f"; oracle top-2 gap histogram ({len(all_gaps)} contexts): {histogram(all_gaps)}; {time.perf_counter() - t_start:.0f} s")
     finally:
         del model

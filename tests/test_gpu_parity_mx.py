@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 from oracle.llama import mx_fake_quant, mx_quantise
 from oracle.model import DetikzifyOracle
 from oracle.ops import f32_to_bits, rb
-from tests.helpers import rel_l2
+from tests.helpers import ENVELOPE, SLACK_MX, rel_l2
 from tests.test_gpu_parity import weights_from_device
 
 
@@ -250,8 +250,8 @@ def test_fp8_matrix_core_step_stays_inside_the_quantising_oracles_envelope(batch
                 for i, lg in enumerate(logs[s]):
                     rq, rbb, truth = rows[0][i], rows[1][i], rows[2][i]
                     d, o = rel_l2(lg, truth), rel_l2(rq, truth)
-                    assert d < 1.5 * o + 4e-3, (mode, s, d, o)
-                    worst = max(worst, d / (1.5 * o + 4e-3))
+                    assert d < ENVELOPE * o + SLACK_MX, (mode, s, d, o)
+                    worst = max(worst, d / (ENVELOPE * o + SLACK_MX))
                     eq, eb = max(eq, rel_l2(lg, rq)), max(eb, rel_l2(lg, rbb))
                 oq.llm.act_quant = False
             report[mode] = (worst, eq, eb)

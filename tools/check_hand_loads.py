@@ -64,6 +64,7 @@ def is_vmem(mn: str) -> bool:
 
 
 def check_kernel(name: str, insts):
+    all_loads = "k_gemv_bc" in name
     """-> (violations, stats)"""
     index = {addr: i for i, (addr, _, _) in enumerate(insts)}
     violations, hand_loads, waits = [], 0, 0
@@ -94,7 +95,9 @@ def check_kernel(name: str, insts):
                 # only the hand-issued loads protect registers: `global_load_dwordx4 v[..], v[..], off nt` (br_load_nt's asm); what
                 # the compiler issues itself (scales, RoPE operands, stores, the loader wave's LDS-DMA) it also waits for itself
                 dst, srcs = frozenset(), touched
-                if mn == "global_load_dwordx4" and re.search(r"\bnt\b", ops):
+                # k_gemv_bc's hand-issued loads (bc_load: the x fragments, L2 hits) carry no `nt`: there EVERY 16-byte global load is
+                # treated as protected — the compiler's own ones are waited for by the compiler, so they cannot raise a false alarm
+                if mn == "global_load_dwordx4" and (re.search(r"\bnt\b", ops) or all_loads):
                     first = ops.split(",")[0]
                     dst = frozenset(regs(first))
                     hand_loads += 1
