@@ -845,14 +845,27 @@ static bool launch_br_units(int units, const GemvBArgs& a, hipStream_t s) {
 template <int N>
 __device__ __forceinline__ void bc_wait(u32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N)); }   // ties the fragment to the wait
 __device__ __forceinline__ void bc_load(u32x4& dst, const void* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
-template <int EPI, int U, int CHP4, bool F8 = false, int R = 4>
+// How far the loader runs ahead (round 6, lease B: the first version kept k_gemv_bl's "issue phase p, wait for phase p - 1" and was
+// exactly as fast as k_gemv_bl / k_gemv_br — 1 us per phase whatever the phase held): with TWO phases in flight a CU has 2 x 8 KiB
+// (fp8 qkv) of weights outstanding against ~2 us of loaded HBM latency = 8 GB/s per CU, 1.5 TB/s for the chip.  The weight pieces of a
+// phase are few here (x no longer rides the DMA queue), so the loader keeps LEAD phases outstanding — as many as a wave's vmcnt
+// counter (63 operations) covers, i.e. up to 56 KiB per CU — in a ring of LEAD + 2 slots.
+template <int U, bool F8> struct bc_shape {
+  static constexpr int PIECES = U * 2 * (F8 ? 2 : 4);
+  static constexpr int LEAD = 56 / PIECES < 2 ? 2 : (56 / PIECES > 8 ? 8 : 56 / PIECES);
+  static constexpr int R = LEAD + 2;
+  static constexpr int LDS = R * PIECES * 1024 + 4 * 5 + 12;
+};
+template <int EPI, int U, int CHP4, bool F8 = false>
 __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
   constexpr int T = 2, NC = 4, PH = 4, XD = 4;
   constexpr int WT = F8 ? PH / 2 : PH;                           // 1 KiB weight pieces per row tile and phase
   constexpr int TILES = U * T;
+  constexpr int LEAD = bc_shape<U, F8>::LEAD, R = bc_shape<U, F8>::R;
   constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase
   constexpr unsigned OFF_FILLED = R * WPH, OFF_DONE = OFF_FILLED + 4;
   constexpr int PIECES = TILES * WT;
+  static_assert(PIECES == bc_shape<U, F8>::PIECES, "shape");
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -891,9 +904,9 @@ __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
         if (F8) glds_run2_nt(wsrc[j] + (size_t)p * WT * 1024, slot * WPH + (unsigned)j * WT * 1024u);
         else glds_run4<true>(wsrc[j] + (size_t)p * PH * 1024, slot * WPH + (unsigned)j * PH * 1024u);
       }
-      if (p >= 1) {                           // the previous phase has landed when only this phase's pieces are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        bl_st(OFF_FILLED, (unsigned)p);
+      if (p >= LEAD - 1) {                    // at most LEAD - 1 phases stay outstanding: phases 0 .. p - (LEAD - 1) have landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LEAD - 1) * PIECES > 63 ? 63 : (LEAD - 1) * PIECES) : "memory");
+        bl_st(OFF_FILLED, (unsigned)(p - (LEAD - 2)));
       }
       slot = slot + 1 == R ? 0 : slot + 1;
     }
@@ -990,11 +1003,11 @@ static bool launch_bc_one(const GemvBArgs& a, hipStream_t s) {
   const int groups = gg_groups<EPI, 2>(a.N, a.ff, a.H, a.KVH);
   const dim3 grid((groups + U - 1) / U), block(5 * 64);
   if (a.W8) {
-    constexpr int lds = 4 * (U * 2 * 2 * 1024) + 4 * 5 + 12;
+    constexpr int lds = bc_shape<U, true>::LDS;
     if (!bc_usable<EPI, U, CHP4, true>(lds)) return false;
     hipLaunchKernelGGL((k_gemv_bc<EPI, U, CHP4, true>), grid, block, lds, s, a);
   } else {
-    constexpr int lds = 4 * (U * 2 * 4 * 1024) + 4 * 5 + 12;
+    constexpr int lds = bc_shape<U, false>::LDS;
     if (!bc_usable<EPI, U, CHP4, false>(lds)) return false;
     hipLaunchKernelGGL((k_gemv_bc<EPI, U, CHP4, false>), grid, block, lds, s, a);
   }

@@ -96,9 +96,20 @@ class CompilePool:
         self.raster_size, self.engines = raster_size, list(TikzDocument.engines) if engines is None else engines
         self.restarts = 0
         self._lock = threading.Lock()
-        self._retry_lock = threading.Lock()
-        self._isolated: Optional[ProcessPoolExecutor] = None      # the executor of the retry in progress (retry_isolated)
+        # retries of jobs that were lost with a dying worker run in executors of their own (retry_isolated), several at a time: a
+        # 64-tree reward wave that loses a worker loses up to 64 innocent siblings at once, and they must not queue behind one lock
+        self.retry_slots = max(1, min(self.workers, 8))
+        self._retry_sem = threading.BoundedSemaphore(self.retry_slots)
+        self.retries = self.retries_lost = 0
+        self.retry_slack_s = 60.0       # on top of the job's own timeout: process spawn, package import, rasterising
+        self._isolated_all: List[ProcessPoolExecutor] = []      # the executors of the retries in progress
         self._pool = self._new_executor()
+
+    @property
+    def _isolated(self) -> Optional[ProcessPoolExecutor]:
+        """the executor of the (latest) retry in progress, None if there is none"""
+        with self._lock:
+            return self._isolated_all[-1] if self._isolated_all else None
 
     def _new_executor(self) -> ProcessPoolExecutor:
         return ProcessPoolExecutor(max_workers=self.workers, mp_context=get_context("spawn"))
@@ -138,18 +149,33 @@ class CompilePool:
             return None
 
     def retry_isolated(self, code: str, timeout: Optional[int] = 60) -> Optional[CompiledFigure]:
-        """second attempt of a job that was lost with a dying worker, in an executor of its OWN (one worker, one job, serialised):
-        the document that killed the worker kills only this one, so the innocent siblings that retry next to it keep their second
-        attempt (a retry on the shared, restarted pool let the poison document break it again: ADVICE r4).  None = lost again."""
-        with self._retry_lock:
-            ex = self._isolated = ProcessPoolExecutor(max_workers=1, mp_context=get_context("spawn"))
+        """second attempt of a job that was lost with a dying worker, in an executor of its OWN (one worker, one job): the document
+        that killed the worker kills only this one, so the innocent siblings that retry next to it keep their second attempt (a
+        retry on the shared, restarted pool let the poison document break it again: ADVICE r4).  Up to `retry_slots` such executors
+        run side by side (one lock made a lost wave of 64 retry strictly one at a time — a process spawn, the package
+        import and a full TeX run each — while the decode batch sat idle).  The wait is bounded: the job's own timeout plus the
+        time a fresh worker needs to start; a worker that hangs beyond it is terminated.  None = lost again (or hung)."""
+        from concurrent.futures import TimeoutError as FutureTimeout
+        with self._retry_sem:
+            ex = ProcessPoolExecutor(max_workers=1, mp_context=get_context("spawn"))
+            with self._lock:
+                self.retries += 1
+                self._isolated_all.append(ex)
             try:
-                return ex.submit(_compile_job, code, timeout, self.raster_size, self.engines, self.document_class).result()
-            except (BrokenProcessPool, CancelledError):
+                limit = None if timeout is None else float(timeout) + self.retry_slack_s
+                return ex.submit(_compile_job, code, timeout, self.raster_size, self.engines, self.document_class).result(timeout=limit)
+            except (BrokenProcessPool, CancelledError, FutureTimeout):
+                with self._lock:
+                    self.retries_lost += 1
                 return None
             finally:
-                self._isolated = None
+                with self._lock:
+                    self._isolated_all.remove(ex)
+                procs = list((getattr(ex, "_processes", None) or {}).values())     # a hung TeX run outlives shutdown(wait=False): end it
                 ex.shutdown(wait=False, cancel_futures=True)
+                for proc in procs:
+                    if proc.is_alive():
+                        proc.terminate()
 
     def imap(self, codes: Iterable[str], timeout: Optional[int] = 60) -> Iterator[CompiledFigure]:
         """all documents in flight at once, results in input order (multiprocessing.Pool.imap, refine.py:176)"""

@@ -243,6 +243,38 @@ def test_a_dying_worker_fails_one_compile_not_the_search(tex_box):
         assert [f.status for f in figs] == [0, 12]
 
 
+def test_lost_siblings_retry_side_by_side_and_a_hung_retry_is_cut_off(monkeypatch):
+    """when a worker dies, concurrent.futures fails every pending job of the executor — a 64-tree reward wave loses up to
+    64 innocent siblings — and they used to retry strictly one at a time behind one lock (a process spawn, the package import and
+    a compile each).  Now up to `retry_slots` isolated executors run side by side, and the wait for one is bounded: a retry whose
+    worker hangs is terminated after the job's timeout + a start-up allowance and reads as lost."""
+    import threading
+    from detikzify_amd.infer.compile_pool import CompilePool
+    from detikzify_amd.infer.tikz import SleepingSyntheticTikzDocument
+    monkeypatch.setenv("DTK_SYNTH_COMPILE_SECONDS", "1.5")
+    with CompilePool(workers=4, document_class=SleepingSyntheticTikzDocument) as pool:
+        assert pool.retry_slots == 4
+        t0 = time.perf_counter()
+        one = pool.retry_isolated("\\draw (0,0) -- (1,1);\nwarm\n", timeout=30)       # what ONE retry costs here: spawn + import + 1.5 s
+        t_one = time.perf_counter() - t0
+        assert one is not None and one.status == 0
+        figs = [None] * 4
+
+        def retry(i):
+            figs[i] = pool.retry_isolated(f"\\draw (0,0) -- ({i},1);\nline {i}\n", timeout=30)
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=retry, args=(i,)) for i in range(4)]
+        [t.start() for t in ths]
+        [t.join(timeout=120) for t in ths]
+        t_four = time.perf_counter() - t0
+        assert all(f is not None and f.status in (0, 12) for f in figs) and pool.retries == 5 and pool.retries_lost == 0
+        assert t_four < 2.5 * t_one + 2.0, f"four retries took {t_four:.1f} s, one takes {t_one:.1f} s: serialised"
+        # a retry that hangs (compile 1.5 s, allowance 0.0 + timeout 0.2): cut off, counted as lost, its worker gone
+        pool.retry_slack_s = 0.0
+        assert pool.retry_isolated("\\draw (0,0) -- (2,2);\nhang\n", timeout=0.2) is None and pool.retries_lost == 1
+        assert pool._isolated is None
+
+
 def test_pool_inherits_the_parents_engines_and_rasterises_other_sizes_from_the_pdf(tex_box):
     from detikzify_amd.infer import TikzDocument
     from detikzify_amd.infer.compile_pool import CompilePool, pooled_document_class
