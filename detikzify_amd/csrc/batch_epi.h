@@ -149,6 +149,103 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
   }
 }
 
+// gg_finish_unit for ONE column tile, in two halves (k_gemv_bc): everything the epilogue READS — the slot's active flag and position,
+// the fp8 row scales, the RoPE table entries — does not depend on the sums, so a kernel issues `gg_pre_load` before its k loop and
+// finds the values in registers at the end (leaving parts of k_gemv_bc out, profiles/r06d_bc_probe.txt: the epilogue cost 4.8 us per
+// launch, two or three dependent L2 round trips behind the last MFMA).  Same arithmetic and rounding points as gg_finish_unit.
+template <int EPI, int T, bool F8>
+struct gg_pre {
+  int act, pos;
+  float sc[T][4];
+  float cs[4], sn[4];
+};
+template <int EPI, int T, bool F8>
+__device__ __forceinline__ void gg_pre_load(const GemvBArgs& a, int g, int lane, int nt0, gg_pre<EPI, T, F8>& o) {
+  static_assert(T == 2, "paired row tiles");
+  const int m0 = (lane >> 4) * 4, n = nt0 * 16 + (lane & 15);
+  o.act = a.bs->active[n];
+  o.pos = (EPI == EPI_QKV) ? a.st[n].pos : 0;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o.sc[t][r] = 1.f;
+      if (F8) {
+        int row = gg_tile_row0<EPI, T>(a, g, t) + m0 + r;
+        if (row >= a.N) row = a.N - 1;
+        o.sc[t][r] = a.wscale[row];
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    o.cs[r] = 1.f; o.sn[r] = 0.f;
+    if (EPI == EPI_QKV) {
+      const int hb = g >> 2;
+      if (hb < a.H + a.KVH) {      // q / k sections (an inactive slot's stale position is clamped: its table entry is read and dropped)
+        const int p = min(max(o.pos, 0), a.T_max - 1), i = (g & 3) * 16 + m0 + r;
+        o.cs[r] = bf2f(a.rope_cos[(size_t)p * 64 + i]);
+        o.sn[r] = bf2f(a.rope_sin[(size_t)p * 64 + i]);
+      }
+    }
+  }
+}
+template <int EPI, int T, bool F8>
+__device__ __forceinline__ void gg_pre_store(const GemvBArgs& a, int g, const f32x4 (&tot)[T], int lane, int nt0, const gg_pre<EPI, T, F8>& o) {
+  // A lane holds FOUR consecutive rows (m0 .. m0 + 3) of its column: their bf16 results are 8 contiguous bytes in every destination
+  // (cache rows, q, the fragment-major activation: xtile_off keeps k & 7 innermost), fp32 logits 16 — one store per lane and tile
+  // instead of four 2-byte ones (the launcher admits only ff % 16 == 0 and N % 32 == 0, so no row of a tile is ragged).
+  if (!o.act) return;
+  const int m0 = (lane >> 4) * 4, n = nt0 * 16 + (lane & 15);
+  if (EPI == EPI_QKV) {
+    const int hb = g >> 2;
+    const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
+    const int head = sec == 0 ? hb : (sec == 1 ? hb - a.H : hb - a.H - a.KVH);
+    const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+    const int i0 = (g & 3) * 16 + m0;
+    float lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x1 = rbf(tot[0][r] * o.sc[0][r]), x2 = rbf(tot[1][r] * o.sc[1][r]);
+      if (sec == 2) { lo[r] = x1; hi[r] = x2; }
+      else {
+        const float c = o.cs[r], sv = o.sn[r];
+        lo[r] = rbf(rbf(x1 * c) + rbf(-x2 * sv));
+        hi[r] = rbf(rbf(x2 * c) + rbf(x1 * sv));
+      }
+    }
+    bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                             : ((sec == 1 ? a.kcache : a.vcache) + slot_kv + ((size_t)head * a.T_max + o.pos) * 128);
+    *reinterpret_cast<u32x2*>(dst + i0) = (u32x2){pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
+    *reinterpret_cast<u32x2*>(dst + i0 + 64) = (u32x2){pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+    return;
+  }
+  if (EPI == EPI_SWIGLU) {
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gte = rbf(tot[0][r] * o.sc[0][r]), up = rbf(tot[1][r] * o.sc[1][r]);
+      const float sl = rbf(gte / (1.f + expf(-gte)));
+      y[r] = sl * up;
+    }
+    *reinterpret_cast<u32x2*>(a.Y + xtile_off(n, g * 16 + m0, (a.ff + 31) >> 5)) = (u32x2){pack2(y[0], y[1]), pack2(y[2], y[3])};
+    return;
+  }
+  if (EPI == EPI_LOGITS) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = gg_tile_row0<EPI, T>(a, g, t) + m0;
+      *reinterpret_cast<f32x4*>(a.logits + (size_t)n * a.N + row) =
+          (f32x4){rbf(tot[t][0] * o.sc[t][0]), rbf(tot[t][1] * o.sc[t][1]), rbf(tot[t][2] * o.sc[t][2]), rbf(tot[t][3] * o.sc[t][3])};
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v[T] = {tot[0][r] * o.sc[0][r], tot[1][r] * o.sc[1][r]};
+    gg_epilogue<EPI, T>(a, g, n, m0 + r, v);
+  }
+}
+
 // One 1 KiB fragment, global -> LDS, no VGPR: lane l's 16 bytes land at lds_byte + 16 l (guides/cdna_hip_programming.md §5.7:
 // M0 carries the wave-uniform LDS address and is restored; the load is invisible to the compiler's vmcnt bookkeeping).
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {

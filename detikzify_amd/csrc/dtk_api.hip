@@ -2015,7 +2015,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
   else if (!strcmp(name, "gemv_bc")) {
-    if (value < 0 || value > 127) return fail(c, DTK_ERR_ARG, "gemv_bc must be 0..127 (0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head through k_gemv_bc; bits 4..6 = units per block, 0 = one CU's share)");
+    if (value < 0 || value > 255) return fail(c, DTK_ERR_ARG, "gemv_bc must be 0..255 (0 off; 128 = the measured default per role and weight format; else bit 0 qkv, bit 1 gate/up, bit 2 lm_head through k_gemv_bc; bits 4..6 = units per block, 0 = one CU's share)");
     set_gemv_bc(value);
     drop_batch_graphs(c);
   }

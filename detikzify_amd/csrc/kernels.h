@@ -119,7 +119,7 @@ void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: k_gemv_bx with both operands streamed into LDS rings by a loader wave (LDS-DMA); false = not covered / off
 bool launch_gemv_bc(int epi, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: a compute wave per COLUMN tile, x from L2 into registers, the weights through an LDS ring (bit-identical to k_gemv_b); false = not covered / off
-void set_gemv_bc(int v);       // 0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head; bits 4..6 force the units per block
+void set_gemv_bc(int v);       // 0 off; 128 = measured default per role; bit 0 qkv, bit 1 gate/up, bit 2 lm_head; bits 4..6 force the units per block
 void set_gemv_bl(int v);       // bit 0: gate/up + lm_head, bit 1: qkv by pair units, bit 2: fp8 weights too, bit 3: qkv as pair unit + V row tile per block where that fills the chip, bit 4: for any MHA model
 void set_gemv_br_wd(int v);    // k_gemv_br with fp8 weights: phases of the register ring, 4 (default) | 8 (measured slower)
 void set_gemv_loaders(int v);  // loader waves of the Q3 qkv kernel: 1 (ring of 3 phases) or 2 (alternate phases, ring of 5)

@@ -856,6 +856,11 @@ template <int U, bool F8> struct bc_shape {
   static constexpr int R = LEAD + 2;
   static constexpr int LDS = R * PIECES * 1024 + 4 * 5 + 12;
 };
+__device__ __forceinline__ unsigned bc_min_done(unsigned off) {      // the four compute waves' DONE words in ONE LDS round trip
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+  return min(min(v[0], v[1]), min(v[2], v[3]));
+}
 template <int EPI, int U, int CHP4, bool F8 = false>
 __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
   constexpr int T = 2, NC = 4, PH = 4, XD = 4;
@@ -863,19 +868,22 @@ __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
   constexpr int TILES = U * T;
   constexpr int LEAD = bc_shape<U, F8>::LEAD, R = bc_shape<U, F8>::R;
   constexpr unsigned WPH = TILES * WT * 1024u;                   // weight bytes of one phase
-  constexpr unsigned OFF_FILLED = R * WPH, OFF_DONE = OFF_FILLED + 4;
+  constexpr unsigned OFF_DONE = R * WPH, OFF_FILLED = OFF_DONE + 16;      // (DONE: 16-byte aligned, read as one b128)
   constexpr int PIECES = TILES * WT;
   static_assert(PIECES == bc_shape<U, F8>::PIECES, "shape");
   constexpr unsigned SPIN = 1u << 22;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nsteps = a.K >> 5, NPH = nsteps / PH;                // the launcher guarantees K = 32 * 8 * 4 * CHP4 (NPH = 16 or 32)
-  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_FILLED + o, 0u); bl_drain(); }
+  if (threadIdx.x == 0) { for (unsigned o = 0; o < 4u * (NC + 1); o += 4) bl_st(OFF_DONE + o, 0u); bl_drain(); }
   __syncthreads();
   const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
 
   if (wave == NC) {
-    // ---- loader wave: the weight tiles of the block's U units, phase by phase, by LDS-DMA
+    // ---- loader wave: the weight tiles of the block's U units, phase by phase, by LDS-DMA.  What the flag skeleton alone costs was
+    // half of the first version's time (profiles/r06d_bc_probe.txt: 13-16 us per launch with every load and MFMA left out): the loader
+    // re-read the four DONE words one LDS round trip at a time before EVERY phase.  Now one b128 read, and only when the cached
+    // minimum no longer proves the slot free.
     const unsigned char* wsrc[TILES];
 #pragma unroll
     for (int j = 0; j < TILES; ++j) {
@@ -886,15 +894,13 @@ __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
       wsrc[j] = F8 ? a.W8 + ((size_t)tn * (nsteps >> 1) * 64 + lane) * 16
                    : reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
     }
-    unsigned slot = 0;
+    unsigned slot = 0, done = 0;
     for (int p = 0; p < NPH; ++p) {
-      if (p >= R) {
+      if (done + R <= (unsigned)p) {          // slot p % R still holds phase p - R: every compute wave must have released it
         unsigned spins = 0;
         for (; spins < SPIN; ++spins) {
-          unsigned lo = bl_ld(OFF_DONE);
-#pragma unroll
-          for (int c = 1; c < NC; ++c) lo = min(lo, bl_ld(OFF_DONE + 4u * c));
-          if (lo + R > (unsigned)p) break;
+          done = bc_min_done(OFF_DONE);
+          if (done + R > (unsigned)p) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (spins == SPIN) bl_timeout(a.err);
@@ -922,21 +928,32 @@ __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
   for (int b = 0; b < XD; ++b)
 #pragma unroll
     for (int j = 0; j < PH; ++j) bc_load(xr[b][j], xsrc + (size_t)(b * PH + j) * 1024);
+  // what the epilogue reads (active flags, positions, row scales, RoPE entries): requested now, behind the first x fragments, used
+  // after the last MFMA (4.8 us per launch when it was two or three dependent round trips at the end)
+  gg_pre<EPI, T, F8> pre[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int g = blockIdx.x * U + u;
+    gg_pre_load<EPI, T, F8>(a, g < groups ? g : groups - 1, lane, wave, pre[u]);
+  }
   f32x4 tot[TILES], c[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) { tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; c[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  unsigned slot = 0;
+  unsigned slot = 0, filled = 0;
   auto group = [&](int p0, auto refill_tag) {       // XD phases on the x ring's slots 0 .. XD - 1; REFILL: a used-up fragment is reloaded for phase p + XD
     constexpr bool REFILL = decltype(refill_tag)::value;
 #pragma unroll
     for (int b = 0; b < XD; ++b) {
       const int p = p0 + b;
-      unsigned spins = 0;
-      for (; spins < SPIN; ++spins) {
-        if (bl_ld(OFF_FILLED) > (unsigned)p) break;
-        __builtin_amdgcn_s_sleep(1);
+      if (filled <= (unsigned)p) {            // (the loader runs LEAD phases ahead: one look usually covers several phases)
+        unsigned spins = 0;
+        for (; spins < SPIN; ++spins) {
+          filled = bl_ld(OFF_FILLED);
+          if (filled > (unsigned)p) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins == SPIN) bl_timeout(a.err);
       }
-      if (spins == SPIN) bl_timeout(a.err);
       const unsigned char* wb = smem + slot * WPH + lane * 16;
       u32x4 wv[TILES];
 #pragma unroll
@@ -981,8 +998,8 @@ __global__ __launch_bounds__(5 * 64, 2) void k_gemv_bc(GemvBArgs a) {
   for (int u = 0; u < U; ++u) {
     const int g = blockIdx.x * U + u;
     if (g >= groups) break;
-    const f32x4 unit[T][1] = {{tot[u * T]}, {tot[u * T + 1]}};
-    gg_finish_unit<EPI, T, F8, 1>(a, g, unit, lane, wave);
+    const f32x4 unit[T] = {tot[u * T], tot[u * T + 1]};
+    gg_pre_store<EPI, T, F8>(a, g, unit, lane, wave, pre[u]);
   }
 }
 // false = this instantiation must not run (see br_usable: hand-issued loads and a spilling compiler do not mix)
@@ -1024,13 +1041,17 @@ static bool launch_bc_units(int units, const GemvBArgs& a, hipStream_t s) {
 }
 static int g_gemv_bc = -1;
 void set_gemv_bc(int v) { g_gemv_bc = v; }
-// variant: 0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head, bits 4..6 = forced units per block (0 = one CU's share, at most 4).  false = not
-// covered (fewer than 49 slots, N = d roles, K other than 2048 / 4096, a ragged ff / vocabulary): the caller goes on to k_gemv_bl / ...
+// variant: 0 off; bit 0 qkv, bit 1 gate/up, bit 2 lm_head, bits 4..6 = forced units per block (0 = one CU's share, at most 4); 128 (default) =
+// by measurement (profiles/r06f_step_bench.txt, 64 slots): qkv always (cl-7b fp8 3.81 -> 3.67 ms per step, ds-7b 4.05 -> 3.96, ds-1.3b
+// 1.78 -> 1.73), gate/up with bf16 weights (ds-1.3b 1.73 -> 1.65; ds-7b neutral; fp8: k_gemv_br's register path stays ahead, 29.4 vs
+// 31.9 us), lm_head never (neutral).  false = not covered (fewer than 49 slots, N = d roles, K other than 2048 / 4096, a ragged ff /
+// vocabulary): the caller goes on to k_gemv_bl / ...
 bool launch_gemv_bc(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (g_gemv_bc < 0) { const char* e = getenv("DTK_GEMV_BC"); g_gemv_bc = e ? atoi(e) : 7; }
+  if (g_gemv_bc < 0) { const char* e = getenv("DTK_GEMV_BC"); g_gemv_bc = e ? atoi(e) : 128; }
   if (g_gemv_bc <= 0 || a.nt < 3) return false;
   if (epi != EPI_QKV && epi != EPI_SWIGLU && epi != EPI_LOGITS) return false;
-  if (!(g_gemv_bc & (epi == EPI_QKV ? 1 : (epi == EPI_SWIGLU ? 2 : 4)))) return false;
+  const int roles = (g_gemv_bc & 128) ? (a.W8 ? 1 : 3) : (g_gemv_bc & 7);
+  if (!(roles & (epi == EPI_QKV ? 1 : (epi == EPI_SWIGLU ? 2 : 4)))) return false;
   if (a.K != 4096 && a.K != 2048) return false;
   if (epi == EPI_SWIGLU && (a.ff & 15)) return false;
   if (epi == EPI_LOGITS && (a.N & 31)) return false;

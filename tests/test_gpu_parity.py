@@ -1494,7 +1494,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_xw", 0)
         model.set_option("gemv_loaders", 1)
         model.set_option("gemv_br_wd", 4)
-        model.set_option("gemv_bc", 7)
+        model.set_option("gemv_bc", 128)
         del model
         gc.collect()
 
