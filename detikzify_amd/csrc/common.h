@@ -86,7 +86,8 @@ struct DecState {
 #ifndef DTK_MAX_BATCH
 #define DTK_MAX_BATCH 64   // == include/dtk.h
 #endif
-#define DTK_PFX_GROUPS 16  // prefix groups a step can hand to k_attn_prefix_g
+#define DTK_PFX_GROUPS 64  // prefix groups a step can hand to k_attn_prefix_g: the worst case of 64 slots that share nothing (64 singleton groups), so that
+                           // whether a slot's prefix goes through the matrix cores never depends on how many OTHER prefixes the step holds (was 16)
 // One shared prefix scored on the matrix cores: the active slots that read the first `len` rows of their cache from slot `src`
 // (forks of one image: dtk_kv_fork), at most 16 of them = the columns of one MFMA tile.  A source with more forks has several groups.
 struct PfxGroup {
@@ -101,7 +102,7 @@ struct BatchState {
   int32_t step;      // global step counter (token ring index)
   // Shared prefixes on the matrix cores (k_attn_prefix_g): the host groups the step's active slots by (share_src, share_len) — a
   // property of the slot alone, so whether and how a slot's prefix is scored never depends on which other slots decode with it —
-  // into at most DTK_PFX_GROUPS groups of <= 16 slots; group_plus1[slot] = the slot's group + 1 (0: none, the slot's whole context
+  // into groups of <= 16 slots (at most DTK_PFX_GROUPS = 64: every slot always finds a group); group_plus1[slot] = the slot's group + 1 (0: none, the slot's whole context
   // is walked by k_attn_tail_b).  n_groups == 0: no prefix kernel work this step.
   int32_t n_groups;
   int32_t pad[14];

@@ -211,6 +211,7 @@ struct dtk_ctx {
   hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
   int attn_full_max = 0;             // contexts below this use the one-block-per-head attention (measured slower: off)
   int attn_threads = 0;              // decode attention: 0 = k_attn_decode (contiguous key range per split), 256 | 512 | 1024 = k_attn_decode_t
+  int probe_skip_attn = 0;           // timing probe (wrong results): the single-sequence step without its attention launch
   int attn_impl = 0;                 // prefill / ViT attention kernel: 0 auto, 1 VALU, 2 MFMA flash (dtk_set_option "attn_impl")
   bool gemm_naive = false;
   int probe = 0;
@@ -634,7 +635,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.threads = c->attn_threads;
     ad.combine = (!ad.threads && short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     if (ad.threads && ad.combine == 1) ad.combine = 2;      // the tile kernel has no in-kernel combine
-    launch_attn_decode(ad, s);
+    if (!c->probe_skip_attn) launch_attn_decode(ad, s);     // (timing probe "probe_skip_attn": the ceiling of any scheme that hides the attention launch)
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
     const bool partials = ad.combine == 0 && !(ad.threads && ad.S == 1);   // o_proj's prologue reduces the split partials
@@ -1504,7 +1505,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   // Shared prefixes for k_attn_prefix_g: the active slots grouped by (share_src, share_len) — both properties of the slot alone, so a
   // slot's arithmetic never depends on which other slots decode with it — in chunks of 16 (one MFMA column tile), sources in slot
   // order.  A source slot that decodes itself is not a member of its forks' groups (that WOULD depend on the others); more than
-  // DTK_PFX_GROUPS groups (over 16 distinct prefixes in one step): the rest walk their whole context in k_attn_tail_b.
+  // DTK_PFX_GROUPS = 64 groups cover the worst case (64 slots that share nothing), so no slot ever falls back because of its company.
   hb->n_groups = 0;
   for (int j = 0; j < DTK_MAX_BATCH; ++j) { hb->group_plus1[j] = 0; hb->pfx_len_of[j] = 0; }
   if (c->prefix_mfma && !mv_family(c)) {
@@ -2014,6 +2015,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemv_br_wd")) { if (value != 4 && value != 8) return fail(c, DTK_ERR_ARG, "gemv_br_wd must be 4 or 8"); set_gemv_br_wd(value); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
+  else if (!strcmp(name, "probe_skip_attn")) { c->probe_skip_attn = value != 0; drop_graph(c); }
   else if (!strcmp(name, "gemv_bc")) {
     if (value < 0 || value > 255) return fail(c, DTK_ERR_ARG, "gemv_bc must be 0..255 (0 off; 128 = the measured default per role and weight format; else bit 0 qkv, bit 1 gate/up, bit 2 lm_head through k_gemv_bc; bits 4..6 = units per block, 0 = one CU's share)");
     set_gemv_bc(value);
