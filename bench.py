@@ -525,13 +525,6 @@ def main():
                                  "slots: b * 8 TB/s / (W + b*K*n_new/2 + images*K*prefix) — the weights once per step, every slot's own "
                                  "keys at the mean depth of a from-the-root rollout, the image prefix once per image"}
 
-        # DTK_REWARD_PREP_WORKERS=N (opt-in; off by default — measured no gain on this host): the rewards' Pillow work (trim,
-        # LANCZOS pad, BICUBIC resize: Pillow holds the GIL through all three) in N worker processes shared by every parallel search of
-        # this process (detikzify_amd/util/image_prep.py; bit-identical pixels); started here so that no search is timed with its start-up
-        from detikzify_amd.util import image_prep
-        prep_pool = image_prep.shared_pool()
-        mcts["reward_prep_workers"] = prep_pool.warm() if prep_pool is not None else 0
-
         def search(the_model, the_proc, images, trees_per_image, expansions, ragged=False, pipe_kw=None, Wk=None, slots=None):
             """This rank's share of a root-parallel search: len(images) * trees_per_image trees as ONE batched decode (one tree:
             the unmodified sequential search), then the path's single exchange — (score, code) records to rank 0 — timed on its
@@ -560,7 +553,6 @@ def main():
             eng = (getattr(the_model, "last_batch_stats", None) or {}) if n_trees > 1 else {}
             tokens = eng.get("tokens_out") if n_trees > 1 else None
             out = {"trees_per_gpu": n_trees, "images_per_gpu": len(images), "expansions_per_tree": expansions, "ragged_lengths": bool(ragged),
-                   "reward_prep_jobs_so_far": prep_pool.jobs if prep_pool is not None else 0,
                    "seconds": total_s, "search_seconds_this_rank": round(t_search, 3), "gather_seconds": round(max_over_ranks(t_gather), 4),
                    "decode_steps_per_gpu": (eng.get("steps") if n_trees > 1 else s1["decode_steps"] - s0["decode_steps"]),
                    "tokens_generated_per_gpu": tokens, "vit_passes_per_gpu": s1["vit_images"] - s0["vit_images"]}

@@ -7,9 +7,7 @@ OUT=detikzify_amd/lib
 mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-variable"
-# DTK_EXPERIMENTS=1 ./build.sh also builds the kernel families that lost their measurements (k_gemm_b, k_gemv_bk, k_gemm_dma, the
-# timing-experiment modes of k_gemv_b): options "gemm_b", "gemv_bk", "gemm_impl" = 1 and tools/probe_batch.py need them
-if [ "${DTK_EXPERIMENTS:-0}" = "1" ]; then FLAGS="$FLAGS -DDTK_EXPERIMENTS"; fi
+
 if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; mkdir -p build; echo "$FLAGS" > build/.flags; fi
 pids=()
 for f in kernels_decode kernels_decode_mv kernels_batch_decode kernels_batch_gemm kernels_batch_mx kernels_batched kernels_sample_mb dtk_api; do

@@ -141,8 +141,6 @@ SYMBOLS = {
     "dtk_set_sampling_slot": (C.c_int, [_P, C.c_int, C.POINTER(DtkSampling)]),
     "dtk_decode_batch_launch": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "dtk_decode_batch_wait": (C.c_int, [_P, C.POINTER(C.c_int64)]),
-    "dtk_decode_batch_run": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int32),
-                                       C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dtk_kv_fork": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "dtk_get_logits_slot": (C.c_int, [_P, C.c_int, _P]),
     "dtk_context_len_slot": (C.c_int, [_P, C.c_int]),

@@ -86,6 +86,7 @@ struct DecState {
 #ifndef DTK_MAX_BATCH
 #define DTK_MAX_BATCH 64   // == include/dtk.h
 #endif
+#define DTK_PFX_GRID 16    // group rows of k_attn_prefix_g's grid: row y takes groups y, y + 16, ...
 #define DTK_PFX_GROUPS 64  // prefix groups a step can hand to k_attn_prefix_g: the worst case of 64 slots that share nothing (64 singleton groups), so that
                            // whether a slot's prefix goes through the matrix cores never depends on how many OTHER prefixes the step holds (was 16)
 // One shared prefix scored on the matrix cores: the active slots that read the first `len` rows of their cache from slot `src`

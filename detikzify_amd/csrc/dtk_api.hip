@@ -211,7 +211,6 @@ struct dtk_ctx {
   hipGraphExec_t graph_exec = nullptr, graph_short_exec = nullptr;
   int attn_full_max = 0;             // contexts below this use the one-block-per-head attention (measured slower: off)
   int attn_threads = 0;              // decode attention: 0 = k_attn_decode (contiguous key range per split), 256 | 512 | 1024 = k_attn_decode_t
-  int probe_skip_attn = 0;           // timing probe (wrong results): the single-sequence step without its attention launch
   int attn_impl = 0;                 // prefill / ViT attention kernel: 0 auto, 1 VALU, 2 MFMA flash (dtk_set_option "attn_impl")
   bool gemm_naive = false;
   int probe = 0;
@@ -635,7 +634,7 @@ void decode_step_launches(dtk_ctx* c, bool with_probe, bool short_ctx = false) {
     ad.threads = c->attn_threads;
     ad.combine = (!ad.threads && short_ctx && c->attn_combine == 2) ? 3 : c->attn_combine; ad.out = c->attn_out; ad.counters = c->attn_ctr;
     if (ad.threads && ad.combine == 1) ad.combine = 2;      // the tile kernel has no in-kernel combine
-    if (!c->probe_skip_attn) launch_attn_decode(ad, s);     // (timing probe "probe_skip_attn": the ceiling of any scheme that hides the attention launch)
+    launch_attn_decode(ad, s);
     // 3. (combine +) o_proj + residual
     g.W = w.wo; g.W8 = w.q_wo; g.wscale = w.s_wo; g.N = c->d; g.K = c->d; g.y = c->x;
     const bool partials = ad.combine == 0 && !(ad.threads && ad.S == 1);   // o_proj's prologue reduces the split partials
@@ -1585,74 +1584,6 @@ int dtk_decode_batch_wait(dtk_ctx* c, int64_t* tokens_out) {
   return DTK_OK;
 }
 
-// Several batched steps per host call: the per-token launch / wait / dispatch loop of 64 sequences in Python
-// cost ~3 ms per step next to a 6 ms GPU step (profiles/r03_host_emulation.txt).  This runs up to max_steps steps for ONE active
-// set, always with the next step in flight while the last one's tokens are inspected, and returns as soon as a step produced a
-// reason for the host to look: a slot emitted one of `stop_ids` (EOS), a slot used up its `budget` (tokens it may still emit:
-// max_length / max_positions), `*interrupt` became non-zero (a sequence wants to join or leave), or max_steps were collected.
-// A step that is in flight on entry (dtk_decode_batch_launch, or left behind by the previous run) must have the same active set;
-// it is collected as this run's first step.  On return *inflight_out says whether one more step — same active set — is in flight:
-// a finished sequence discards its token of that step, exactly as with the launch / wait pair.
-int dtk_decode_batch_run(dtk_ctx* c, const int32_t* active, int max_steps, const int32_t* budget, const int64_t* stop_ids, int n_stop,
-                         const volatile int32_t* interrupt, int64_t* tokens_out, int32_t* steps_out, int32_t* inflight_out) {
-  if (!c || !active || !tokens_out || !steps_out || max_steps < 1 || n_stop < 0 || (n_stop > 0 && !stop_ids))
-    return fail(c, DTK_ERR_ARG, "dtk_decode_batch_run: bad argument");
-  *steps_out = 0;
-  if (inflight_out) *inflight_out = 0;
-  if (c->blaunched - c->bwaited > 1) return fail(c, DTK_ERR_STATE, "dtk_decode_batch_run: more than one step in flight");
-  if (c->blaunched > c->bwaited) {          // the step in flight becomes step 0 of this run
-    const BatchState* hb = c->bs_host + ((c->blaunched - 1) % DTK_MAX_INFLIGHT);
-    for (int j = 0; j < DTK_MAX_BATCH; ++j)
-      if ((hb->active[j] != 0) != (active[j] != 0)) return fail(c, DTK_ERR_STATE, "dtk_decode_batch_run: the step in flight has another active set (slot %d)", j);
-  }
-  int remaining[DTK_MAX_BATCH];
-  int min_budget = 1 << 30;
-  for (int j = 0; j < DTK_MAX_BATCH; ++j) {
-    remaining[j] = 1 << 30;
-    if (!active[j]) continue;
-    if (j >= max_decode_slots(c)) return fail(c, DTK_ERR_ARG, "dtk_decode_batch_run: slot %d of %d decoding slots", j, max_decode_slots(c));
-    int b = budget ? budget[j] : (1 << 30);
-    const int room = c->Tmax - (c->bseq[(size_t)j].host_next_pos - (int)(c->blaunched - c->bwaited));   // tokens the cache still takes, before the step in flight
-    if (room < b) b = room;
-    if (b < 1) return fail(c, DTK_ERR_RANGE, "slot %d: no budget left (context %d of %d)", j, c->bseq[(size_t)j].host_next_pos, c->Tmax);
-    remaining[j] = b;
-    if (b < min_budget) min_budget = b;
-  }
-  int launched = (int)(c->blaunched - c->bwaited), collected = 0;
-  bool done = false;
-  while (!done) {
-    // keep one step ahead — also of the LAST collected step (the host dispatches the run's tokens under it, as the per-step loop
-    // does) — unless that step would take some slot past its budget
-    while (launched < collected + 2 && launched <= max_steps && launched < min_budget) {
-      const int rc = dtk_decode_batch_launch(c, active);
-      if (rc) {        // the caller must still learn what the run produced before the failure: rows [0, collected) of tokens_out are valid
-        *steps_out = collected;
-        if (inflight_out) *inflight_out = launched > collected ? 1 : 0;
-        return rc;
-      }
-      ++launched;
-    }
-    if (collected >= launched) break;
-    int64_t* out = tokens_out + (size_t)collected * DTK_MAX_BATCH;
-    const int rc = dtk_decode_batch_wait(c, out);
-    if (rc) {
-      *steps_out = collected;
-      if (inflight_out) *inflight_out = (c->blaunched > c->bwaited) ? 1 : 0;
-      return rc;
-    }
-    ++collected;
-    for (int j = 0; j < DTK_MAX_BATCH && !done; ++j) {
-      if (!active[j]) continue;
-      if (collected >= remaining[j]) done = true;
-      for (int k = 0; k < n_stop; ++k) if (out[j] == stop_ids[k]) done = true;
-    }
-    if (collected >= max_steps || (interrupt && *interrupt)) done = true;
-  }
-  *steps_out = collected;
-  if (inflight_out) *inflight_out = launched > collected ? 1 : 0;
-  return DTK_OK;
-}
-
 // Copy the KV of the first n_tokens positions of slot src into slot dst (SURVEY §8 f1 / the proposed
 // dtk_kv_fork): rollouts that share a prefix (always: the 243 image tokens) reuse its KV bit for bit instead
 // of re-running ViT + prefill.  dst then needs a dtk_prefill_slot(..., DTK_PREFILL_REUSE_PREFIX) of the full
@@ -1883,31 +1814,7 @@ int dtk_bench_gemv(dtk_ctx* c, int role, int variant, int reps, float* avg_us) {
   if (!c || !avg_us || reps < 1) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  if (role == 5 || role == 6) {  // batched gate/up kernel, experiment modes (variant = mode; role 6: k_gemm_b, variant = shape * 16 + mode)
-    if (c->nb <= 0) return fail(c, DTK_ERR_STATE, "no batch slots");
-    ensure_tiled_weights(c);
-    BatchState hb{}; for (int j = 0; j < c->nb && j < DTK_MAX_BATCH; ++j) hb.active[j] = 1;
-    for (int j = 0; j < DTK_MAX_BATCH; ++j) hb.share_src[j] = -1;
-    HIPCHK(c, hipMemcpy(c->bs_dev, &hb, sizeof hb, hipMemcpyHostToDevice));
-    auto pass = [&]() {
-      for (int l = 0; l < c->L; ++l) {
-        GemvBArgs g{};
-        g.bs = c->bs_dev; g.st = c->st_b; g.T_max = c->Tmax; g.d = c->d; g.ff = c->ff; g.H = c->H; g.KVH = c->KVH; g.nt = c->nt;
-        g.W = c->layers[l].t_wgu; g.W8 = c->layers[l].t8_wgu; g.wscale = c->layers[l].s_wgu; g.N = 2 * c->ff; g.K = c->d; g.X = c->xnb; g.ldx = c->d; g.Y = c->actb; g.ldy = c->ff;
-        if (role == 6) launch_gemm_b_mode(variant >> 4, variant & 15, g, s);
-        else launch_gemv_b_mode(variant, g, s);
-      }
-    };
-    pass();
-    HIPCHK(c, hipEventRecord(c->ev_a, s));
-    for (int r = 0; r < reps; ++r) pass();
-    HIPCHK(c, hipEventRecord(c->ev_b, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    float ms = 0.f;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-    *avg_us = ms * 1e3f / (float)(reps * c->L);
-    return DTK_OK;
-  }
+  if (role < 0 || role > 4) return fail(c, DTK_ERR_ARG, "dtk_bench_gemv: role %d (0 qkv, 1 o_proj, 2 gate/up, 3 down, 4 lm_head)", role);
   const bool same_layer = (variant & 0x100) != 0;  // every launch re-reads layer 0 (Infinity Cache probe)
   const int plain = (variant >> 9) & 3;            // 0x200: same weights through PRO_COPY + EPI_STORE; 0x400: PRO_RMSNORM + EPI_STORE
   variant &= 0xff;
@@ -1955,16 +1862,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   if (!c || !name) return DTK_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-#ifdef DTK_EXPERIMENTS
-  constexpr bool kExperiments = true;
-#else
-  constexpr bool kExperiments = false;
-#endif
-  // kernels that lost their measurements are only built with DTK_EXPERIMENTS=1 ./build.sh: "experiments" (any value) tells a test
-  // whether they are there; selecting one in a default build is an error, not a silent fall-back
-  if (!strcmp(name, "experiments")) return kExperiments ? DTK_OK : fail(c, DTK_ERR_ARG, "built without DTK_EXPERIMENTS");
-  if (!kExperiments && ((!strcmp(name, "gemm_b") && value != 0) || (!strcmp(name, "gemv_bk") && value != 0) || (!strcmp(name, "gemm_impl") && value == 1)))
-    return fail(c, DTK_ERR_ARG, "option %s = %d selects a kernel that is only built with DTK_EXPERIMENTS=1 ./build.sh", name, value);
   if (!strcmp(name, "attn_full_max")) c->attn_full_max = value;
   else if (!strcmp(name, "gemm_tile")) {   // MFMA GEMM block tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (process-wide)
     if (value < 0 || value > 5) return fail(c, DTK_ERR_ARG, "gemm_tile must be 0..5");
@@ -1972,16 +1869,15 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   }
   else if (!strcmp(name, "share_prefix_reads")) c->share_reads = value != 0;
   else if (!strcmp(name, "prefix_mfma") || !strcmp(name, "pfx_splits") || !strcmp(name, "gemv_b_wide") ||
-           !strcmp(name, "tail_threads") || !strcmp(name, "gemm_b")) {
+           !strcmp(name, "tail_threads")) {
     if (!strcmp(name, "prefix_mfma")) c->prefix_mfma = value != 0;
-    else if (!strcmp(name, "gemm_b")) { if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_b must be 0..4"); set_gemm_b_shape(value); }
     else if (!strcmp(name, "tail_threads")) { if (value != 64 && value != 128 && value != 256 && value != 512) return fail(c, DTK_ERR_ARG, "tail_threads must be 64, 128, 256 or 512"); c->tail_threads = value; }
     else if (!strcmp(name, "pfx_splits")) { if (value < 1 || value > 4) return fail(c, DTK_ERR_ARG, "pfx_splits must be 1..4"); c->pfx_splits = value; }
     else { if (value < 0 || value > 6) return fail(c, DTK_ERR_ARG, "gemv_b_wide must be 0..6"); set_gemv_b_wide(value); }
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemm_impl")) {
-    if (value < 0 || value > 4) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 1 (k_gemm_dma), 2 (k_gemm_glds where the shape has the tiles), 3 (auto) or 4 (k_gemm_g3: 8 waves, 3 LDS stages)");
+    if (value < 0 || value > 4 || value == 1) return fail(c, DTK_ERR_ARG, "gemm_impl must be 0 (registers), 2 (k_gemm_glds where the shape has the tiles), 3 (auto) or 4 (k_gemm_g3: 8 waves, 3 LDS stages)");
     set_gemm_impl(value);
   }
   else if (!strcmp(name, "gemm_g3_min_blocks")) {
@@ -2015,7 +1911,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "gemv_br_wd")) { if (value != 4 && value != 8) return fail(c, DTK_ERR_ARG, "gemv_br_wd must be 4 or 8"); set_gemv_br_wd(value); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_loaders")) { set_gemv_loaders(value >= 2 ? 2 : 1); drop_batch_graphs(c); }
   else if (!strcmp(name, "gemv_xw")) { set_gemv_xw(value < 0 ? 0 : (value > 2 ? 2 : value)); drop_batch_graphs(c); }   // x waves of k_gemv_bl / k_gemv_bkl
-  else if (!strcmp(name, "probe_skip_attn")) { c->probe_skip_attn = value != 0; drop_graph(c); }
   else if (!strcmp(name, "gemv_bc")) {
     if (value < 0 || value > 255) return fail(c, DTK_ERR_ARG, "gemv_bc must be 0..255 (0 off; 128 = the measured default per role and weight format; else bit 0 qkv, bit 1 gate/up, bit 2 lm_head through k_gemv_bc; bits 4..6 = units per block, 0 = one CU's share)");
     set_gemv_bc(value);
@@ -2052,11 +1947,6 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
   }
   else if (!strcmp(name, "resid_kparts")) {     // batched N = d roles as k_gemv_bkp + k_resid_norm_b (64 slots, bf16 weights)
     c->resid_kparts = value != 0;
-    drop_batch_graphs(c);
-  }
-  else if (!strcmp(name, "gemv_bk")) {
-    if (value < 0 || value > 1) return fail(c, DTK_ERR_ARG, "gemv_bk must be 0 or 1");
-    set_gemv_bk(value);
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bx")) {

@@ -113,9 +113,6 @@ struct GemvBArgs {
   uint8_t* Y8; uint8_t* YS;
 };
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s);
-void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s);
-bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s);   // kernels_batch_gemm.hip; false = not covered, use k_gemv_b
-void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s);   // timing experiments
 bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: x once per CU through LDS phases (64 slots; bit-identical to k_gemv_b); false = not covered
 bool launch_gemv_bl(int epi, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: k_gemv_bx with both operands streamed into LDS rings by a loader wave (LDS-DMA); false = not covered / off
 bool launch_gemv_bc(int epi, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: a compute wave per COLUMN tile, x from L2 into registers, the weights through an LDS ring (bit-identical to k_gemv_b); false = not covered / off
@@ -125,8 +122,6 @@ void set_gemv_br_wd(int v);    // k_gemv_br with fp8 weights: phases of the regi
 void set_gemv_loaders(int v);  // loader waves of the Q3 qkv kernel: 1 (ring of 3 phases) or 2 (alternate phases, ring of 5)
 void set_gemv_xw(int v);       // k_gemv_bl / k_gemv_bkl: 1 = x fragments by an extra wave's ordinary loads + ds_write_b128 instead of LDS-DMA pieces
 void set_gemv_bkl(int v);      // 1: the resid_kparts weight kernel with LDS-DMA operand rings (k_gemv_bkl) instead of k_gemv_bkp
-bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s);    // kernels_batch_gemm.hip: N = d roles at 64 slots, K split over 8 CUs per row group; false = not covered
-void set_gemv_bk(int v);       // 0: off, 1: on
 // N = d roles at 33..64 slots as two launches (kernels_batch_gemm.hip): k_gemv_bkp = K split over the CUs of a row group, plain stores
 // of the fp32 partials; k_resid_norm_b = reduce + residual + the RMSNorm that follows the role anyway (replaces k_rmsnorm_b there)
 bool resid_kparts_covers(const GemvBArgs& a);
@@ -135,7 +130,6 @@ void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w,
                          int nslots, hipStream_t s, uint8_t* Y8 = nullptr, uint8_t* YS = nullptr);
 void set_resid_split(int v);   // batched N = d roles at 64 slots: 0 = one row tile x 64 slots per block, 1 = two row tiles x 32 slots
 void set_gemv_bx(int v);       // 0: off, 1: on (units per block from the CU count), 2..4: on with that many units per block
-void set_gemm_b_shape(int v);  // 0: k_gemv_b (x fragments in registers), 1..4: k_gemm_b block shapes (x through LDS)
 void set_gemv_b_wide(int v);   // row tiles per block of the batched kernels: 0 round-1 shapes, 1 twice as many, 2 auto (wide from 32 slots)
 void launch_retile(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
 static inline size_t tiled_elems(int N, int K) { return (size_t)((N + 15) >> 4) * ((K + 31) >> 5) * 512; }

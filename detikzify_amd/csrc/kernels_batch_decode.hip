@@ -262,33 +262,6 @@ __global__ __launch_bounds__(WAVES * 64, (MODE & 8) ? 4 : 1) void k_gemv_b(GemvB
   }
 }
 
-void launch_gemv_b_mode(int mode, const GemvBArgs& a, hipStream_t s) {  // SWIGLU role, timing experiments (mode bits: 1 no x loads, 2 no MFMA, 4 no reduction / epilogue)
-  if (mode >= 128 && mode <= 131) { if (!launch_gemv_bx(EPI_SWIGLU, mode - 127, a, s)) launch_gemv_b(EPI_SWIGLU, a, s); return; }   // the x-once-per-CU kernel: 128 auto, 129..131 = 2..4 units per block
-  const dim3 g((a.ff + 15) / 16), b(GB_THREADS);
-#define GBM(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV>), g, b, 0, s, a)
-#define GBM2(M, NTV) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, M, false, GB_WAVES, NTV, 2>), g, b, 0, s, a)   // 2 k-steps per stage
-#ifdef DTK_EXPERIMENTS      // the timing-experiment instantiations (tools/probe_batch.py): 16 modes x 3 tile counts of a 0.5 MB kernel each
-#define GBMS(NTV) switch (mode) { case 1: GBM(1, NTV); break; case 2: GBM(2, NTV); break; case 3: GBM(3, NTV); break; case 4: GBM(4, NTV); break; \
-                                  case 5: GBM(5, NTV); break; case 6: GBM(6, NTV); break; case 7: GBM(7, NTV); break; \
-                                  case 8: GBM(8, NTV); break; case 16: GBM2(16, NTV); break; case 24: GBM2(24, NTV); break; case 17: GBM(16, NTV); break; \
-                                  case 32: GBM(32, NTV); break; case 40: GBM(40, NTV); break; case 48: GBM2(48, NTV); break; case 56: GBM2(56, NTV); break; \
-                                  case 64: GBM(64, NTV); break; default: GBM(0, NTV); }
-#else
-#define GBMS(NTV) GBM(0, NTV);
-#endif
-  if (a.W8) {
-    if (a.nt >= 3) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 4>), g, b, 0, s, a);
-    else if (a.nt == 2) hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true, GB_WAVES, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_gemv_b<EPI_SWIGLU, 2, 0, true>), g, b, 0, s, a);
-    return;
-  }
-  if (a.nt >= 3) { GBMS(4) }
-  else if (a.nt == 2) { GBMS(2) }
-  else { GBMS(1) }
-#undef GBMS
-#undef GBM2
-#undef GBM
-}
 
 // waves per block of the N = d kernels (o_proj, down: only N/16 = 256 blocks, so the K split is what fills a CU)
 static int resid_waves() {
@@ -349,17 +322,9 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemv_b<EPI_STORE, 1, 0, F8, GB_WAVES, NT>), dim3((a.N + 15) / 16), dim3(GB_THREADS), 0, s, a);
   }
 }
-static int g_gemv_bk = -1;
-void set_gemv_bk(int v) { g_gemv_bk = v; }
 static int g_gemv_bx = -1;
 void set_gemv_bx(int v) { g_gemv_bx = v; }
-static int g_gemm_b_shape = -1;
-void set_gemm_b_shape(int v) { g_gemm_b_shape = v; }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
-  if (g_gemm_b_shape < 0) { const char* e = getenv("DTK_GEMM_B"); g_gemm_b_shape = e ? atoi(e) : 0; }
-  if (launch_gemm_b(epi, g_gemm_b_shape, a, s)) return;     // x staged through LDS (kernels_batch_gemm.hip); false: not covered
-  if (g_gemv_bk < 0) { const char* e = getenv("DTK_GEMV_BK"); g_gemv_bk = e ? atoi(e) : 0; }
-  if (launch_gemv_bk(epi, g_gemv_bk, a, s)) return;         // 64 slots, N = d roles: K split over the CUs of a row group (kernels_batch_gemm.hip)
   if (launch_gemv_bc(epi, a, s)) return;                    // 64 slots, rows >> d roles: a compute wave per column tile (x from L2 into registers, weights through an LDS ring)
   if (launch_gemv_bl(epi, a, s)) return;                    // 64 slots, rows >> d roles: both operands through LDS rings filled by a loader wave
   if (g_gemv_bx < 0) { const char* e = getenv("DTK_GEMV_BX"); g_gemv_bx = e ? atoi(e) : 1; }
@@ -426,8 +391,12 @@ void launch_rmsnorm_b(const bf16_t* X, int ldx, const bf16_t* w, bf16_t* Y, int 
 __global__ __launch_bounds__(64) void k_attn_prefix_g(AttnDecBArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PFX_HDP];
   const BatchState* bs = a.bs;
-  const int h = blockIdx.x, gi = blockIdx.y, z = blockIdx.z, NPS = gridDim.z;
+  const int h = blockIdx.x, z = blockIdx.z, NPS = gridDim.z;
   const int lane = threadIdx.x, lq = lane & 15, g = lane >> 4;
+  // The grid has DTK_PFX_GRID = 16 group rows; a step may hold up to DTK_PFX_GROUPS = 64 groups (64 slots that share nothing): block row
+  // y takes groups y, y + 16, ... — one trip in every measured configuration (config 5: 8 groups), and no slot's prefix ever leaves the
+  // matrix cores because of how many OTHER prefixes the step holds (a 64-row grid cost 1.5 % of the step in idle blocks).
+  for (int gi = blockIdx.y; gi < DTK_PFX_GROUPS; gi += DTK_PFX_GRID) {
   // the whole group record is requested at once, BEFORE n_groups is known (the table is plain memory whatever it holds): one memory
   // round trip, then the q / K / V loads — the block is a chain of dependent loads, and each link costs 1-2 us under a full chip
   const PfxGroup* grp = bs->groups + gi;
@@ -547,6 +516,8 @@ __global__ __launch_bounds__(64) void k_attn_prefix_g(AttnDecBArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16 + g * 4) = o[dt];
     if (g == 0) { a.pfx_m[rec] = m; a.pfx_l[rec] = l; }
+  }
+  __syncthreads();          // (the next group of this block row reuses Vs)
   }
 }
 
@@ -748,7 +719,7 @@ __global__ __launch_bounds__(THREADS) void k_attn_tail_b(AttnDecBArgs a) {
 
 void launch_attn_decode_b(const AttnDecBArgs& a, hipStream_t s) {
   {   // shared prefixes once per group on the matrix cores (optional) + one block per (head, slot) for the private keys
-    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_g, dim3(a.H, DTK_PFX_GROUPS, a.pfx_splits), dim3(64), 0, s, a);
+    if (a.use_prefix) hipLaunchKernelGGL(k_attn_prefix_g, dim3(a.H, DTK_PFX_GRID, a.pfx_splits), dim3(64), 0, s, a);
     // one block shape for every slot count: a slot's result must not depend on how many column tiles the step has
     if (a.G == 4 && a.gqa_fused == 2) {   // pairs of query heads: half the sharing, twice the blocks
       hipLaunchKernelGGL((k_attn_tail_b<256, 2>), dim3(a.H / 2, a.nslots), dim3(256), 0, s, a);

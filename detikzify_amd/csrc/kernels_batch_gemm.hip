@@ -20,147 +20,6 @@
 #include "mx_quant.h"
 
 
-#ifdef DTK_EXPERIMENTS      // k_gemm_b: measured not faster than k_gemv_b / k_gemv_bl at any slot count; built with DTK_EXPERIMENTS=1 ./build.sh only
-// T tiles per wave, KQ splits of K x RP row groups per block, NT column tiles of 16 slots, SK k-steps per stage, both streams
-// XA stages ahead.  Iteration t issues stage u = t + XA of both streams — weights first, then the x fragments — and computes
-// stage t; the prologue is iterations -XA .. -1.
-// MODE (timing experiments, dtk_bench_gemv role 6): 1 no x DMA, 2 no MFMA, 4 no barriers / waits, 8 no weight loads
-template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA, int MODE = 0>
-__global__ __launch_bounds__(KQ * RP * 64) void k_gemm_b(GemvBArgs a) {
-  constexpr int WAVES = KQ * RP, THREADS = WAVES * 64;
-  constexpr int SF = KQ * SK * NT;                  // 1 KiB x fragments of one stage (all K splits)
-  constexpr int FPW = (SF + WAVES - 1) / WAVES;     // fragments (LDS-DMA instructions) per staging wave and stage; with fewer
-  static_assert(SF % FPW == 0, "a wave stages FPW fragments or none");   // fragments than waves the last waves stage nothing
-  constexpr int RING = XA + 1;                      // LDS slots = weight register stages
-  constexpr int PER_STAGE = T * SK + FPW;           // vector-memory instructions a wave issues per stage
-  static_assert((XA - 1) * PER_STAGE < 64, "vmcnt is a 6-bit counter");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // max(RING x SF, KQ x RP x T x NT) KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = wave / RP, r = wave % RP;
-  const int K = a.K;
-  const int nsteps = (K + 31) >> 5;
-  const int per = (nsteps + KQ - 1) / KQ;           // k-steps per K split (the last split may be shorter)
-  const int nstages = (per + SK - 1) / SK;
-  const int s0 = min(nsteps, q * per), s1 = min(nsteps, s0 + per);
-  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
-  const int g = blockIdx.x * RP + r;
-  const int gc = g < groups ? g : groups - 1;       // clamped: a surplus row group streams valid memory and stores nothing
-  const unsigned lds0 = __builtin_amdgcn_groupstaticsize();   // byte address of the dynamic region
-  const bool stager = wave * FPW < SF;              // wave-uniform: this wave has fragments to fetch
-
-  const unsigned char* wrow[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    int tn = gg_tile_row0<EPI, T>(a, gc, t) >> 4;
-    const int tn_max = ((a.N + 15) >> 4) - 1;
-    if (tn > tn_max) tn = tn_max;
-    wrow[t] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16;
-  }
-  const bf16_t* xlane = a.X + lane * 8;
-
-  f32x4 acc[T][NT];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // Stage u of this wave's weights -> registers.  A k-step past the end of the split is loaded from a valid tile and ZEROED:
-  // its x fragment (also fetched, from a clamped k-step: the instruction counts stay exact) then contributes nothing.
-  auto load_w = [&](u32x4 (&w)[T][SK], int u) {
-#pragma unroll
-    for (int i = 0; i < SK; ++i) {
-      const int st = s0 + u * SK + i;
-      const int stc = st < s1 ? st : (s1 > s0 ? s1 - 1 : 0);
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        u32x4 v = (MODE & 8) ? (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)stc} : ld_nt(reinterpret_cast<const u32x4*>(wrow[t] + (size_t)stc * 1024));
-        if (st >= s1) v = (u32x4){0u, 0u, 0u, 0u};
-        w[t][i] = v;
-      }
-    }
-  };
-  // This wave's FPW fragments of stage u -> LDS slot.  Fragment f = ((qq * NT) + nt) * SK + i: the FPW fragments of a wave are
-  // consecutive k-steps of one (split, column tile) wherever FPW divides SK — consecutive KiB in memory.
-  auto dma_x = [&](int u, int slot) {
-    if (!stager || (MODE & 1)) return;
-#pragma unroll
-    for (int j = 0; j < FPW; ++j) {
-      const int f = wave * FPW + j;
-      const int qq = f / (NT * SK), nt = (f / SK) % NT, i = f % SK;
-      const int b0 = min(nsteps, qq * per);
-      int st = b0 + u * SK + i;
-      if (st >= nsteps) st = nsteps - 1;            // valid memory; the matching weights are zero
-      const unsigned dst = lds0 + (unsigned)((slot * SF + f) * 1024);
-      glds16(xlane + ((size_t)nt * nsteps + st) * 512, __builtin_amdgcn_readfirstlane(dst));
-    }
-  };
-  auto compute = [&](const u32x4 (&w)[T][SK], int slot) {
-    const unsigned char* xb = smem + ((size_t)slot * SF + (size_t)q * NT * SK) * 1024 + lane * 16;
-#pragma unroll
-    for (int i = 0; i < SK; ++i)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * SK + i) * 1024));
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (MODE & 2) {
-            const u32x4 xa = __builtin_bit_cast(u32x4, bf);
-            acc[t][nt][0] = __uint_as_float(__float_as_uint(acc[t][nt][0]) ^ w[t][i][0] ^ w[t][i][1] ^ w[t][i][2] ^ w[t][i][3] ^ xa[0] ^ xa[1] ^ xa[2] ^ xa[3]);
-          } else
-          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][i]), bf, acc[t][nt], 0, 0, 0);
-        }
-      }
-  };
-
-  u32x4 w[RING][T][SK];
-#pragma unroll
-  for (int u = 0; u < XA; ++u)
-    if (u < nstages) { load_w(w[u], u); dma_x(u, u); }
-  for (int sg = 0; sg < nstages; sg += RING) {
-#pragma unroll
-    for (int j = 0; j < RING; ++j) {        // unrolled: ring slot j holds stage sg + j, stage sg + j + XA goes to slot (j + XA) % RING
-      const int st = sg + j;
-      if (st < nstages) {                    // block-uniform
-        // this wave's fragments of stage st have landed once at most the (XA - 1) younger stages are outstanding; near the end
-        // fewer were issued, so drain
-        if (!(MODE & 4)) {
-          if (stager && !(MODE & 1)) { if (st + XA - 1 < nstages) wait_vmcnt<(XA - 1) * PER_STAGE>(); else wait_vmcnt<0>(); }
-          __syncthreads();                   // everybody's fragments of stage st are in LDS; everybody is done with stage st - 1
-        }
-        if (st + XA < nstages) { load_w(w[(j + XA) % RING], st + XA); dma_x(st + XA, (j + XA) % RING); }
-        compute(w[j], j);
-      }
-    }
-  }
-  // ---- the KQ partial sums of a row group meet in LDS (aliasing the staging buffers), summed in split order
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);     // [q][r][t][nt][256]
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[((((size_t)q * RP + r) * T + t) * NT + nt) * 256 + lane * 4 + e] = acc[t][nt][e];
-  __syncthreads();
-  for (int it = tid; it < RP * NT * 256; it += THREADS) {
-    const int ti = it & 255, nt = (it >> 8) % NT, rr = it / (256 * NT);
-    const int l2 = ti >> 2, r2 = ti & 3;
-    const int n = nt * 16 + (l2 & 15);     // slot: C/D layout col = lane & 15
-    const int m = (l2 >> 4) * 4 + r2;      // row inside the tile
-    float v[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      float sum = 0.f;
-#pragma unroll
-      for (int qq = 0; qq < KQ; ++qq) sum += red[((((size_t)qq * RP + rr) * T + t) * NT + nt) * 256 + ti];
-      v[t] = sum;
-    }
-    const int gg = blockIdx.x * RP + rr;
-    if (gg < groups && a.bs->active[n]) gg_epilogue<EPI, T>(a, gg, n, m, v);
-  }
-}
-
-#endif  // DTK_EXPERIMENTS (k_gemm_b)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_gemv_bx — the rows >> d roles (qkv, gate/up, lm_head) at 49..64 slots with the x operand read ONCE PER CU.
@@ -1153,175 +1012,6 @@ bool launch_gemv_bx(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
 #undef BX
 }
 
-#ifdef DTK_EXPERIMENTS      // k_gemv_bk: the in-kernel exchange of its K split lost to k_gemv_bkp / k_gemv_bkl + k_resid_norm_b (partials stored, reduced by the norm kernel)
-// ------------------------------------------------------------------------------------------------------------------------
-// k_gemv_bk — the N = d roles (o_proj, down: 256 row tiles) at 49..64 slots: K split over the CUs of a row group.
-//
-// k_gemv_b gives each of the 256 one-tile blocks the whole K (8 waves x 1/8 of K): every block reads all of x — 1.4 MB for the
-// down projection at 64 slots, 360 MB per launch next to 90 MB of weights (o_proj: 131 MB next to 33.5).  Here the grid is
-// 32 row groups x 8 K slices = 256 blocks, one per CU:
-//   * block (rg, ks): TPG = 8 compute waves, wave w owns row tile rg * 8 + w over K slice ks — exactly the k-steps wave ks of the
-//     k_gemv_b block of that tile owns, accumulated the same way (MFMA accumulation from zero in k order), so the partial it
-//     produces is bit-identical to that wave's;
-//   * x: only the slice's fragments, through LDS in phases of 8 k-steps filled by a loader wave as in k_gemv_bx: x traffic =
-//     one pass over x per ROW GROUP = 32 x 1.4 MB = 45 MB for down (1/8);
-//   * the 8 partials of a tile meet in memory: a wave publishes its 16 x 64 fp32 tile with 8-byte agent-scope stores, drains
-//     them, draws a ticket from the tile's counter; the wave that draws the last ticket reads the 8 partials back with
-//     agent-scope loads, adds them in slice order 0..7 (the order of k_gemv_b's LDS reduction: bit-identical result) and runs
-//     the residual epilogue.  Nobody ever waits for another block (no spinning), so residency plays no role in correctness;
-//     8 MB of partials per launch; the 8 blocks of a row group are given consecutive-mod-8 block indices so that they land on
-//     one XCD (a placement hint only: correctness rests on the agent-scope accesses).
-// A chain of `per` k-steps is walked in phases of 8 with a ragged tail: the steady phases are branch-free (refills clamped to
-// the chain's last k-step, re-read from L2), the last phase zeroes the weights of the k-steps past the end.
-template <int TPG>
-__global__ __launch_bounds__((TPG + 1) * 64) void k_gemv_bk(GemvBArgs a) {
-  constexpr int NT = 4, PH = 8, FR = PH * NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x FR KiB
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nsteps = (a.K + 31) >> 5;
-  const int per = (nsteps + 7) >> 3;
-  const int ntiles = (a.N + 15) >> 4;
-  const int b = blockIdx.x, idx = b >> 3;
-  const int rgs_per_xcd = (int)(gridDim.x >> 6);                // grid = 8 XCDs x rgs_per_xcd row groups x 8 slices
-  const int rg = (b & 7) * rgs_per_xcd + (idx >> 3), ks = idx & 7;
-  const int s0 = min(nsteps, ks * per), s1 = min(nsteps, s0 + per);
-  const int Lc = s1 - s0;                                       // >= 1 (launcher)
-  const int nph = (Lc + PH - 1) / PH;
-
-  if (wave == TPG) {   // ---- loader wave
-    const bf16_t* xlane = a.X + lane * 8;
-    auto src = [&](int q, int f) { return xlane + ((size_t)(f / PH) * nsteps + min(s0 + q * PH + (f % PH), s1 - 1)) * 512; };
-    u32x4 xr[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(0, f));
-#pragma unroll
-    for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(smem + (size_t)f * 1024 + lane * 16) = xr[f];
-    if (nph > 1) {
-#pragma unroll
-      for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(1, f));
-    }
-    __syncthreads();
-    for (int q = 0; q < nph; ++q) {
-      if (q + 1 < nph) {
-        unsigned char* xn = smem + (size_t)((q + 1) & 1) * FR * 1024 + lane * 16;
-#pragma unroll
-        for (int f = 0; f < FR; ++f) *reinterpret_cast<u32x4*>(xn + (size_t)f * 1024) = xr[f];
-      }
-      if (q + 2 < nph) {
-#pragma unroll
-        for (int f = 0; f < FR; ++f) xr[f] = *reinterpret_cast<const u32x4*>(src(q + 2, f));
-      }
-      __syncthreads();
-    }
-    return;
-  }
-
-  // ---- compute waves
-  const int tn = rg * TPG + wave;                               // < ntiles (launcher: ntiles = row groups x TPG)
-  const unsigned char* wrow = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)tn * nsteps * 64 + lane) * 16 + (size_t)s0 * 1024;
-  u32x4 wr[PH];
-#pragma unroll
-  for (int i = 0; i < PH; ++i) wr[i] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min(i, Lc - 1) * 1024));
-  f32x4 c[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  for (int p = 0; p + 1 < nph; ++p) {                            // steady phases: all 8 k-steps inside the chain
-    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      bf16x8_t xf[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wr[j]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
-      wr[j] = ld_nt(reinterpret_cast<const u32x4*>(wrow + (size_t)min((p + 1) * PH + j, Lc - 1) * 1024));
-    }
-    __syncthreads();
-  }
-  {                                                              // last phase: k-steps past the end contribute nothing
-    const int p = nph - 1;
-    const unsigned char* xb = smem + (size_t)(p & 1) * FR * 1024 + lane * 16;
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      bf16x8_t xf[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) xf[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(xb + (size_t)(nt * PH + j) * 1024));
-      u32x4 w = wr[j];
-      if (p * PH + j >= Lc) w = (u32x4){0u, 0u, 0u, 0u};
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[nt], c[nt], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // ---- publish the partial, draw a ticket, the last arrival reduces in slice order and applies the epilogue
-  typedef unsigned long long u64;
-  u64* mine = reinterpret_cast<u64*>(a.kpart) + (((size_t)ks * ntiles + tn) * NT) * 128 + lane * 2;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    __hip_atomic_store(mine + nt * 128, (u64)__float_as_uint(c[nt][0]) | ((u64)__float_as_uint(c[nt][1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(mine + nt * 128 + 1, (u64)__float_as_uint(c[nt][2]) | ((u64)__float_as_uint(c[nt][3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing lane is in this wave
-  unsigned ticket = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(a.kctr + tn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __shfl(ticket, 0, 64);
-  if (ticket != 7u) return;
-  f32x4 sum[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) sum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < 8; ++s) {
-    const u64* src = reinterpret_cast<const u64*>(a.kpart) + (((size_t)s * ntiles + tn) * NT) * 128 + lane * 2;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const u64 lo = __hip_atomic_load(src + nt * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 hi = __hip_atomic_load(src + nt * 128 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sum[nt][0] += __uint_as_float((unsigned)lo); sum[nt][1] += __uint_as_float((unsigned)(lo >> 32));
-      sum[nt][2] += __uint_as_float((unsigned)hi); sum[nt][3] += __uint_as_float((unsigned)(hi >> 32));
-    }
-  }
-  if (lane == 0) __hip_atomic_store(a.kctr + tn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + (lane & 15);
-    if (!a.bs->active[n]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = tn * 16 + (lane >> 4) * 4 + r;
-      if (row < a.N) {
-        bf16_t* y = a.Y + (size_t)n * a.ldy + row;
-        *y = f2bf(bf2f(*y) + rbf(sum[nt][r]));
-      }
-    }
-  }
-}
-
-// false = not covered: fp8 weights, fewer than 49 slots, other roles, a tile count that is not 32 row groups of 4 or 8 tiles,
-// a K that leaves one of the 8 slices empty, no partial buffer
-bool launch_gemv_bk(int epi, int variant, const GemvBArgs& a, hipStream_t s) {
-  if (a.W8 || a.nt < 3 || variant <= 0 || epi != EPI_RESID || !a.kpart || !a.kctr) return false;
-  const int ntiles = (a.N + 15) >> 4, nsteps = (a.K + 31) >> 5, per = (nsteps + 7) >> 3;
-  if ((a.N & 15) || (a.K & 31) || 7 * per >= nsteps) return false;
-  constexpr int lds = 2 * 8 * 4 * 1024;
-  if (ntiles == 256) {
-    static unsigned long long attr8 = 0;
-    if (dtk_lds_attr_todo(attr8)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
-    hipLaunchKernelGGL((k_gemv_bk<8>), dim3(256), dim3(9 * 64), lds, s, a);
-    return true;
-  }
-  if (ntiles == 128) {
-    static unsigned long long attr4 = 0;
-    if (dtk_lds_attr_todo(attr4)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_bk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
-    hipLaunchKernelGGL((k_gemv_bk<4>), dim3(256), dim3(5 * 64), lds, s, a);
-    return true;
-  }
-  return false;
-}
-#else
-bool launch_gemv_bk(int, int, const GemvBArgs&, hipStream_t) { return false; }
-#endif  // DTK_EXPERIMENTS (k_gemv_bk)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_gemv_bkp + k_resid_norm_b — the N = d roles at 33..64 slots as TWO launches: K split over the CUs of a row group, the
@@ -1736,74 +1426,3 @@ void launch_resid_norm_b(const float* part, bf16_t* X, int ldx, const bf16_t* w,
   else hipLaunchKernelGGL((k_resid_norm_b<4>), dim3(nslots), dim3(1024), 0, s, part, X, ldx, w, Y, D, eps, bs, Y8, YS);
 }
 
-#ifdef DTK_EXPERIMENTS
-template <int EPI, int T, int KQ, int RP, int NT, int SK, int XA>
-static void launch_one(const GemvBArgs& a, hipStream_t s) {
-  const int groups = gg_groups<EPI, T>(a.N, a.ff, a.H, a.KVH);
-  constexpr size_t staging = (size_t)(XA + 1) * KQ * SK * NT * 1024, reduction = (size_t)KQ * RP * T * NT * 1024;
-  const size_t lds = staging > reduction ? staging : reduction;
-  static unsigned long long attr_set = 0;
-  if (lds > 48 * 1024 && dtk_lds_attr_todo(attr_set)) {
-    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL((k_gemm_b<EPI, T, KQ, RP, NT, SK, XA>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a);
-}
-
-// shape (K splits x row groups, k-steps per stage, stages ahead); 8 waves per block:
-//        rows >> d roles (qkv, gate/up, lm_head)                       |   N = d roles (o_proj, down: 256 row tiles)
-//   1    2 x 4, 4, 3   172 blocks for gate/up, x traffic / 4           |   4 x 2, 2, 3  (128 blocks, x traffic / 2)
-//   2    4 x 2, 2, 3   344 blocks, x traffic / 2                       |   4 x 2, 2, 3
-//   3    2 x 4, 4, 2                                                   |   4 x 2, 2, 2
-//   4    2 x 4, 2, 3   shorter stages                                  |   8 x 1, 2, 1  (256 blocks, no sharing)
-template <int EPI, int T, int NT>
-static bool launch_shape(int shape, const GemvBArgs& a, hipStream_t s) {
-  if constexpr (EPI == EPI_RESID) {
-    switch (shape) {
-      case 1: case 2: launch_one<EPI, T, 4, 2, NT, 2, 3>(a, s); return true;
-      case 3: launch_one<EPI, T, 4, 2, NT, 2, 2>(a, s); return true;
-      case 4: launch_one<EPI, T, 8, 1, NT, 2, 1>(a, s); return true;
-      default: return false;
-    }
-  } else {
-    switch (shape) {
-      case 1: launch_one<EPI, T, 2, 4, NT, 4, 3>(a, s); return true;
-      case 2: launch_one<EPI, T, 4, 2, NT, 2, 3>(a, s); return true;
-      case 3: launch_one<EPI, T, 2, 4, NT, 4, 2>(a, s); return true;
-      case 4: launch_one<EPI, T, 2, 4, NT, 2, 3>(a, s); return true;
-      default: return false;
-    }
-  }
-}
-template <int NT>
-static bool launch_nt(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
-  if (epi == EPI_QKV) return launch_shape<EPI_QKV, 2, NT>(shape, a, s);
-  if (epi == EPI_SWIGLU) return launch_shape<EPI_SWIGLU, 2, NT>(shape, a, s);
-  if (epi == EPI_RESID) return launch_shape<EPI_RESID, 1, NT>(shape, a, s);
-  if (epi == EPI_LOGITS) return launch_shape<EPI_LOGITS, 2, NT>(shape, a, s);
-  return false;
-}
-// timing experiments: the gate/up role at 64 slots, shape 1 or 2, with parts of the kernel removed (MODE bits above)
-void launch_gemm_b_mode(int shape, int mode, const GemvBArgs& a, hipStream_t s) {
-  const int groups = gg_groups<EPI_SWIGLU, 2>(a.N, a.ff, a.H, a.KVH);
-#define GMM(KQ, RP, SK, XA, M) do { const size_t lds = (size_t)(XA + 1) * KQ * SK * 4 * 1024; \
-    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_gemm_b<EPI_SWIGLU, 2, KQ, RP, 4, SK, XA, M>), dim3((groups + RP - 1) / RP), dim3(KQ * RP * 64), lds, s, a); } while (0)
-#define GMS(KQ, RP, SK, XA) switch (mode) { case 1: GMM(KQ, RP, SK, XA, 1); break; case 2: GMM(KQ, RP, SK, XA, 2); break; case 4: GMM(KQ, RP, SK, XA, 4); break; \
-    case 5: GMM(KQ, RP, SK, XA, 5); break; case 8: GMM(KQ, RP, SK, XA, 8); break; case 9: GMM(KQ, RP, SK, XA, 9); break; case 13: GMM(KQ, RP, SK, XA, 13); break; \
-    case 7: GMM(KQ, RP, SK, XA, 7); break; default: GMM(KQ, RP, SK, XA, 0); }
-  if (shape == 2) { GMS(4, 2, 2, 3) } else { GMS(2, 4, 4, 3) }
-#undef GMS
-#undef GMM
-}
-
-// returns false when this path does not cover the request (fp8 weights, EPI_STORE, shape 0): the caller uses k_gemv_b
-bool launch_gemm_b(int epi, int shape, const GemvBArgs& a, hipStream_t s) {
-  if (a.W8 || shape <= 0) return false;
-  if (a.nt >= 3) return launch_nt<4>(epi, shape, a, s);
-  if (a.nt == 2) return launch_nt<2>(epi, shape, a, s);
-  return launch_nt<1>(epi, shape, a, s);
-}
-#else   // the LDS-staged batched GEMM is an experiment: not built, "gemm_b" stays 0
-void launch_gemm_b_mode(int, int mode, const GemvBArgs& a, hipStream_t s) { launch_gemv_b_mode(mode, a, s); }
-bool launch_gemm_b(int, int, const GemvBArgs&, hipStream_t) { return false; }
-#endif  // DTK_EXPERIMENTS

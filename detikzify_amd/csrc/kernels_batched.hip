@@ -198,117 +198,6 @@ __device__ __forceinline__ void gemm_glds16(const void* gsrc, unsigned lds_byte)
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-#ifdef DTK_EXPERIMENTS      // k_gemm_dma: no faster than k_gemm_mfma (round 2); superseded by k_gemm_glds / k_gemm_g3
-template <int TBM, int TBN, int RING>
-__global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs a) {
-  constexpr int TM = TBM / 32, TN = TBN / 32;        // MFMA tiles per wave (2 x 2 wave grid)
-  constexpr int AF = (TBM / 16) * 2, WF = (TBN / 16) * 2;   // 1 KiB fragments of one k-tile: (row tile, k-step) of A, of W
-  constexpr int SF = AF + WF;
-  constexpr int FPW = SF / 4;                        // fills per wave and k-tile
-  constexpr int XA = RING - 1;                       // k-tiles in flight ahead of the one being multiplied
-  static_assert(SF % 4 == 0 && (XA - 1) * FPW < 64, "fills divide over the four waves; vmcnt is 6 bits");
-  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];   // RING x SF KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int MB = (a.M + TBM - 1) / TBM, NB = (a.N + TBN - 1) / TBN;
-  const int b = blockIdx.x;
-  const int nt = (b & 7) + 8 * ((b >> 3) / MB), mb = (b >> 3) % MB;   // XCD-aware map (see k_gemm_mfma)
-  if (nt >= NB) return;
-  const int m0 = mb * TBM, n0 = nt * TBN;
-  const int K = a.K;
-  const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
-
-  // this wave's FPW fragments: f < AF -> A rows, else W rows; source pointer of this lane at k = 0
-  const bf16_t* src[FPW];
-#pragma unroll
-  for (int j = 0; j < FPW; ++j) {
-    const int f = wave * FPW + j;
-    const bool isA = f < AF;
-    const int ff = isA ? f : f - AF;
-    const int rt = ff >> 1, ks = ff & 1;
-    int row = (isA ? m0 : n0) + rt * 16 + (lane & 15);
-    const int lim = isA ? a.M : a.N;
-    if (row >= lim) row = lim - 1;                   // valid memory; such rows / columns are never stored
-    src[j] = (isA ? a.A + (size_t)row * a.lda : a.W + (size_t)row * a.ldw) + ks * 32 + (lane >> 4) * 8;
-  }
-  auto fill = [&](int t, int slot) {                 // k-tile t -> ring slot
-#pragma unroll
-    for (int j = 0; j < FPW; ++j) {
-      const unsigned dst = lds0 + (unsigned)((slot * SF + wave * FPW + j) * 1024);
-      gemm_glds16(src[j] + (size_t)t * 64, __builtin_amdgcn_readfirstlane(dst));
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto multiply = [&](int slot) {
-    const unsigned char* sb = gsm + (size_t)slot * SF * 1024 + lane * 16;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (size_t)(((wr * TM + i) << 1) + ks) * 1024);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + (size_t)(AF + ((wc * TN + j) << 1) + ks) * 1024);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nkf = K >> 6;                            // full 64-wide k-tiles: these go through the DMA ring
-#pragma unroll
-  for (int u = 0; u < XA; ++u)
-    if (u < nkf) fill(u, u);
-  for (int t0 = 0; t0 < nkf; t0 += RING) {
-#pragma unroll
-    for (int j = 0; j < RING; ++j) {
-      const int t = t0 + j;
-      if (t < nkf) {
-        if (t + XA - 1 < nkf) gemm_wait_vmcnt<(XA - 1) * FPW>(); else gemm_wait_vmcnt<0>();   // this wave's fills of k-tile t have landed
-        __syncthreads();                             // everybody's have; everybody is done with k-tile t - 1
-        if (t + XA < nkf) fill(t + XA, (j + XA) % RING);
-        multiply(j);
-      }
-    }
-  }
-  // K tail (K % 64 != 0, K % 8 == 0): one zero-filled k-tile through registers
-  if (K & 63) {
-    __syncthreads();
-    const int k0 = nkf << 6;
-#pragma unroll
-    for (int j = 0; j < FPW; ++j) {
-      const int f = wave * FPW + j;
-      const int ks = (f < AF ? f : f - AF) & 1;
-      const int k = k0 + ks * 32 + (lane >> 4) * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (k < K) v = *reinterpret_cast<const u32x4*>(src[j] + (size_t)k0);
-      *reinterpret_cast<u32x4*>(gsm + (size_t)f * 1024 + lane * 16) = v;
-    }
-    __syncthreads();
-    multiply(0);
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * (TBM / 2) + i * 16 + (lane >> 4) * 4 + r;
-        const int n = n0 + wc * (TBN / 2) + j * 16 + (lane & 15);
-        if (m < a.M && n < a.N)
-          a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc[i][j][r], m, n, a));
-      }
-}
-
-#endif  // DTK_EXPERIMENTS (k_gemm_dma)
 
 // ------------------------------------------------------------------------------------------
 // k_gemm_glds: the GEMM for shapes with enough tiles to fill the chip at 128 x 128 (batched ViT M = images x 729, long prompts, the
@@ -645,17 +534,6 @@ static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
 void set_gemm_ring(int v) { g_gemm_ring = v; }
-#ifdef DTK_EXPERIMENTS
-template <int BM, int BN, int RING>
-static void launch_gemm_dma_t(const GemmArgs& a, hipStream_t s, dim3 grid) {
-  constexpr size_t lds = (size_t)RING * ((BM / 16) * 2 + (BN / 16) * 2) * 1024;
-  static unsigned long long attr_set = 0;
-  if (lds > 48 * 1024 && dtk_lds_attr_todo(attr_set)) {
-    DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<BM, BN, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL((k_gemm_dma<BM, BN, RING>), grid, dim3(256), lds, s, a);
-}
-#endif
 
 static int g_gemm_stages = -1;  // register stages of the 64x64 kernel: 1..4 (dtk_set_option "gemm_stages" / DTK_GEMM_STAGES), default 3
 void set_gemm_stages(int v) { g_gemm_stages = v; }
@@ -690,19 +568,6 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s) {
   // ViT + projector + prefill) — then k_gemm_glds for M >= 1024, then k_gemm_mfma; all bit-identical
   if ((g_gemm_impl == 3 || g_gemm_impl == 4) && !gemm_tile_override() && launch_gemm_g3(a, s)) return;
   if ((g_gemm_impl == 2 || ((g_gemm_impl == 3 || g_gemm_impl == 4) && a.M >= 1024)) && !gemm_tile_override() && launch_gemm_glds(a, s)) return;
-#ifdef DTK_EXPERIMENTS
-  if (g_gemm_impl == 1 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.K >= 64 && tile != 5) {   // 16-byte aligned rows; 32x32 tiles stay on k_gemm_mfma
-    const int ring = g_gemm_ring;
-#define DMA_LAUNCH(BM_, BN_) do { if (ring == 2) launch_gemm_dma_t<BM_, BN_, 2>(a, s, grid(BM_, BN_)); else if (ring == 4) launch_gemm_dma_t<BM_, BN_, 4>(a, s, grid(BM_, BN_)); \
-                                  else launch_gemm_dma_t<BM_, BN_, 3>(a, s, grid(BM_, BN_)); } while (0)
-    if (tile == 3) DMA_LAUNCH(128, 128);
-    else if (tile == 2) DMA_LAUNCH(128, 64);
-    else if (tile == 4) DMA_LAUNCH(64, 32);
-    else DMA_LAUNCH(64, 64);
-#undef DMA_LAUNCH
-    return;
-  }
-#endif
   if (g_gemm_stages < 0) { const char* e = getenv("DTK_GEMM_STAGES"); g_gemm_stages = e ? atoi(e) : 3; }
   const int D = g_gemm_stages;
 #define GEMM_LAUNCH(BM_, BN_)                                                                                         \

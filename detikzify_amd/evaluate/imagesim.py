@@ -68,9 +68,6 @@ class ImageSim:
         self.model, self.processor = model, processor
         self.mode, self.preprocess = mode, preprocess
         self.cache_reference = cache_reference
-        # util.image_prep.PrepPool or None: expand(trim) + the processor's resize of a rendered figure in a worker process (Pillow
-        # holds the GIL through both; a parallel search's reward wave is 64 of them at once) — same functions, bit-identical pixels
-        self.prep_pool = None
         self._ref_cache: Dict[bytes, torch.Tensor] = {}
         self._acc = threading.local()
         self.reset()
@@ -88,17 +85,10 @@ class ImageSim:
     # ---- features --------------------------------------------------------------------------------
     def get_vision_features(self, image: Union[Image.Image, str]) -> torch.Tensor:
         image = load(image)
-        enc = None
-        spec = getattr(self.processor, "resize_spec", lambda: None)() if (self.prep_pool is not None and self.preprocess) else None
-        if spec is not None:
-            arr = self.prep_pool.expand_and_resize(image, *spec)
-            if arr is not None:
-                enc = self.processor.resized_pixel_values(arr, return_tensors="pt")
-        if enc is None and self.preprocess:
+        if self.preprocess:
             image = expand(image, max(image.size), do_trim=True)
         with torch.inference_mode():
-            if enc is None:
-                enc = self.processor(images=image, return_tensors="pt")
+            enc = self.processor(images=image, return_tensors="pt")
             if self.mode == "cos" and hasattr(self.model, "pooled_only"):
                 return self.model.pooled_only(enc["pixel_values"]).squeeze()    # same value, no patch-feature copy-back
             out = self.model(**enc)

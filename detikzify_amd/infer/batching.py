@@ -120,19 +120,6 @@ class BatchEngine:
         # trickle in one pipeline flush at a time); gives up after gather_timeout seconds
         self.gather_left = min(int(gather), self.capacity)
         self.gather_deadline = time.perf_counter() + gather_timeout
-        # Multi-step runs (dtk_decode_batch_run): while every active sequence is a push sequence the driver can hand the device up to
-        # `run_steps` steps per native call and wake only when a sequence ends (EOS / length), somebody wants the context (join,
-        # leave: `_interrupt`), or the run is used up — instead of one launch / wait / dispatch round trip per token.  OPT-IN
-        # (DTK_ENGINE_RUN_STEPS=8): measured on the MI355X it LOSES to the per-step loop — 64 trees x 2 expansions, stub reward: 18.7
-        # rollouts/s per step, 17.0 with runs of 8, 16.5 with runs of 32 (profiles/r04_engine_run_steps.json) — the per-step loop
-        # already hides its Python under the GPU's next step (2 host-bound steps of 1032), while a run hands the GIL to the 64
-        # rollout / reward threads for tens of milliseconds and the driver then queues for it behind them.  What it does buy is host
-        # CPU: the driver thread spends its time in native code (tools/host_emulation.py).  The C entry point is there for native
-        # callers either way.
-        import ctypes
-        self.run_steps = max(1, int(os.environ.get("DTK_ENGINE_RUN_STEPS", "1"))) if callable(getattr(model, "decode_batch_run", None)) else 1
-        self._interrupt = ctypes.c_int32(0)
-        self.runs = 0
         model.batch_engine = self
 
     @contextmanager
@@ -141,7 +128,6 @@ class BatchEngine:
         next step the moment it has released it would starve joining / leaving sequences — it waits while `pending` > 0"""
         with self._plock:
             self.pending += 1
-            self._interrupt.value = 1       # a multi-step run in progress returns after its current step
         try:
             with self.cv:
                 yield
@@ -162,7 +148,7 @@ class BatchEngine:
         return {"engine": "python", "steps": self.steps, "tokens_out": self.tokens_out, "wait_s": round(self.t_wait, 3), "launch_s": round(self.t_launch, 3),
                 "prefill_s": round(self.t_prefill, 3), "host_bound_steps": self.host_bound_steps, "prefix_encodes": self.prefix_encodes,
                 "inplace_reuses": self.inplace_reuses, "joins": self.joins, "resumed_in_place": self.resumes, "idle_between_steps_s": round(self.t_idle, 3),
-                "steps_below_half_occupancy": self.slot_steps_short, "native_runs": self.runs}
+                "steps_below_half_occupancy": self.slot_steps_short}
 
     def close(self):
         with self._locked():
@@ -417,8 +403,6 @@ class BatchEngine:
             if time.perf_counter() < self.gather_deadline:
                 return False            # more sequences are about to join
             self.gather_left = 0
-        if self.run_steps > 1 and self.pipeline and self.active <= set(self.sinks) and self._run_many():
-            return True
         if self.inflight is None:
             self._launch()
         pushed = self._collect(dispatch=False)
@@ -427,85 +411,6 @@ class BatchEngine:
             self._launch()              # speculative, like for the pull sequences: the push sequences' host work below
         self._dispatch(pushed)          # runs under the GPU's next step; one that stops discards its token of that step
         self.ready.update(s for s in self.sinks if s in self.active)     # push sequences never run dry
-        return True
-
-    def _run_many(self) -> bool:
-        """one native call = up to run_steps decode steps for the current active set (all push sequences), then every sequence gets
-        its tokens of the run in one piece.  False: not applicable right now (the step in flight belongs to another active set, a
-        slot has no room) — the caller takes the per-step path."""
-        lim = self.model.config.max_positions
-        slots = [s for s in sorted(self.active) if self.model.lib.dtk_context_len_slot(self.model._ctx, s) < lim]
-        if not slots or self.error is not None or len(slots) != len(self.active):
-            return False
-        if self.inflight is not None and self.inflight != slots:
-            return False                # that step is collected the old way first; the next call starts a run
-        budgets = {}
-        stop_ids: set = set()
-        for s in slots:
-            emit = self.sinks[s]
-            b = getattr(emit, "budget", None)
-            # (a resumed slot's first step forwards its forced prompt token: not counted against the sequence's length budget)
-            budgets[s] = (int(b()) if callable(b) else (1 << 30)) + (1 if s in self.skip_first else 0)
-            stop_ids |= set(getattr(emit, "stop_ids", ()) or ())
-            if budgets[s] < 1:
-                return False
-        try:
-            t0 = time.perf_counter()
-            if self.t_first_launch is None:
-                self.t_first_launch = t0
-            if self._t_free_since is not None and self.inflight is None:
-                self.t_idle += t0 - self._t_free_since
-            self._t_free_since = None
-            if 2 * len(slots) < self.capacity:
-                self.slot_steps_short += 1
-            with self._plock:
-                self._interrupt.value = 1 if self.pending > 0 else 0
-            toks, steps, inflight = self.model.decode_batch_run(slots, self.run_steps, budgets, stop_ids, self._interrupt)
-            dt = time.perf_counter() - t0
-            self.t_wait += dt
-            self.t_last_collect = t0 + dt
-            self.runs += 1
-        except BaseException as e:
-            self._fail(e)
-            return True
-        self.steps += steps
-        self.inflight = slots if inflight else None
-        if not inflight:
-            self._t_free_since = time.perf_counter()
-        self.ready.clear()
-        n = len(toks) // steps if steps else 0
-        for s in slots:
-            emit = self.sinks.get(s)
-            if emit is None or s not in self.active:
-                continue
-            mine = toks[s::n][:steps] if steps else []
-            if mine and s in self.skip_first:       # the forced last prompt token of a resumed slot: already part of the prompt
-                self.skip_first.discard(s)
-                mine = mine[1:]
-            if not mine:
-                continue
-            self.tokens_out += len(mine)
-            exc = None
-            try:
-                many = getattr(emit, "many", None)
-                if many is not None:
-                    stop = many(mine)
-                else:
-                    stop = False
-                    for tok in mine:
-                        if emit(tok):
-                            stop = True
-                            break
-            except BaseException as e:  # noqa: BLE001  (re-raised in the sequence's own thread)
-                stop, exc = True, e
-            if stop:
-                self.active.discard(s)
-                self.ready.discard(s)
-                del self.sinks[s]
-                self.finished[s] = exc
-                self.tokq[s].put(_NUDGE)
-        self.ready.update(s for s in self.sinks if s in self.active)
-        self.cv.notify_all()
         return True
 
     def _run(self, slot: int, emit: Callable[[int], bool]):
@@ -620,12 +525,6 @@ def simulate_parallel_images(pipeline, images, trees_per_image: int, expansions_
     # another tree to finish its rollout and go off to its reward — with rewards that take seconds that keeps the batch full
     engine = make_engine(pipeline.model, processor=pipeline.processor, max_batch=min(trees, slots) if slots else trees, gather=trees,
                          resume_in_place=resume_in_place) if trees > 1 else None
-    # the trees' rewards arrive in waves: their Pillow work (trim, LANCZOS pad, BICUBIC resize: all under the GIL) goes to the
-    # process-wide worker pool when there is one (util/image_prep.py; bit-identical pixels)
-    metric = getattr(pipeline, "metric", None)
-    if trees > 1 and metric is not None and hasattr(metric, "prep_pool") and metric.prep_pool is None:
-        from ..util.image_prep import shared_pool
-        metric.prep_pool = shared_pool()
     out: "queue.Queue" = queue.Queue()
     trace_path = os.environ.get("DTK_TRACE_MCTS")
     trace: Optional[List[Tuple[float, int, str]]] = [(time.perf_counter(), -1, "start")] if trace_path else None

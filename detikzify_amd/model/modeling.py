@@ -383,31 +383,6 @@ class DetikzifyForCausalLM:
         self._check(self.lib.dtk_decode_batch_wait(self._ctx, out), "dtk_decode_batch_wait")
         return [int(v) for v in out]
 
-    def decode_batch_run(self, active_slots: Iterable[int], max_steps: int, budgets: Optional[Dict[int, int]] = None,
-                         stop_ids: Iterable[int] = (), interrupt=None) -> Tuple[List[int], int, bool]:
-        """dtk_decode_batch_run: up to max_steps steps for one active set in ONE native call (GIL released throughout); returns
-        (tokens [steps * DTK_MAX_BATCH], steps, a further step of the same set is still in flight).  `interrupt`: a
-        ctypes.c_int32 another thread sets to make the run return after its current step."""
-        n = _lib.DTK_MAX_BATCH
-        arr = (C.c_int32 * n)()
-        for j in active_slots:
-            arr[int(j)] = 1
-        bud = None
-        if budgets is not None:
-            bud = (C.c_int32 * n)()
-            for j, b in budgets.items():
-                bud[int(j)] = max(0, min(int(b), 2 ** 30))
-        stops = [int(t) for t in stop_ids]
-        stop_arr = (C.c_int64 * max(1, len(stops)))(*stops)
-        buf = getattr(self, "_run_buf", None)
-        if buf is None or len(buf) < max_steps * n:
-            buf = self._run_buf = (C.c_int64 * (max_steps * n))()
-        steps, infl = C.c_int32(0), C.c_int32(0)
-        self._check(self.lib.dtk_decode_batch_run(self._ctx, arr, int(max_steps), bud, stop_arr, len(stops),
-                                                  C.byref(interrupt) if interrupt is not None else None, buf, C.byref(steps), C.byref(infl)),
-                    "dtk_decode_batch_run")
-        return buf[:steps.value * n], int(steps.value), bool(infl.value)
-
     def kv_fork(self, src_slot: int, dst_slot: int, n_tokens: int):
         self._check(self.lib.dtk_kv_fork(self._ctx, int(src_slot), int(dst_slot), int(n_tokens)), "dtk_kv_fork")
 

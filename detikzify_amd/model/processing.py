@@ -98,22 +98,6 @@ class DetikzifyImageProcessor:
         pil = Image.fromarray(arr)
         return np.array(pil.resize((w, h), resample=Image.Resampling(self.resample), reducing_gap=None))
 
-    def resize_spec(self):
-        """(width, height, PIL resample) of this processor's resize step, or None — what util.image_prep's workers need to run it"""
-        return (self.size["width"], self.size["height"], int(self.resample)) if self.do_resize else None
-
-    def resized_pixel_values(self, arr: np.ndarray, return_tensors: Optional[str] = None) -> BatchFeature:
-        """the rest of preprocess() for ONE image that already went through _to_numpy + _resize (uint8 [h, w, 3], e.g. in a worker
-        process of util.image_prep): rescale + normalise by the same per-channel lookup, same values bit for bit"""
-        if not (arr.dtype == np.uint8 and arr.ndim == 3 and arr.shape[2] == len(self.image_mean)):
-            raise ValueError("resized_pixel_values expects the uint8 [h, w, channels] output of the resize step")
-        x = np.ascontiguousarray(np.stack([self._lut(c)[arr[:, :, c]] for c in range(arr.shape[2])]))
-        if return_tensors == "pt":
-            return BatchFeature(pixel_values=torch.from_numpy(x[None]))
-        if return_tensors == "np":
-            return BatchFeature(pixel_values=x[None])
-        return BatchFeature(pixel_values=[x])
-
     def preprocess(self, images, return_tensors: Optional[str] = None, **_) -> BatchFeature:
         if not isinstance(images, (list, tuple)):
             images = [images]

@@ -25,9 +25,10 @@ extern "C" {
 #endif
 
 #define DTK_ABI_VERSION 6   /* 2: batch arrays of 32 entries (were 16); 3: DTK_MAX_BATCH = 64; 4: dtk_max_decode_slots,
-                             * dtk_decode_batch_run, contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels);
+                             * contexts with <= 5 slots decode in slots 0..3 (multi-vector kernels);
                              * 5: dtk_op_gemv_mx, dtk_mx_layout, dtk_stats.last_batch_step_fp8_mfma;
-                             * 6: dtk_engine_* (the native run loop of a batch), dtk_max_positions; dtk_last_error is per calling thread */
+                             * 6: dtk_engine_* (the native run loop of a batch; replaces ABI 4's dtk_decode_batch_run), dtk_max_positions; dtk_last_error is
+                             * per calling thread */
 
 typedef struct dtk_ctx dtk_ctx;
 
@@ -212,18 +213,6 @@ int  dtk_prefill_slot(dtk_ctx* ctx, int slot, const int64_t* ids, int T, const f
 int  dtk_set_sampling_slot(dtk_ctx* ctx, int slot, const dtk_sampling* s);
 int  dtk_decode_batch_launch(dtk_ctx* ctx, const int32_t* active /* [DTK_MAX_BATCH] */);
 int  dtk_decode_batch_wait(dtk_ctx* ctx, int64_t* tokens_out /* [DTK_MAX_BATCH] */);
-/* Up to max_steps steps for one active set without returning to the host in between (the next step is launched before the last
- * one's tokens are inspected).  Returns after the step in which a slot emitted one of stop_ids[0..n_stop), or used up budget[slot]
- * (tokens it may still emit; NULL = bounded by max_positions only), or *interrupt became non-zero (NULL = never: polled once per
- * step, set by another host thread that wants the context), or max_steps were collected.  tokens_out[k * DTK_MAX_BATCH + slot] = the
- * token of the k-th collected step (-1: inactive); *steps_out = collected steps; *inflight_out = 1 if one more step of the same
- * active set is still in flight (collect it with dtk_decode_batch_wait or the next run: a sequence that ended discards its token of
- * that step).  A step in flight on entry must have the same active set and is collected first.  Replaces the per-token
- * launch / wait / dispatch round trip of the host loop (reference: HF GenerationMixin._sample's per-token Python iteration,
- * generation/utils.py:2875-2936, under detikzify/infer/generate.py:246-282). */
-int  dtk_decode_batch_run(dtk_ctx* ctx, const int32_t* active /* [DTK_MAX_BATCH] */, int max_steps, const int32_t* budget /* [DTK_MAX_BATCH] or NULL */,
-                          const int64_t* stop_ids, int n_stop, const volatile int32_t* interrupt, int64_t* tokens_out /* [max_steps][DTK_MAX_BATCH] */,
-                          int32_t* steps_out, int32_t* inflight_out);
 int  dtk_kv_fork(dtk_ctx* ctx, int src_slot, int dst_slot, int n_tokens);   /* share a prefix's KV (f1) */
 /* f1, same-slot reuse for returning MCTS trees (reference infer/generate.py:305-353 re-prefills the path to the selected node
  * on every rollout): dtk_slot_lcp = how many leading tokens of `ids` the slot's KV cache still holds (prefilled or decoded, same

@@ -49,17 +49,6 @@ def bf16_bits(t):
     return f32_to_bits(torch.as_tensor(t, dtype=torch.float32))
 
 
-def has_experiments(model) -> bool:
-    """the kernel families that lost their measurements (k_gemm_b, k_gemv_bk, k_gemm_dma) are only built with
-    DTK_EXPERIMENTS=1 ./build.sh; the tests of their bit-identity run where they exist"""
-    from detikzify_amd._lib import DtkError
-    try:
-        model.set_option("experiments", 1)
-        return True
-    except DtkError:
-        return False
-
-
 def ulp_report(got_bits, ref_f32):
     """fraction of elements that differ, max difference in bf16 ulps of the reference"""
     got = bits_to_f32(got_bits).reshape(-1)
@@ -150,17 +139,6 @@ def test_op_gemm_tile_variants_are_bit_identical(tiny, M, N, K, flags):
     model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
     model.set_option("gemm_bk", 64); model.set_option("gemm_tile", 0)
     assert np.array_equal(out, outs[1])
-    # k_gemm_dma (DTK_EXPERIMENTS builds): operand tiles written to LDS by the LDS-DMA path in MFMA fragment order, ring of 2..4 stages — same k order
-    try:
-        if has_experiments(model):
-            model.set_option("gemm_impl", 1)
-        for tile, ring in ((1, 3), (1, 2), (1, 4), (2, 3), (3, 3), (3, 2), (4, 3), (0, 3)) if has_experiments(model) else ():
-            model.set_option("gemm_tile", tile); model.set_option("gemm_ring", ring)
-            out = np.empty((M, N), dtype=np.uint16)
-            model._check(model.lib.dtk_op_gemm(model._ctx, p(Ab), p(Wb), p(bb), p(Rb), M, N, K, flags, p(out)), "dtk_op_gemm")
-            assert np.array_equal(out, outs[1]), (tile, ring)
-    finally:
-        model.set_option("gemm_impl", 3); model.set_option("gemm_tile", 0); model.set_option("gemm_ring", 3)
     # k_gemm_glds: 128 x 128 tiles, both operands by LDS-DMA in full 128-byte lines into an XOR-swizzled [row][chunk] image, two
     # LDS stages; K % 64 != 0 ends in a register-staged zero-filled tile (432, 304, 688, 4304 here); M, N tails clamp + mask
     try:
@@ -1374,55 +1352,20 @@ def test_v2_checkpoint_roundtrip_and_emd_selfsim(tmp_path, tiny_v2):
 
 
 # ------------------------------------------------------------------------------------------ 32 slots (two MFMA column tiles)
-@pytest.mark.parametrize("nslots,gemm_b", [(32, 0), (64, 0), (32, 1), (64, 1), (64, 2), (64, 3), (64, 4)])
-def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots, gemm_b):
+@pytest.mark.parametrize("nslots", [32, 64])
+def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots):
     """load(batch_slots=33 | 65): slots 0..31 | 0..63 decode in one step (two | four 16-column MFMA tiles reuse each
     weight fragment).  Every slot's tokens and logits equal the same sequence decoded on the 16-slot build: the
-    per-column arithmetic (k order, reduction order) does not depend on the tile count — for the register-operand kernels
-    (gemm_b 0) and for every block shape of the LDS-staged ones (gemm_b 1..4, kernels_batch_gemm.hip)."""
+    per-column arithmetic (k order, reduction order) does not depend on the tile count."""
     from detikzify_amd.model import load
     m16, proc = tiny_batched
-    if gemm_b and not has_experiments(m16):
-        pytest.skip("k_gemm_b is built with DTK_EXPERIMENTS=1 ./build.sh only")
     m32, _ = load("detikzify-tiny", synthetic=1234, batch_slots=nslots + 1)
     assert m32.num_slots() == nslots + 1
     # the attention block shape is a property of the context's size (2-wave blocks with 64 decoding slots, 4-wave blocks below:
     # csrc/dtk_api.hip, dtk_create); bit-identity ACROSS contexts holds for equal shapes, so the larger context takes m16's here
     m32.set_option("tail_threads", 256)
     m32.set_option("prefix_mfma", 0)
-    m16.set_option("gemm_b", gemm_b)          # process-wide switch; each context drops its captured graphs
-    m32.set_option("gemm_b", gemm_b)
-    try:
-        _check_slot_count_invariance(m16, m32, proc, nslots)
-    finally:
-        m16.set_option("gemm_b", 0)
-        m32.set_option("gemm_b", 0)
-
-
-def test_lds_staged_batched_gemm_tracks_the_register_kernels(tiny_batched):
-    """k_gemm_b (x through LDS, K split 4 / 8 ways) vs k_gemv_b (x in registers, K split 8 ways): same greedy tokens, logits
-    within fp32 summation order"""
-    model, proc = tiny_batched
-    if not has_experiments(model):
-        pytest.skip("k_gemm_b is built with DTK_EXPERIMENTS=1 ./build.sh only")
-    prompts = _batch_prompts(proc)
-    runs = {}
-    try:
-        for shape in (0, 1, 2, 3, 4):
-            model.set_option("gemm_b", shape)
-            for s_, (ids, px) in enumerate(prompts):
-                model.set_sampling(do_sample=False, bad_ids=[1], slot=s_)
-                model.prefill(ids, px, slot=s_)
-            toks = []
-            for _ in range(20):
-                model.decode_batch_launch([0, 1, 2])
-                toks.append(model.decode_batch_wait()[:3])
-            runs[shape] = (toks, [model.get_logits_slot(s_) for s_ in range(3)])
-    finally:
-        model.set_option("gemm_b", 0)
-    for shape in (1, 2, 3, 4):
-        assert runs[shape][0] == runs[0][0], shape
-        assert all(rel_l2(a, b) < 2e-3 for a, b in zip(runs[shape][1], runs[0][1])), shape
+    _check_slot_count_invariance(m16, m32, proc, nslots)
 
 
 @pytest.mark.parametrize("name,layers,weight_format", [("detikzify-ds-7b", 2, "bf16"), ("detikzify-ds-1.3b", 3, "bf16"), ("detikzify-cl-7b", 2, "fp8")])
@@ -1463,10 +1406,9 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                         (1, 0, 1, 2, 33, 0, 1, 4, 7 + 48), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 64), (1, 0, 1, 2, 33, 0, 1, 4, 1), (1, 0, 1, 2, 33, 0, 1, 4, 2),
                         (1, 0, 1, 2, 33, 0, 1, 4, 4)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
                         # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
-            if variant[1] and not has_experiments(model):
-                continue                    # k_gemv_bk: DTK_EXPERIMENTS builds only
+            if variant[1]:
+                continue                    # (k_gemv_bk, the K split with an in-kernel exchange: removed in round 6 with the other DTK_EXPERIMENTS families)
             model.set_option("gemv_bx", variant[0])
-            model.set_option("gemv_bk", variant[1])
             model.set_option("resid_split", variant[2])     # N = d roles: two row tiles x 32 slots per block
             model.set_option("resid_kparts", 1 if variant[3] else 0)
             model.set_option("gemv_bkl", 1 if variant[3] == 2 else 0)
@@ -1488,7 +1430,6 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
             assert torch.equal(runs[variant][1], runs[(0, 0, 0, 0, 0)][1]), (name, variant)
     finally:
         model.set_option("gemv_bx", 1)      # process-wide switches: back to the defaults
-        model.set_option("gemv_bk", 0)
         model.set_option("resid_split", 1)
         model.set_option("resid_kparts", 1)
         model.set_option("gemv_bl", 33)

@@ -161,10 +161,12 @@ def test_a_slots_result_does_not_depend_on_its_company(name, size):
         gc.collect()
 
 
-def test_more_prefixes_than_groups_fall_back_to_the_per_slot_walk():
-    """20 images with two forks each in one step: DTK_PFX_GROUPS = 16 groups are scored on the matrix cores, the forks of the last
-    four images walk their whole context per slot — every slot's tokens as the per-slot path's, logits within 1e-2, the overflow
-    slots bit-identical to it."""
+def test_more_prefixes_than_grid_rows_stay_on_the_matrix_cores():
+    """20 images with two forks each in one step = 20 groups for a grid of DTK_PFX_GRID = 16 group rows: rows 0..3 take a second
+    group (round 6; rounds 4-5 capped a step at 16 groups and let the rest walk their whole context per slot — so whether a slot's
+    prefix went through the matrix cores depended on how many OTHER prefixes the step held: ADVICE r5).  Every slot's tokens as the
+    per-slot path's, logits within 1e-2 of it; and a fork of the 20th image decoded ALONE (one group) is bit-identical to itself in
+    the 40-slot step (group 19, the second trip of row 3)."""
     model, proc = _load("detikzify-tiny", slots=65)
     try:
         img_tok = model.config.image_token_id
@@ -177,11 +179,13 @@ def test_more_prefixes_than_groups_fall_back_to_the_per_slot_walk():
             if not prefix_on:
                 first = {s: model.get_logits_slot(s) for s in active}
             runs[prefix_on] = _decode(model, active, 6, active)
-        _compare(runs[1], runs[0], active, first, 1e-2, "overflow")
+        _compare(runs[1], runs[0], active, first, 1e-2, "20 groups")
         l0, l1 = runs[0][1], runs[1][1]
-        for s in range(2 * N_GROUPS, 40):
-            assert all(torch.equal(x, y) for x, y in zip(l1[s], l0[s])), f"slot {s} lies beyond the 16th group: it must take the per-slot walk"
-        assert sum(not torch.equal(l1[s][0], l0[s][0]) for s in range(2 * N_GROUPS)) > 0, "the grouped path did not run at all"
+        assert sum(not torch.equal(l1[s][0], l0[s][0]) for s in range(2 * N_GROUPS, 40)) > 0, "the forks beyond the 16th group did not take the grouped path"
+        _setup(model, proc, 96, layout, img_tok)
+        alone = _decode(model, [39], 6, [39])
+        assert [t[39] for t in runs[1][0]] == [t[0] for t in alone[0]]
+        assert all(torch.equal(x, y) for x, y in zip(alone[1][39], l1[39])), "slot 39's result depends on its company"
     finally:
         del model
         gc.collect()
