@@ -25,11 +25,16 @@ static inline bool dtk_lds_attr_todo(unsigned long long& done) {
   done |= bit;
   return true;
 }
-int& dtk_lds_attr_error();                                                          // dtk_api.hip: first hipError_t a launcher's attribute call returned (0 = none)
+int& dtk_lds_attr_error(int device);                                                // dtk_api.hip: the first hipError_t a launcher's attribute call returned ON THAT DEVICE (0 = none):
+                                                                                    // a refusal on one GPU does not fail the contexts of another
 static inline void dtk_lds_attr(hipError_t e, const char* file, int line) {
   if (e == hipSuccess) return;
-  if (!dtk_lds_attr_error()) fprintf(stderr, "libdtk_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed at %s:%d: %s\n", file, line, hipGetErrorString(e));
-  dtk_lds_attr_error() = (int)e;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!dtk_lds_attr_error(dev)) {
+    fprintf(stderr, "libdtk_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d at %s:%d: %s\n", dev, file, line, hipGetErrorString(e));
+    dtk_lds_attr_error(dev) = (int)e;
+  }
 }
 #define DTK_LDS_ATTR(call) dtk_lds_attr((call), __FILE__, __LINE__)
 

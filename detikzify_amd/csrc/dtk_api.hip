@@ -23,7 +23,10 @@
 #include "kernels.h"
 #include "mx_quant.h"
 
-int& dtk_lds_attr_error() { static int e = 0; return e; }     // common.h: set by a launcher whose hipFuncSetAttribute was refused
+int& dtk_lds_attr_error(int device) {     // common.h: set by a launcher whose hipFuncSetAttribute was refused, per device
+  static int e[65] = {};
+  return e[(device >= 0 && device < 64) ? device : 64];
+}
 
 namespace {
 
@@ -903,7 +906,7 @@ int ensure_batch_graph(dtk_ctx* c) {   // for c->nt_step / c->mv_step
   HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamEndCapture(c->stream, &c->bgraph[gi]));
-  if (c->launch_refused || dtk_lds_attr_error()) {       // an incomplete step must never be replayed
+  if (c->launch_refused || dtk_lds_attr_error(c->device)) {       // an incomplete step must never be replayed
     (void)hipGraphDestroy(c->bgraph[gi]); c->bgraph[gi] = nullptr;
     return fail(c, DTK_ERR_STATE, c->launch_refused ? "batched step: a projection's shape has no kernel in its family (nothing launched for it)"
                                                     : "batched step: raising a kernel's dynamic-LDS limit failed (hipFuncSetAttribute, see stderr)");
@@ -1539,7 +1542,7 @@ int dtk_decode_batch_launch(dtk_ctx* c, const int32_t* active) {
   } else {
     c->launch_refused = false;
     if (c->mv_step) batch_step_launches_mv(c); else batch_step_launches(c);
-    if (c->launch_refused || dtk_lds_attr_error())
+    if (c->launch_refused || dtk_lds_attr_error(c->device))
       return fail(c, DTK_ERR_STATE, c->launch_refused ? "batched step: a projection's shape has no kernel in its family (nothing launched for it)"
                                                       : "batched step: raising a kernel's dynamic-LDS limit failed (hipFuncSetAttribute, see stderr)");
     HIPCHK(c, hipMemcpyAsync(c->tokb_host, c->tokb_dev, sizeof(int64_t) * TOKB_WORDS, hipMemcpyDeviceToHost, c->stream));

@@ -199,12 +199,22 @@ def pin_to_gpu_numa_node(device_index: Optional[int] = None, sysfs: str = "/sys"
         except ValueError:
             local_world = 1
     if local_world > 1 and not os.environ.get("DTK_PIN_WHOLE_NODE"):
-        # the local ranks (device j = local rank j, as bench.py and the examples place them) whose GPUs sit on MY node, in rank order
-        mates = [j for j in range(local_world) if j == i or gpu_numa_cpus(_device_bdf(j) or "", sysfs) == cpus]
-        if i in mates and len(mates) > 1:
-            mine = share_of_cpus(allowed, mates.index(i), len(mates))
-            if len(mine) >= 4:          # never squeeze a rank onto a handful of CPUs (its tree threads, reward work, compile workers)
-                allowed = mine
+        # The share is taken by LOCAL RANK among the local ranks whose GPUs sit on MY node (taking it by device index gave
+        # several ranks that drive ONE device — N gloo ranks on a single GPU, a custom device_map — the same share).  Which device
+        # rank j drives: j itself with one rank per GPU (bench.py, the examples); j modulo the device count when there are more ranks
+        # than devices (bench.py's gloo control-flow path).  A LOCAL_RANK that contradicts both leaves the whole node to this rank.
+        try:
+            me = int(os.environ.get("LOCAL_RANK", str(i)))
+        except ValueError:
+            me = i
+        n_dev = max(1, torch.cuda.device_count())
+        dev_of = (lambda j: j) if local_world <= n_dev else (lambda j: j % n_dev)
+        if 0 <= me < local_world and dev_of(me) == i:
+            mates = [j for j in range(local_world) if dev_of(j) == i or gpu_numa_cpus(_device_bdf(dev_of(j)) or "", sysfs) == cpus]
+            if me in mates and len(mates) > 1:
+                mine = share_of_cpus(allowed, mates.index(me), len(mates))
+                if len(mine) >= 4:          # never squeeze a rank onto a handful of CPUs (its tree threads, reward work, compile workers)
+                    allowed = mine
     try:
         os.sched_setaffinity(0, allowed)
     except OSError:             # a container that forbids it: placement is advice, never a reason to fail the run

@@ -152,6 +152,8 @@ def test_ranks_on_one_numa_node_get_disjoint_cpu_shares(tmp_path, monkeypatch):
         dev.mkdir(parents=True)
         (dev / "numa_node").write_text(f"{j // 4}\n")
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda j: SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + j, pci_device_id=0))
     monkeypatch.setattr(dd.os, "sched_getaffinity", lambda pid: set(range(256)))
     pinned = {}
@@ -162,6 +164,18 @@ def test_ranks_on_one_numa_node_get_disjoint_cpu_shares(tmp_path, monkeypatch):
     assert sorted(c for sh in shares[:4] for c in sh) == dd.parse_cpulist(lists[0]) and sorted(c for sh in shares[4:] for c in sh) == dd.parse_cpulist(lists[1])
     assert shares[1] == list(range(16, 32)) + list(range(144, 160))                 # 16 cores + their 16 siblings
     assert dd.pin_to_gpu_numa_node(5, str(tmp_path), local_world=1) == dd.parse_cpulist(lists[1])       # one rank per host: the whole node
+    # four ranks that all drive device 0 of a one-GPU box (bench.py's gloo control-flow path; ADVICE r5: they used to get the SAME share)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    quarters = []
+    for r in range(4):
+        monkeypatch.setenv("LOCAL_RANK", str(r))
+        quarters.append(dd.pin_to_gpu_numa_node(0, str(tmp_path), local_world=4))
+    assert all(len(q) == 32 for q in quarters) and sorted(c for q in quarters for c in q) == dd.parse_cpulist(lists[0])
+    monkeypatch.setenv("LOCAL_RANK", "3")           # a local rank that does not drive the device it asks about: no split, the whole node
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert dd.pin_to_gpu_numa_node(5, str(tmp_path), local_world=8) == dd.parse_cpulist(lists[1])
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")                                     # two ranks, one GPU per node: each keeps its whole node
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda j: SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + 4 * j, pci_device_id=0))
     assert dd.pin_to_gpu_numa_node(1, str(tmp_path)) == dd.parse_cpulist(lists[1])
