@@ -95,6 +95,10 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
         sc[t][r] = a.wscale[row];                                 // power of two: exact
       }
     }
+  // A lane holds FOUR consecutive rows (m0 .. m0 + 3) of each of its columns: 8 contiguous bytes of bf16 in every destination (cache
+  // rows, q, the fragment-major activation), 16 of fp32 logits — one store per lane, tile and column instead of four 2-byte ones
+  // (round 6, profiles/r06d_bc_probe.txt: the epilogue's cost was its stores; the launchers of these kernels admit only ff % 16 == 0
+  // and N % 32 == 0, so no tile is ragged — the ragged shapes go to k_gemv_b, which stores element by element through gg_epilogue).
   if (EPI == EPI_QKV) {
     const int hb = g >> 2;
     const int sec = hb < a.H ? 0 : (hb < a.H + a.KVH ? 1 : 2);
@@ -111,29 +115,27 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
           sn[nt][r] = bf2f(a.rope_sin[(size_t)p * 64 + i]);
         }
       }
+    const int i0 = (g & 3) * 16 + m0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + (lane & 15);
       if (!act[nt]) continue;
       const size_t slot_kv = (size_t)n * a.kv_slot_stride;
+      float lo[4], hi[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = (g & 3) * 16 + m0 + r;
         const float x1 = rbf(tot[0][nt][r] * sc[0][r]), x2 = rbf(tot[1][nt][r] * sc[1][r]);
-        if (sec == 2) {
-          bf16_t* dst = a.vcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128;
-          dst[i] = f2bf(x1);
-          dst[i + 64] = f2bf(x2);
-        } else {
+        if (sec == 2) { lo[r] = x1; hi[r] = x2; }
+        else {
           const float c = cs[nt][r], sv = sn[nt][r];
-          const float o1 = rbf(rbf(x1 * c) + rbf(-x2 * sv));
-          const float o2 = rbf(rbf(x2 * c) + rbf(x1 * sv));
-          bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
-                                   : (a.kcache + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128);
-          dst[i] = f2bf(o1);
-          dst[i + 64] = f2bf(o2);
+          lo[r] = rbf(rbf(x1 * c) + rbf(-x2 * sv));
+          hi[r] = rbf(rbf(x2 * c) + rbf(x1 * sv));
         }
       }
+      bf16_t* dst = (sec == 0) ? (a.q_out + (size_t)n * a.d + head * 128)
+                               : ((sec == 1 ? a.kcache : a.vcache) + slot_kv + ((size_t)head * a.T_max + pos[nt]) * 128);
+      *reinterpret_cast<u32x2*>(dst + i0) = (u32x2){pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
+      *reinterpret_cast<u32x2*>(dst + i0 + 64) = (u32x2){pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
     }
     return;
   }
@@ -141,10 +143,34 @@ __device__ __forceinline__ void gg_finish_unit(const GemvBArgs& a, int g, const 
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (nt0 + nt) * 16 + (lane & 15);
     if (!act[nt]) continue;
+    if (EPI == EPI_SWIGLU) {
+      float y[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v[T] = {tot[0][nt][r] * sc[0][r], tot[1][nt][r] * sc[1][r]};
-      gg_epilogue<EPI, T>(a, g, n, m0 + r, v);                    // SwiGLU / logits: stores only
+      for (int r = 0; r < 4; ++r) {
+        const float gte = rbf(tot[0][nt][r] * sc[0][r]), up = rbf(tot[1][nt][r] * sc[1][r]);
+        const float sl = rbf(gte / (1.f + expf(-gte)));
+        y[r] = sl * up;
+      }
+      *reinterpret_cast<u32x2*>(a.Y + xtile_off(n, g * 16 + m0, (a.ff + 31) >> 5)) = (u32x2){pack2(y[0], y[1]), pack2(y[2], y[3])};
+    } else if (EPI == EPI_LOGITS) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int row = gg_tile_row0<EPI, T>(a, g, t) + m0;
+        if (!(a.N & 3) && row + 3 < a.N) {
+          *reinterpret_cast<f32x4*>(a.logits + (size_t)n * a.N + row) =
+              (f32x4){rbf(tot[t][nt][0] * sc[t][0]), rbf(tot[t][nt][1] * sc[t][1]), rbf(tot[t][nt][2] * sc[t][2]), rbf(tot[t][nt][3] * sc[t][3])};
+        } else {                          // the last tile of a vocabulary that is no multiple of 32 (k_gemv_mxu: cl-7b's 32 024)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row + r < a.N) a.logits[(size_t)n * a.N + row + r] = rbf(tot[t][nt][r] * sc[t][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v[T] = {tot[0][nt][r] * sc[0][r], tot[1][nt][r] * sc[1][r]};
+        gg_epilogue<EPI, T>(a, g, n, m0 + r, v);
+      }
     }
   }
 }

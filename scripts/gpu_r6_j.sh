@@ -20,6 +20,17 @@ DTK_TRACE_MCTS="$OUT/${R}_mcts_trace.json" timeout 600 python bench.py $C5 > "$O
 python tools/mcts_timeline.py "$OUT/${R}_mcts_trace.json" > "$OUT/${R}_mcts_timeline_config5.txt" 2>&1; rm -f "$OUT/${R}_mcts_trace.json"; head -8 "$OUT/${R}_mcts_timeline_config5.txt" | cut -c1-200
 SHORT="--steps 1 --warmup 0 --new-tokens 128 --no-cpu-baseline --batch 0 --mcts-seq-expansions 0 --no-config5 --probe-tokens 4"
 SB=$REPO/tools/probe/step_bench
+{
+echo "== cl-7b fp8, 64 slots, 8 images: 4 / 260 private keys"
+STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 STEP_BENCH_STEPS=48 timeout 600 $SB "" "gemv_bc=0"
+STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 STEP_BENCH_WARM=260 STEP_BENCH_STEPS=32 timeout 600 $SB ""
+echo "== ds-7b bf16, 64 slots: 4 / 260 private keys; 16 slots"
+STEP_BENCH_MODEL=ds-7b STEP_BENCH_SLOTS=64 STEP_BENCH_STEPS=48 timeout 600 $SB "" "gemv_bc=0"
+STEP_BENCH_MODEL=ds-7b STEP_BENCH_SLOTS=64 STEP_BENCH_WARM=260 STEP_BENCH_STEPS=32 timeout 600 $SB ""
+STEP_BENCH_MODEL=ds-7b STEP_BENCH_SLOTS=16 STEP_BENCH_STEPS=48 timeout 600 $SB ""
+echo "== ds-1.3b bf16, 64 slots"
+STEP_BENCH_MODEL=ds-1.3b STEP_BENCH_SLOTS=64 STEP_BENCH_STEPS=48 timeout 600 $SB "" "gemv_bc=0"
+} 2>&1 | sed -E 's/; last token.*//' | tee "$OUT/${R}_step_bench.txt"
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, counters ("" = kernel stats), command...; rocprofv3 on this image sometimes dies with a segmentation fault before the program starts: three tries
   local name=$1 ctrs=$2; shift 2
@@ -35,12 +46,12 @@ prof() {   # name, counters ("" = kernel stats), command...; rocprofv3 on this i
 prof kernel_stats "" python "$REPO/bench.py" $SHORT
 prof pmc_fetch "FETCH_SIZE" python "$REPO/bench.py" --steps 1 --warmup 0 --new-tokens 16 --no-cpu-baseline --batch 0 --mcts-seq-expansions 0 --no-config5 --probe-tokens 2
 prof pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" python "$REPO/bench.py" --steps 2 --warmup 0 --new-tokens 8 --no-cpu-baseline --batch 0 --mcts-seq-expansions 0 --no-config5 --probe-tokens 2
-STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 prof batch64_fp8_kernel_stats "" $SB ""
-STEP_BENCH_SLOTS=64 STEP_BENCH_MODEL=ds-7b prof batch64_kernel_stats "" $SB ""
-STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 prof batch64_fp8_pmc_fetch "FETCH_SIZE" $SB ""
-STEP_BENCH_SLOTS=64 STEP_BENCH_MODEL=ds-7b prof batch64_pmc_fetch "FETCH_SIZE" $SB ""
-STEP_BENCH_SLOTS=16 STEP_BENCH_MODEL=ds-7b prof batch16_kernel_stats "" $SB ""
-STEP_BENCH_MODEL=ds-1.3b STEP_BENCH_SLOTS=1 STEP_BENCH_STEPS=256 prof ds13b_single_kernel_stats "" $SB ""
+STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 STEP_BENCH_STEPS=24 prof batch64_fp8_kernel_stats "" $SB ""
+STEP_BENCH_SLOTS=64 STEP_BENCH_MODEL=ds-7b STEP_BENCH_STEPS=24 prof batch64_kernel_stats "" $SB ""
+STEP_BENCH_SLOTS=64 STEP_BENCH_IMAGES=8 STEP_BENCH_STEPS=24 prof batch64_fp8_pmc_fetch "FETCH_SIZE" $SB ""
+STEP_BENCH_SLOTS=64 STEP_BENCH_MODEL=ds-7b STEP_BENCH_STEPS=24 prof batch64_pmc_fetch "FETCH_SIZE" $SB ""
+STEP_BENCH_SLOTS=16 STEP_BENCH_MODEL=ds-7b STEP_BENCH_STEPS=24 prof batch16_kernel_stats "" $SB ""
+STEP_BENCH_MODEL=ds-1.3b STEP_BENCH_SLOTS=1 STEP_BENCH_STEPS=64 prof ds13b_single_kernel_stats "" $SB ""
 cd "$REPO"
 python tools/make_dominant_kernel_json.py "$OUT/${R}_kernel_stats.csv" "$OUT/${R}_pmc_fetch.csv" detikzify-ds-7b > /dev/null && cp profiles/dominant_kernel.json "$OUT/dominant_kernel.json" && sed -i "s#gpurun_out/${R}_pmc_fetch.csv#profiles/${R}_pmc_fetch.csv#" profiles/dominant_kernel.json "$OUT/dominant_kernel.json"
 python tools/make_mfma_busy_json.py "$OUT/${R}_pmc_mfma.csv" detikzify-ds-7b > /dev/null && cp profiles/mfma_busy.json "$OUT/mfma_busy.json"
