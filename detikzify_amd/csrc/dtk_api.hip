@@ -1901,6 +1901,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     drop_batch_graphs(c);
   }
   else if (!strcmp(name, "gemv_bkl")) { set_gemv_bkl(value != 0); drop_batch_graphs(c); }
+  else if (!strcmp(name, "gemv_bus")) { set_gemv_bus(value); drop_batch_graphs(c); }          // 64-slot qkv / gate-up by k_gemv_bus (kernels_batch_ks.hip): 0 off, 128 default per role, bit 0 qkv, bit 1 gate/up
   else if (!strcmp(name, "act_fp8")) {          // fp8 models: the MFMA-family step on the fp8 matrix cores with MXFP8 activations (kernels_batch_mx.hip)
     if (value && c->wfmt == 1 && c->nb > 0 && !c->mx_ok) return fail(c, DTK_ERR_ARG, "act_fp8: the model's shapes are not covered by the fp8 matrix-core kernels");
     c->act_fp8 = value != 0;

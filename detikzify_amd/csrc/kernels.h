@@ -121,6 +121,8 @@ void set_gemv_bl(int v);       // bit 0: gate/up + lm_head, bit 1: qkv by pair u
 void set_gemv_br_wd(int v);    // k_gemv_br with fp8 weights: phases of the register ring, 4 (default) | 8 (measured slower)
 void set_gemv_loaders(int v);  // loader waves of the Q3 qkv kernel: 1 (ring of 3 phases) or 2 (alternate phases, ring of 5)
 void set_gemv_xw(int v);       // k_gemv_bl / k_gemv_bkl: 1 = x fragments by an extra wave's ordinary loads + ds_write_b128 instead of LDS-DMA pieces
+bool launch_gemv_bus(int epi, const GemvBArgs& a, hipStream_t s);   // kernels_batch_ks.hip: qkv / gate-up at 64 slots, a block per CU whose 8 waves are the 8 K slices, every operand straight into the wave's registers (bit-identical to k_gemv_b); false = not covered / off
+void set_gemv_bus(int v);      // 0 off; 128 = measured default per role and weight format; else bit 0 qkv, bit 1 gate/up
 void set_gemv_bkl(int v);      // 1: the resid_kparts weight kernel with LDS-DMA operand rings (k_gemv_bkl) instead of k_gemv_bkp
 // N = d roles at 33..64 slots as two launches (kernels_batch_gemm.hip): k_gemv_bkp = K split over the CUs of a row group, plain stores
 // of the fp32 partials; k_resid_norm_b = reduce + residual + the RMSNorm that follows the role anyway (replaces k_rmsnorm_b there)

@@ -325,6 +325,7 @@ static void launch_gemv_b_impl(int epi, const GemvBArgs& a, hipStream_t s) {
 static int g_gemv_bx = -1;
 void set_gemv_bx(int v) { g_gemv_bx = v; }
 void launch_gemv_b(int epi, const GemvBArgs& a, hipStream_t s) {
+  if (launch_gemv_bus(epi, a, s)) return;                   // 64 slots, qkv / gate-up: a block per CU, its 8 waves = the 8 K slices, every operand straight into registers (kernels_batch_ks.hip)
   if (launch_gemv_bc(epi, a, s)) return;                    // 64 slots, rows >> d roles: a compute wave per column tile (x from L2 into registers, weights through an LDS ring)
   if (launch_gemv_bl(epi, a, s)) return;                    // 64 slots, rows >> d roles: both operands through LDS rings filled by a loader wave
   if (g_gemv_bx < 0) { const char* e = getenv("DTK_GEMV_BX"); g_gemv_bx = e ? atoi(e) : 1; }

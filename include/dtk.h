@@ -339,7 +339,9 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * "attn_full_max" (contexts below it use the one-block-per-head kernel).  Batched decode: "tail_threads" (64 | 128 | 256 | 512) and "prefix_mfma" (1: the prefix a group of <= 16 forked slots
  * shares — same source slot, same length — is scored once for the group on the matrix cores by k_attn_prefix_g, the slots' private
  * keys per slot; 0 = every slot walks its whole context) default by the CONTEXT's size: 128 / 1 with 64 decoding slots, 256 / 0 below;
- * "pfx_splits" (1..4 key splits of that kernel, default 4), "gemv_bc" (64-slot qkv / gate-up / lm_head by k_gemv_bc — a compute wave per 16-slot
+ * "pfx_splits" (1..4 key splits of that kernel, default 4), "gemv_bus" (64-slot qkv / gate-up by k_gemv_bus — a block per CU whose 8
+ * waves are the 8 K slices, every operand straight from memory into the wave's registers, the slice sums met in LDS once: 0 off, 128 = the measured
+ * default per role and weight format, else bit 0 qkv, bit 1 gate/up), "gemv_bc" (64-slot qkv / gate-up / lm_head by k_gemv_bc — a compute wave per 16-slot
  * column tile, x from L2 into registers, the weights through an LDS ring: 0 off, 128 = the measured default per role and weight format, else bit 0 qkv, bit 1
  * gate/up, bit 2 lm_head, bits 4..6 units per block), "gemv_b_wide" (0..6: row tiles per block), "gemm_b" (0 = x fragments in
  * registers, 1..4 = x through LDS by LDS-DMA), "gemv_bx" (0 off, 1 = x once per CU for gate/up + lm_head at 49..64 slots, 2..4 =

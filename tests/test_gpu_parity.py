@@ -1368,7 +1368,8 @@ def test_32_slot_batch_matches_16_slot_kernels_bit_for_bit(tiny_batched, nslots)
     _check_slot_count_invariance(m16, m32, proc, nslots)
 
 
-@pytest.mark.parametrize("name,layers,weight_format", [("detikzify-ds-7b", 2, "bf16"), ("detikzify-ds-1.3b", 3, "bf16"), ("detikzify-cl-7b", 2, "fp8")])
+@pytest.mark.parametrize("name,layers,weight_format", [("detikzify-ds-7b", 2, "bf16"), ("detikzify-ds-1.3b", 3, "bf16"), ("detikzify-cl-7b", 2, "fp8"),
+                                                       ("detikzify-v2-8b", 2, "bf16")])     # v2-8b: GQA (8 K/V heads) — k_gemv_bus's block map of pair units + V row tiles
 def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, layers, weight_format):
     """k_gemv_bx (64 slots: the x fragments of a phase shared through LDS, one wave per row-tile pair over the full K) and
     k_gemv_bk (N = d roles: K split over the 8 CUs of a row group, partials met in memory by the last arrival) against
@@ -1404,7 +1405,11 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
                         # an LDS ring) — bit 0 qkv, bit 1 gate/up, bit 2 lm_head, bits 4..6 force 1..4 units per block
                         (1, 0, 1, 2, 33, 0, 1, 4, 7), (0, 0, 0, 0, 0, 0, 1, 4, 7), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 16), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 32),
                         (1, 0, 1, 2, 33, 0, 1, 4, 7 + 48), (1, 0, 1, 2, 33, 0, 1, 4, 7 + 64), (1, 0, 1, 2, 33, 0, 1, 4, 1), (1, 0, 1, 2, 33, 0, 1, 4, 2),
-                        (1, 0, 1, 2, 33, 0, 1, 4, 4)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
+                        (1, 0, 1, 2, 33, 0, 1, 4, 4),
+                        # 10th entry: gemv_bus (round 6: k_gemv_bus — qkv / gate-up, a block per CU whose 8 waves are the 8 K slices, every
+                        # operand straight into the wave's registers): bit 0 qkv, bit 1 gate/up, 128 = the default per role
+                        (1, 0, 1, 2, 33, 0, 1, 4, 128, 128), (1, 0, 1, 2, 33, 0, 1, 4, 128, 3), (1, 0, 1, 2, 33, 0, 1, 4, 128, 1),
+                        (1, 0, 1, 2, 33, 0, 1, 4, 128, 2), (0, 0, 0, 0, 0, 0, 1, 4, 0, 3)):     # bit 6: bf16 qkv through k_gemv_br too   # bit 5: fp8 weights through registers (k_gemv_br)   # 6th entry: gemv_xw (x by an extra wave's ordinary
                         # loads instead of LDS-DMA); gemv_bl bit 4: qkv as a RoPE pair unit + a V row tile per block; 7th: its loader waves
             if variant[1]:
                 continue                    # (k_gemv_bk, the K split with an in-kernel exchange: removed in round 6 with the other DTK_EXPERIMENTS families)
@@ -1417,6 +1422,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
             model.set_option("gemv_loaders", variant[6] if len(variant) > 6 else 1)
             model.set_option("gemv_br_wd", variant[7] if len(variant) > 7 else 4)
             model.set_option("gemv_bc", variant[8] if len(variant) > 8 else 0)
+            model.set_option("gemv_bus", variant[9] if len(variant) > 9 else 0)
             for s_, ids in enumerate(prompts):
                 model.set_sampling(do_sample=True, temperature=0.8, top_p=0.95, seed=900 + s_, bad_ids=[cfg.patch_token_id], slot=s_)
                 model.prefill(ids, None, slot=s_)
@@ -1438,6 +1444,7 @@ def test_x_once_per_cu_kernel_is_bit_identical_to_the_register_kernel(name, laye
         model.set_option("gemv_loaders", 1)
         model.set_option("gemv_br_wd", 4)
         model.set_option("gemv_bc", 128)
+        model.set_option("gemv_bus", 128)
         del model
         gc.collect()
 
