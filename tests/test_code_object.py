@@ -110,6 +110,32 @@ def test_no_instruction_touches_a_hand_loaded_register_before_its_wait(tmp_path)
 
 
 @pytest.mark.skipif(not (LLVM / "clang-offload-bundler").exists(), reason="needs the ROCm LLVM tools")
+def test_bus_kernels_wait_for_every_hand_issued_load_and_do_not_spill(tmp_path):
+    """k_gemv_bus (round 6, csrc/kernels_batch_ks.hip) issues EVERY operand load by hand — the 64 slots' x fragments and the weight
+    tiles, a ring of 2-4 k-step groups per wave — and counts vmcnt itself.  The shipped code object, instantiation by instantiation
+    (qkv / gate-up x 1-3 units x bf16 / fp8 x K = 4096 / 2048): no instruction touches a register of a hand-issued load before a wait
+    has retired it, on any path, and nothing spills (a spilled ring register would be stored before its load has landed; the
+    launcher also refuses an instantiation with scratch at run time)."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_hand_loads as ch
+    obj = ROOT / "build" / "kernels_batch_ks.o"
+    if not obj.exists():
+        subprocess.run(["bash", str(ROOT / "build.sh")], check=True, capture_output=True, cwd=str(ROOT))
+    meta = {k: v for k, v in _kernel_metadata(obj, tmp_path).items() if "k_gemv_bus" in k}
+    assert len(meta) == 16, sorted(meta)
+    for name, m in meta.items():
+        assert m.get("private_segment_fixed_size") == 0 and m.get("vgpr_spill_count") == 0 and m.get("sgpr_spill_count") == 0, (name, m)
+        assert m.get("vgpr_count", 0) <= 256, (name, m)          # two waves per SIMD: 8 waves = the 8 K slices on one CU
+    kernels = ch.kernels_of(ch.disassemble(obj, tmp_path), "k_gemv_bus")
+    assert len(kernels) == 16
+    for name, insts in kernels.items():
+        violations, stats = ch.check_kernel(name, insts)
+        assert stats["hand_loads"] >= 48 and stats["vmcnt_waits"] >= 9 and stats["points_given_up"] == 0, (name, stats)
+        assert not violations, (name, violations[:4])
+
+
+@pytest.mark.skipif(not (LLVM / "clang-offload-bundler").exists(), reason="needs the ROCm LLVM tools")
 def test_fp8_matrix_core_kernels_issue_the_scaled_fp8_mfma_and_nothing_spills(tmp_path):
     """BASELINE config 5 names "CDNA4 fp8 MFMA": the shipped code object of csrc/kernels_batch_mx.hip, instantiation by instantiation —
     every k_gemv_mxu / k_gemv_mxk issues v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 x fp8 on the matrix cores, E8M0 block scales) and not a

@@ -64,7 +64,7 @@ def is_vmem(mn: str) -> bool:
 
 
 def check_kernel(name: str, insts):
-    all_loads = "k_gemv_bc" in name
+    all_loads = "k_gemv_bc" in name or "k_gemv_bus" in name     # (k_gemv_bus: the x fragments too are hand-issued, without `nt`)
     """-> (violations, stats)"""
     index = {addr: i for i, (addr, _, _) in enumerate(insts)}
     violations, hand_loads, waits = [], 0, 0
