@@ -362,7 +362,11 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * DESIGN.md 3.4 has the defaults and what each switch measured.
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.
- * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create. */
+ * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create.
+ * SCOPE: the switches that select a kernel VARIANT ("gemv_*", "resid_*", "gemm_*", "mx_*", "attn_impl") are process-wide — they live in the
+ * launchers, not in the context: a later context of the same process inherits what an earlier one set, and an A/B inside one process must set
+ * the switch on both sides.  The per-context ones: "act_fp8", "prefix_mfma", "tail_threads", "pfx_splits", "share_prefix_reads", "mv_slots",
+ * "attn_threads" / "attn_splits" / "attn_combine", "vit_feature_layer", "gemm_naive", "resid_kparts". */
 int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the

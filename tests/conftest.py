@@ -8,8 +8,40 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+def _cpu_share():
+    """CPUs this process may actually use: the affinity mask, cut to the cgroup's CFS quota.  The GPU boxes give a container 16 CPUs'
+    worth of quota (cpu.max = 1600000 100000) on a 256-thread host, and torch sizes its intra-op pool from the HOST: 128 threads fighting
+    for 16 CPUs ran the CPU oracle's fp32 Linear 3.5 x slower than 16 threads do (61.6 vs 17.5 ms for 243 x 4096 x 11008,
+    profiles/r06q_threads_probe.txt) — the round-6 GPU suite took 894 s on one box and 1199.6 s on the next, against the driver's 1200 s."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except Exception:
+            pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import os
+    if not os.environ.get("OMP_NUM_THREADS"):       # the oracle is torch on the CPU: its pool follows what the container may use
+        try:
+            import torch
+            share = _cpu_share()
+            if torch.get_num_threads() > share:
+                torch.set_num_threads(share)
+        except Exception:  # pragma: no cover - torch-less environment
+            pass
     # threads + a device: a test that hangs must fail on its own instead of taking the whole run with it
     # (pytest-timeout; the slowest test, the ds-1.3b CPU-oracle comparison, takes ~15 s)
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
