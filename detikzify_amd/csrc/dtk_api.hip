@@ -105,6 +105,9 @@ struct dtk_ctx {
 
   // activations: decoder prefill
   bf16_t *X, *Xn, *QKV, *Qh, *AO, *GU, *ACT;
+  float* skpart = nullptr;           // fp32 partials of the sliced-K prefill GEMMs: [kslices][SK_CHUNK_ROWS][N], one role at a time
+  size_t skpart_floats = 0;
+  int prefill_sk = 1;                // sliced-K prefill GEMMs for the roles with <= 128 tiles of 256 x 128 (dtk_set_option "prefill_sk": 0 = the one-chain kernels, 2 / 4 / 8 = a cap on the slices)
   int32_t* ids_dev = nullptr;
   // decode step
   bf16_t *x, *q, *act;
@@ -407,6 +410,13 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
   c->AO = P.take<bf16_t>((size_t)T * d);
   c->GU = P.take<bf16_t>((size_t)T * 2 * ff);
   c->ACT = P.take<bf16_t>((size_t)T * ff);
+  {
+    size_t need = 0;
+    const int roles[4][2] = {{qkvn, d}, {d, d}, {2 * ff, d}, {d, ff}};
+    for (auto& r : roles) need = std::max(need, (size_t)sk_role_slices(r[0], r[1]) * SK_CHUNK_ROWS * (size_t)r[0]);
+    c->skpart_floats = need;
+    c->skpart = P.take<float>(need);
+  }
   c->ids_dev = P.take<int32_t>(T);
   c->x = P.take<bf16_t>(d);
   c->q = P.take<bf16_t>(d);
@@ -524,6 +534,32 @@ void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   hipStream_t s = c->cur_stream ? c->cur_stream : c->stream;
   if (c->gemm_naive) launch_gemm_naive(g, s);
   else launch_gemm_mfma(g, s);
+}
+
+// One decoder-prefill Linear (+ residual) and, when norm_w is given, the RMSNorm that follows it (-> Y).  Roles whose weight shape gives the
+// 256 x 128 tile fewer than 128 blocks run as sliced-K GEMMs (kernels_batched.hip: launch_gemm_sk) — the slice count is a function of the
+// WEIGHT shape alone, so a row's arithmetic does not depend on how many rows are prefilled with it (tail prefill == full prefill).
+void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* res, int ldr, bf16_t* C, int ldc,
+               int M, int N, int K, int flags, const bf16_t* norm_w, bf16_t* Y, int ldy) {
+  hipStream_t s = c->cur_stream ? c->cur_stream : c->stream;
+  const int S = c->prefill_sk ? std::min(sk_role_slices(N, K), c->prefill_sk == 1 ? 8 : c->prefill_sk) : 1;
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = nullptr; g.residual = res; g.ldr = ldr;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags; g.kslices = S;
+  bool done = false;
+  if (S > 1 && c->gemm_naive) { launch_gemm_naive(g, s); done = true; }
+  else if (S > 1 && gemm_sk_supported(g) && (size_t)S * SK_CHUNK_ROWS * (size_t)N <= c->skpart_floats) {
+    for (int m0 = 0; m0 < M; m0 += SK_CHUNK_ROWS) {      // rows are independent: chunks keep the partials inside the Infinity Cache
+      GemmArgs h = g;
+      h.M = std::min(SK_CHUNK_ROWS, M - m0);
+      h.A = A + (size_t)m0 * lda; h.C = C + (size_t)m0 * ldc; h.residual = res ? res + (size_t)m0 * ldr : nullptr;
+      h.part = c->skpart; h.part_stride = (long)SK_CHUNK_ROWS * N;
+      if (!launch_gemm_sk(h, norm_w, norm_w ? Y + (size_t)m0 * ldy : nullptr, ldy, c->cfg.rms_eps, s)) { c->launch_refused = true; return; }
+    }
+    return;
+  } else if (S > 1) { c->launch_refused = true; return; }    // a sliced role has one canonical order: no silent change of kernel
+  if (!done) { g.kslices = 1; if (c->gemm_naive) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s); }
+  if (norm_w) launch_rmsnorm_rows(C, ldc, norm_w, Y, ldy, M, N, c->cfg.rms_eps, s);
 }
 
 int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
@@ -1342,11 +1378,11 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     if (hi > lo) launch_copy_rows(c->IMG + (size_t)(lo - img_start) * d, d, c->X + (size_t)(lo - start) * d, d, hi - lo, d, s);
   }
   const float scale = 1.0f / sqrtf(128.f);
+  launch_rmsnorm_rows(c->X, d, c->layers[0].ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
-    launch_rmsnorm_rows(c->X, d, w.ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
     const int qkvn = d + 2 * c->KVH * 128;
-    gemm(c, c->Xn, d, w.wqkv, d, nullptr, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0);
+    gemm_role(c, c->Xn, d, w.wqkv, d, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0, nullptr, nullptr, 0);
     launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
     AttnArgs a;
     a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
@@ -1355,12 +1391,13 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     a.O = c->AO; a.o_sh = 128; a.o_st = d;
     a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl; a.kv_group = c->H / c->KVH;
     launch_attention(a, s);
-    gemm(c, c->AO, d, w.wo, d, nullptr, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL);
-    launch_rmsnorm_rows(c->X, d, w.ln2, c->Xn, d, n, d, c->cfg.rms_eps, s);
-    gemm(c, c->Xn, d, w.wgu, d, nullptr, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0);
+    gemm_role(c, c->AO, d, w.wo, d, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL, w.ln2, c->Xn, d);     // + post_attention_layernorm -> Xn
+    gemm_role(c, c->Xn, d, w.wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
     launch_silu_mul(c->GU, ff, c->ACT, n, s);
-    gemm(c, c->ACT, ff, w.wdown, ff, nullptr, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL);
+    // + the next layer's input_layernorm -> Xn (the final norm runs on the last row only, inside the lm_head GEMV below)
+    gemm_role(c, c->ACT, ff, w.wdown, ff, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL, l + 1 < c->L ? c->layers[l + 1].ln1 : nullptr, c->Xn, d);
   }
+  if (c->launch_refused) { c->launch_refused = false; return fail(c, DTK_ERR_STATE, "prefill: a sliced-K projection was refused by its kernel (nothing launched for it)"); }
   // final norm + lm_head on the last position only (the sampler consumes logits[:, -1])
   GemvArgs g{};
   g.W = c->lm_head; g.W8 = c->q_lm_head; g.wscale = c->s_lm_head; g.N = c->V; g.K = d; g.x = c->X + (size_t)(n - 1) * d; g.norm_w = c->final_norm;
@@ -1970,6 +2007,16 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     c->seq0.image_key = 0; c->seq0.cached_ids.clear();
     for (SeqHost& sh : c->bseq) { sh.image_key = 0; sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
   }
+  else if (!strcmp(name, "gemm_sk_tile")) {   // block tile of the sliced-K GEMM: 0 = 256 x 128, 1 = 128 x 256, 2 = by M (process-wide; bit-identical)
+    if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gemm_sk_tile must be 0, 1 or 2");
+    set_gemm_sk_tile(value);
+  }
+  else if (!strcmp(name, "prefill_sk")) {   // sliced-K prefill GEMMs (default 1).  The two settings round differently: cached prefixes are dropped
+    if (value < 0 || value > 8 || (value & (value - 1))) return fail(c, DTK_ERR_ARG, "prefill_sk must be 0 (one-chain GEMMs), 1 (sliced by the weight shape: the default) or a cap of 2 / 4 / 8 slices");
+    c->prefill_sk = value;
+    c->seq0.cached_ids.clear();
+    for (SeqHost& sh : c->bseq) { sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
+  }
   else if (!strcmp(name, "gemm_bk")) {
     if (value != 64 && value != 128) return fail(c, DTK_ERR_ARG, "gemm_bk must be 64 or 128");
     set_gemm_bk(value);
@@ -2041,7 +2088,18 @@ int dtk_op_gemm(dtk_ctx* c, const uint16_t* A, const uint16_t* W, const uint16_t
   GemmArgs g;
   g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.residual = dR; g.ldr = N; g.C = dC; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.flags = gf;
-  if (flags & DTK_GEMM_NAIVE) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s);
+  const int S = (flags >> DTK_GEMM_KSLICES_SHIFT) & 15;       // 0 = a one-chain GEMM; 1..8 = the sliced-K family (1: one slice through the partial + reduce path)
+  if (S) {
+    if (S > 8) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: at most 8 K slices");
+    g.kslices = S;
+    if (flags & DTK_GEMM_NAIVE) launch_gemm_naive(g, s);
+    else {
+      OPBUF(float, dP, (size_t)S * M * N);
+      g.part = dP; g.part_stride = (long)M * N;
+      if (!launch_gemm_sk(g, nullptr, nullptr, 0, 0.f, s)) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: the sliced-K kernel does not take this shape");
+    }
+  }
+  else if (flags & DTK_GEMM_NAIVE) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s);
   HIPCHK(c, hipMemcpyAsync(C, dC, (size_t)M * N * 2, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());

@@ -207,8 +207,32 @@ struct GemmArgs {
   bf16_t* C; int ldc;            // [M][N]
   int M, N, K;                   // K multiple of 8
   int flags;
+  // sliced-K roles (launch_gemm_sk / the naive twin): K's 64-wide k-tiles are cut into `kslices` contiguous runs of
+  // sk_tiles_per_slice(K, kslices) tiles; every run is an accumulation chain from zero and the runs' sums are added in run order
+  // in fp32 — the canonical order of such a role at ANY M and tile shape.  part = fp32 [kslices][part_rows][N] (launch_gemm_sk).
+  int kslices = 1;
+  float* part = nullptr; long part_stride = 0;
 };
+__host__ __device__ inline int sk_tiles_per_slice(int K, int S) { const int T = K / 64; return (T + S - 1) / S; }
+// slices of a decoder-prefill role, from its WEIGHT shape alone: the largest power of two <= 8 that keeps 256 x 128 tiles x slices within
+// the 256 CUs, every slice at least 4 k-tiles long; 1 = the role stays a one-chain GEMM (it fills the chip, or the sliced kernel does not take it)
+#define SK_CHUNK_ROWS 512
+inline int sk_role_slices(int N, int K) {
+  if ((N % 4) || (K % 8) || K < 128) return 1;
+  const int tiles = (N + 127) / 128;
+  int S = 1;
+  while (S < 8 && tiles * S * 2 <= 256) S *= 2;
+  while (S > 1 && (K / 64) / S < 4) S /= 2;
+  return S;
+}
 void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
+// sliced-K GEMM (the decoder prefill's N = d and q/k/v roles): k_gemm_g3's tile and pipeline with a block per (tile, K slice) writing
+// fp32 partials, then k_sk_reduce: partials summed in slice order + the GEMM epilogue (+ the RMSNorm that follows the role, fused:
+// norm_w / Y / ldy / eps; norm_w = null: none).  false = the shape is not one the kernel takes (nothing launched).
+bool gemm_sk_supported(const GemmArgs& a);
+void set_gemm_sk_tile(int v);   // 0 = 256 x 128, 1 = 128 x 256, 2 = by M (default); bit-identical
+bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
+void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
 void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4
 void set_gemm_tile(int v);   // 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128, 4 = 64x32, 5 = 32x32

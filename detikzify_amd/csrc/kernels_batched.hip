@@ -345,7 +345,11 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
 //     columns of one row: the epilogue stores 8 bytes per lane instead of four scattered 2-byte values.
 // LDS image, swizzle and fill map are k_gemm_glds's ([row][8 x 16 B], chunk ^ ((row >> 1) & 7), applied on the SOURCE address).
 // Same k order per output element as every other GEMM here (32-wide k-steps in order from zero).
-template <int BM, int BN>
+// SK (sliced-K roles, launch_gemm_sk): a block is (tile, K slice ks) — grid = tiles x kslices, ks = blockIdx % kslices, so that under the
+// round-robin dispatch over the 8 XCDs an XCD's L2 holds ONE slice of the activations (kslices = 8; two XCDs per slice at 4) — runs the
+// k-tiles of its slice through the same pipeline from zero and stores its fp32 accumulators to part[ks]; k_sk_reduce adds the slices in
+// order and applies the epilogue.  The ragged K tail belongs to the last slice.
+template <int BM, int BN, bool SK = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   constexpr int BK = 64, NST = 3, WAVES = 8;
   constexpr unsigned OPA = BM * BK * 2, OPW = BN * BK * 2, STB = OPA + OPW;   // 48 KiB per stage
@@ -357,10 +361,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   const int wr = wave / WN, wc = wave % WN;
   const int MB = (a.M + BM - 1) / BM, NB = (a.N + BN - 1) / BN;
   const int b = blockIdx.x;
-  const int nt = (b & 7) + 8 * ((b >> 3) / MB), mb = (b >> 3) % MB;            // XCD-aware map (see k_gemm_mfma)
+  int nt, mb, ks = 0, kt0 = 0;
+  if (SK) { ks = b % a.kslices; const int tile = b / a.kslices; nt = tile / MB; mb = tile % MB; }
+  else { nt = (b & 7) + 8 * ((b >> 3) / MB); mb = (b >> 3) % MB; }             // XCD-aware map (see k_gemm_mfma)
   if (nt >= NB) return;
   const int m0 = mb * BM, n0 = nt * BN;
   const int K = a.K;
+  int nk = K / BK;
+  if (SK) { const int q = sk_tiles_per_slice(K, a.kslices); kt0 = min(ks * q, nk); nk = min(kt0 + q, nk) - kt0; }
+  const bool tail = (K % BK) && (!SK || ks == a.kslices - 1);
 
   // fill map: piece p covers 8 tile rows of one operand (A: pieces 0 .. BM/8-1, then W); lane l fills LDS chunk (row l >> 3,
   // position l & 7) from source chunk (l & 7) ^ swz(row)
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   auto fill = [&](int t) {
     const unsigned base = (unsigned)(t % NST) * STB + (unsigned)wave * (unsigned)PPW * 1024u;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16_row(src[i] + (size_t)t * BK, base + (unsigned)i * 1024u);
+    for (int i = 0; i < PPW; ++i) glds16_row(src[i] + (size_t)(kt0 + t) * BK, base + (unsigned)i * 1024u);
   };
 
   f32x4 acc[4][4];      // acc[i][j]: m tile i, n tile j; register r = column n + r of row m (transposed MFMA)
@@ -411,7 +420,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     }
   };
 
-  const int nk = K / BK;
   if (nk > 0) fill(0);
   if (nk > 1) fill(1);
   for (int t = 0; t < nk; ++t) {
@@ -422,8 +430,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     if (t + 2 < nk && !(a.flags & GEMM_PROBE_NOFILL)) fill(t + 2);
     if (!(a.flags & GEMM_PROBE_NOMFMA)) compute(t % NST);
   }
-  if (K % BK) {                                    // ragged tail: register-staged, zero-filled, same image (swizzle included)
-    const int stage = nk % NST, k0 = nk * BK;
+  if (tail) {                                      // ragged tail: register-staged, zero-filled, same image (swizzle included)
+    const int stage = nk % NST, k0 = (kt0 + nk) * BK;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // nothing in flight; stage last read by compute(nk - 3)
     unsigned char* st = gsm + (unsigned)stage * STB;
     for (int c = tid; c < (BM + BN) * 8; c += 512) {
@@ -442,6 +450,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     compute(stage);
   }
   // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n.
+  if (SK) {                                        // the slice's fp32 sums, 16 bytes per lane (N % 4 == 0: launch_gemm_sk)
+    float* pbase = a.part + (size_t)ks * (size_t)a.part_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+        if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(pbase + (size_t)m * a.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // All bias / residual loads first (8 bytes each, clamped), then the arithmetic, then 8-byte stores.
   const int flags = a.flags;
   const bool vec = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
@@ -530,6 +551,103 @@ static bool launch_gemm_g3(const GemmArgs& a, hipStream_t s) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sliced-K GEMM: the prefill's N = d roles (o_proj, down) give the 256 x 128 tile 32 blocks for 256 CUs and q/k/v 96; the small tiles that
+// filled the chip instead ran them at 230-390 TFLOP/s (down_proj: 90 MB of weights in 96 us).  Here every CU gets a block of the big tile:
+// (tile, K slice), fp32 partials, one reduction pass that is also the role's epilogue and the RMSNorm behind it.
+static int g_sk_force_wide = -1;     // DTK_SK_TILE: 0 = 256 x 128, 1 = 128 x 256, unset = by M (<= 128 rows: the wide tile wastes fewer activation fills)
+void set_gemm_sk_tile(int v) { g_sk_force_wide = v; }
+bool gemm_sk_supported(const GemmArgs& a) {
+  if ((a.lda % 8) || (a.ldw % 8) || a.K < 128 || (a.K % 8) || (a.N % 4) || a.kslices < 1 || a.kslices > 8) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
+  return true;
+}
+template <int BM, int BN>
+static void launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (BM + BN) * 64 * 2;
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
+  const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm_g3<BM, BN, true>), dim3((unsigned)(mbs * nbs * a.kslices)), dim3(512), lds, s, a);
+}
+
+// Partials added in slice order (fp32), the GEMM epilogue, the row stored as bf16; then — norm_w — the HF RMSNorm of the stored row.  1024
+// threads = 4096 columns of one row per pass, every slice's 16 bytes requested before the first add (S x 16 KiB in flight per block): without
+// a norm the grid is (row, 4096-column chunk); with one a block owns its whole row (fp32 sum of squares: per thread over its columns in
+// order, wave_sum, the 16 waves' sums in wave order) and keeps the row in registers (N <= 4096) or reads its own stores back.
+template <int S>
+__device__ __forceinline__ f32x4 sk_sum(const float* p, size_t stride) {
+  f32x4 u[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) u[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)k * stride));
+  f32x4 v = u[0];
+#pragma unroll
+  for (int k = 1; k < S; ++k) { v[0] += u[k][0]; v[1] += u[k][1]; v[2] += u[k][2]; v[3] += u[k][3]; }
+  return v;
+}
+template <int S>
+__global__ __launch_bounds__(1024) void k_sk_reduce(GemmArgs a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps) {
+  __shared__ float red[16];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int flags = a.flags;
+  const float* p0 = a.part + (size_t)m * a.N;
+  bf16_t* crow = a.C + (size_t)m * a.ldc;
+  const bool vec = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
+  const bool rvec = (flags & GEMM_RESIDUAL) && (a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.residual) & 7) == 0;
+  const bool bvec = (flags & GEMM_BIAS) && (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0;
+  const int nbeg = norm_w ? 0 : blockIdx.y * 4096, nend = norm_w ? a.N : min(a.N, nbeg + 4096);
+  float ss = 0.f, keep[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = nbeg + tid * 4; n < nend; n += 4096) {
+    const f32x4 v = sk_sum<S>(p0 + n, (size_t)a.part_stride);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bvec) { const u32x2 p2 = *reinterpret_cast<const u32x2*>(a.bias + n); bv[0] = pk_lo(p2[0]); bv[1] = pk_hi(p2[0]); bv[2] = pk_lo(p2[1]); bv[3] = pk_hi(p2[1]); }
+    else if (flags & GEMM_BIAS) { for (int r = 0; r < 4; ++r) bv[r] = bf2f(a.bias[n + r]); }
+    if (rvec) { const u32x2 p2 = *reinterpret_cast<const u32x2*>(a.residual + (size_t)m * a.ldr + n); rv[0] = pk_lo(p2[0]); rv[1] = pk_hi(p2[0]); rv[2] = pk_lo(p2[1]); rv[3] = pk_hi(p2[1]); }
+    else if (flags & GEMM_RESIDUAL) { for (int r = 0; r < 4; ++r) rv[r] = bf2f(a.residual[(size_t)m * a.ldr + n + r]); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { keep[r] = bf2f(f2bf(gemm_epilogue_pre(v[r], bv[r], rv[r], flags))); ss += keep[r] * keep[r]; }
+    if (vec) { const u32x2 pk = {pack2(keep[0], keep[1]), pack2(keep[2], keep[3])}; *reinterpret_cast<u32x2*>(crow + n) = pk; }
+    else { for (int r = 0; r < 4; ++r) crow[n + r] = f2bf(keep[r]); }
+  }
+  if (!norm_w) return;
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  float tot = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) tot += red[w];
+  const float inv = rsqrtf(tot / (float)a.N + eps);
+  bf16_t* yrow = Y + (size_t)m * ldy;
+  const bool yvec = (ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(norm_w)) & 7) == 0;
+  for (int n = tid * 4; n < a.N; n += 4096) {
+    float x[4];
+    if (a.N <= 4096) { for (int r = 0; r < 4; ++r) x[r] = keep[r]; }
+    else { for (int r = 0; r < 4; ++r) x[r] = bf2f(crow[n + r]); }         // the thread's own stores above
+    if (yvec) {
+      const u32x2 g = *reinterpret_cast<const u32x2*>(norm_w + n);
+      const u32x2 pk = {pack2(pk_lo(g[0]) * rbf(x[0] * inv), pk_hi(g[0]) * rbf(x[1] * inv)), pack2(pk_lo(g[1]) * rbf(x[2] * inv), pk_hi(g[1]) * rbf(x[3] * inv))};
+      *reinterpret_cast<u32x2*>(yrow + n) = pk;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yrow[n + r] = f2bf(bf2f(norm_w[n + r]) * rbf(x[r] * inv));
+    }
+  }
+}
+void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s) {
+  const dim3 grid((unsigned)a.M, norm_w ? 1u : (unsigned)((a.N + 4095) / 4096));
+#define SK_RED(S_) case S_: hipLaunchKernelGGL(k_sk_reduce<S_>, grid, dim3(1024), 0, s, a, norm_w, Y, ldy, eps); break;
+  switch (a.kslices) { SK_RED(1) SK_RED(2) SK_RED(3) SK_RED(4) SK_RED(5) SK_RED(6) SK_RED(7) SK_RED(8) default: break; }
+#undef SK_RED
+}
+bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s) {
+  if (!gemm_sk_supported(a) || !a.part || a.part_stride < (long)a.M * a.N) return false;
+  if (g_sk_force_wide < 0) { const char* e = getenv("DTK_SK_TILE"); g_sk_force_wide = e ? (atoi(e) ? 1 : 0) : 2; }
+  const bool wide = g_sk_force_wide == 2 ? a.M <= 128 : g_sk_force_wide == 1;
+  if (wide) launch_gemm_sk_t<128, 256>(a, s); else launch_gemm_sk_t<256, 128>(a, s);
+  launch_sk_reduce(a, norm_w, Y, ldy, eps, s);
+  return true;
+}
+
 static int g_gemm_impl = -1;    // 0 = k_gemm_mfma (register-staged), 1 = k_gemm_dma (LDS-DMA ring), 2 = k_gemm_glds for shapes with >= g_glds_min_tiles 128 x 128 tiles (else k_gemm_mfma), 3 = auto (default: 2 for M >= 1024, else 0); dtk_set_option "gemm_impl" / DTK_GEMM_IMPL
 void set_gemm_impl(int v) { g_gemm_impl = v; }
 static int g_gemm_ring = 3;
@@ -601,6 +719,15 @@ __global__ void k_gemm_naive(GemmArgs a) {
   const bf16_t* ar = a.A + (size_t)m * a.lda;
   const bf16_t* wr = a.W + (size_t)n * a.ldw;
   float acc = 0.f;
+  if (a.kslices > 1) {                  // a sliced-K role: a chain per slice of k-tiles, the slices' sums added in order
+    const int q = sk_tiles_per_slice(a.K, a.kslices) * 64;
+    for (int ks = 0; ks < a.kslices; ++ks) {
+      const int k0 = min(ks * q, (a.K / 64) * 64), k1 = ks == a.kslices - 1 ? a.K : min(k0 + q, (a.K / 64) * 64);
+      float sl = 0.f;
+      for (int k = k0; k < k1; ++k) sl = fmaf(bf2f(ar[k]), bf2f(wr[k]), sl);
+      acc = ks ? acc + sl : sl;
+    }
+  } else
   for (int k = 0; k < a.K; ++k) acc = fmaf(bf2f(ar[k]), bf2f(wr[k]), acc);
   a.C[(size_t)m * a.ldc + n] = f2bf(gemm_epilogue(acc, m, n, a));
 }

@@ -180,6 +180,54 @@ def test_op_gemm_three_stage_kernel_is_bit_identical(tiny, M, N, K, flags):
     assert diff == 0, f"{diff} of {M * N} elements differ"
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(243, 512, 4096, 4), (243, 384, 5504, 4), (5, 260, 1408, 4), (130, 1000, 2048, 0), (300, 128, 4304, 5), (16, 512, 200, 1)])
+def test_op_gemm_sliced_k_family(tiny, M, N, K, flags):
+    """the sliced-K GEMM of the decoder prefill (k_gemm_g3<.., SK> writes a K slice's fp32 sums per block, k_sk_reduce adds the slices
+    in order and applies the epilogue): ONE slice through that path is the one-chain GEMM bit for bit; for every slice count the two
+    block tiles agree bit for bit (a row's arithmetic depends on neither the tile nor on the rows beside it: M rows alone == the first
+    rows of a larger call); the naive twin (a chain per slice, sums in order) differs by rare 1-ulp flips only; operands whose sums are
+    exact in fp32 give the exact result (indexing of slices, ragged K tail, M / N edges)."""
+    from detikzify_amd import _lib
+    model, _ = tiny
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    A = rb(torch.randn(M, K, generator=g)); W = rb(torch.randn(N, K, generator=g) * 0.05)
+    b = rb(torch.randn(N, generator=g) * 0.1); R = rb(torch.randn(M, N, generator=g))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    Ab, Wb, bb, Rb = bf16_bits(A), bf16_bits(W), bf16_bits(b), bf16_bits(R)
+
+    def run(a_bits, m, fl):
+        out = np.empty((m, N), dtype=np.uint16)
+        model._check(model.lib.dtk_op_gemm(model._ctx, p(a_bits), p(Wb), p(bb), p(Rb), m, N, K, fl, p(out)), "dtk_op_gemm")
+        return out
+    sk = lambda S: S << _lib.DTK_GEMM_KSLICES_SHIFT
+    try:
+        model.set_option("gemm_sk_tile", 0)
+        one_chain = run(Ab, M, flags)
+        assert np.array_equal(run(Ab, M, flags | sk(1)), one_chain), "one slice through partials + reduce"
+        for S in (2, 4, 8):
+            tall = run(Ab, M, flags | sk(S))
+            model.set_option("gemm_sk_tile", 1)
+            wide = run(Ab, M, flags | sk(S))
+            model.set_option("gemm_sk_tile", 0)
+            assert np.array_equal(tall, wide), f"S = {S}: 256 x 128 vs 128 x 256"
+            m1 = max(1, M // 3)
+            assert np.array_equal(run(np.ascontiguousarray(Ab[:m1]), m1, (flags & ~4) | sk(S)), run(Ab, M, (flags & ~4) | sk(S))[:m1]), f"S = {S}: rows alone"
+            naive = run(Ab, M, flags | sk(S) | _lib.DTK_GEMM_NAIVE)
+            frac = float((tall != naive).mean())
+            print(f"sliced-K {M}x{N}x{K} S={S}: vs naive twin differing {frac:.5f}")
+            assert frac < 2e-3      # fmaf chain vs the MFMA's tree inside a 32-wide k-step: rare 1-ulp flips only
+        # exact operands: small integers (|sum| < 2^24 in fp32 whatever the order), results kept below 256 so that bf16 holds them
+        Ai = torch.randint(-2, 3, (M, K), generator=g).float(); Wi = (torch.rand(N, K, generator=g) < 8.0 / K).float()
+        exact = (Ai.double() @ Wi.double().T)
+        assert float(exact.abs().max()) < 256
+        Aib, Wb = bf16_bits(Ai), bf16_bits(Wi)
+        for S in (1, 2, 4, 8):
+            got = run(Aib, M, sk(S))
+            assert np.array_equal(got, bf16_bits(exact.float())), f"S = {S}: exact operands"
+    finally:
+        model.set_option("gemm_sk_tile", 2)
+
+
 @pytest.mark.parametrize("N,K,mode", [(512, 256, 0), (256, 688, 0), (100, 2048, 1), (37, 4096, 1), (2048, 5504, 0)])
 def test_op_gemv(tiny, N, K, mode):
     model, _ = tiny
