@@ -62,6 +62,7 @@ struct SeqHost {   // host-side mirror of one sequence's decode state
 struct LayerW {
   bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
   bf16_t *t_wqkv = nullptr, *t_wo = nullptr, *t_wgu = nullptr, *t_wdown = nullptr;  // fragment-major copies (batched decode)
+  bf16_t *p_wqkv = nullptr, *p_wo = nullptr, *p_wgu = nullptr, *p_wdown = nullptr;  // fragment-major bf16 copies the prefill GEMMs stream (= t_* where those exist)
   uint8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;  // fp8 e4m3 copies (weight_format 1)
   float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;    // per-row power-of-two scales
   uint8_t *t8_wqkv = nullptr, *t8_wo = nullptr, *t8_wgu = nullptr, *t8_wdown = nullptr;  // fp8 pair-tiled copies (batched decode, fp8)
@@ -107,6 +108,7 @@ struct dtk_ctx {
   bf16_t *X, *Xn, *QKV, *Qh, *AO, *GU, *ACT;
   float* skpart = nullptr;           // fp32 partials of the sliced-K prefill GEMMs: [kslices][SK_CHUNK_ROWS][N], one role at a time
   size_t skpart_floats = 0;
+  int qkv_rope_fused = 1;            // a sliced q/k/v role reduces inside the RoPE + KV-append kernel (dtk_set_option "qkv_rope_fused"; bit-identical)
   int prefill_sk = 1;                // sliced-K prefill GEMMs for the roles with <= 128 tiles of 256 x 128 (dtk_set_option "prefill_sk": 0 = the one-chain kernels, 2 / 4 / 8 = a cap on the slices)
   int32_t* ids_dev = nullptr;
   // decode step
@@ -174,6 +176,7 @@ struct dtk_ctx {
   int act_fp8 = 0;
   bool launch_refused = false;       // a launcher of the step being issued had no kernel for its shape (nothing was launched for that role)
   bool tiled_ready = false;          // the fragment-major copies match the row-major weights
+  bool ptiled_ready = false;         // ... and the prefill's own (LayerW::p_*)
   BatchState* bs_host = nullptr;     // pinned ring [DTK_MAX_INFLIGHT]
   SamplingDev* sp_stage = nullptr; uint32_t* draw_stage = nullptr;   // pinned [DTK_MAX_SLOTS]: per-slot set_sampling uploads queued on the stream
   DecState* st_stage = nullptr;      // pinned [DTK_MAX_SLOTS]: dtk_resume_slot's state upload (no stream sync: a slot is resumed again only sequences later)
@@ -522,6 +525,14 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     }
     c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH + 1);   // + the sticky device error word (TOKB_ERR)
   }
+  for (int i = 0; i < L; ++i) {     // the prefill GEMMs' fragment-major weights: the batched step's copies where a bf16 context has them
+    if (c->nb > 0 && c->wfmt != 1) { if (reg) { LayerW& w = c->layers[i]; w.p_wqkv = w.t_wqkv; w.p_wo = w.t_wo; w.p_wgu = w.t_wgu; w.p_wdown = w.t_wdown; } continue; }
+    bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
+    bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
+    bf16_t* a3 = P.take<bf16_t>(tiled_elems(2 * ff, d));
+    bf16_t* a4 = P.take<bf16_t>(tiled_elems(d, ff));
+    if (reg) { LayerW& w = c->layers[i]; w.p_wqkv = a1; w.p_wo = a2; w.p_wgu = a3; w.p_wdown = a4; }
+  }
   c->scratch_bytes = (size_t)64 << 20;
   c->scratch = P.take<unsigned char>(c->scratch_bytes);
 }
@@ -539,13 +550,13 @@ void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 // One decoder-prefill Linear (+ residual) and, when norm_w is given, the RMSNorm that follows it (-> Y).  Roles whose weight shape gives the
 // 256 x 128 tile fewer than 128 blocks run as sliced-K GEMMs (kernels_batched.hip: launch_gemm_sk) — the slice count is a function of the
 // WEIGHT shape alone, so a row's arithmetic does not depend on how many rows are prefilled with it (tail prefill == full prefill).
-void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* res, int ldr, bf16_t* C, int ldc,
+void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* Wt, int ldw, const bf16_t* res, int ldr, bf16_t* C, int ldc,
                int M, int N, int K, int flags, const bf16_t* norm_w, bf16_t* Y, int ldy) {
   hipStream_t s = c->cur_stream ? c->cur_stream : c->stream;
   const int S = c->prefill_sk ? std::min(sk_role_slices(N, K), c->prefill_sk == 1 ? 8 : c->prefill_sk) : 1;
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = nullptr; g.residual = res; g.ldr = ldr;
-  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags; g.kslices = S;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags; g.kslices = S; g.Wt = Wt;
   bool done = false;
   if (S > 1 && c->gemm_naive) { launch_gemm_naive(g, s); done = true; }
   else if (S > 1 && gemm_sk_supported(g) && (size_t)S * SK_CHUNK_ROWS * (size_t)N <= c->skpart_floats) {
@@ -560,6 +571,22 @@ void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, c
   } else if (S > 1) { c->launch_refused = true; return; }    // a sliced role has one canonical order: no silent change of kernel
   if (!done) { g.kslices = 1; if (c->gemm_naive) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s); }
   if (norm_w) launch_rmsnorm_rows(C, ldc, norm_w, Y, ldy, M, N, c->cfg.rms_eps, s);
+}
+
+// q/k/v of n <= SK_CHUNK_ROWS prefill rows as a sliced-K GEMM whose reduction is fused with RoPE + the KV append (no [n][qkvn] buffer);
+// false = the role is not sliced here (the caller runs Linear + k_rope_scatter).  Same values as that pair, bit for bit.
+bool qkv_rope_fused(dtk_ctx* c, const LayerW& w, int n, int start, bf16_t* kc, bf16_t* vc, hipStream_t s) {
+  const int d = c->d, qkvn = d + 2 * c->KVH * 128;
+  const int S = c->prefill_sk ? std::min(sk_role_slices(qkvn, d), c->prefill_sk == 1 ? 8 : c->prefill_sk) : 1;
+  if (S <= 1 || c->gemm_naive || !c->qkv_rope_fused || n > SK_CHUNK_ROWS || (size_t)S * SK_CHUNK_ROWS * (size_t)qkvn > c->skpart_floats) return false;
+  GemmArgs g;
+  g.A = c->Xn; g.lda = d; g.W = w.wqkv; g.Wt = w.p_wqkv; g.ldw = d; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
+  g.C = c->QKV; g.ldc = qkvn; g.M = n; g.N = qkvn; g.K = d; g.flags = 0; g.kslices = S;
+  g.part = c->skpart; g.part_stride = (long)SK_CHUNK_ROWS * qkvn;
+  if (!gemm_sk_supported(g)) return false;
+  if (!launch_gemm_sk_partials(g, s)) { c->launch_refused = true; return true; }
+  launch_sk_rope_scatter(g.part, g.part_stride, S, c->Qh, kc, vc, c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
+  return true;
 }
 
 int gelu_flag(const dtk_ctx* c) { return c->cfg.vit_gelu_tanh ? GEMM_GELU_TANH : GEMM_GELU_ERF; }
@@ -875,6 +902,23 @@ void ensure_fp8_weights(dtk_ctx* c) {
   launch_quant_fp8_rows(c->lm_head, c->q_lm_head, c->s_lm_head, c->V, c->d, c->stream);
   c->fp8_ready = true;
   c->tiled_ready = false;
+  c->ptiled_ready = false;
+}
+
+void ensure_tiled_weights(dtk_ctx* c);
+// fragment-major bf16 copies for the prefill GEMMs (of the de-quantised weights in fp8 mode)
+void ensure_prefill_tiles(dtk_ctx* c) {
+  ensure_fp8_weights(c);
+  if (c->ptiled_ready) return;
+  if (c->nb > 0 && c->wfmt != 1) { ensure_tiled_weights(c); c->ptiled_ready = true; return; }
+  for (int l = 0; l < c->L; ++l) {
+    LayerW& w = c->layers[l];
+    launch_retile(w.wqkv, w.p_wqkv, c->d + 2 * c->KVH * 128, c->d, c->stream);
+    launch_retile(w.wo, w.p_wo, c->d, c->d, c->stream);
+    launch_retile(w.wgu, w.p_wgu, 2 * c->ff, c->d, c->stream);
+    launch_retile(w.wdown, w.p_wdown, c->d, c->ff, c->stream);
+  }
+  c->ptiled_ready = true;
 }
 
 void ensure_tiled_weights(dtk_ctx* c) {
@@ -1236,6 +1280,7 @@ int dtk_load_tensor(dtk_ctx* c, const char* name, const void* host, int dtype, c
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
   c->tiled_ready = false;
+  c->ptiled_ready = false;
   c->fp8_ready = false;
   return DTK_OK;
 }
@@ -1274,6 +1319,7 @@ int dtk_fill_synthetic(dtk_ctx* c, uint64_t seed) {
   c->seq0.cached_ids.clear();
   for (auto& b : c->bseq) b.cached_ids.clear();
   c->tiled_ready = false;
+  c->ptiled_ready = false;
   c->fp8_ready = false;
   return DTK_OK;
 }
@@ -1322,7 +1368,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   HIPCHK(c, hipSetDevice(c->device));
   // drain pending decode steps (their tokens are dropped)
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  ensure_fp8_weights(c);
+  ensure_prefill_tiles(c);
   if (is_single) c->waited = c->launched = 0;  // the device draw counter restarts with this prefill
   else c->bwaited = c->blaunched;
   // ---- locate the image placeholder run (reference v1/modeling_detikzify.py:179-184)
@@ -1382,8 +1428,10 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
     const int qkvn = d + 2 * c->KVH * 128;
-    gemm_role(c, c->Xn, d, w.wqkv, d, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0, nullptr, nullptr, 0);
-    launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
+    if (!qkv_rope_fused(c, w, n, start, kc(l), vc(l), s)) {
+      gemm_role(c, c->Xn, d, w.wqkv, w.p_wqkv, d, nullptr, 0, c->QKV, qkvn, n, qkvn, d, 0, nullptr, nullptr, 0);
+      launch_rope_scatter(c->QKV, c->Qh, kc(l), vc(l), c->rope_cos, c->rope_sin, n, start, c->H, c->KVH, c->Tmax, s);
+    }
     AttnArgs a;
     a.Q = c->Qh; a.q_sh = (long)n * 128; a.q_st = 128;
     a.K = kc(l); a.k_sh = (long)c->Tmax * 128; a.k_st = 128;
@@ -1391,11 +1439,11 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     a.O = c->AO; a.o_sh = 128; a.o_st = d;
     a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl; a.kv_group = c->H / c->KVH;
     launch_attention(a, s);
-    gemm_role(c, c->AO, d, w.wo, d, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL, w.ln2, c->Xn, d);     // + post_attention_layernorm -> Xn
-    gemm_role(c, c->Xn, d, w.wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
+    gemm_role(c, c->AO, d, w.wo, w.p_wo, d, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL, w.ln2, c->Xn, d);     // + post_attention_layernorm -> Xn
+    gemm_role(c, c->Xn, d, w.wgu, w.p_wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
     launch_silu_mul(c->GU, ff, c->ACT, n, s);
     // + the next layer's input_layernorm -> Xn (the final norm runs on the last row only, inside the lm_head GEMV below)
-    gemm_role(c, c->ACT, ff, w.wdown, ff, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL, l + 1 < c->L ? c->layers[l + 1].ln1 : nullptr, c->Xn, d);
+    gemm_role(c, c->ACT, ff, w.wdown, w.p_wdown, ff, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL, l + 1 < c->L ? c->layers[l + 1].ln1 : nullptr, c->Xn, d);
   }
   if (c->launch_refused) { c->launch_refused = false; return fail(c, DTK_ERR_STATE, "prefill: a sliced-K projection was refused by its kernel (nothing launched for it)"); }
   // final norm + lm_head on the last position only (the sampler consumes logits[:, -1])
@@ -2007,6 +2055,9 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     c->seq0.image_key = 0; c->seq0.cached_ids.clear();
     for (SeqHost& sh : c->bseq) { sh.image_key = 0; sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
   }
+  else if (!strcmp(name, "qkv_rope_fused")) c->qkv_rope_fused = value != 0;
+  else if (!strcmp(name, "gemm_epi_direct")) set_gemm_epi_direct(value != 0);   // k_gemm_g3 without the LDS-transposed epilogue (default 0; process-wide; bit-identical)
+  else if (!strcmp(name, "gemm_wt")) set_gemm_wt(value != 0);     // k_gemm_g3's W stage from the fragment-major copy (default 1; process-wide; bit-identical)
   else if (!strcmp(name, "gemm_sk_tile")) {   // block tile of the sliced-K GEMM: 0 = 256 x 128, 1 = 128 x 256, 2 = by M (process-wide; bit-identical)
     if (value < 0 || value > 2) return fail(c, DTK_ERR_ARG, "gemm_sk_tile must be 0, 1 or 2");
     set_gemm_sk_tile(value);
@@ -2088,6 +2139,11 @@ int dtk_op_gemm(dtk_ctx* c, const uint16_t* A, const uint16_t* W, const uint16_t
   GemmArgs g;
   g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.residual = dR; g.ldr = N; g.C = dC; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.flags = gf;
+  if (flags & DTK_GEMM_WT) {          // + the fragment-major copy of W (k_gemm_g3's W stage is filled from it)
+    OPBUF(bf16_t, dWt, tiled_elems(N, K));
+    launch_retile(dW, dWt, N, K, s);
+    g.Wt = dWt;
+  }
   const int S = (flags >> DTK_GEMM_KSLICES_SHIFT) & 15;       // 0 = a one-chain GEMM; 1..8 = the sliced-K family (1: one slice through the partial + reduce path)
   if (S) {
     if (S > 8) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: at most 8 K slices");

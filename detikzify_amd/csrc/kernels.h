@@ -197,6 +197,7 @@ void set_gemv_mv_shape(int role, int shape);   // role = epilogue id (5 = o_proj
 #define GEMM_GELU_ERF 2
 #define GEMM_GELU_TANH 4
 #define GEMM_RESIDUAL 8
+#define GEMM_EPI_DIRECT 32768       // k_gemm_g3: the lanes store their accumulators directly (the epilogue before round 6's LDS-transposed one; A/B and bit-identity tests)
 #define GEMM_PROBE_NOFILL 65536    // k_gemm_g3 timing experiments (DTK_G3_PROBE): leave parts of the kernel out
 #define GEMM_PROBE_NOMFMA 131072
 struct GemmArgs {
@@ -212,6 +213,10 @@ struct GemmArgs {
   // in fp32 — the canonical order of such a role at ANY M and tile shape.  part = fp32 [kslices][part_rows][N] (launch_gemm_sk).
   int kslices = 1;
   float* part = nullptr; long part_stride = 0;
+  // W again as fragment-major tiles (launch_retile's image: 1 KiB per (16 rows, 32-wide k-step)), or null.  k_gemm_g3 fills its W stage from
+  // it when present: a fill instruction then reads 1 KiB CONTIGUOUS instead of 8 rows x 128 B that lie K x 2 bytes apart (the row-major
+  // stream of the prefill GEMMs reached 2.4 TB/s of HBM), and the piece lands in LDS as the MFMA operand.  Same values, same k order.
+  const bf16_t* Wt = nullptr;
 };
 __host__ __device__ inline int sk_tiles_per_slice(int K, int S) { const int T = K / 64; return (T + S - 1) / S; }
 // slices of a decoder-prefill role, from its WEIGHT shape alone: the largest power of two <= 8 that keeps 256 x 128 tiles x slices within
@@ -230,8 +235,14 @@ void launch_gemm_mfma(const GemmArgs& a, hipStream_t s);
 // fp32 partials, then k_sk_reduce: partials summed in slice order + the GEMM epilogue (+ the RMSNorm that follows the role, fused:
 // norm_w / Y / ldy / eps; norm_w = null: none).  false = the shape is not one the kernel takes (nothing launched).
 bool gemm_sk_supported(const GemmArgs& a);
+void set_gemm_wt(int v);        // 1 (default): k_gemm_g3 fills its W stage from GemmArgs::Wt when given; 0: always from the row-major weights (bit-identical)
+void set_gemm_epi_direct(int v);   // 1: k_gemm_g3 stores from the accumulator layout (no LDS transpose); bit-identical
 void set_gemm_sk_tile(int v);   // 0 = 256 x 128, 1 = 128 x 256, 2 = by M (default); bit-identical
 bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
+bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s);     // the GEMM alone: a.part holds the slices' sums afterwards
+// the q/k/v role's reduction fused with k_rope_scatter (same rounding points: bf16 of the summed slices, then RoPE)
+void launch_sk_rope_scatter(const float* part, long part_stride, int kslices, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
+                            const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H, int KVH, int T_max, hipStream_t s);
 void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
 void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4

@@ -349,7 +349,8 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
 // round-robin dispatch over the 8 XCDs an XCD's L2 holds ONE slice of the activations (kslices = 8; two XCDs per slice at 4) — runs the
 // k-tiles of its slice through the same pipeline from zero and stores its fp32 accumulators to part[ks]; k_sk_reduce adds the slices in
 // order and applies the epilogue.  The ragged K tail belongs to the last slice.
-template <int BM, int BN, bool SK = false>
+// WT: the W stage is filled from the fragment-major copy a.Wt (GemmArgs) and read back as whole 1 KiB operands.
+template <int BM, int BN, bool SK = false, bool WT = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   constexpr int BK = 64, NST = 3, WAVES = 8;
   constexpr unsigned OPA = BM * BK * 2, OPW = BN * BK * 2, STB = OPA + OPW;   // 48 KiB per stage
@@ -373,7 +374,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
 
   // fill map: piece p covers 8 tile rows of one operand (A: pieces 0 .. BM/8-1, then W); lane l fills LDS chunk (row l >> 3,
   // position l & 7) from source chunk (l & 7) ^ swz(row)
+  // WT: W piece pw = p - BM/8 is fragment (row tile pw >> 1, k-step pw & 1) of the k-tile — 1 KiB contiguous in a.Wt, lane-linear in LDS
   const bf16_t* src[PPW];
+  const int K32 = (K + 31) >> 5, N16 = (a.N + 15) >> 4;
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int p = wave * PPW + i;
@@ -381,12 +384,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     const int row = (isA ? p : p - BM / 8) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (isA) { int am = m0 + row; if (am >= a.M) am = a.M - 1; src[i] = a.A + (size_t)am * a.lda + chunk * 8; }
+    else if (WT) { const int pw = p - BM / 8; const int tn = min(n0 / 16 + (pw >> 1), N16 - 1); src[i] = a.Wt + ((size_t)tn * K32 + (pw & 1)) * 512 + lane * 8; }
     else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; src[i] = a.W + (size_t)wn * a.ldw + chunk * 8; }
   }
   auto fill = [&](int t) {
     const unsigned base = (unsigned)(t % NST) * STB + (unsigned)wave * (unsigned)PPW * 1024u;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16_row(src[i] + (size_t)(kt0 + t) * BK, base + (unsigned)i * 1024u);
+    for (int i = 0; i < PPW; ++i) {
+      const bool isW = WT && wave * PPW + i >= BM / 8;                         // a fragment-major k-tile is two 1 KiB tiles further on
+      glds16_row(src[i] + (size_t)(kt0 + t) * (isW ? 1024 : BK), base + (unsigned)i * 1024u);
+    }
   };
 
   f32x4 acc[4][4];      // acc[i][j]: m tile i, n tile j; register r = column n + r of row m (transposed MFMA)
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const unsigned ra = (unsigned)(wr * 64 + i * 16 + (lane & 15)), rb = (unsigned)(wc * 64 + i * 16 + (lane & 15));
-    aoff[i] = ra * 128u; boff[i] = OPA + rb * 128u;
+    aoff[i] = ra * 128u; boff[i] = WT ? OPA + (unsigned)((wc * 4 + i) * 2) * 1024u + (unsigned)lane * 16u : OPA + rb * 128u;
   }
   const unsigned swz = (unsigned)(((lane & 15) >> 1) & 7);
   const unsigned q0 = (unsigned)(lane >> 4);
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i] + coff);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + boff[j] + coff);
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + boff[j] + (WT ? (unsigned)ks * 1024u : coff));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -444,12 +451,76 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
         if (isA) { int am = m0 + row; if (am >= a.M) am = a.M - 1; v = *reinterpret_cast<const u32x4*>(a.A + (size_t)am * a.lda + k); }
         else { int wn = n0 + row; if (wn >= a.N) wn = a.N - 1; v = *reinterpret_cast<const u32x4*>(a.W + (size_t)wn * a.ldw + k); }
       }
-      *reinterpret_cast<u32x4*>(st + (isA ? 0u : OPA) + (unsigned)row * 128u + (unsigned)pos * 16u) = v;
+      if (WT && !isA) *reinterpret_cast<u32x4*>(st + OPA + (unsigned)((row >> 4) * 2 + (chunk >> 2)) * 1024u + (unsigned)((chunk & 3) * 16 + (row & 15)) * 16u) = v;
+      else *reinterpret_cast<u32x4*>(st + (isA ? 0u : OPA) + (unsigned)row * 128u + (unsigned)pos * 16u) = v;
     }
     __syncthreads();
     compute(stage);
   }
   // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n.
+  // Epilogue through LDS (default): a lane's direct stores are 8 bytes (16 as a K slice's fp32) at 16 different rows per instruction — 32-byte
+  // pieces, 15 of the 77 us of the prefill's gate/up launch.  The stages are free now: every wave parks its 64 x 64 fp32 tile in its own
+  // 17 KiB of LDS (row stride 272 B: the 16-byte slots of a store instruction spread evenly over the banks), then walks it row by row — 8
+  // lanes per row, 8 consecutive columns each: bias / residual arrive as 16-byte loads, the output leaves as 16-byte stores, 8 rows x 128 B
+  // per instruction (a K slice: 32-byte stores, 256 B per row).  Same arithmetic per element.
+  if (!(a.flags & GEMM_EPI_DIRECT) && (a.N & 7) == 0 && (SK || ((a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0))) {
+    constexpr unsigned ROWB = 272u, WREG = 64u * ROWB;
+    unsigned char* reg = gsm + (unsigned)wave * WREG;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                  // every wave is done with the last stage
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(reg + (unsigned)(i * 16 + (lane & 15)) * ROWB + (unsigned)(j * 16 + (lane >> 4) * 4) * 4u) = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   // the wave's own tile: no barrier
+    const int flags = a.flags;
+    const int nl = (lane & 7) * 8, n = n0 + wc * 64 + nl;
+    const bool nin = n < a.N;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!SK && (flags & GEMM_BIAS)) {
+      const int nb = min(n, a.N - 8);
+      if ((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) {
+        const u32x4 b4 = *reinterpret_cast<const u32x4*>(a.bias + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[2 * e] = pk_lo(b4[e]); bv[2 * e + 1] = pk_hi(b4[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = bf2f(a.bias[nb + e]);
+      }
+    }
+    const bool rvec = !SK && (flags & GEMM_RESIDUAL) && (a.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0;
+    float* pbase = SK ? a.part + (size_t)ks * (size_t)a.part_stride : nullptr;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ml = it * 8 + (lane >> 3), m = m0 + wr * 64 + ml;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(reg + (unsigned)ml * ROWB + (unsigned)nl * 4u);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(reg + (unsigned)ml * ROWB + (unsigned)nl * 4u + 16u);
+      if (SK) {
+        if (m < a.M && nin) { float* d = pbase + (size_t)m * a.N + n; *reinterpret_cast<f32x4*>(d) = v0; *reinterpret_cast<f32x4*>(d + 4) = v1; }
+        continue;
+      }
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (flags & GEMM_RESIDUAL) {
+        const bf16_t* rp = a.residual + (size_t)min(m, a.M - 1) * a.ldr + min(n, a.N - 8);
+        if (rvec) {
+          const u32x4 r4 = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { rv[2 * e] = pk_lo(r4[e]); rv[2 * e + 1] = pk_hi(r4[e]); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = bf2f(rp[e]);
+        }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
+        o[e] = (uint32_t)f2bf(gemm_epilogue_pre(x0, bv[2 * e], rv[2 * e], flags)) | ((uint32_t)f2bf(gemm_epilogue_pre(x1, bv[2 * e + 1], rv[2 * e + 1], flags)) << 16);
+      }
+      if (m < a.M && nin) *reinterpret_cast<u32x4*>(a.C + (size_t)m * a.ldc + n) = o;
+    }
+    return;
+  }
   if (SK) {                                        // the slice's fp32 sums, 16 bytes per lane (N % 4 == 0: launch_gemm_sk)
     float* pbase = a.part + (size_t)ks * (size_t)a.part_stride;
 #pragma unroll
@@ -521,15 +592,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     }
   }
 }
+static int g_g3_epi_direct = 0;       // 1: k_gemm_g3's lanes store their accumulators directly (dtk_set_option "gemm_epi_direct"; bit-identical)
+void set_gemm_epi_direct(int v) { g_g3_epi_direct = v; }
 static int g_g3_min_blocks = 128;     // blocks a shape must give k_gemm_g3 (one per CU): below that the smaller tiles fill the chip better
 void set_gemm_g3_min_blocks(int v) { g_g3_min_blocks = v; }
-template <int BM, int BN>
+static bool use_wt(const GemmArgs& a);
+template <int BM, int BN, bool WT = false>
 static void launch_gemm_g3_t(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * 64 * 2;
   static unsigned long long attr_set = 0;
-  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN, false, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_gemm_g3<BM, BN>), dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((k_gemm_g3<BM, BN, false, WT>), dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(512), lds, s, a);
 }
 static bool launch_gemm_g3(const GemmArgs& a, hipStream_t s) {
   if ((a.lda % 8) || (a.ldw % 8) || a.K < 128 || (a.K % 8)) return false;
@@ -545,9 +619,11 @@ static bool launch_gemm_g3(const GemmArgs& a, hipStream_t s) {
   static int probe = -1;          // DTK_G3_PROBE: 1 = no fills after the first two k-tiles, 2 = no MFMAs (timing experiments: wrong results)
   if (probe < 0) { const char* e = getenv("DTK_G3_PROBE"); probe = e ? atoi(e) : 0; }
   GemmArgs b = a;
+  if (g_g3_epi_direct) b.flags |= GEMM_EPI_DIRECT;
   if (probe & 1) b.flags |= GEMM_PROBE_NOFILL;
   if (probe & 2) b.flags |= GEMM_PROBE_NOMFMA;
-  if (use_wide) launch_gemm_g3_t<128, 256>(b, s); else launch_gemm_g3_t<256, 128>(b, s);
+  if (use_wt(b)) { if (use_wide) launch_gemm_g3_t<128, 256, true>(b, s); else launch_gemm_g3_t<256, 128, true>(b, s); }
+  else if (use_wide) launch_gemm_g3_t<128, 256>(b, s); else launch_gemm_g3_t<256, 128>(b, s);
   return true;
 }
 
@@ -562,14 +638,17 @@ bool gemm_sk_supported(const GemmArgs& a) {
   if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
   return true;
 }
-template <int BM, int BN>
+template <int BM, int BN, bool WT>
 static void launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * 64 * 2;
   static unsigned long long attr_set = 0;
-  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN, true, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
   const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_gemm_g3<BM, BN, true>), dim3((unsigned)(mbs * nbs * a.kslices)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((k_gemm_g3<BM, BN, true, WT>), dim3((unsigned)(mbs * nbs * a.kslices)), dim3(512), lds, s, a);
 }
+static int g_gemm_wt = 1;      // 0: ignore GemmArgs::Wt (dtk_set_option "gemm_wt")
+void set_gemm_wt(int v) { g_gemm_wt = v; }
+static bool use_wt(const GemmArgs& a) { return g_gemm_wt && a.Wt && !(reinterpret_cast<uintptr_t>(a.Wt) & 15); }
 
 // Partials added in slice order (fp32), the GEMM epilogue, the row stored as bf16; then — norm_w — the HF RMSNorm of the stored row.  1024
 // threads = 4096 columns of one row per pass, every slice's 16 bytes requested before the first add (S x 16 KiB in flight per block): without
@@ -640,11 +719,26 @@ void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ld
 #undef SK_RED
 }
 bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s) {
+  if (!launch_gemm_sk_partials(a, s)) return false;
+  launch_sk_reduce(a, norm_w, Y, ldy, eps, s);
+  return true;
+}
+bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s) {
   if (!gemm_sk_supported(a) || !a.part || a.part_stride < (long)a.M * a.N) return false;
   if (g_sk_force_wide < 0) { const char* e = getenv("DTK_SK_TILE"); g_sk_force_wide = e ? (atoi(e) ? 1 : 0) : 2; }
   const bool wide = g_sk_force_wide == 2 ? a.M <= 128 : g_sk_force_wide == 1;
-  if (wide) launch_gemm_sk_t<128, 256>(a, s); else launch_gemm_sk_t<256, 128>(a, s);
-  launch_sk_reduce(a, norm_w, Y, ldy, eps, s);
+  static int probe = -1;          // DTK_G3_PROBE (timing experiments: wrong results), as in launch_gemm_g3
+  if (probe < 0) { const char* e = getenv("DTK_G3_PROBE"); probe = e ? atoi(e) : 0; }
+  if (g_g3_epi_direct && !probe) { GemmArgs b = a; b.flags |= GEMM_EPI_DIRECT;
+    if (use_wt(b)) { if (wide) launch_gemm_sk_t<128, 256, true>(b, s); else launch_gemm_sk_t<256, 128, true>(b, s); }
+    else if (wide) launch_gemm_sk_t<128, 256, false>(b, s); else launch_gemm_sk_t<256, 128, false>(b, s);
+    return true; }
+  if (probe) { GemmArgs b = a; if (probe & 1) b.flags |= GEMM_PROBE_NOFILL; if (probe & 2) b.flags |= GEMM_PROBE_NOMFMA;
+               if (use_wt(b)) { if (wide) launch_gemm_sk_t<128, 256, true>(b, s); else launch_gemm_sk_t<256, 128, true>(b, s); }
+               else if (wide) launch_gemm_sk_t<128, 256, false>(b, s); else launch_gemm_sk_t<256, 128, false>(b, s);
+               return true; }
+  if (use_wt(a)) { if (wide) launch_gemm_sk_t<128, 256, true>(a, s); else launch_gemm_sk_t<256, 128, true>(a, s); }
+  else if (wide) launch_gemm_sk_t<128, 256, false>(a, s); else launch_gemm_sk_t<256, 128, false>(a, s);
   return true;
 }
 
@@ -925,6 +1019,49 @@ void launch_rope_scatter(const bf16_t* QKV, bf16_t* Qh, bf16_t* kcache, bf16_t* 
                          int T_max, hipStream_t s) {
   hipLaunchKernelGGL(k_rope_scatter, dim3(T, H), dim3(64), 0, s, QKV, Qh, kcache, vcache, cos_t,
                      sin_t, T, start_pos, H, KVH, T_max);
+}
+
+// The q/k/v role as a sliced-K GEMM: its reduction IS k_rope_scatter's input — the slices' fp32 sums added in order, rounded to bf16 (the
+// Linear's output: what k_sk_reduce would have stored), then k_rope_scatter's arithmetic; no [T][qkvn] buffer in between.
+template <int S>
+__global__ void k_sk_rope_scatter(const float* part, long part_stride, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
+                                  const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H, int KVH, int T_max) {
+  const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
+  const int qd = H * 128, kvd = KVH * 128, N = qd + 2 * kvd;
+  const int pos = start_pos + t;
+  const float* row = part + (size_t)t * N;
+  auto val = [&](int n) {
+    float v = row[n];
+#pragma unroll
+    for (int k = 1; k < S; ++k) v += row[(size_t)k * (size_t)part_stride + n];
+    return rbf(v);
+  };
+  const float c = bf2f(cos_t[(size_t)pos * 64 + i]);
+  const float s = bf2f(sin_t[(size_t)pos * 64 + i]);
+  {
+    const float x1 = val(h * 128 + i), x2 = val(h * 128 + i + 64);
+    bf16_t* dst = Qh + ((size_t)h * T + t) * 128;
+    dst[i] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+    dst[i + 64] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+  }
+  if (h >= KVH) return;
+  {
+    const float x1 = val(qd + h * 128 + i), x2 = val(qd + h * 128 + i + 64);
+    bf16_t* dst = kcache + ((size_t)h * T_max + pos) * 128;
+    dst[i] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+    dst[i + 64] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+  }
+  {
+    bf16_t* dst = vcache + ((size_t)h * T_max + pos) * 128;
+    dst[i] = f2bf(val(qd + kvd + h * 128 + i));
+    dst[i + 64] = f2bf(val(qd + kvd + h * 128 + i + 64));
+  }
+}
+void launch_sk_rope_scatter(const float* part, long part_stride, int kslices, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
+                            const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H, int KVH, int T_max, hipStream_t s) {
+#define SK_ROPE(S_) case S_: hipLaunchKernelGGL(k_sk_rope_scatter<S_>, dim3(T, H), dim3(64), 0, s, part, part_stride, Qh, kcache, vcache, cos_t, sin_t, T, start_pos, H, KVH, T_max); break;
+  switch (kslices) { SK_ROPE(1) SK_ROPE(2) SK_ROPE(3) SK_ROPE(4) SK_ROPE(5) SK_ROPE(6) SK_ROPE(7) SK_ROPE(8) default: break; }
+#undef SK_ROPE
 }
 
 // ------------------------------------------------------------------------------------------

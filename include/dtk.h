@@ -377,6 +377,7 @@ int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 #define DTK_EPI_GELU 2        /* gelu(acc + bias)                   */
 #define DTK_EPI_RESIDUAL 4    /* bf16(acc + bias) + residual[m,n]   */
 #define DTK_GEMM_NAIVE 256    /* use the non-MFMA reference kernel  */
+#define DTK_GEMM_WT 512       /* also hand the kernel W as fragment-major tiles (what the decoder prefill does): same result, bit for bit */
 #define DTK_GEMM_KSLICES_SHIFT 12   /* flags |= S << 12 (S = 1..8): the sliced-K family of the decoder prefill — K's 64-wide k-tiles cut into S
                                      * runs, a chain per run, the runs' sums added in order (fp32); either kernel (MFMA / naive) */
 /* C[M,N] = A[M,K] . W[N,K]^T (+epilogue) */
