@@ -17,6 +17,7 @@ DTK_MAX_INFLIGHT = 4
 DTK_MAX_BATCH = 64          # entries of the active / tokens_out arrays of dtk_decode_batch_*
 DTK_EPI_BIAS, DTK_EPI_GELU, DTK_EPI_RESIDUAL, DTK_GEMM_NAIVE = 1, 2, 4, 256
 DTK_GEMM_WT = 512
+DTK_GEMM_SL = 1024
 DTK_GEMM_KSLICES_SHIFT = 12     # dtk_op_gemm: flags |= S << 12 selects the sliced-K family (include/dtk.h)
 
 

@@ -106,6 +106,7 @@ struct dtk_ctx {
 
   // activations: decoder prefill
   bf16_t *X, *Xn, *QKV, *Qh, *AO, *GU, *ACT;
+  int sk_sl_min_rows = SK_SL_MIN_ROWS;   // above this many rows a sliced role is one launch with the slices folded in registers (dtk_set_option "sk_sl_min_rows"; bit-identical)
   float* skpart = nullptr;           // fp32 partials of the sliced-K prefill GEMMs: [kslices][SK_CHUNK_ROWS][N], one role at a time
   size_t skpart_floats = 0;
   int qkv_rope_fused = 1;            // a sliced q/k/v role reduces inside the RoPE + KV-append kernel (dtk_set_option "qkv_rope_fused"; bit-identical)
@@ -547,6 +548,25 @@ void gemm(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   else launch_gemm_mfma(g, s);
 }
 
+// A sliced-K role (g.kslices > 1) at g.M rows: up to SK_SL_MIN_ROWS rows as (tile, slice) blocks + the reduction, in chunks of SK_CHUNK_ROWS
+// rows whose partials stay inside the Infinity Cache; above, where the tiles alone fill the chip, as one launch that folds the slices in
+// registers.  Same arithmetic per row either way (tested), so a row never depends on how many rows travel with it.
+bool gemm_sliced(dtk_ctx* c, const GemmArgs& g, float* part, size_t part_floats, const bf16_t* norm_w, bf16_t* Y, int ldy, hipStream_t s) {
+  if (!gemm_sk_supported(g) || (size_t)g.kslices * SK_CHUNK_ROWS * (size_t)g.N > part_floats) return false;
+  if (g.M > c->sk_sl_min_rows && launch_gemm_g3_sliced(g, s)) {
+    if (norm_w) launch_rmsnorm_rows_sk(g.C, g.ldc, norm_w, Y, ldy, g.M, g.N, c->cfg.rms_eps, s);
+    return true;
+  }
+  for (int m0 = 0; m0 < g.M; m0 += SK_CHUNK_ROWS) {
+    GemmArgs h = g;
+    h.M = std::min(SK_CHUNK_ROWS, g.M - m0);
+    h.A = g.A + (size_t)m0 * g.lda; h.C = g.C + (size_t)m0 * g.ldc; h.residual = g.residual ? g.residual + (size_t)m0 * g.ldr : nullptr;
+    h.part = part; h.part_stride = (long)SK_CHUNK_ROWS * g.N;
+    if (!launch_gemm_sk(h, norm_w, norm_w ? Y + (size_t)m0 * ldy : nullptr, ldy, c->cfg.rms_eps, s)) return false;
+  }
+  return true;
+}
+
 // One decoder-prefill Linear (+ residual) and, when norm_w is given, the RMSNorm that follows it (-> Y).  Roles whose weight shape gives the
 // 256 x 128 tile fewer than 128 blocks run as sliced-K GEMMs (kernels_batched.hip: launch_gemm_sk) — the slice count is a function of the
 // WEIGHT shape alone, so a row's arithmetic does not depend on how many rows are prefilled with it (tail prefill == full prefill).
@@ -559,16 +579,10 @@ void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, const bf16
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.flags = flags; g.kslices = S; g.Wt = Wt;
   bool done = false;
   if (S > 1 && c->gemm_naive) { launch_gemm_naive(g, s); done = true; }
-  else if (S > 1 && gemm_sk_supported(g) && (size_t)S * SK_CHUNK_ROWS * (size_t)N <= c->skpart_floats) {
-    for (int m0 = 0; m0 < M; m0 += SK_CHUNK_ROWS) {      // rows are independent: chunks keep the partials inside the Infinity Cache
-      GemmArgs h = g;
-      h.M = std::min(SK_CHUNK_ROWS, M - m0);
-      h.A = A + (size_t)m0 * lda; h.C = C + (size_t)m0 * ldc; h.residual = res ? res + (size_t)m0 * ldr : nullptr;
-      h.part = c->skpart; h.part_stride = (long)SK_CHUNK_ROWS * N;
-      if (!launch_gemm_sk(h, norm_w, norm_w ? Y + (size_t)m0 * ldy : nullptr, ldy, c->cfg.rms_eps, s)) { c->launch_refused = true; return; }
-    }
+  else if (S > 1) {
+    if (!gemm_sliced(c, g, c->skpart, c->skpart_floats, norm_w, Y, ldy, s)) c->launch_refused = true;
     return;
-  } else if (S > 1) { c->launch_refused = true; return; }    // a sliced role has one canonical order: no silent change of kernel
+  }    // a sliced role has one canonical order: no silent change of kernel
   if (!done) { g.kslices = 1; if (c->gemm_naive) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s); }
   if (norm_w) launch_rmsnorm_rows(C, ldc, norm_w, Y, ldy, M, N, c->cfg.rms_eps, s);
 }
@@ -578,7 +592,7 @@ void gemm_role(dtk_ctx* c, const bf16_t* A, int lda, const bf16_t* W, const bf16
 bool qkv_rope_fused(dtk_ctx* c, const LayerW& w, int n, int start, bf16_t* kc, bf16_t* vc, hipStream_t s) {
   const int d = c->d, qkvn = d + 2 * c->KVH * 128;
   const int S = c->prefill_sk ? std::min(sk_role_slices(qkvn, d), c->prefill_sk == 1 ? 8 : c->prefill_sk) : 1;
-  if (S <= 1 || c->gemm_naive || !c->qkv_rope_fused || n > SK_CHUNK_ROWS || (size_t)S * SK_CHUNK_ROWS * (size_t)qkvn > c->skpart_floats) return false;
+  if (S <= 1 || c->gemm_naive || !c->qkv_rope_fused || n > SK_CHUNK_ROWS || n > c->sk_sl_min_rows || (size_t)S * SK_CHUNK_ROWS * (size_t)qkvn > c->skpart_floats) return false;
   GemmArgs g;
   g.A = c->Xn; g.lda = d; g.W = w.wqkv; g.Wt = w.p_wqkv; g.ldw = d; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
   g.C = c->QKV; g.ldc = qkvn; g.M = n; g.N = qkvn; g.K = d; g.flags = 0; g.kslices = S;
@@ -2056,6 +2070,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     for (SeqHost& sh : c->bseq) { sh.image_key = 0; sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
   }
   else if (!strcmp(name, "qkv_rope_fused")) c->qkv_rope_fused = value != 0;
+  else if (!strcmp(name, "sk_sl_min_rows")) { if (value < 1) return fail(c, DTK_ERR_ARG, "sk_sl_min_rows must be >= 1"); c->sk_sl_min_rows = value; }
   else if (!strcmp(name, "gemm_epi_direct")) set_gemm_epi_direct(value != 0);   // k_gemm_g3 without the LDS-transposed epilogue (default 0; process-wide; bit-identical)
   else if (!strcmp(name, "gemm_wt")) set_gemm_wt(value != 0);     // k_gemm_g3's W stage from the fragment-major copy (default 1; process-wide; bit-identical)
   else if (!strcmp(name, "gemm_sk_tile")) {   // block tile of the sliced-K GEMM: 0 = 256 x 128, 1 = 128 x 256, 2 = by M (process-wide; bit-identical)
@@ -2152,7 +2167,8 @@ int dtk_op_gemm(dtk_ctx* c, const uint16_t* A, const uint16_t* W, const uint16_t
     else {
       OPBUF(float, dP, (size_t)S * M * N);
       g.part = dP; g.part_stride = (long)M * N;
-      if (!launch_gemm_sk(g, nullptr, nullptr, 0, 0.f, s)) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: the sliced-K kernel does not take this shape");
+      if (flags & DTK_GEMM_SL) { if (!launch_gemm_g3_sliced(g, s)) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: the in-register sliced kernel does not take this shape"); }
+      else if (!launch_gemm_sk(g, nullptr, nullptr, 0, 0.f, s)) return fail(c, DTK_ERR_ARG, "dtk_op_gemm: the sliced-K kernel does not take this shape");
     }
   }
   else if (flags & DTK_GEMM_NAIVE) launch_gemm_naive(g, s); else launch_gemm_mfma(g, s);

@@ -222,6 +222,7 @@ __host__ __device__ inline int sk_tiles_per_slice(int K, int S) { const int T = 
 // slices of a decoder-prefill role, from its WEIGHT shape alone: the largest power of two <= 8 that keeps 256 x 128 tiles x slices within
 // the 256 CUs, every slice at least 4 k-tiles long; 1 = the role stays a one-chain GEMM (it fills the chip, or the sliced kernel does not take it)
 #define SK_CHUNK_ROWS 512
+#define SK_SL_MIN_ROWS 768      // measured (ds-7b, profiles/r06ab_long_prompts.txt): 600 rows 16.0 ms in chunks / 16.7 in one launch, 1100 rows 28.3 / 24.3, 1900 rows 46.4 / 34.8
 inline int sk_role_slices(int N, int K) {
   if ((N % 4) || (K % 8) || K < 128) return 1;
   const int tiles = (N + 127) / 128;
@@ -239,6 +240,8 @@ void set_gemm_wt(int v);        // 1 (default): k_gemm_g3 fills its W stage from
 void set_gemm_epi_direct(int v);   // 1: k_gemm_g3 stores from the accumulator layout (no LDS transpose); bit-identical
 void set_gemm_sk_tile(int v);   // 0 = 256 x 128, 1 = 128 x 256, 2 = by M (default); bit-identical
 bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
+void launch_rmsnorm_rows_sk(const bf16_t* X, int ldx, const bf16_t* norm_w, bf16_t* Y, int ldy, int M, int N, float eps, hipStream_t s);   // k_sk_reduce's RMSNorm alone
+bool launch_gemm_g3_sliced(const GemmArgs& a, hipStream_t s);        // the same role in ONE launch (second accumulator set, slices folded in registers): for large M; bit-identical
 bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s);     // the GEMM alone: a.part holds the slices' sums afterwards
 // the q/k/v role's reduction fused with k_rope_scatter (same rounding points: bf16 of the summed slices, then RoPE)
 void launch_sk_rope_scatter(const float* part, long part_stride, int kslices, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,

@@ -350,7 +350,10 @@ static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
 // k-tiles of its slice through the same pipeline from zero and stores its fp32 accumulators to part[ks]; k_sk_reduce adds the slices in
 // order and applies the epilogue.  The ragged K tail belongs to the last slice.
 // WT: the W stage is filled from the fragment-major copy a.Wt (GemmArgs) and read back as whole 1 KiB operands.
-template <int BM, int BN, bool SK = false, bool WT = false>
+// SL (a sliced-K role at an M that fills the chip by its tiles alone, launch_gemm_g3_sliced): ONE block per tile walks all k-tiles and keeps a
+// second accumulator set — at every slice boundary tot = tot + acc (the first: tot = acc), acc = 0, an empty slice adds its zeros — i.e. the
+// sums k_sk_reduce would have formed from the SK blocks' partials, in the same order: bit-identical to that pair, no partials in memory.
+template <int BM, int BN, bool SK = false, bool WT = false, bool SL = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   constexpr int BK = 64, NST = 3, WAVES = 8;
   constexpr unsigned OPA = BM * BK * 2, OPW = BN * BK * 2, STB = OPA + OPW;   // 48 KiB per stage
@@ -401,6 +404,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 tot[4][4];
+  int cur = 0;                                     // SL: the slice the accumulators belong to
+  const int slq = SL ? sk_tiles_per_slice(K, a.kslices) : 0;
+  auto fold = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cur == 0) tot[i][j] = acc[i][j];
+        else { tot[i][j][0] += acc[i][j][0]; tot[i][j][1] += acc[i][j][1]; tot[i][j][2] += acc[i][j][2]; tot[i][j][3] += acc[i][j][3]; }
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    ++cur;
+  };
   unsigned aoff[4], boff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -435,8 +452,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + 2 < nk && !(a.flags & GEMM_PROBE_NOFILL)) fill(t + 2);
+    if (SL) { while (cur < a.kslices - 1 && t >= (cur + 1) * slq) fold(); }         // k-tile t opens a later slice
     if (!(a.flags & GEMM_PROBE_NOMFMA)) compute(t % NST);
   }
+  if (SL) { while (cur < a.kslices - 1) fold(); }     // the ragged tail (and nothing else, if its tiles ran out) belongs to the last slice
   if (tail) {                                      // ragged tail: register-staged, zero-filled, same image (swizzle included)
     const int stage = nk % NST, k0 = (kt0 + nk) * BK;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // nothing in flight; stage last read by compute(nk - 3)
@@ -456,6 +475,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
     }
     __syncthreads();
     compute(stage);
+  }
+  if (SL) {
+    fold();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
   }
   // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n.
   // Epilogue through LDS (default): a lane's direct stores are 8 bytes (16 as a K slice's fp32) at 16 different rows per instruction — 32-byte
@@ -712,6 +738,33 @@ __global__ __launch_bounds__(1024) void k_sk_reduce(GemmArgs a, const bf16_t* no
     }
   }
 }
+// k_sk_reduce's RMSNorm on rows that are already stored (behind launch_gemm_g3_sliced): the same thread -> column map and the same order of
+// the sum of squares, so Y equals what the fused reduction writes, bit for bit
+__global__ __launch_bounds__(1024) void k_rmsnorm_rows_sk(const bf16_t* X, int ldx, const bf16_t* norm_w, bf16_t* Y, int ldy, int N, float eps) {
+  __shared__ float red[16];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* xrow = X + (size_t)m * ldx;
+  float ss = 0.f;
+  for (int n = tid * 4; n < N; n += 4096) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float x = bf2f(xrow[n + r]); ss += x * x; }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  float tot = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) tot += red[w];
+  const float inv = rsqrtf(tot / (float)N + eps);
+  bf16_t* yrow = Y + (size_t)m * ldy;
+  for (int n = tid * 4; n < N; n += 4096) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yrow[n + r] = f2bf(bf2f(norm_w[n + r]) * rbf(bf2f(xrow[n + r]) * inv));
+  }
+}
+void launch_rmsnorm_rows_sk(const bf16_t* X, int ldx, const bf16_t* norm_w, bf16_t* Y, int ldy, int M, int N, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(k_rmsnorm_rows_sk, dim3((unsigned)M), dim3(1024), 0, s, X, ldx, norm_w, Y, ldy, N, eps);
+}
 void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s) {
   const dim3 grid((unsigned)a.M, norm_w ? 1u : (unsigned)((a.N + 4095) / 4096));
 #define SK_RED(S_) case S_: hipLaunchKernelGGL(k_sk_reduce<S_>, grid, dim3(1024), 0, s, a, norm_w, Y, ldy, eps); break;
@@ -739,6 +792,26 @@ bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s) {
                return true; }
   if (use_wt(a)) { if (wide) launch_gemm_sk_t<128, 256, true>(a, s); else launch_gemm_sk_t<256, 128, true>(a, s); }
   else if (wide) launch_gemm_sk_t<128, 256, false>(a, s); else launch_gemm_sk_t<256, 128, false>(a, s);
+  return true;
+}
+
+// a sliced-K role in ONE launch (k_gemm_g3<.., SL>): for M large enough that tiles alone fill the chip; bit-identical to launch_gemm_sk
+template <int BM, int BN, bool WT>
+static void launch_gemm_g3_sl_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (BM + BN) * 64 * 2;
+  static unsigned long long attr_set = 0;
+  if (dtk_lds_attr_todo(attr_set)) { DTK_LDS_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_g3<BM, BN, false, WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); }
+  const long mbs = (a.M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm_g3<BM, BN, false, WT, true>), dim3((unsigned)(8 * ((nbs + 7) / 8) * mbs)), dim3(512), lds, s, a);
+}
+bool launch_gemm_g3_sliced(const GemmArgs& a, hipStream_t s) {
+  if (!gemm_sk_supported(a) || a.kslices < 2) return false;
+  auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  const bool wide = blocks(128, 256) < blocks(256, 128);
+  GemmArgs b = a;
+  if (g_g3_epi_direct) b.flags |= GEMM_EPI_DIRECT;
+  if (use_wt(b)) { if (wide) launch_gemm_g3_sl_t<128, 256, true>(b, s); else launch_gemm_g3_sl_t<256, 128, true>(b, s); }
+  else if (wide) launch_gemm_g3_sl_t<128, 256, false>(b, s); else launch_gemm_g3_sl_t<256, 128, false>(b, s);
   return true;
 }
 

@@ -362,11 +362,16 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * DESIGN.md 3.4 has the defaults and what each switch measured.
  * Diagnostic: "vit_feature_layer" (0..depth-1) = the block whose normed output dtk_vit_encode returns as features (tests walk
  * the tower block by block with it); every cached image prefix is dropped.
+ * Decoder prefill: "prefill_sk" (1 = roles sliced along K by their weight shape, the default; 0 = one-chain GEMMs — another fp32
+ * summation order, cached prefixes are dropped; 2 / 4 / 8 = a cap on the slices), and three bit-identical choices: "gemm_wt" (k_gemm_g3's W stage from the
+ * fragment-major weight copy), "gemm_epi_direct" (k_gemm_g3 stores from the accumulator layout instead of through LDS), "qkv_rope_fused" (the
+ * sliced q/k/v role reduces inside the RoPE + KV-append kernel), "gemm_sk_tile" (0 = 256 x 128, 1 = 128 x 256, 2 = by M).  "sk_sl_min_rows": above this many prefill rows a sliced role is ONE launch that folds
+ * its slices in registers (k_gemm_g3<.., SL>) instead of (tile, slice) blocks + reduction per 512 rows; bit-identical.
  * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create.
  * SCOPE: the switches that select a kernel VARIANT ("gemv_*", "resid_*", "gemm_*", "mx_*", "attn_impl") are process-wide — they live in the
  * launchers, not in the context: a later context of the same process inherits what an earlier one set, and an A/B inside one process must set
  * the switch on both sides.  The per-context ones: "act_fp8", "prefix_mfma", "tail_threads", "pfx_splits", "share_prefix_reads", "mv_slots",
- * "attn_threads" / "attn_splits" / "attn_combine", "vit_feature_layer", "gemm_naive", "resid_kparts". */
+ * "attn_threads" / "attn_splits" / "attn_combine", "vit_feature_layer", "gemm_naive", "resid_kparts", "prefill_sk", "qkv_rope_fused". */
 int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the
@@ -378,6 +383,7 @@ int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 #define DTK_EPI_RESIDUAL 4    /* bf16(acc + bias) + residual[m,n]   */
 #define DTK_GEMM_NAIVE 256    /* use the non-MFMA reference kernel  */
 #define DTK_GEMM_WT 512       /* also hand the kernel W as fragment-major tiles (what the decoder prefill does): same result, bit for bit */
+#define DTK_GEMM_SL 1024      /* with K slices: ONE launch that folds the slices in registers (what large M takes) instead of (tile, slice) blocks + reduction */
 #define DTK_GEMM_KSLICES_SHIFT 12   /* flags |= S << 12 (S = 1..8): the sliced-K family of the decoder prefill — K's 64-wide k-tiles cut into S
                                      * runs, a chain per run, the runs' sums added in order (fp32); either kernel (MFMA / naive) */
 /* C[M,N] = A[M,K] . W[N,K]^T (+epilogue) */
