@@ -63,6 +63,7 @@ struct LayerW {
   bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
   bf16_t *t_wqkv = nullptr, *t_wo = nullptr, *t_wgu = nullptr, *t_wdown = nullptr;  // fragment-major copies (batched decode)
   bf16_t *p_wqkv = nullptr, *p_wo = nullptr, *p_wgu = nullptr, *p_wdown = nullptr;  // fragment-major bf16 copies the prefill GEMMs stream (= t_* where those exist)
+  bf16_t* p_wgui = nullptr;          // gate/up again with its row tiles in (gate, up) pair order: the W stage of the SwiGLU-fused prefill GEMM (models whose gate/up role is one chain)
   uint8_t *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;  // fp8 e4m3 copies (weight_format 1)
   float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;    // per-row power-of-two scales
   uint8_t *t8_wqkv = nullptr, *t8_wo = nullptr, *t8_wgu = nullptr, *t8_wdown = nullptr;  // fp8 pair-tiled copies (batched decode, fp8)
@@ -109,6 +110,7 @@ struct dtk_ctx {
   int sk_sl_min_rows = SK_SL_MIN_ROWS;   // above this many rows a sliced role is one launch with the slices folded in registers (dtk_set_option "sk_sl_min_rows"; bit-identical)
   float* skpart = nullptr;           // fp32 partials of the sliced-K prefill GEMMs: [kslices][SK_CHUNK_ROWS][N], one role at a time
   size_t skpart_floats = 0;
+  int swiglu_fused = 1;              // gate/up's epilogue is SiLU*mul (dtk_set_option "swiglu_fused"; bit-identical)
   int qkv_rope_fused = 1;            // a sliced q/k/v role reduces inside the RoPE + KV-append kernel (dtk_set_option "qkv_rope_fused"; bit-identical)
   int prefill_sk = 1;                // sliced-K prefill GEMMs for the roles with <= 128 tiles of 256 x 128 (dtk_set_option "prefill_sk": 0 = the one-chain kernels, 2 / 4 / 8 = a cap on the slices)
   int32_t* ids_dev = nullptr;
@@ -527,6 +529,7 @@ void plan(dtk_ctx* c, Planner& P, bool reg) {
     c->tokb_dev = P.take<int64_t>((size_t)DTK_MAX_INFLIGHT * DTK_MAX_BATCH + 1);   // + the sticky device error word (TOKB_ERR)
   }
   for (int i = 0; i < L; ++i) {     // the prefill GEMMs' fragment-major weights: the batched step's copies where a bf16 context has them
+    if (sk_role_slices(2 * ff, d) == 1) { bf16_t* ai = P.take<bf16_t>(tiled_elems(2 * ff, d)); if (reg) c->layers[i].p_wgui = ai; }
     if (c->nb > 0 && c->wfmt != 1) { if (reg) { LayerW& w = c->layers[i]; w.p_wqkv = w.t_wqkv; w.p_wo = w.t_wo; w.p_wgu = w.t_wgu; w.p_wdown = w.t_wdown; } continue; }
     bf16_t* a1 = P.take<bf16_t>(tiled_elems(qkvn, d));
     bf16_t* a2 = P.take<bf16_t>(tiled_elems(d, d));
@@ -924,6 +927,8 @@ void ensure_tiled_weights(dtk_ctx* c);
 void ensure_prefill_tiles(dtk_ctx* c) {
   ensure_fp8_weights(c);
   if (c->ptiled_ready) return;
+  for (int l = 0; l < c->L; ++l)
+    if (c->layers[l].p_wgui) launch_retile_pairs(c->layers[l].wgu, c->layers[l].p_wgui, c->ff, c->d, c->stream);
   if (c->nb > 0 && c->wfmt != 1) { ensure_tiled_weights(c); c->ptiled_ready = true; return; }
   for (int l = 0; l < c->L; ++l) {
     LayerW& w = c->layers[l];
@@ -1454,8 +1459,17 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     a.H = c->H; a.Tq = n; a.Tk = T; a.hd = 128; a.causal = 1; a.q_offset = start; a.scale = scale; a.impl = c->attn_impl; a.kv_group = c->H / c->KVH;
     launch_attention(a, s);
     gemm_role(c, c->AO, d, w.wo, w.p_wo, d, c->X, d, c->X, d, n, d, d, GEMM_RESIDUAL, w.ln2, c->Xn, d);     // + post_attention_layernorm -> Xn
-    gemm_role(c, c->Xn, d, w.wgu, w.p_wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
-    launch_silu_mul(c->GU, ff, c->ACT, n, s);
+    bool fused = false;      // gate/up + SiLU*mul in one launch where the role is one chain and the shape takes k_gemm_g3 (bit-identical to the pair below)
+    if (c->swiglu_fused && w.p_wgui && !c->gemm_naive) {
+      GemmArgs g;
+      g.A = c->Xn; g.lda = d; g.W = w.wgu; g.Wt = w.p_wgui; g.ldw = d; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
+      g.C = c->ACT; g.ldc = ff; g.M = n; g.N = 2 * ff; g.K = d; g.flags = 0;
+      fused = launch_gemm_g3_swiglu(g, s);
+    }
+    if (!fused) {
+      gemm_role(c, c->Xn, d, w.wgu, w.p_wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
+      launch_silu_mul(c->GU, ff, c->ACT, n, s);
+    }
     // + the next layer's input_layernorm -> Xn (the final norm runs on the last row only, inside the lm_head GEMV below)
     gemm_role(c, c->ACT, ff, w.wdown, w.p_wdown, ff, c->X, d, c->X, d, n, d, ff, GEMM_RESIDUAL, l + 1 < c->L ? c->layers[l + 1].ln1 : nullptr, c->Xn, d);
   }
@@ -2070,6 +2084,7 @@ int dtk_set_option(dtk_ctx* c, const char* name, int value) {
     for (SeqHost& sh : c->bseq) { sh.image_key = 0; sh.cached_ids.clear(); sh.share_src = -1; sh.share_len = 0; }
   }
   else if (!strcmp(name, "qkv_rope_fused")) c->qkv_rope_fused = value != 0;
+  else if (!strcmp(name, "swiglu_fused")) c->swiglu_fused = value != 0;
   else if (!strcmp(name, "sk_sl_min_rows")) { if (value < 1) return fail(c, DTK_ERR_ARG, "sk_sl_min_rows must be >= 1"); c->sk_sl_min_rows = value; }
   else if (!strcmp(name, "gemm_epi_direct")) set_gemm_epi_direct(value != 0);   // k_gemm_g3 without the LDS-transposed epilogue (default 0; process-wide; bit-identical)
   else if (!strcmp(name, "gemm_wt")) set_gemm_wt(value != 0);     // k_gemm_g3's W stage from the fragment-major copy (default 1; process-wide; bit-identical)

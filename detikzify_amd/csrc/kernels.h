@@ -197,6 +197,8 @@ void set_gemv_mv_shape(int role, int shape);   // role = epilogue id (5 = o_proj
 #define GEMM_GELU_ERF 2
 #define GEMM_GELU_TANH 4
 #define GEMM_RESIDUAL 8
+#define GEMM_SWIGLU 16384           // k_gemm_g3 (W stage from a PAIR-INTERLEAVED fragment-major copy of [gate rows | up rows]: launch_retile_pairs): the epilogue is
+                                    // k_silu_mul's arithmetic on a lane's (gate, up) accumulator pair, C = [M][N / 2] activations — no [M][N] buffer, no second pass
 #define GEMM_EPI_DIRECT 32768       // k_gemm_g3: the lanes store their accumulators directly (the epilogue before round 6's LDS-transposed one; A/B and bit-identity tests)
 #define GEMM_PROBE_NOFILL 65536    // k_gemm_g3 timing experiments (DTK_G3_PROBE): leave parts of the kernel out
 #define GEMM_PROBE_NOMFMA 131072
@@ -241,6 +243,10 @@ void set_gemm_epi_direct(int v);   // 1: k_gemm_g3 stores from the accumulator l
 void set_gemm_sk_tile(int v);   // 0 = 256 x 128, 1 = 128 x 256, 2 = by M (default); bit-identical
 bool launch_gemm_sk(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
 void launch_rmsnorm_rows_sk(const bf16_t* X, int ldx, const bf16_t* norm_w, bf16_t* Y, int ldy, int M, int N, float eps, hipStream_t s);   // k_sk_reduce's RMSNorm alone
+// gate/up + SiLU*mul in one launch (GEMM_SWIGLU): a.Wt = the pair-interleaved copy, a.C / a.ldc = the activations [M][N / 2]; false = the shape does not
+// take k_gemm_g3 (fewer than its minimum of blocks, misaligned operands, gemm_wt off): nothing launched, the caller runs Linear + k_silu_mul
+bool launch_gemm_g3_swiglu(const GemmArgs& a, hipStream_t s);
+void launch_retile_pairs(const bf16_t* src, bf16_t* dst, int ff, int K, hipStream_t s);    // [2 ff][K] row-major (gate rows, then up rows) -> fragment-major tiles in the order gate tile 0, up tile 0, gate tile 1, ...
 bool launch_gemm_g3_sliced(const GemmArgs& a, hipStream_t s);        // the same role in ONE launch (second accumulator set, slices folded in registers): for large M; bit-identical
 bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s);     // the GEMM alone: a.part holds the slices' sums afterwards
 // the q/k/v role's reduction fused with k_rope_scatter (same rounding points: bf16 of the summed slices, then RoPE)

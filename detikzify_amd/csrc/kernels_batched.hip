@@ -483,6 +483,29 @@ __global__ __launch_bounds__(512, 1) void k_gemm_g3(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
   }
+  if (!SK && WT && (a.flags & GEMM_SWIGLU)) {
+    // W row tiles arrive as (gate tile q, up tile q) pairs: this wave's tiles j = 0, 2 are gate tiles, j = 1, 3 the up tiles of the same 16
+    // channels; a lane holds 4 consecutive channels of output row m.  k_silu_mul's rounding points: both Linear outputs to bf16, SiLU to bf16,
+    // the product to bf16.
+    const int ff = a.N >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int ch = ((n0 >> 4) + wc * 4 + 2 * jp) / 2 * 16 + (lane >> 4) * 4;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = rbf(acc[i][2 * jp][r]), u = rbf(acc[i][2 * jp + 1][r]);
+          const float sl = rbf(g / (1.f + expf(-g)));
+          o[r] = sl * u;
+        }
+        if (m < a.M && ch < ff) { const u32x2 pk = {pack2(o[0], o[1]), pack2(o[2], o[3])}; *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + ch) = pk; }
+      }
+    }
+    return;
+  }
   // transposed C/D layout: column (lane & 15) = row m of the output, rows (lane >> 4) * 4 + r = 4 consecutive output columns n.
   // Epilogue through LDS (default): a lane's direct stores are 8 bytes (16 as a K slice's fp32) at 16 different rows per instruction — 32-byte
   // pieces, 15 of the 77 us of the prefill's gate/up launch.  The stages are free now: every wave parks its 64 x 64 fp32 tile in its own
@@ -793,6 +816,34 @@ bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s) {
   if (use_wt(a)) { if (wide) launch_gemm_sk_t<128, 256, true>(a, s); else launch_gemm_sk_t<256, 128, true>(a, s); }
   else if (wide) launch_gemm_sk_t<128, 256, false>(a, s); else launch_gemm_sk_t<256, 128, false>(a, s);
   return true;
+}
+
+// gate/up + SiLU*mul: k_gemm_g3 with its W stage from the pair-interleaved copy
+bool launch_gemm_g3_swiglu(const GemmArgs& a, hipStream_t s) {
+  if (!use_wt(a) || (a.N & 31) || (a.ldc & 3) || (reinterpret_cast<uintptr_t>(a.C) & 7)) return false;
+  GemmArgs b = a;
+  b.flags |= GEMM_SWIGLU;
+  return launch_gemm_g3(b, s);
+}
+// Row-major [2 ff][K] (gate rows, then up rows) -> fragment-major tiles (k_retile's image) in pair order: tile 2 q = gate rows 16 q .. 16 q + 15,
+// tile 2 q + 1 = up rows ff + 16 q ..; one thread per 16-byte lane slot
+__global__ void k_retile_pairs(const bf16_t* src, bf16_t* dst, int ff, int K) {
+  const int K32 = (K + 31) >> 5, N16 = (2 * ff + 15) >> 4;
+  const long total = (long)N16 * K32 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long tile = i >> 6;
+    const int tk = (int)(tile % K32), tn = (int)(tile / K32);
+    const int n = ((tn & 1) ? ff : 0) + (tn >> 1) * 16 + (lane & 15), k = tk * 32 + (lane >> 4) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((tn >> 1) * 16 + (lane & 15) < ff && k < K) v = *reinterpret_cast<const u32x4*>(src + (size_t)n * K + k);
+    reinterpret_cast<u32x4*>(dst)[i] = v;
+  }
+}
+void launch_retile_pairs(const bf16_t* src, bf16_t* dst, int ff, int K, hipStream_t s) {
+  const long total = (long)((2 * ff + 15) >> 4) * ((K + 31) >> 5) * 64;
+  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_retile_pairs, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, ff, K);
 }
 
 // a sliced-K role in ONE launch (k_gemm_g3<.., SL>): for M large enough that tiles alone fill the chip; bit-identical to launch_gemm_sk

@@ -365,13 +365,13 @@ int  dtk_set_gemv_variant(dtk_ctx* ctx, int epi, int variant);
  * Decoder prefill: "prefill_sk" (1 = roles sliced along K by their weight shape, the default; 0 = one-chain GEMMs — another fp32
  * summation order, cached prefixes are dropped; 2 / 4 / 8 = a cap on the slices), and three bit-identical choices: "gemm_wt" (k_gemm_g3's W stage from the
  * fragment-major weight copy), "gemm_epi_direct" (k_gemm_g3 stores from the accumulator layout instead of through LDS), "qkv_rope_fused" (the
- * sliced q/k/v role reduces inside the RoPE + KV-append kernel), "gemm_sk_tile" (0 = 256 x 128, 1 = 128 x 256, 2 = by M).  "sk_sl_min_rows": above this many prefill rows a sliced role is ONE launch that folds
+ * sliced q/k/v role reduces inside the RoPE + KV-append kernel), "swiglu_fused" (SiLU*mul is the epilogue of the gate/up GEMM), "gemm_sk_tile" (0 = 256 x 128, 1 = 128 x 256, 2 = by M).  "sk_sl_min_rows": above this many prefill rows a sliced role is ONE launch that folds
  * its slices in registers (k_gemm_g3<.., SL>) instead of (tile, slice) blocks + reduction per 512 rows; bit-identical.
  * The environment variable DTK_OPTIONS="name=value,name=value" applies the same switches at dtk_create.
  * SCOPE: the switches that select a kernel VARIANT ("gemv_*", "resid_*", "gemm_*", "mx_*", "attn_impl") are process-wide — they live in the
  * launchers, not in the context: a later context of the same process inherits what an earlier one set, and an A/B inside one process must set
  * the switch on both sides.  The per-context ones: "act_fp8", "prefix_mfma", "tail_threads", "pfx_splits", "share_prefix_reads", "mv_slots",
- * "attn_threads" / "attn_splits" / "attn_combine", "vit_feature_layer", "gemm_naive", "resid_kparts", "prefill_sk", "qkv_rope_fused". */
+ * "attn_threads" / "attn_splits" / "attn_combine", "vit_feature_layer", "gemm_naive", "resid_kparts", "prefill_sk", "qkv_rope_fused", "swiglu_fused". */
 int  dtk_set_option(dtk_ctx* ctx, const char* name, int value);
 
 /* Op-level entry points used by the parity tests (tests/): run ONE kernel of the

@@ -362,11 +362,11 @@ def test_prefill_logits(tiny, tiny_oracle):
     assert r2 < 1e-2
 
 
-@pytest.mark.parametrize("name", ["detikzify-tiny", "detikzify-ds-1.3b"])
+@pytest.mark.parametrize("name", ["detikzify-tiny", "detikzify-ds-1.3b", "detikzify-ds-7b"])
 def test_prefill_kernel_switches_are_bit_identical(name, tiny):
     """the decoder prefill's choices that must not change a bit: the sliced-K GEMM's block tile, its W stage filled from the fragment-major
     weight copy or from the row-major weights, k_gemm_g3's epilogue through LDS or from the accumulator layout, the q/k/v role reduced inside
-    the RoPE + KV-append kernel or by k_sk_reduce + k_rope_scatter — and a tail of the prompt prefilled behind its cached head (few rows, the
+    the RoPE + KV-append kernel or by k_sk_reduce + k_rope_scatter, SiLU*mul as the epilogue of the gate/up GEMM or as its own pass — and a tail of the prompt prefilled behind its cached head (few rows, the
     other block tile) against the same rows of the full prefill; every sliced role in one launch (slices folded in registers) instead of blocks + reduction.  (prefill_sk = 0, the one-chain GEMMs, is a different rounding: close only.)"""
     g = torch.Generator().manual_seed(11)
     if name == "detikzify-tiny":
@@ -377,14 +377,14 @@ def test_prefill_kernel_switches_are_bit_identical(name, tiny):
         from detikzify_amd.model.config import preset
         from detikzify_amd.model.modeling import DetikzifyForCausalLM
         cfg = preset(name)
-        cfg.layers, cfg.max_positions = 4, 512
+        cfg.layers, cfg.max_positions = (4 if name == "detikzify-ds-1.3b" else 2), 512      # (ds-7b: gate/up is one chain there, its epilogue is SiLU*mul)
         model = DetikzifyForCausalLM(cfg, 0)
         model.fill_synthetic(31)
         ids, px = torch.randint(10, cfg.vocab - 1, (300,), generator=g), None
     base = model.prefill(ids, px, return_logits=True, reuse=False)
     try:
         for opt, val, back in (("gemm_sk_tile", 0, 2), ("gemm_sk_tile", 1, 2), ("gemm_wt", 0, 1), ("gemm_epi_direct", 1, 0), ("qkv_rope_fused", 0, 1),
-                               ("sk_sl_min_rows", 8, 768)):        # the last: every sliced role as ONE launch with its slices folded in registers (what long prompts take)
+                               ("swiglu_fused", 0, 1), ("sk_sl_min_rows", 8, 768)):        # the last: every sliced role as ONE launch with its slices folded in registers (what long prompts take)
             model.set_option(opt, val)
             got = model.prefill(ids, px, return_logits=True, reuse=False)
             model.set_option(opt, back)
@@ -398,7 +398,7 @@ def test_prefill_kernel_switches_are_bit_identical(name, tiny):
         print(f"{name}: one-chain GEMMs vs sliced-K roles: logits rel_l2 {r:.2e}")
         assert r < 3e-2 and (r > 0 or name == "detikzify-tiny")      # two bf16 pipelines of the same arithmetic (the oracle envelope's own scale); the tiny widths leave every role one slice
     finally:
-        for opt, back in (("gemm_sk_tile", 2), ("gemm_wt", 1), ("gemm_epi_direct", 0), ("qkv_rope_fused", 1), ("prefill_sk", 1), ("sk_sl_min_rows", 768)):
+        for opt, back in (("gemm_sk_tile", 2), ("gemm_wt", 1), ("gemm_epi_direct", 0), ("qkv_rope_fused", 1), ("prefill_sk", 1), ("sk_sl_min_rows", 768), ("swiglu_fused", 1)):
             model.set_option(opt, back)
         if name != "detikzify-tiny":
             import gc
