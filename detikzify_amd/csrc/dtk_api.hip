@@ -1466,6 +1466,19 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
       g.C = c->ACT; g.ldc = ff; g.M = n; g.N = 2 * ff; g.K = d; g.flags = 0;
       fused = launch_gemm_g3_swiglu(g, s);
     }
+    if (!fused && c->swiglu_fused && !c->gemm_naive && c->prefill_sk && n <= SK_CHUNK_ROWS && n <= c->sk_sl_min_rows && (ff % 4) == 0) {
+      // a SLICED gate/up role (d = 2048 models): its reduction is SiLU*mul (one chunk of rows; larger prompts take the pair below)
+      const int S = std::min(sk_role_slices(2 * ff, d), c->prefill_sk == 1 ? 8 : c->prefill_sk);
+      GemmArgs g;
+      g.A = c->Xn; g.lda = d; g.W = w.wgu; g.Wt = w.p_wgu; g.ldw = d; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
+      g.C = c->GU; g.ldc = 2 * ff; g.M = n; g.N = 2 * ff; g.K = d; g.flags = 0; g.kslices = S;
+      g.part = c->skpart; g.part_stride = (long)SK_CHUNK_ROWS * 2 * ff;
+      if (S > 1 && (size_t)S * SK_CHUNK_ROWS * 2 * (size_t)ff <= c->skpart_floats && gemm_sk_supported(g)) {
+        if (!launch_gemm_sk_partials(g, s)) c->launch_refused = true;
+        else launch_sk_reduce_swiglu(g, c->ACT, ff, s);
+        fused = true;
+      }
+    }
     if (!fused) {
       gemm_role(c, c->Xn, d, w.wgu, w.p_wgu, d, nullptr, 0, c->GU, 2 * ff, n, 2 * ff, d, 0, nullptr, nullptr, 0);
       launch_silu_mul(c->GU, ff, c->ACT, n, s);

@@ -252,6 +252,7 @@ bool launch_gemm_sk_partials(const GemmArgs& a, hipStream_t s);     // the GEMM 
 // the q/k/v role's reduction fused with k_rope_scatter (same rounding points: bf16 of the summed slices, then RoPE)
 void launch_sk_rope_scatter(const float* part, long part_stride, int kslices, bf16_t* Qh, bf16_t* kcache, bf16_t* vcache,
                             const bf16_t* cos_t, const bf16_t* sin_t, int T, int start_pos, int H, int KVH, int T_max, hipStream_t s);
+void launch_sk_reduce_swiglu(const GemmArgs& a, bf16_t* ACT, int ldact, hipStream_t s);    // a sliced gate/up role's partials (a.part, a.N = 2 ff) -> SiLU(gate) * up, [M][ff]
 void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s);
 void set_gemm_bk(int v);     // k-tile of the 64x64 GEMM: 64 | 128
 void set_gemm_stages(int v); // register prefetch depth of the 64x64 tile: 1..4

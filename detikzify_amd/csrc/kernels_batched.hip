@@ -788,6 +788,31 @@ __global__ __launch_bounds__(1024) void k_rmsnorm_rows_sk(const bf16_t* X, int l
 void launch_rmsnorm_rows_sk(const bf16_t* X, int ldx, const bf16_t* norm_w, bf16_t* Y, int ldy, int M, int N, float eps, hipStream_t s) {
   hipLaunchKernelGGL(k_rmsnorm_rows_sk, dim3((unsigned)M), dim3(1024), 0, s, X, ldx, norm_w, Y, ldy, N, eps);
 }
+// A sliced gate/up role (d = 2048 models): the reduction is SiLU*mul — per channel the slices' sums of the gate column and of the up column
+// (ff further on) added in slice order, both rounded to bf16 (the Linear's outputs), then k_silu_mul's arithmetic; 1024 threads x 4 channels
+template <int S>
+__global__ __launch_bounds__(1024) void k_sk_reduce_swiglu(const float* part, long part_stride, int M, int ff, bf16_t* ACT, int ldact) {
+  const int m = blockIdx.x, ch = blockIdx.y * 4096 + threadIdx.x * 4;
+  if (ch >= ff) return;
+  const float* row = part + (size_t)m * 2 * ff;
+  const f32x4 g4 = sk_sum<S>(row + ch, (size_t)part_stride), u4 = sk_sum<S>(row + ff + ch, (size_t)part_stride);
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float g = rbf(g4[r]), u = rbf(u4[r]);
+    const float sl = rbf(g / (1.f + expf(-g)));
+    o[r] = sl * u;
+  }
+  const u32x2 pk = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+  *reinterpret_cast<u32x2*>(ACT + (size_t)m * ldact + ch) = pk;
+}
+void launch_sk_reduce_swiglu(const GemmArgs& a, bf16_t* ACT, int ldact, hipStream_t s) {
+  const int ff = a.N >> 1;
+  const dim3 grid((unsigned)a.M, (unsigned)((ff + 4095) / 4096));
+#define SK_SWI(S_) case S_: hipLaunchKernelGGL(k_sk_reduce_swiglu<S_>, grid, dim3(1024), 0, s, a.part, a.part_stride, a.M, ff, ACT, ldact); break;
+  switch (a.kslices) { SK_SWI(1) SK_SWI(2) SK_SWI(3) SK_SWI(4) SK_SWI(5) SK_SWI(6) SK_SWI(7) SK_SWI(8) default: break; }
+#undef SK_SWI
+}
 void launch_sk_reduce(const GemmArgs& a, const bf16_t* norm_w, bf16_t* Y, int ldy, float eps, hipStream_t s) {
   const dim3 grid((unsigned)a.M, norm_w ? 1u : (unsigned)((a.N + 4095) / 4096));
 #define SK_RED(S_) case S_: hipLaunchKernelGGL(k_sk_reduce<S_>, grid, dim3(1024), 0, s, a, norm_w, Y, ldy, eps); break;
