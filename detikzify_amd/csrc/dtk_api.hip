@@ -1443,6 +1443,7 @@ static int prefill_impl(dtk_ctx* c, SeqHost& sh, bf16_t* kvbase, float* logits_d
     if (hi > lo) launch_copy_rows(c->IMG + (size_t)(lo - img_start) * d, d, c->X + (size_t)(lo - start) * d, d, hi - lo, d, s);
   }
   const float scale = 1.0f / sqrtf(128.f);
+  c->launch_refused = false;      // (a batched step that was refused leaves it set: this prefill judges its own launches)
   launch_rmsnorm_rows(c->X, d, c->layers[0].ln1, c->Xn, d, n, d, c->cfg.rms_eps, s);
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
